@@ -1,0 +1,96 @@
+"""ctypes binding of the CPU oracle (oracle/liblphoracle.so) -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(_ROOT, "oracle", "liblphoracle.so")
+
+PARTITIONED, UNPARTITIONED = 0, 1
+
+
+def _lib():
+    if not os.path.exists(_SO):
+        subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle")])
+    lib = C.CDLL(_SO)
+    lib.orc_load.restype = C.c_void_p
+    lib.orc_load.argtypes = [C.c_char_p, C.c_int, C.c_int]
+    lib.orc_free.argtypes = [C.c_void_p]
+    lib.orc_last_error.restype = C.c_char_p
+    for f in ("orc_k", "orc_m", "orc_mm_seed", "orc_kmer_count", "orc_minimizer_L0", "orc_fallback_keys"):
+        getattr(lib, f).restype = C.c_uint64
+        getattr(lib, f).argtypes = [C.c_void_p]
+    lib.orc_query.restype = C.c_int64
+    lib.orc_query.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
+    lib.orc_query_packed.restype = None
+    lib.orc_query_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.orc_build.restype = C.c_int
+    lib.orc_build.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int,
+                              C.c_uint64, C.c_double, C.c_int, C.c_int, C.c_char_p]
+    lib.orc_murmur64a.restype = C.c_uint64
+    lib.orc_murmur64a.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64]
+    lib.orc_minimizer_order.restype = C.c_uint64
+    lib.orc_minimizer_order.argtypes = [C.c_void_p, C.c_uint64]
+    return lib
+
+
+lib = _lib()
+
+
+def build(contigs, k, m, out_path, kind=PARTITIONED, kmer_bits=64, mm_seed=42, c=3.0):
+    """contigs: list of bytes (one record each, what kseq_read yields)."""
+    n = len(contigs)
+    arr = (C.c_char_p * n)(*contigs)
+    lens = (C.c_size_t * n)(*[len(s) for s in contigs])
+    rc = lib.orc_build(arr, lens, n, k, m, mm_seed, c, kind, kmer_bits, out_path.encode())
+    if rc != 0:
+        raise RuntimeError(lib.orc_last_error().decode())
+
+
+class Index:
+    def __init__(self, path, kind=PARTITIONED, kmer_bits=64):
+        self.h = lib.orc_load(path.encode(), kind, kmer_bits)
+        if not self.h:
+            raise RuntimeError(lib.orc_last_error().decode())
+        self.kind, self.kmer_bits = kind, kmer_bits
+        self.k, self.m = lib.orc_k(self.h), lib.orc_m(self.h)
+        self.mm_seed = lib.orc_mm_seed(self.h)
+        self.nkmers = lib.orc_kmer_count(self.h)
+        self.distinct_minimizers = lib.orc_minimizer_L0(self.h)
+        self.fallback_keys = lib.orc_fallback_keys(self.h)
+
+    def __call__(self, contig: bytes, streaming=True):
+        cap = max(len(contig), 1)
+        out = np.empty(cap, dtype=np.uint64)
+        n = lib.orc_query(self.h, contig, len(contig), 1 if streaming else 0, out.ctypes.data, cap)
+        if n < 0:
+            raise RuntimeError(lib.orc_last_error().decode())
+        assert n <= cap
+        return out[:n].copy()
+
+    def query_packed(self, kmers: np.ndarray):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        wpk = 1 if self.kmer_bits == 64 else 2
+        n = kmers.size // wpk
+        out = np.empty(n, dtype=np.uint64)
+        lib.orc_query_packed(self.h, kmers.ctypes.data, n, out.ctypes.data)
+        return out
+
+    def minimizer_order(self, mm):
+        return lib.orc_minimizer_order(self.h, mm)
+
+    def close(self):
+        if self.h:
+            lib.orc_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
