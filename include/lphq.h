@@ -1,0 +1,131 @@
+/*
+ * lphq.h -- C ABI of the MI355X-native LPHash query engine (liblphq.so).
+ *
+ * This is the drop-in boundary for LPHash's `query-p` / `query-u` hot path.  The reference has
+ * no FFI layer; what a binding would wrap is (paths relative to the reference tree):
+ *   - essentials::load(hf, path)                                   src/query.cpp:35-37
+ *   - std::vector<uint64_t> MPHF::operator()(contig, length, streaming)
+ *                                      include/partitioned_mphf.hpp:21-23,73-197 (class mphf,     query-p)
+ *                                      include/unpartitioned_mphf.hpp:22-23,72-192 (class mphf_alt, query-u)
+ *   - MPHF::get_kmer_count() / get_minimizer_L0()                  src/partitioned_mphf.cpp:270-272
+ * and the on-disk format fixed by the visit() order (include/partitioned_mphf.hpp:204-219,
+ * include/unpartitioned_mphf.hpp:199-211).  See INTEGRATION.md for the reference-side stub.
+ *
+ * All query entry points run on the GPU (hand-written gfx950 kernels).  There is NO CPU
+ * fallback: every call that needs a device fails with LPHQ_ERR_NO_DEVICE / LPHQ_ERR_HIP when
+ * none is usable.  Plain pointers and sizes only; no exceptions cross this boundary.
+ */
+#ifndef LPHQ_H
+#define LPHQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ---- */
+enum {
+    LPHQ_OK = 0,
+    LPHQ_ERR_ARG = 1,        /* bad argument (NULL, kind, kmer_bits, k/m out of range)       */
+    LPHQ_ERR_IO = 2,         /* cannot open / read the file (CLI exit code 2, query.cpp:43-46) */
+    LPHQ_ERR_FORMAT = 3,     /* truncated file or a redundant field disagrees                 */
+    LPHQ_ERR_NO_DEVICE = 4,  /* no usable HIP device                                          */
+    LPHQ_ERR_HIP = 5,        /* a HIP call failed; lphq_last_error() has the text             */
+    LPHQ_ERR_STATE = 6,      /* index not attached to a device / wrong order of calls         */
+    LPHQ_ERR_UNSUPPORTED = 7 /* index exceeds a limit of the device layout    */
+};
+
+/* which reference class wrote the file: build-p -> class mphf, build-u -> class mphf_alt
+ * (src/lphash.cpp:25-32).  The file carries no magic, so the caller says. */
+enum { LPHQ_PARTITIONED = 0, LPHQ_UNPARTITIONED = 1 };
+
+/* Sentinel written by the device streaming entry point for a window that contains a non-ACGT
+ * base (the reference's streaming branch emits nothing for those windows,
+ * include/partitioned_mphf.hpp:179-183).  The host entry point compacts them away. */
+#define LPHQ_INVALID UINT64_MAX
+
+typedef struct lphq_index lphq_index;
+
+typedef struct lphq_info {
+    uint32_t kind;       /* LPHQ_PARTITIONED / LPHQ_UNPARTITIONED                       */
+    uint32_t kmer_bits;  /* 64 or 128: the reference's compile-time kmer_t width          */
+    uint32_t k, m;
+    uint64_t mm_seed;
+    uint64_t num_kmers;            /* get_kmer_count()                                  */
+    uint64_t distinct_minimizers;  /* get_minimizer_L0()                                */
+    uint64_t fallback_kmers;       /* fallback_kmer_order.num_keys()                    */
+    uint64_t file_bytes;           /* bytes consumed by the loader (essentials::load)   */
+    uint64_t image_bytes;          /* size of the flat device image                     */
+    int32_t device;                /* attached device, -1 if none                       */
+    uint32_t reserved;
+} lphq_info;
+
+/* Thread-local text of the last error raised on the calling thread. */
+const char* lphq_last_error(void);
+
+/* ---- load: replaces `MPHF hf; essentials::load(hf, path)` (src/query.cpp:35-37) ----
+ * Parses the serialized mphf / mphf_alt, cross-checks its redundant fields and builds the flat
+ * device image on the host.  kmer_bits is the reference's compile-time kmer_t width
+ * (include/compile_constants.tpd:1-2): 64 or 128; it changes the fallback hash
+ * (include/constants.hpp:56-70) and is not recorded in the file. */
+int lphq_open(const char* path, int kind, int kmer_bits, lphq_index** out);
+int lphq_open_memory(const void* buf, size_t len, int kind, int kmer_bits, lphq_index** out);
+void lphq_close(lphq_index* idx);
+int lphq_get_info(const lphq_index* idx, lphq_info* info);
+
+/* ---- flat image (position independent; what gets RCCL-broadcast between GPUs) ---- */
+int lphq_image_bytes(const lphq_index* idx, size_t* nbytes);
+int lphq_image_copy(const lphq_index* idx, void* host_dst, size_t cap);
+/* Create an index handle around an image that is ALREADY resident on `device` (e.g. received
+ * by ncclBroadcast).  The library reads the header back and keeps the pointer; the caller keeps
+ * ownership of the memory and must keep it alive until lphq_close. */
+int lphq_open_device_image(const void* d_image, size_t nbytes, int device, lphq_index** out);
+
+/* Upload the image to `device` (hipMalloc + hipMemcpy).  One device per handle. */
+int lphq_attach(lphq_index* idx, int device);
+/* Device pointer of the attached image (for broadcast from the root rank). */
+int lphq_device_image(const lphq_index* idx, const void** d_image, size_t* nbytes);
+
+/* ---- queries on device-resident buffers (stream = hipStream_t, NULL = default stream) ----
+ * All are asynchronous with respect to the host. */
+
+/* Random (non-streaming) lookups of n packed k-mers: the `streaming == false` branch
+ * (include/partitioned_mphf.hpp:185-195) applied to kmer_t values as produced by
+ * debug::string_to_integer_no_reverse (include/mphf_utils.hpp:110-116): first base in the most
+ * significant used bits.  kmer_bits 64: one uint64 per k-mer; 128: two (low, high). */
+int lphq_query_packed(const lphq_index* idx, const void* d_kmers, size_t n, uint64_t* d_out, void* stream);
+
+/* All windows of a batch of records laid out back to back in d_seq (ASCII, no separators):
+ * record r = d_seq[d_seq_offsets[r] .. d_seq_offsets[r+1]), d_seq_offsets[0] = 0,
+ * d_seq_offsets[n_records] = total_bases (n_records + 1 entries) ; its codes go to
+ * d_out[d_out_offsets[r] + i] for window i.  d_out_offsets[r+1]-d_out_offsets[r] must be
+ * max(0, len_r - k + 1).  streaming != 0: one minimizer hash per base, super-k-mer leaders do the
+ * lookup (the reference's streaming branch, include/partitioned_mphf.hpp:78-184); windows holding
+ * a non-ACGT base get LPHQ_INVALID.  streaming == 0: every window does the full random lookup
+ * with non-ACGT bases read as 'A' (include/mphf_utils.hpp:108). */
+int lphq_query_records(const lphq_index* idx, const char* d_seq, size_t total_bases, const uint64_t* d_seq_offsets,
+                       size_t n_records, uint64_t* d_out, const uint64_t* d_out_offsets, int streaming, void* stream);
+
+/* Pack windows of d_seq into kmer_t values: out[i] = string_to_integer_no_reverse(d_seq + d_pos[i], k). */
+int lphq_pack_kmers(const lphq_index* idx, const char* d_seq, const uint64_t* d_pos, size_t n, void* d_kmers, void* stream);
+
+/* ---- host-buffer convenience: mirrors MPHF::operator()(contig, length, streaming) ----
+ * Copies the record to the device, runs the GPU path, copies the codes back and (streaming
+ * only) drops invalid windows, so *n_out is what the reference's vector.size() would be for
+ * ACGT input.  length < k yields 0 codes in both modes. */
+int lphq_query_contig(const lphq_index* idx, const char* contig, size_t length, int streaming,
+                      uint64_t* out, size_t cap, size_t* n_out);
+
+/* ---- index construction (writes the reference's format) ----
+ * In-memory build of a partitioned / unpartitioned LP-MPHF over the k-mers of the records
+ * (src/partitioned_mphf.cpp:33-145, src/unpartitioned_mphf.cpp:23-136) and essentials::save
+ * (src/build.cpp:28).  Host-side, multi-threaded. threads <= 0: all cores. */
+int lphq_build(const char* const* records, const size_t* lengths, size_t n_records, int k, int m,
+               uint64_t mm_seed, double c, int kind, int kmer_bits, int threads, const char* out_path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPHQ_H */

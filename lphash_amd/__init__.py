@@ -1,0 +1,7 @@
+"""lphash_amd -- MI355X-native LPHash query engine (query-p / query-u hot path).
+
+C ABI: include/lphq.h (liblphq.so).  This package is the Python host mirror of the reference's MPHF
+interface over that ABI.
+"""
+from ._lib import INVALID, PARTITIONED, UNPARTITIONED, LphqError  # noqa: F401
+from .api import Mphf, MphfAlt, build  # noqa: F401

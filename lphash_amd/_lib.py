@@ -1,0 +1,74 @@
+"""ctypes binding of liblphq.so (the C ABI declared in include/lphq.h).
+
+The shared library holds the loader, the flat-image builder, the index builder and the gfx950 kernels.
+There is no Python or CPU implementation of the query path: if the library is missing, importing this
+module raises, and every query call needs a HIP device.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblphq.so")
+
+OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(8)
+PARTITIONED, UNPARTITIONED = 0, 1
+INVALID = 0xFFFFFFFFFFFFFFFF
+
+
+class LphqError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"lphq error {code}: {msg}")
+        self.code = code
+
+
+class Info(C.Structure):
+    _fields_ = [
+        ("kind", C.c_uint32), ("kmer_bits", C.c_uint32), ("k", C.c_uint32), ("m", C.c_uint32),
+        ("mm_seed", C.c_uint64), ("num_kmers", C.c_uint64), ("distinct_minimizers", C.c_uint64),
+        ("fallback_kmers", C.c_uint64), ("file_bytes", C.c_uint64), ("image_bytes", C.c_uint64),
+        ("device", C.c_int32), ("reserved", C.c_uint32),
+    ]
+
+
+# every symbol include/lphq.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "lphq_last_error": (C.c_char_p, []),
+    "lphq_open": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "lphq_open_memory": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "lphq_close": (None, [C.c_void_p]),
+    "lphq_get_info": (C.c_int, [C.c_void_p, C.POINTER(Info)]),
+    "lphq_image_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "lphq_image_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "lphq_open_device_image": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "lphq_attach": (C.c_int, [C.c_void_p, C.c_int]),
+    "lphq_device_image": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "lphq_query_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "lphq_query_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_void_p]),
+    "lphq_pack_kmers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "lphq_query_contig": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
+                                    C.POINTER(C.c_size_t)]),
+    "lphq_build": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int, C.c_uint64,
+                             C.c_double, C.c_int, C.c_int, C.c_int, C.c_char_p]),
+}
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C lphash_amd/csrc`). There is no fallback implementation.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = load()
+
+
+def check(rc):
+    if rc != OK:
+        raise LphqError(rc, (lib.lphq_last_error() or b"").decode(errors="replace"))

@@ -1,0 +1,161 @@
+"""Host-side mirror of the reference's MPHF interface for the query path.
+
+Reference (paths relative to the reference tree):
+  class mphf      include/partitioned_mphf.hpp:10-71   -> Mphf      (`lphash query-p`)
+  class mphf_alt  include/unpartitioned_mphf.hpp:10-69 -> MphfAlt   (`lphash query-u`)
+  essentials::load(hf, path)  src/query.cpp:35-37      -> Mphf.load(path)
+  hf(contig, length, streaming)                        -> hf(contig, streaming=True) -> np.ndarray[uint64]
+  hf.get_kmer_count(), hf.get_minimizer_L0()           same names
+
+Everything that computes goes through the C ABI (include/lphq.h) to the gfx950 kernels; PyTorch is
+only used by callers for device memory, streams and torch.distributed.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import PARTITIONED, UNPARTITIONED, LphqError, check, lib
+
+
+def build(records, k, m, out_path, kind=PARTITIONED, kmer_bits=None, mm_seed=42, c=3.0, threads=0):
+    """`lphash build-p|build-u -i ... -k k -m m -s seed -c c -t threads -o out_path` over in-memory records
+    (src/build.cpp:10-51).  records: iterable of bytes, one per FASTA/FASTQ record (what kseq_read yields)."""
+    records = [bytes(r) for r in records]
+    if kmer_bits is None:
+        kmer_bits = 64 if k <= 31 else 128
+    n = len(records)
+    arr = (C.c_char_p * n)(*records)
+    lens = (C.c_size_t * n)(*[len(r) for r in records])
+    check(lib.lphq_build(arr, lens, n, int(k), int(m), int(mm_seed), float(c), int(kind), int(kmer_bits), int(threads),
+                         str(out_path).encode()))
+
+
+class _MphfBase:
+    KIND = None
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        self._info = None
+
+    # -- essentials::load ---------------------------------------------------------------------
+    @classmethod
+    def load(cls, path, kmer_bits=128, device=None):
+        """kmer_bits: the reference's compile-time kmer_t width (include/compile_constants.tpd:1-2, default
+        __uint128_t).  device: HIP ordinal to attach to (None = do not attach yet)."""
+        self = cls()
+        check(lib.lphq_open(str(path).encode(), cls.KIND, int(kmer_bits), C.byref(self._h)))
+        self._refresh()
+        if device is not None:
+            self.attach(device)
+        return self
+
+    @classmethod
+    def from_bytes(cls, data, kmer_bits=128, device=None):
+        self = cls()
+        buf = (C.c_char * len(data)).from_buffer_copy(data)
+        check(lib.lphq_open_memory(buf, len(data), cls.KIND, int(kmer_bits), C.byref(self._h)))
+        self._refresh()
+        if device is not None:
+            self.attach(device)
+        return self
+
+    @classmethod
+    def from_device_image(cls, d_image_ptr, nbytes, device):
+        """Wrap a flat image already resident on `device` (e.g. received by an RCCL broadcast)."""
+        self = cls()
+        check(lib.lphq_open_device_image(C.c_void_p(d_image_ptr), nbytes, int(device), C.byref(self._h)))
+        self._refresh()
+        if self._info.kind != cls.KIND:
+            self.close()
+            raise LphqError(_lib.ERR_ARG, "image kind does not match the class")
+        return self
+
+    def _refresh(self):
+        info = _lib.Info()
+        check(lib.lphq_get_info(self._h, C.byref(info)))
+        self._info = info
+
+    def attach(self, device=0):
+        check(lib.lphq_attach(self._h, int(device)))
+        self._refresh()
+        return self
+
+    def close(self):
+        if self._h:
+            lib.lphq_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- accessors ------------------------------------------------------------------------------
+    @property
+    def info(self):
+        return self._info
+
+    @property
+    def k(self):
+        return self._info.k
+
+    @property
+    def m(self):
+        return self._info.m
+
+    @property
+    def kmer_bits(self):
+        return self._info.kmer_bits
+
+    def get_kmer_count(self):
+        return self._info.num_kmers
+
+    def get_minimizer_L0(self):
+        return self._info.distinct_minimizers
+
+    # -- flat image -----------------------------------------------------------------------------
+    def image(self):
+        n = C.c_size_t()
+        check(lib.lphq_image_bytes(self._h, C.byref(n)))
+        out = np.empty(n.value, dtype=np.uint8)
+        check(lib.lphq_image_copy(self._h, out.ctypes.data, n.value))
+        return out
+
+    def device_image(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        check(lib.lphq_device_image(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    # -- MPHF::operator()(contig, length, streaming) ------------------------------------------------
+    def __call__(self, contig, streaming=True):
+        if isinstance(contig, str):
+            contig = contig.encode()
+        contig = bytes(contig)
+        cap = max(len(contig), 1)
+        out = np.empty(cap, dtype=np.uint64)
+        n = C.c_size_t()
+        check(lib.lphq_query_contig(self._h, contig, len(contig), 1 if streaming else 0, out.ctypes.data, cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    # -- device-resident batches (pointers are raw device addresses, e.g. tensor.data_ptr()) -------
+    def query_packed(self, d_kmers, n, d_out, stream=0):
+        check(lib.lphq_query_packed(self._h, C.c_void_p(d_kmers), n, C.c_void_p(d_out), C.c_void_p(stream)))
+
+    def query_records(self, d_seq, total_bases, d_seq_offsets, n_records, d_out, d_out_offsets, streaming=True, stream=0):
+        check(lib.lphq_query_records(self._h, C.c_void_p(d_seq), total_bases, C.c_void_p(d_seq_offsets), n_records,
+                                     C.c_void_p(d_out), C.c_void_p(d_out_offsets), 1 if streaming else 0, C.c_void_p(stream)))
+
+    def pack_kmers(self, d_seq, d_pos, n, d_kmers, stream=0):
+        check(lib.lphq_pack_kmers(self._h, C.c_void_p(d_seq), C.c_void_p(d_pos), n, C.c_void_p(d_kmers), C.c_void_p(stream)))
+
+
+class Mphf(_MphfBase):
+    """Partitioned LP-MPHF (reference class `mphf`, tool `query-p`)."""
+    KIND = PARTITIONED
+
+
+class MphfAlt(_MphfBase):
+    """Unpartitioned LP-MPHF (reference class `mphf_alt`, tool `query-u`)."""
+    KIND = UNPARTITIONED

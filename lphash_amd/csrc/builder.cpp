@@ -1,0 +1,832 @@
+// builder.cpp -- in-memory, multi-threaded construction of a partitioned / unpartitioned LP-MPHF in the
+// reference's serialization (lphq_build in include/lphq.h).
+//
+// What it reproduces (paths relative to the reference tree):
+//   Part 1  super-k-mer records           include/minimizer.hpp:11-170  (from_string)
+//   Part 2  classify + PTHash over minimizers  src/minimizer.cpp:5-50, src/partitioned_mphf.cpp:85-91,147-154
+//   Part 3  inverted index                src/partitioned_mphf.cpp:163-268, src/unpartitioned_mphf.cpp:156-176
+//   Part 4  fallback PTHash over k-mers of colliding minimizers  include/minimizer.hpp:172-319
+//   save    essentials::save walk over visit()   src/build.cpp:28
+// It is a position-parallel re-design (records are cut into chunks, super-k-mers are runs of windows
+// that share the position of their leftmost minimum), not a translation of the reference's streaming
+// state machines.  PTHash search = first valid pilot per bucket, buckets by non-increasing size
+// (PTHash v1), run speculatively in parallel with in-order commit, so the result
+// does not depend on the thread count.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/lphq.h"
+#include "lph_format.hpp"
+
+namespace lphq {
+namespace {
+
+typedef unsigned __int128 u128;
+
+// ---------------------------------------------------------------------------------------------
+// tiny task pool
+// ---------------------------------------------------------------------------------------------
+void parallel_for(size_t n_tasks, int threads, const std::function<void(size_t)>& fn) {
+    if (threads <= 1 || n_tasks <= 1) {
+        for (size_t i = 0; i < n_tasks; ++i) fn(i);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    int nt = (int)std::min<size_t>((size_t)threads, n_tasks);
+    for (int t = 0; t < nt; ++t)
+        pool.emplace_back([&] {
+            for (;;) {
+                size_t i = next.fetch_add(1);
+                if (i >= n_tasks) break;
+                fn(i);
+            }
+        });
+    for (auto& th : pool) th.join();
+}
+
+inline uint64_t words_for(uint64_t bits) { return (bits + 63) / 64; }
+inline unsigned msb64(uint64_t x) { return 63u - (unsigned)__builtin_clzll(x); }
+
+inline uint8_t nt4(uint8_t c) {  // constants::seq_nt4_table, src/constants.cpp:5-13
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': case 'U': case 'u': return 3;
+        default: return 4;
+    }
+}
+
+inline uint64_t mul128_u64(u128 lowbits, uint64_t d) {
+    u128 bottom = ((lowbits & (u128)0xFFFFFFFFFFFFFFFFULL) * d) >> 64;
+    u128 top = (lowbits >> 64) * d;
+    return (uint64_t)((bottom + top) >> 64);
+}
+inline uint64_t fastmod_u64(uint64_t a, u128 M, uint64_t d) { return mul128_u64(M * a, d); }
+
+// ---------------------------------------------------------------------------------------------
+// serialized building blocks (writer side of lph_format.hpp)
+// ---------------------------------------------------------------------------------------------
+void bv_init(BitVector& b, uint64_t size) {
+    b.size = size;
+    b.bits.assign(words_for(size), 0);
+}
+inline void bv_set(BitVector& b, uint64_t i) { b.bits[i >> 6] |= 1ULL << (i & 63); }
+
+void cv_init(CompactVector& c, uint64_t n, uint64_t w) {  // compact_vector::builder(n, w)
+    c.size = n;
+    c.width = w;
+    c.mask = w == 64 ? ~0ULL : ((1ULL << w) - 1);
+    c.bits.assign(words_for(n * w) + 1, 0);
+}
+inline void cv_set(CompactVector& c, uint64_t i, uint64_t v) {
+    if (!c.width) return;
+    uint64_t pos = i * c.width, blk = pos >> 6, sh = pos & 63;
+    c.bits[blk] |= v << sh;
+    if (sh + c.width > 64) c.bits[blk + 1] |= v >> (64 - sh);
+}
+void cv_build(CompactVector& c, const std::vector<uint64_t>& v) {  // compact_vector::build(begin, n)
+    uint64_t mx = 0;
+    for (uint64_t x : v) mx = std::max(mx, x);
+    cv_init(c, v.size(), mx == 0 ? 1 : msb64(mx) + 1);
+    for (size_t i = 0; i < v.size(); ++i) cv_set(c, i, v[i]);
+}
+
+void d1_build(DArray1& d, const BitVector& bv) {  // pthash::darray1::build
+    d = DArray1();
+    std::vector<uint64_t> cur;
+    cur.reserve(1024);
+    auto flush = [&] {
+        if (cur.back() - cur.front() < (1u << 16)) {
+            d.block_inventory.push_back((int64_t)cur.front());
+            for (size_t i = 0; i < cur.size(); i += 32) d.subblock_inventory.push_back((uint16_t)(cur[i] - cur.front()));
+        } else {
+            d.block_inventory.push_back(-(int64_t)d.overflow_positions.size() - 1);
+            for (uint64_t p : cur) d.overflow_positions.push_back(p);
+            for (size_t i = 0; i < cur.size(); i += 32) d.subblock_inventory.push_back((uint16_t)-1);
+        }
+        cur.clear();
+    };
+    for (uint64_t w = 0; w < bv.bits.size(); ++w) {
+        uint64_t word = bv.bits[w];
+        while (word) {
+            uint64_t pos = (w << 6) + (uint64_t)__builtin_ctzll(word);
+            word &= word - 1;
+            if (pos >= bv.size) break;
+            cur.push_back(pos);
+            d.positions += 1;
+            if (cur.size() == 1024) flush();
+        }
+    }
+    if (!cur.empty()) flush();
+}
+
+// Elias-Fano over a non-decreasing sequence given by get(i), i < n, universe u.
+// leading_zero: lphash ef_sequence::encode (ef_sequence.hpp:37-75) prepends a 0; otherwise pthash::ef_sequence<false>.
+template <typename Get>
+void ef_encode(EliasFano& e, uint64_t n, uint64_t u, bool leading_zero, Get get) {
+    e = EliasFano();
+    if (n == 0) return;
+    const uint64_t nn = n + (leading_zero ? 1 : 0);
+    const uint64_t l = (nn && u / nn) ? msb64(u / nn) : 0;
+    bv_init(e.high, nn + (u >> l) + 1);
+    cv_init(e.low, nn, l);
+    const uint64_t low_mask = (1ULL << l) - 1;
+    uint64_t at = 0;
+    if (leading_zero) {
+        bv_set(e.high, 0);
+        at = 1;
+    }
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t v = get(i);
+        if (l) cv_set(e.low, i + at, v & low_mask);
+        bv_set(e.high, (v >> l) + i + at);
+    }
+    d1_build(e.d1, e.high);
+}
+
+void rs_build(RsBitVector& r) {  // rs_bit_vector::build_indices(false), rs_bit_vector.hpp:120-157
+    const std::vector<uint64_t>& bits = r.bv.bits;
+    std::vector<uint64_t>& prs = r.block_rank_pairs;
+    prs.clear();
+    uint64_t next_rank = 0, cur_subrank = 0, subranks = 0;
+    prs.push_back(0);
+    for (uint64_t i = 0; i < bits.size(); ++i) {
+        uint64_t word_pop = (uint64_t)__builtin_popcountll(bits[i]);
+        uint64_t shift = i % 8;
+        if (shift) {
+            subranks <<= 9;
+            subranks |= cur_subrank;
+        }
+        next_rank += word_pop;
+        cur_subrank += word_pop;
+        if (shift == 7) {
+            prs.push_back(subranks);
+            prs.push_back(next_rank);
+            subranks = 0;
+            cur_subrank = 0;
+        }
+    }
+    uint64_t left = 8 - bits.size() % 8;
+    for (uint64_t i = 0; i < left; ++i) {
+        subranks <<= 9;
+        subranks |= cur_subrank;
+    }
+    prs.push_back(subranks);
+    if (bits.size() % 8) {
+        prs.push_back(next_rank);
+        prs.push_back(0);
+    }
+    r.select_hints.clear();
+}
+
+// ---------------------------------------------------------------------------------------------
+// essentials::saver
+// ---------------------------------------------------------------------------------------------
+struct Writer {
+    std::vector<uint8_t> buf;
+    void raw(const void* p, size_t n) {
+        const uint8_t* b = (const uint8_t*)p;
+        buf.insert(buf.end(), b, b + n);
+    }
+    void u64(uint64_t v) { raw(&v, 8); }
+    template <typename T>
+    void vec(const std::vector<T>& v) {
+        u64(v.size());
+        if (!v.empty()) raw(v.data(), v.size() * sizeof(T));
+    }
+    void put(const BitVector& b) {
+        u64(b.size);
+        vec(b.bits);
+    }
+    void put(const CompactVector& c) {
+        u64(c.size);
+        u64(c.width);
+        u64(c.mask);
+        vec(c.bits);
+    }
+    void put(const DArray1& d) {
+        u64(d.positions);
+        vec(d.block_inventory);
+        vec(d.subblock_inventory);
+        vec(d.overflow_positions);
+    }
+    void put(const EliasFano& e) {
+        put(e.high);
+        put(e.d1);
+        put(e.low);
+    }
+    void put(const RsBitVector& r) {
+        put(r.bv);
+        vec(r.block_rank_pairs);
+        vec(r.select_hints);
+    }
+    void put(const SinglePhf& f) {
+        u64(f.seed);
+        u64(f.num_keys);
+        u64(f.table_size);
+        raw(&f.M, 16);
+        u64(f.num_dense);
+        u64(f.num_sparse);
+        raw(&f.M_dense, 16);
+        raw(&f.M_sparse, 16);
+        put(f.front.ranks);
+        put(f.front.dict);
+        put(f.back.ranks);
+        put(f.back.dict);
+        put(f.free_slots);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// PTHash single_phf build
+// ---------------------------------------------------------------------------------------------
+inline uint64_t bucket_of(const SinglePhf& f, uint64_t hash) {  // skew_bucketer::bucket
+    static const uint64_t T = 0x9999999999999800ULL;             // uint64_t(0.6 * UINT64_MAX)
+    return hash < T ? fastmod_u64(hash, f.M_dense, f.num_dense) : f.num_dense + fastmod_u64(hash, f.M_sparse, f.num_sparse);
+}
+
+void dict_encode(Dictionary& d, const uint64_t* v, uint64_t n) {  // pthash::dictionary::encode
+    std::vector<uint64_t> s(v, v + n);
+    std::sort(s.begin(), s.end());
+    std::vector<std::pair<uint64_t, uint64_t>> vf;  // (value, freq)
+    for (uint64_t i = 0; i < n;) {
+        uint64_t j = i;
+        while (j < n && s[j] == s[i]) ++j;
+        vf.emplace_back(s[i], j - i);
+        i = j;
+    }
+    // codewords by non-increasing frequency; ties (unordered in PTHash) by increasing value
+    std::sort(vf.begin(), vf.end(), [](const auto& a, const auto& b) { return a.second != b.second ? a.second > b.second : a.first < b.first; });
+    std::vector<uint64_t> dict(vf.size());
+    std::vector<std::pair<uint64_t, uint64_t>> byval(vf.size());
+    for (size_t i = 0; i < vf.size(); ++i) {
+        dict[i] = vf[i].first;
+        byval[i] = {vf[i].first, i};
+    }
+    std::sort(byval.begin(), byval.end());
+    std::vector<uint64_t> ranks(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        auto it = std::lower_bound(byval.begin(), byval.end(), std::make_pair(v[i], (uint64_t)0));
+        ranks[i] = it->second;
+    }
+    cv_build(d.ranks, ranks);
+    cv_build(d.dict, dict);
+}
+
+bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed, double c, double alpha, int threads, std::string& err) {
+    f = SinglePhf();
+    f.seed = seed;
+    const uint64_t n = hashes.size();
+    f.num_keys = n;
+    if (n == 0) return true;  // all-zero function; the reference never builds one
+    uint64_t table_size = (uint64_t)((double)n / alpha);
+    if ((table_size & (table_size - 1)) == 0) table_size += 1;
+    const uint64_t num_buckets = n < 2 ? 6 : (uint64_t)std::ceil((c * (double)n) / std::log2((double)n));
+    f.table_size = table_size;
+    f.M = compute_M_u64(table_size);
+    f.num_dense = (uint64_t)(0.3 * (double)num_buckets);
+    f.num_sparse = num_buckets - f.num_dense;
+    f.M_dense = compute_M_u64(f.num_dense);
+    f.M_sparse = compute_M_u64(f.num_sparse);
+    if (num_buckets > 0xFFFFFFFFull || n > 0xFFFFFFFFull) {
+        err = "pthash build: more than 2^32-1 keys/buckets is not supported by this builder";
+        return false;
+    }
+
+    // group hashes by bucket (counting sort), hashes sorted inside each bucket
+    std::vector<uint32_t> bucket_id(n);
+    std::vector<std::atomic<uint32_t>> counts(num_buckets + 1);
+    for (auto& x : counts) x.store(0, std::memory_order_relaxed);
+    const size_t chunk = 1 << 16;
+    const size_t nchunks = (n + chunk - 1) / chunk;
+    parallel_for(nchunks, threads, [&](size_t t) {
+        for (size_t i = t * chunk, e = std::min<size_t>(n, i + chunk); i < e; ++i) {
+            uint32_t b = (uint32_t)bucket_of(f, hashes[i]);
+            bucket_id[i] = b;
+            counts[b + 1].fetch_add(1, std::memory_order_relaxed);
+        }
+    });
+    std::vector<uint64_t> bstart(num_buckets + 1, 0);
+    uint64_t max_size = 0;
+    for (uint64_t b = 0; b < num_buckets; ++b) {
+        uint64_t sz = counts[b + 1].load(std::memory_order_relaxed);
+        max_size = std::max(max_size, sz);
+        bstart[b + 1] = bstart[b] + sz;
+    }
+    std::vector<uint64_t> hs(n);
+    {
+        std::vector<std::atomic<uint32_t>> cursor(num_buckets);
+        for (auto& x : cursor) x.store(0, std::memory_order_relaxed);
+        parallel_for(nchunks, threads, [&](size_t t) {
+            for (size_t i = t * chunk, e = std::min<size_t>(n, i + chunk); i < e; ++i) {
+                uint32_t b = bucket_id[i];
+                hs[bstart[b] + cursor[b].fetch_add(1, std::memory_order_relaxed)] = hashes[i];
+            }
+        });
+    }
+    std::vector<uint32_t>().swap(bucket_id);
+    std::atomic<bool> dup{false};
+    const size_t bchunk = 1 << 12;
+    parallel_for((num_buckets + bchunk - 1) / bchunk, threads, [&](size_t t) {
+        for (uint64_t b = t * bchunk, e = std::min<uint64_t>(num_buckets, b + bchunk); b < e; ++b) {
+            std::sort(hs.begin() + bstart[b], hs.begin() + bstart[b + 1]);
+            for (uint64_t i = bstart[b] + 1; i < bstart[b + 1]; ++i)
+                if (hs[i] == hs[i - 1]) dup.store(true);
+        }
+    });
+    if (dup.load()) {
+        err = "pthash seed failure: duplicate 64-bit hash inside a bucket (duplicate key in the input?)";
+        return false;
+    }
+    // buckets by non-increasing size, then increasing id
+    std::vector<uint32_t> order(num_buckets);
+    {
+        std::vector<uint64_t> cnt(max_size + 2, 0);
+        for (uint64_t b = 0; b < num_buckets; ++b) cnt[max_size - (bstart[b + 1] - bstart[b]) + 1]++;
+        for (uint64_t s = 0; s <= max_size; ++s) cnt[s + 1] += cnt[s];
+        for (uint64_t b = 0; b < num_buckets; ++b) order[cnt[max_size - (bstart[b + 1] - bstart[b])]++] = (uint32_t)b;
+    }
+    uint64_t n_nonempty = num_buckets;
+    while (n_nonempty && bstart[order[n_nonempty - 1] + 1] == bstart[order[n_nonempty - 1]]) --n_nonempty;
+
+    // search
+    std::vector<uint64_t> pilots(num_buckets, 0);
+    std::vector<std::atomic<uint64_t>> taken(words_for(table_size) + 1);
+    for (auto& x : taken) x.store(0, std::memory_order_relaxed);
+    const uint64_t HP_CACHE = 1ull << 20;
+    std::vector<uint64_t> hp_cache(HP_CACHE);
+    parallel_for(HP_CACHE >> 12, threads, [&](size_t t) {
+        for (uint64_t p = t << 12; p < (t + 1) << 12; ++p) hp_cache[p] = murmur64a_u64(p, seed);
+    });
+    std::atomic<uint64_t> next_commit{0};
+    const u128 M = f.M;
+    auto is_taken = [&](uint64_t p) { return (taken[p >> 6].load(std::memory_order_relaxed) >> (p & 63)) & 1; };
+    const int T = std::max(1, threads);
+    auto worker = [&](int tid) {
+        std::vector<uint64_t> pos(max_size ? max_size : 1);
+        for (uint64_t oi = (uint64_t)tid; oi < n_nonempty; oi += (uint64_t)T) {
+            const uint32_t b = order[oi];
+            const uint64_t* keys = hs.data() + bstart[b];
+            const uint64_t s = bstart[b + 1] - bstart[b];
+            uint64_t pilot = 0;
+            bool my_turn = false;
+            for (;;) {
+                // first pilot (>= current) whose positions are free under the bits visible now
+                for (;; ++pilot) {
+                    const uint64_t hp = pilot < HP_CACHE ? hp_cache[pilot] : murmur64a_u64(pilot, seed);
+                    uint64_t j = 0;
+                    for (; j < s; ++j) {
+                        const uint64_t p = fastmod_u64(keys[j] ^ hp, M, table_size);
+                        if (is_taken(p)) break;
+                        pos[j] = p;
+                    }
+                    if (j < s) continue;
+                    bool d2 = false;
+                    for (uint64_t a = 1; a < s && !d2; ++a)
+                        for (uint64_t q = 0; q < a; ++q)
+                            if (pos[a] == pos[q]) {
+                                d2 = true;
+                                break;
+                            }
+                    if (!d2) break;
+                }
+                if (my_turn) break;  // searched under the exact table: done
+                while (next_commit.load(std::memory_order_acquire) != oi) std::this_thread::yield();
+                my_turn = true;
+                bool still_free = true;
+                for (uint64_t j = 0; j < s; ++j)
+                    if (is_taken(pos[j])) {
+                        still_free = false;
+                        break;
+                    }
+                if (still_free) break;
+                // else: keep scanning from this pilot, now under the exact table
+            }
+            for (uint64_t j = 0; j < s; ++j) taken[pos[j] >> 6].fetch_or(1ULL << (pos[j] & 63), std::memory_order_relaxed);
+            pilots[b] = pilot;
+            next_commit.store(oi + 1, std::memory_order_release);
+        }
+    };
+    if (T == 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; ++t) pool.emplace_back(worker, t);
+        for (auto& th : pool) th.join();
+    }
+
+    // dual<dictionary, dictionary>::encode: front = first 0.3 * num_buckets pilots
+    const uint64_t front_size = (uint64_t)((double)num_buckets * 0.3);
+    dict_encode(f.front, pilots.data(), front_size);
+    dict_encode(f.back, pilots.data() + front_size, num_buckets - front_size);
+
+    // minimal: fill_free_slots + ef_sequence<false>::encode
+    if (n < table_size) {
+        std::vector<uint64_t> fs;
+        fs.reserve(table_size - n);
+        uint64_t next_used_slot = n, last_free_slot = 0, last_valid_free_slot = 0;
+        for (;;) {
+            while (last_free_slot < n && is_taken(last_free_slot)) ++last_free_slot;
+            if (last_free_slot == n) break;
+            while (!is_taken(next_used_slot)) {
+                fs.push_back(last_free_slot);
+                ++next_used_slot;
+            }
+            fs.push_back(last_free_slot);
+            last_valid_free_slot = last_free_slot;
+            ++next_used_slot;
+            ++last_free_slot;
+        }
+        while (next_used_slot != table_size) {
+            fs.push_back(last_valid_free_slot);
+            ++next_used_slot;
+        }
+        ef_encode(f.free_slots, fs.size(), fs.back(), false, [&](uint64_t i) { return fs[i]; });
+    }
+    return true;
+}
+
+uint64_t phf_eval(const SinglePhf& f, uint64_t hash, const std::vector<uint64_t>* free_table) {
+    uint64_t b = bucket_of(f, hash);
+    uint64_t pilot = b < f.front.ranks.size ? f.front.dict.access(f.front.ranks.access(b))
+                                            : f.back.dict.access(f.back.ranks.access(b - f.front.ranks.size));
+    uint64_t p = fastmod_u64(hash ^ murmur64a_u64(pilot, f.seed), f.M, f.table_size);
+    if (p < f.num_keys) return p;
+    return (*free_table)[p - f.num_keys];
+}
+
+// ---------------------------------------------------------------------------------------------
+// super-k-mers
+// ---------------------------------------------------------------------------------------------
+struct Run {          // one super-k-mer: windows [first, first + size) of the batch share the minimizer at q
+    uint64_t mm;      // minimizer value (2-bit packed m-mer)
+    uint64_t first;   // batch coordinate of the first window
+    uint64_t q;       // batch coordinate of the minimizer
+    uint32_t size;
+};
+
+// Windows [wa, wb) of one record (record base pointer s, window w covers bases [w, w+k)).
+// Windows holding a non-ACGT base are skipped and cut runs (the reference resets there, minimizer.hpp:150-164).
+void extract_runs(const char* s, uint64_t rec_off, uint64_t wa, uint64_t wb, uint32_t k, uint32_t m, uint64_t seed, std::vector<Run>& out) {
+    if (wa >= wb) return;
+    const uint32_t W = k - m + 1;
+    const uint64_t mask = m >= 32 ? ~0ULL : ((1ULL << (2 * m)) - 1);
+    std::vector<uint64_t> hbuf(W), vbuf(W);  // ring over m-mer positions
+    uint64_t mmer = 0;
+    uint64_t valid_run = 0;  // consecutive valid bases ending at the current base
+    // m-mer positions needed: wa .. wb-1+W-1 ; bases wa .. wb+k-2
+    uint64_t cur_q = ~0ULL, cur_hash = 0;  // current minimum (leftmost) among the window's m-mers
+    Run run{0, 0, ~0ULL, 0};
+    auto flush = [&] {
+        if (run.size) out.push_back(run);
+        run.size = 0;
+        run.q = ~0ULL;
+    };
+    for (uint64_t i = wa; i < wb + k - 1; ++i) {
+        const uint8_t c = nt4((uint8_t)s[i]);
+        if (c > 3) {
+            valid_run = 0;
+            mmer = 0;
+            flush();
+            cur_q = ~0ULL;
+            continue;
+        }
+        mmer = ((mmer << 2) | c) & mask;
+        ++valid_run;
+        if (valid_run < m) continue;
+        const uint64_t pq = i + 1 - m;  // position of this m-mer
+        const uint64_t h = murmur64a_u64(mmer, seed);
+        hbuf[pq % W] = h;
+        vbuf[pq % W] = mmer;
+        if (valid_run < k) continue;
+        const uint64_t w = i + 1 - k;  // window ending at base i
+        if (w < wa) continue;
+        // leftmost minimum over m-mer positions [w, w+W-1] (pq == w+W-1)
+        if (cur_q == ~0ULL || cur_q < w || valid_run == k) {
+            // (re)scan the whole window
+            cur_q = w;
+            cur_hash = hbuf[w % W];
+            for (uint64_t t = w + 1; t <= pq; ++t)
+                if (hbuf[t % W] < cur_hash) {
+                    cur_hash = hbuf[t % W];
+                    cur_q = t;
+                }
+        } else if (h < cur_hash) {
+            cur_hash = h;
+            cur_q = pq;
+        }
+        if (run.size && run.q == rec_off + cur_q) {
+            ++run.size;
+        } else {
+            flush();
+            run.mm = vbuf[cur_q % W];
+            run.first = rec_off + w;
+            run.q = rec_off + cur_q;
+            run.size = 1;
+        }
+    }
+    flush();
+}
+
+template <typename T, typename KeyFn>
+void parallel_sort_by_key(std::vector<T>& v, int threads, uint32_t key_bits, KeyFn key) {
+    // partition by the top 10 key bits, then std::sort each partition
+    const size_t n = v.size();
+    if (n < (1u << 16) || threads <= 1) {
+        std::sort(v.begin(), v.end(), [&](const T& a, const T& b) { return key(a) < key(b); });
+        return;
+    }
+    const uint32_t PB = 10, NP = 1u << PB;
+    const uint32_t shift = key_bits > PB ? key_bits - PB : 0;
+    const size_t chunk = (n + threads - 1) / threads;
+    const size_t nch = (n + chunk - 1) / chunk;
+    std::vector<std::vector<uint64_t>> hist(nch, std::vector<uint64_t>(NP, 0));
+    auto part = [&](const T& x) { return (uint32_t)std::min<uint64_t>(key(x) >> shift, NP - 1); };
+    parallel_for(nch, threads, [&](size_t c) {
+        for (size_t i = c * chunk, e = std::min(n, i + chunk); i < e; ++i) hist[c][part(v[i])]++;
+    });
+    std::vector<uint64_t> pstart(NP + 1, 0);
+    for (uint32_t p = 0; p < NP; ++p) {
+        uint64_t s = 0;
+        for (size_t c = 0; c < nch; ++c) {
+            uint64_t t = hist[c][p];
+            hist[c][p] = pstart[p] + s;
+            s += t;
+        }
+        pstart[p + 1] = pstart[p] + s;
+    }
+    std::vector<T> tmp(n);
+    parallel_for(nch, threads, [&](size_t c) {
+        for (size_t i = c * chunk, e = std::min(n, i + chunk); i < e; ++i) tmp[hist[c][part(v[i])]++] = v[i];
+    });
+    parallel_for(NP, threads, [&](size_t p) {
+        std::sort(tmp.begin() + pstart[p], tmp.begin() + pstart[p + 1], [&](const T& a, const T& b) { return key(a) < key(b); });
+    });
+    v.swap(tmp);
+}
+
+struct Triplet {  // mm_triplet_t, include/constants.hpp:37-43 (itself is replaced by the minimizer order)
+    uint64_t itself;
+    uint8_t p1, size;
+};
+
+}  // namespace
+}  // namespace lphq
+
+using namespace lphq;
+
+namespace lphq { void set_last_error(const std::string& s); }  // capi.cpp
+
+extern "C" int lphq_build(const char* const* records, const size_t* lengths, size_t n_records, int k_, int m_, uint64_t mm_seed, double c, int kind,
+                          int kmer_bits, int threads, const char* out_path) {
+    auto fail = [&](int code, const std::string& msg) {
+        set_last_error(msg);
+        return code;
+    };
+    if ((n_records && (!records || !lengths)) || !out_path) return fail(LPHQ_ERR_ARG, "null argument");
+    if (kind != LPHQ_PARTITIONED && kind != LPHQ_UNPARTITIONED) return fail(LPHQ_ERR_ARG, "kind must be LPHQ_PARTITIONED or LPHQ_UNPARTITIONED");
+    if (kmer_bits != 64 && kmer_bits != 128) return fail(LPHQ_ERR_ARG, "kmer_bits must be 64 or 128");
+    // parser_build.cpp:64-68 with constants::max_k of the chosen kmer_t (constants.hpp:16)
+    if (k_ < 1 || k_ > kmer_bits / 2 - 1) return fail(LPHQ_ERR_ARG, "k cannot be larger than " + std::to_string(kmer_bits / 2 - 1));
+    if (m_ < 1 || m_ > k_ || m_ > 32) return fail(LPHQ_ERR_ARG, "m cannot be larger than k (and must be <= 32)");
+    if (c < 3.0 || c > 10.0) return fail(LPHQ_ERR_ARG, "3.0 <= c <= 10.0");  // parser_build.cpp:78-81
+    if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    const uint32_t k = (uint32_t)k_, m = (uint32_t)m_, W = k - m + 1;
+    const double alpha = 0.94;       // partitioned_mphf.cpp:48
+    const uint64_t pthash_seed = 1;  // constants::default_pthash_seed
+
+    // ---- Part 1: super-k-mers, chunked over windows -------------------------------------------------
+    std::vector<uint64_t> rec_off(n_records + 1, 0);
+    for (size_t r = 0; r < n_records; ++r) rec_off[r + 1] = rec_off[r] + lengths[r];
+    struct Chunk { size_t rec; uint64_t wa, wb; };
+    std::vector<Chunk> chunks;
+    const uint64_t CH = 1u << 20;
+    uint64_t nkmers_upper = 0;
+    for (size_t r = 0; r < n_records; ++r) {
+        if (lengths[r] < k) continue;
+        const uint64_t nw = lengths[r] - k + 1;
+        nkmers_upper += nw;
+        for (uint64_t a = 0; a < nw; a += CH) chunks.push_back({r, a, std::min(nw, a + CH)});
+    }
+    std::vector<std::vector<Run>> chunk_runs(chunks.size());
+    parallel_for(chunks.size(), threads, [&](size_t ci) {
+        const Chunk& ch = chunks[ci];
+        chunk_runs[ci].reserve((ch.wb - ch.wa) * 2 / (W + 1) + 16);
+        extract_runs(records[ch.rec], rec_off[ch.rec], ch.wa, ch.wb, k, m, mm_seed, chunk_runs[ci]);
+    });
+    std::vector<Run> runs;
+    {
+        size_t total = 0;
+        for (auto& v : chunk_runs) total += v.size();
+        runs.reserve(total);
+        for (size_t ci = 0; ci < chunks.size(); ++ci) {
+            for (const Run& r : chunk_runs[ci]) {
+                // a super-k-mer cut by a chunk boundary: same minimizer position, contiguous windows
+                if (!runs.empty() && runs.back().q == r.q && runs.back().first + runs.back().size == r.first && ci > 0 &&
+                    chunks[ci].rec == chunks[ci - 1].rec)
+                    runs.back().size += r.size;
+                else
+                    runs.push_back(r);
+            }
+            std::vector<Run>().swap(chunk_runs[ci]);
+        }
+    }
+    uint64_t nkmers = 0;
+    for (const Run& r : runs) nkmers += r.size;
+    (void)nkmers_upper;
+
+    // ---- Part 2: classify (src/minimizer.cpp:5-50) + PTHash over the distinct minimizers -------------
+    parallel_sort_by_key(runs, threads, 2 * m, [](const Run& r) { return r.mm; });
+    std::vector<Triplet> uniq;
+    std::vector<uint64_t> uniq_mm;
+    std::vector<std::pair<uint64_t, uint32_t>> colliding;  // (first window, size) of every super-k-mer of a repeated minimizer
+    uniq.reserve(runs.size());
+    uniq_mm.reserve(runs.size());
+    for (size_t i = 0; i < runs.size();) {
+        size_t j = i + 1;
+        while (j < runs.size() && runs[j].mm == runs[i].mm) ++j;
+        uniq_mm.push_back(runs[i].mm);
+        if (j - i == 1) {
+            uniq.push_back({0, (uint8_t)(runs[i].q - runs[i].first), (uint8_t)runs[i].size});
+        } else {
+            uniq.push_back({0, 0, 0});
+            for (size_t t = i; t < j; ++t) colliding.emplace_back(runs[t].first, runs[t].size);
+        }
+        i = j;
+    }
+    std::vector<Run>().swap(runs);
+    const uint64_t D = uniq.size();
+
+    LphFile x;
+    x.kind = kind;
+    x.kmer_bits = kmer_bits;
+    x.k = (uint8_t)k;
+    x.m = (uint8_t)m;
+    x.mm_seed = mm_seed;
+    x.nkmers = nkmers;
+    x.distinct_minimizers = D;
+    std::string err;
+    {
+        std::vector<uint64_t> hashes(D);
+        parallel_for((D + 65535) / 65536, threads, [&](size_t t) {
+            for (size_t i = t * 65536, e = std::min<size_t>(D, i + 65536); i < e; ++i) hashes[i] = murmur64a_u64(uniq_mm[i], pthash_seed);
+        });
+        if (!phf_build(x.minimizer_order, hashes, pthash_seed, c, alpha, threads, err)) return fail(LPHQ_ERR_FORMAT, err);
+    }
+
+    // ---- Part 3: order by the minimizer MPHF (a bijection onto [0, D): direct placement) ---------------
+    std::vector<Triplet> by_order(D);
+    {
+        std::vector<uint64_t> free_table;
+        if (!x.minimizer_order.free_slots.decode(free_table, err)) return fail(LPHQ_ERR_FORMAT, err);
+        std::atomic<bool> bad{false};
+        parallel_for((D + 65535) / 65536, threads, [&](size_t t) {
+            for (size_t i = t * 65536, e = std::min<size_t>(D, i + 65536); i < e; ++i) {
+                uint64_t o = phf_eval(x.minimizer_order, murmur64a_u64(uniq_mm[i], pthash_seed), &free_table);
+                if (o >= D) {
+                    bad.store(true);
+                    continue;
+                }
+                by_order[o] = uniq[i];
+                by_order[o].itself = 1;  // mark filled
+            }
+        });
+        if (bad.load()) return fail(LPHQ_ERR_FORMAT, "internal: minimizer MPHF out of range");
+        for (uint64_t i = 0; i < D; ++i)
+            if (by_order[i].itself != 1) return fail(LPHQ_ERR_FORMAT, "internal: minimizer MPHF is not a bijection");
+    }
+    std::vector<Triplet>().swap(uniq);
+    std::vector<uint64_t>().swap(uniq_mm);
+
+    if (kind == LPHQ_PARTITIONED) {  // build_inverted_index, src/partitioned_mphf.cpp:163-268
+        bv_init(x.root.bv, D);
+        std::vector<uint8_t> lr, mn;
+        lr.reserve(D);
+        mn.reserve(D);
+        std::vector<uint8_t> left_positions, right_or_collision_sizes, none_sizes, none_positions;
+        uint64_t universe = 0;
+        for (uint64_t i = 0; i < D; ++i) {
+            const Triplet& t = by_order[i];
+            if (t.size == 0) {  // RIGHT_OR_COLLISION, size 0 marks a repeated minimizer
+                lr.push_back(1);
+                right_or_collision_sizes.push_back(0);
+            } else if (t.p1 == k - m) {
+                if (t.size == W) {  // MAXIMAL
+                    bv_set(x.root.bv, i);
+                    mn.push_back(0);
+                    ++x.n_maximal;
+                } else {  // RIGHT
+                    lr.push_back(1);
+                    right_or_collision_sizes.push_back(t.size);
+                    universe += t.size;
+                }
+            } else if (t.p1 == t.size - 1) {  // LEFT: stores p1 + 1
+                lr.push_back(0);
+                left_positions.push_back((uint8_t)(t.p1 + 1));
+                universe += (uint64_t)t.p1 + 1;
+            } else {  // NONE
+                bv_set(x.root.bv, i);
+                mn.push_back(1);
+                none_positions.push_back(t.p1);
+                none_sizes.push_back(t.size);
+                universe += (uint64_t)t.p1 + t.size;
+            }
+        }
+        bv_init(x.left_right.bv, lr.size());
+        for (size_t i = 0; i < lr.size(); ++i)
+            if (lr[i]) bv_set(x.left_right.bv, i);
+        bv_init(x.max_none.bv, mn.size());
+        for (size_t i = 0; i < mn.size(); ++i)
+            if (mn[i]) bv_set(x.max_none.bv, i);
+        rs_build(x.root);
+        rs_build(x.left_right);
+        rs_build(x.max_none);
+        x.right_coll_sizes_start = left_positions.size();
+        x.none_sizes_start = x.right_coll_sizes_start + right_or_collision_sizes.size();
+        x.none_pos_start = x.none_sizes_start + none_sizes.size();
+        // append_iterator + cumulative_iterator over the four arrays
+        std::vector<uint64_t> cum;
+        cum.reserve(x.none_pos_start + none_positions.size());
+        uint64_t s = 0;
+        for (uint8_t v : left_positions) cum.push_back(s += v);
+        for (uint8_t v : right_or_collision_sizes) cum.push_back(s += v);
+        for (uint8_t v : none_sizes) cum.push_back(s += v);
+        for (uint8_t v : none_positions) cum.push_back(s += v);
+        ef_encode(x.sizes_and_positions, cum.size(), universe, true, [&](uint64_t i) { return cum[i]; });
+    } else {  // build_pos_index / build_size_index, src/unpartitioned_mphf.cpp:156-176
+        uint64_t pos_sum = 0, size_sum = 0;
+        std::vector<uint64_t> cp(D), cs(D);
+        for (uint64_t i = 0; i < D; ++i) {
+            cp[i] = pos_sum += by_order[i].p1;
+            cs[i] = size_sum += by_order[i].size;
+        }
+        ef_encode(x.positions, D, pos_sum, true, [&](uint64_t i) { return cp[i]; });
+        ef_encode(x.sizes, D, size_sum, true, [&](uint64_t i) { return cs[i]; });
+        x.num_kmers_in_main_index = size_sum;
+    }
+    std::vector<Triplet>().swap(by_order);
+
+    // ---- Part 4: fallback PTHash over the k-mers of repeated minimizers, in input order ----------------
+    {
+        std::sort(colliding.begin(), colliding.end());
+        std::vector<uint64_t> fh;
+        size_t rec = 0;
+        for (const auto& cw : colliding) {
+            while (rec_off[rec + 1] <= cw.first) ++rec;  // cw.first < total bases, so this stops
+            const char* s = records[rec] + (cw.first - rec_off[rec]);
+            u128 km = 0;
+            const u128 km_mask = (((u128)1) << (2 * k)) - 1;
+            for (uint32_t j = 0; j < k - 1; ++j) km = (km << 2) | (u128)(nt4((uint8_t)s[j]) & 3);
+            for (uint32_t w = 0; w < cw.second; ++w) {
+                km = ((km << 2) | (u128)(nt4((uint8_t)s[w + k - 1]) & 3)) & km_mask;
+                // fallback_hasher, include/constants.hpp:56-70
+                uint64_t h;
+                if (kmer_bits == 64) h = murmur64a_u64((uint64_t)km, pthash_seed);
+                else h = murmur64a_u64((uint64_t)km, pthash_seed) ^ murmur64a_u64((uint64_t)(km >> 64), ~pthash_seed);
+                fh.push_back(h);
+            }
+        }
+        if (!phf_build(x.fallback_kmer_order, fh, pthash_seed, c, alpha, threads, err)) return fail(LPHQ_ERR_FORMAT, err);
+    }
+
+    // ---- essentials::save ----------------------------------------------------------------------------
+    Writer w;
+    w.raw(&x.k, 1);
+    w.raw(&x.m, 1);
+    w.u64(x.mm_seed);
+    w.u64(x.nkmers);
+    w.u64(x.distinct_minimizers);
+    if (kind == LPHQ_PARTITIONED) {
+        w.u64(x.n_maximal);
+        w.u64(x.right_coll_sizes_start);
+        w.u64(x.none_sizes_start);
+        w.u64(x.none_pos_start);
+        w.put(x.minimizer_order);
+        w.put(x.root);
+        w.put(x.left_right);
+        w.put(x.max_none);
+        w.put(x.sizes_and_positions);
+        w.put(x.fallback_kmer_order);
+    } else {
+        w.u64(x.num_kmers_in_main_index);
+        w.put(x.minimizer_order);
+        w.put(x.positions);
+        w.put(x.sizes);
+        w.put(x.fallback_kmer_order);
+    }
+    FILE* fo = fopen(out_path, "wb");
+    if (!fo) return fail(LPHQ_ERR_IO, std::string("cannot write ") + out_path);
+    size_t put = fwrite(w.buf.data(), 1, w.buf.size(), fo);
+    fclose(fo);
+    if (put != w.buf.size()) return fail(LPHQ_ERR_IO, std::string("short write on ") + out_path);
+    return LPHQ_OK;
+}

@@ -1,0 +1,288 @@
+// capi.cpp -- the C ABI of include/lphq.h over the loader, the flat image and the gfx950 kernels.
+// No CPU query path exists here: every query entry point launches HIP kernels or fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/lphq.h"
+#include "image.hpp"
+#include "kernels.hpp"
+#include "lph_format.hpp"
+
+using namespace lphq;
+
+struct lphq_index {
+    lphq_image_header hdr;
+    std::vector<uint8_t> image;  // host copy of the flat image (empty for lphq_open_device_image handles)
+    uint64_t file_bytes = 0;
+    size_t image_bytes = 0;
+    int device = -1;
+    uint8_t* d_image = nullptr;
+    bool owns_device_image = false;
+    // grow-only scratch of the host-buffer convenience path
+    std::mutex scratch_mu;
+    char* d_seq = nullptr;
+    size_t d_seq_cap = 0;
+    uint64_t* d_out = nullptr;
+    size_t d_out_cap = 0;
+    uint64_t* d_offs = nullptr;
+};
+
+static thread_local std::string g_err;
+extern "C" const char* lphq_last_error(void) { return g_err.c_str(); }
+namespace lphq {
+void set_last_error(const std::string& s) { g_err = s; }
+}  // namespace lphq
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+static int fail_hip(hipError_t e, const char* what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return e == hipErrorNoDevice || e == hipErrorInvalidDevice ? LPHQ_ERR_NO_DEVICE : LPHQ_ERR_HIP;
+}
+#define HIP_TRY(call)                                   \
+    do {                                                \
+        hipError_t e_ = (call);                         \
+        if (e_ != hipSuccess) return fail_hip(e_, #call); \
+    } while (0)
+
+struct DeviceGuard {  // make idx->device current for the duration of a call
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+extern "C" int lphq_open_memory(const void* buf, size_t len, int kind, int kmer_bits, lphq_index** out) {
+    if (!buf || !out) return fail(LPHQ_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (kind != LPHQ_PARTITIONED && kind != LPHQ_UNPARTITIONED) return fail(LPHQ_ERR_ARG, "kind must be LPHQ_PARTITIONED or LPHQ_UNPARTITIONED");
+    if (kmer_bits != 64 && kmer_bits != 128) return fail(LPHQ_ERR_ARG, "kmer_bits must be 64 or 128");
+    LphFile file;
+    std::string err;
+    if (!parse_lph((const uint8_t*)buf, len, kind, kmer_bits, file, err)) return fail(LPHQ_ERR_FORMAT, err);
+    lphq_index* idx = new (std::nothrow) lphq_index();
+    if (!idx) return fail(LPHQ_ERR_ARG, "out of memory");
+    if (!build_image(file, idx->image, err)) {
+        delete idx;
+        return fail(err.find("beyond the device layout") != std::string::npos ? LPHQ_ERR_UNSUPPORTED : LPHQ_ERR_FORMAT, err);
+    }
+    memcpy(&idx->hdr, idx->image.data(), sizeof idx->hdr);
+    idx->file_bytes = file.bytes_read;
+    idx->image_bytes = idx->image.size();
+    *out = idx;
+    return LPHQ_OK;
+}
+
+extern "C" int lphq_open(const char* path, int kind, int kmer_bits, lphq_index** out) {
+    if (!path || !out) return fail(LPHQ_ERR_ARG, "null argument");
+    *out = nullptr;
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(LPHQ_ERR_IO, std::string("Unable to open the input file ") + path);
+    std::vector<uint8_t> buf;
+    if (fseek(f, 0, SEEK_END) == 0) {
+        long n = ftell(f);
+        if (n > 0) buf.resize((size_t)n);
+        fseek(f, 0, SEEK_SET);
+    }
+    size_t got = buf.empty() ? 0 : fread(buf.data(), 1, buf.size(), f);
+    fclose(f);
+    if (got != buf.size()) return fail(LPHQ_ERR_IO, std::string("short read on ") + path);
+    return lphq_open_memory(buf.data(), buf.size(), kind, kmer_bits, out);
+}
+
+extern "C" void lphq_close(lphq_index* idx) {
+    if (!idx) return;
+    if (idx->device >= 0) {
+        DeviceGuard g(idx->device);
+        if (idx->owns_device_image && idx->d_image) (void)hipFree(idx->d_image);
+        if (idx->d_seq) (void)hipFree(idx->d_seq);
+        if (idx->d_out) (void)hipFree(idx->d_out);
+        if (idx->d_offs) (void)hipFree(idx->d_offs);
+    }
+    delete idx;
+}
+
+extern "C" int lphq_get_info(const lphq_index* idx, lphq_info* info) {
+    if (!idx || !info) return fail(LPHQ_ERR_ARG, "null argument");
+    memset(info, 0, sizeof *info);
+    info->kind = idx->hdr.kind;
+    info->kmer_bits = idx->hdr.kmer_bits;
+    info->k = idx->hdr.k;
+    info->m = idx->hdr.m;
+    info->mm_seed = idx->hdr.mm_seed;
+    info->num_kmers = idx->hdr.nkmers;
+    info->distinct_minimizers = idx->hdr.distinct_minimizers;
+    info->fallback_kmers = idx->hdr.fallback_kmers;
+    info->file_bytes = idx->file_bytes;
+    info->image_bytes = idx->image_bytes;
+    info->device = idx->device;
+    return LPHQ_OK;
+}
+
+extern "C" int lphq_image_bytes(const lphq_index* idx, size_t* nbytes) {
+    if (!idx || !nbytes) return fail(LPHQ_ERR_ARG, "null argument");
+    *nbytes = idx->image_bytes;
+    return LPHQ_OK;
+}
+
+extern "C" int lphq_image_copy(const lphq_index* idx, void* host_dst, size_t cap) {
+    if (!idx || !host_dst) return fail(LPHQ_ERR_ARG, "null argument");
+    if (idx->image.empty()) return fail(LPHQ_ERR_STATE, "handle has no host copy of the image");
+    if (cap < idx->image.size()) return fail(LPHQ_ERR_ARG, "destination too small");
+    memcpy(host_dst, idx->image.data(), idx->image.size());
+    return LPHQ_OK;
+}
+
+static int check_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(LPHQ_ERR_NO_DEVICE, std::string("no usable HIP device: ") + hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(LPHQ_ERR_ARG, "device ordinal out of range");
+    return LPHQ_OK;
+}
+
+extern "C" int lphq_attach(lphq_index* idx, int device) {
+    if (!idx) return fail(LPHQ_ERR_ARG, "null argument");
+    if (idx->device >= 0) return idx->device == device ? LPHQ_OK : fail(LPHQ_ERR_STATE, "already attached to another device");
+    if (idx->image.empty()) return fail(LPHQ_ERR_STATE, "no host image to upload");
+    int rc = check_device(device);
+    if (rc) return rc;
+    DeviceGuard g(device);
+    if (!g.ok) return fail(LPHQ_ERR_HIP, "hipSetDevice failed");
+    uint8_t* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, idx->image.size()));
+    hipError_t e = hipMemcpy(d, idx->image.data(), idx->image.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return fail_hip(e, "hipMemcpy(image)");
+    }
+    idx->d_image = d;
+    idx->owns_device_image = true;
+    idx->device = device;
+    return LPHQ_OK;
+}
+
+extern "C" int lphq_open_device_image(const void* d_image, size_t nbytes, int device, lphq_index** out) {
+    if (!d_image || !out) return fail(LPHQ_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (nbytes < sizeof(lphq_image_header)) return fail(LPHQ_ERR_FORMAT, "image smaller than its header");
+    int rc = check_device(device);
+    if (rc) return rc;
+    DeviceGuard g(device);
+    if (!g.ok) return fail(LPHQ_ERR_HIP, "hipSetDevice failed");
+    lphq_index* idx = new (std::nothrow) lphq_index();
+    if (!idx) return fail(LPHQ_ERR_ARG, "out of memory");
+    hipError_t e = hipMemcpy(&idx->hdr, d_image, sizeof idx->hdr, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        delete idx;
+        return fail_hip(e, "hipMemcpy(header)");
+    }
+    if (idx->hdr.magic != LPHQ_IMAGE_MAGIC || idx->hdr.total_bytes != nbytes) {
+        delete idx;
+        return fail(LPHQ_ERR_FORMAT, "not a flat LPHQ image (magic/size mismatch)");
+    }
+    idx->d_image = (uint8_t*)d_image;
+    idx->owns_device_image = false;
+    idx->image_bytes = nbytes;
+    idx->device = device;
+    *out = idx;
+    return LPHQ_OK;
+}
+
+extern "C" int lphq_device_image(const lphq_index* idx, const void** d_image, size_t* nbytes) {
+    if (!idx || !d_image || !nbytes) return fail(LPHQ_ERR_ARG, "null argument");
+    if (idx->device < 0) return fail(LPHQ_ERR_STATE, "index is not attached to a device");
+    *d_image = idx->d_image;
+    *nbytes = idx->image_bytes;
+    return LPHQ_OK;
+}
+
+#define REQUIRE_ATTACHED(idx)                                                                        \
+    do {                                                                                             \
+        if (!(idx)) return fail(LPHQ_ERR_ARG, "null index");                                         \
+        if ((idx)->device < 0) return fail(LPHQ_ERR_STATE, "index is not attached to a device (no CPU fallback exists)"); \
+    } while (0)
+
+extern "C" int lphq_query_packed(const lphq_index* idx, const void* d_kmers, size_t n, uint64_t* d_out, void* stream) {
+    REQUIRE_ATTACHED(idx);
+    if (n && (!d_kmers || !d_out)) return fail(LPHQ_ERR_ARG, "null buffer");
+    DeviceGuard g(idx->device);
+    HIP_TRY(launch_query_packed(idx->hdr, idx->d_image, d_kmers, n, d_out, (hipStream_t)stream));
+    return LPHQ_OK;
+}
+
+extern "C" int lphq_query_records(const lphq_index* idx, const char* d_seq, size_t total_bases, const uint64_t* d_seq_offsets, size_t n_records,
+                                  uint64_t* d_out, const uint64_t* d_out_offsets, int streaming, void* stream) {
+    REQUIRE_ATTACHED(idx);
+    if (n_records && (!d_seq_offsets || !d_out_offsets)) return fail(LPHQ_ERR_ARG, "null buffer");
+    if (n_records > 0xFFFFFFFFull) return fail(LPHQ_ERR_ARG, "more than 2^32-1 records in one batch");
+    if (total_bases && !d_seq) return fail(LPHQ_ERR_ARG, "null buffer");
+    DeviceGuard g(idx->device);
+    HIP_TRY(launch_query_records(idx->hdr, idx->d_image, d_seq, total_bases, d_seq_offsets, d_out_offsets, n_records, d_out, streaming, (hipStream_t)stream));
+    return LPHQ_OK;
+}
+
+extern "C" int lphq_pack_kmers(const lphq_index* idx, const char* d_seq, const uint64_t* d_pos, size_t n, void* d_kmers, void* stream) {
+    REQUIRE_ATTACHED(idx);
+    if (n && (!d_seq || !d_pos || !d_kmers)) return fail(LPHQ_ERR_ARG, "null buffer");
+    DeviceGuard g(idx->device);
+    HIP_TRY(launch_pack_kmers(idx->hdr, d_seq, d_pos, n, d_kmers, (hipStream_t)stream));
+    return LPHQ_OK;
+}
+
+extern "C" int lphq_query_contig(const lphq_index* cidx, const char* contig, size_t length, int streaming, uint64_t* out, size_t cap, size_t* n_out) {
+    lphq_index* idx = const_cast<lphq_index*>(cidx);
+    REQUIRE_ATTACHED(idx);
+    if (!n_out || (length && !contig)) return fail(LPHQ_ERR_ARG, "null argument");
+    *n_out = 0;
+    const uint32_t k = idx->hdr.k;
+    if (length < k) return LPHQ_OK;  // partitioned_mphf.hpp:79 (streaming); the random branch is undefined there
+    const size_t nwin = length - k + 1;
+    if (!out || cap < nwin) return fail(LPHQ_ERR_ARG, "output buffer too small");
+    DeviceGuard g(idx->device);
+    std::lock_guard<std::mutex> lk(idx->scratch_mu);
+    if (idx->d_seq_cap < length + 64) {
+        if (idx->d_seq) (void)hipFree(idx->d_seq);
+        idx->d_seq = nullptr;
+        idx->d_seq_cap = 0;
+        size_t want = (length + 64) * 5 / 4;
+        HIP_TRY(hipMalloc((void**)&idx->d_seq, want));
+        idx->d_seq_cap = want;
+    }
+    if (idx->d_out_cap < nwin) {
+        if (idx->d_out) (void)hipFree(idx->d_out);
+        idx->d_out = nullptr;
+        idx->d_out_cap = 0;
+        size_t want = nwin * 5 / 4 + 16;
+        HIP_TRY(hipMalloc((void**)&idx->d_out, want * 8));
+        idx->d_out_cap = want;
+    }
+    if (!idx->d_offs) HIP_TRY(hipMalloc((void**)&idx->d_offs, 4 * sizeof(uint64_t)));
+    const uint64_t offs[4] = {0, (uint64_t)length, 0, (uint64_t)nwin};
+    HIP_TRY(hipMemcpyAsync(idx->d_seq, contig, length, hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(idx->d_offs, offs, sizeof offs, hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(launch_query_records(idx->hdr, idx->d_image, idx->d_seq, length, idx->d_offs, idx->d_offs + 2, 1, idx->d_out, streaming, nullptr));
+    HIP_TRY(hipMemcpyAsync(out, idx->d_out, nwin * 8, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    size_t n = nwin;
+    if (streaming) {  // drop windows holding a non-ACGT base (the reference emits nothing for them)
+        n = 0;
+        for (size_t i = 0; i < nwin; ++i)
+            if (out[i] != LPHQ_INVALID) out[n++] = out[i];
+    }
+    *n_out = n;
+    return LPHQ_OK;
+}

@@ -1,0 +1,228 @@
+// image.cpp -- re-pack a parsed `.lph` (lph_format.hpp) into the flat device image (image_layout.h).
+#include "image.hpp"
+
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/lphq.h"
+
+namespace lphq {
+namespace {
+
+struct ImageWriter {
+    std::vector<uint8_t>& img;
+    explicit ImageWriter(std::vector<uint8_t>& v) : img(v) {}
+    uint64_t reserve(size_t bytes) {  // 256-B aligned section, zero filled, 64 B of slack after it
+        size_t off = (img.size() + 255) & ~(size_t)255;
+        img.resize(off + bytes + 64, 0);
+        return off;
+    }
+    template <typename T>
+    T* at(uint64_t off) {
+        return reinterpret_cast<T*>(img.data() + off);
+    }
+};
+
+lphq_divisor make_divisor(uint64_t d) {
+    lphq_divisor r;
+    memset(&r, 0, sizeof r);
+    r.d64 = d;
+    if (d != 0 && d <= 0xFFFFFFFFull) {
+        r.d = (uint32_t)d;
+        r.shift = (uint32_t)__builtin_clz((uint32_t)d);
+        r.dn = (uint32_t)d << r.shift;
+        r.inv = (uint32_t)(~(uint64_t)0 / r.dn - (1ull << 32));
+    }
+    return r;
+}
+
+bool build_phf(const SinglePhf& f, ImageWriter& w, lphq_phf_desc& d, const char* what, std::string& err) {
+    memset(&d, 0, sizeof d);
+    d.seed = f.seed;
+    d.num_keys = f.num_keys;
+    d.table_size = f.table_size;
+    d.num_dense = f.num_dense;
+    d.num_sparse = f.num_sparse;
+    d.front_size = f.front.ranks.size;
+    d.div_table = make_divisor(f.table_size);
+    d.div_dense = make_divisor(f.num_dense);
+    d.div_sparse = make_divisor(f.num_sparse);
+    if (f.num_keys == 0) return true;
+    if (f.num_keys > 0xFFFFFFFFull || f.table_size > 0xFFFFFFFFull) {
+        err = std::string(what) + ": more than 2^32-1 keys is beyond the device layout's u32 free-slot table";
+        return false;
+    }
+    if (f.front.ranks.width > 32 || f.back.ranks.width > 32) {
+        err = std::string(what) + ": pilot codewords wider than 32 bits";
+        return false;
+    }
+    d.front_width = (uint32_t)f.front.ranks.width;
+    d.back_width = (uint32_t)f.back.ranks.width;
+    d.n_front_dict = (uint32_t)f.front.dict.size;
+    d.n_back_dict = (uint32_t)f.back.dict.size;
+    const Dictionary* dicts[2] = {&f.front, &f.back};
+    uint64_t* off_ranks[2] = {&d.off_front_ranks, &d.off_back_ranks};
+    uint64_t* off_hp[2] = {&d.off_front_hp, &d.off_back_hp};
+    for (int s = 0; s < 2; ++s) {
+        const Dictionary& dc = *dicts[s];
+        size_t nw = dc.ranks.bits.size() + 1;  // one more padding word: the kernel reads two dwords
+        *off_ranks[s] = w.reserve(nw * 8);
+        memcpy(w.at<uint64_t>(*off_ranks[s]), dc.ranks.bits.data(), dc.ranks.bits.size() * 8);
+        *off_hp[s] = w.reserve((dc.dict.size ? dc.dict.size : 1) * 8);
+        uint64_t* hp = w.at<uint64_t>(*off_hp[s]);
+        // single_phf::position: hashed_pilot = default_hash64(pilot, m_seed)
+        for (uint64_t i = 0; i < dc.dict.size; ++i) hp[i] = murmur64a_u64(dc.dict.access(i), f.seed);
+    }
+    std::vector<uint64_t> fs;
+    if (!f.free_slots.decode(fs, err)) {
+        err = std::string(what) + " free slots: " + err;
+        return false;
+    }
+    d.off_free = w.reserve((fs.size() ? fs.size() : 1) * 4);
+    uint32_t* ft = w.at<uint32_t>(d.off_free);
+    for (size_t i = 0; i < fs.size(); ++i) {
+        if (fs[i] >= f.num_keys) {
+            err = std::string(what) + ": free slot >= num_keys";
+            return false;
+        }
+        ft[i] = (uint32_t)fs[i];
+    }
+    return true;
+}
+
+// single-value plane blocks: value j of block b sits at bit j%32 of word p*T + j/32, plane p
+bool fill_lr_blocks(ImageWriter& w, uint64_t off, const uint64_t* prefix /* prefix[i] = sum of values before entry i, n+1 long */, uint64_t n,
+                    uint64_t base, uint32_t P, std::string& err) {
+    const uint32_t T = LPHQ_LR_T(P), E = LPHQ_LR_PER_BLOCK(P);
+    uint64_t nblocks = (n + E - 1) / E;
+    for (uint64_t b = 0; b < nblocks; ++b) {
+        lphq_plane_block* blk = w.at<lphq_plane_block>(off) + b;
+        blk->abs = base + prefix[b * E];
+        for (uint32_t j = 0; j < E && b * E + j < n; ++j) {
+            uint64_t v = prefix[b * E + j + 1] - prefix[b * E + j];
+            if (v >> P) {
+                err = "stored value does not fit the plane width (value > k-m+1?)";
+                return false;
+            }
+            for (uint32_t p = 0; p < P; ++p)
+                if ((v >> p) & 1) blk->w[p * T + (j >> 5)] |= 1u << (j & 31);
+        }
+    }
+    return true;
+}
+// pair blocks: size planes w[0..P), position planes w[P..2P), 32 entries
+bool fill_pair_blocks(ImageWriter& w, uint64_t off, const uint64_t* size_prefix, const uint64_t* pos_prefix, uint64_t n, uint64_t base, uint32_t P,
+                      std::string& err) {
+    const uint32_t E = LPHQ_PAIR_PER_BLOCK;
+    uint64_t nblocks = (n + E - 1) / E;
+    for (uint64_t b = 0; b < nblocks; ++b) {
+        lphq_plane_block* blk = w.at<lphq_plane_block>(off) + b;
+        blk->abs = base + size_prefix[b * E];
+        for (uint32_t j = 0; j < E && b * E + j < n; ++j) {
+            uint64_t sz = size_prefix[b * E + j + 1] - size_prefix[b * E + j];
+            uint64_t ps = pos_prefix[b * E + j + 1] - pos_prefix[b * E + j];
+            if ((sz >> P) || (ps >> P)) {
+                err = "stored size/position does not fit the plane width";
+                return false;
+            }
+            for (uint32_t p = 0; p < P; ++p) {
+                if ((sz >> p) & 1) blk->w[p] |= 1u << j;
+                if ((ps >> p) & 1) blk->w[P + p] |= 1u << j;
+            }
+        }
+    }
+    return true;
+}
+
+}  // namespace
+
+bool build_image(const LphFile& x, std::vector<uint8_t>& img, std::string& err) {
+    img.clear();
+    ImageWriter w(img);
+    w.reserve(sizeof(lphq_image_header));
+    lphq_image_header h;
+    memset(&h, 0, sizeof h);
+    h.magic = LPHQ_IMAGE_MAGIC;
+    h.kind = (uint32_t)x.kind;
+    h.kmer_bits = (uint32_t)x.kmer_bits;
+    h.k = x.k;
+    h.m = x.m;
+    h.W = (uint32_t)x.k - x.m + 1;
+    h.P = h.W <= 15 ? 4 : 6;  // stored sizes/positions are <= W <= 63
+    h.mm_seed = x.mm_seed;
+    h.nkmers = x.nkmers;
+    h.distinct_minimizers = x.distinct_minimizers;
+    h.fallback_kmers = x.fallback_kmer_order.num_keys;
+    h.n_maximal = x.n_maximal;
+    const uint64_t D = x.distinct_minimizers;
+    if (D > 0xFFFFFFFFull) {
+        err = "more than 2^32-1 distinct minimizers is beyond the device layout's u32 rank counters";
+        return false;
+    }
+    if (!build_phf(x.minimizer_order, w, h.mm, "minimizer_order", err)) return false;
+    if (!build_phf(x.fallback_kmer_order, w, h.fb, "fallback_kmer_order", err)) return false;
+
+    if (x.kind == LPHQ_PARTITIONED) {
+        const uint64_t base = (uint64_t)h.W * x.n_maximal;  // (k - m + 1) * n_maximal, partitioned_mphf.cpp:300
+        std::vector<uint64_t> vals;                          // EF[0..n]: prefix sums with the leading 0
+        if (!x.sizes_and_positions.decode(vals, err)) return false;
+        if (vals.empty()) vals.push_back(0);
+        const uint64_t rcs = x.right_coll_sizes_start, nss = x.none_sizes_start, nps = x.none_pos_start;
+        const uint64_t n_left = rcs, n_right = nss - rcs, n_none = nps - nss;
+        if (vals.size() != nps + n_none + 1) {
+            err = "sizes_and_positions: entry count does not match the region starts";
+            return false;
+        }
+        h.collision_base = vals[nps] + base;  // sizes_and_positions.access(none_pos_start) + W*n_maximal, partitioned_mphf.cpp:309-311
+
+        // wavelet blocks
+        uint64_t nwt = (D + LPHQ_WT_PER_BLOCK - 1) / LPHQ_WT_PER_BLOCK;
+        h.off_wt = w.reserve((nwt ? nwt : 1) * sizeof(lphq_wt_block));
+        uint32_t cnt[4] = {0, 0, 0, 0};
+        uint64_t i_lr = 0, i_mn = 0;
+        for (uint64_t i = 0; i < D; ++i) {
+            lphq_wt_block* blk = w.at<lphq_wt_block>(h.off_wt) + i / LPHQ_WT_PER_BLOCK;
+            uint32_t j = (uint32_t)(i % LPHQ_WT_PER_BLOCK);
+            if (j == 0) memcpy(blk->cnt, cnt, sizeof cnt);
+            bool msb = x.root.bv.get(i);
+            bool lsb = msb ? x.max_none.bv.get(i_mn++) : x.left_right.bv.get(i_lr++);
+            if (msb) blk->msb[j >> 5] |= 1u << (j & 31);
+            if (lsb) blk->lsb[j >> 5] |= 1u << (j & 31);
+            cnt[(msb ? 2 : 0) | (lsb ? 1 : 0)]++;  // LEFT=0 RIGHT_OR_COLLISION=1 MAXIMAL=2 NONE=3, quartet_wtree.hpp:7
+        }
+        const uint32_t E = LPHQ_LR_PER_BLOCK(h.P);
+        h.off_left = w.reserve(((n_left + E - 1) / E + 1) * sizeof(lphq_plane_block));
+        if (!fill_lr_blocks(w, h.off_left, vals.data(), n_left, base, h.P, err)) return false;
+        h.off_right = w.reserve(((n_right + E - 1) / E + 1) * sizeof(lphq_plane_block));
+        if (!fill_lr_blocks(w, h.off_right, vals.data() + rcs, n_right, base, h.P, err)) return false;
+        h.off_none = w.reserve(((n_none + LPHQ_PAIR_PER_BLOCK - 1) / LPHQ_PAIR_PER_BLOCK + 1) * sizeof(lphq_plane_block));
+        if (!fill_pair_blocks(w, h.off_none, vals.data() + nss, vals.data() + nps, n_none, base, h.P, err)) return false;
+        // consistency: every k-mer is counted exactly once (maximal + EF sizes + fallback)
+        if (base + vals[nps] + x.fallback_kmer_order.num_keys != x.nkmers) {
+            err = "k-mer census mismatch: W*n_maximal + sum(sizes) + fallback != nkmers";
+            return false;
+        }
+    } else {
+        std::vector<uint64_t> sz, ps;
+        if (!x.sizes.decode(sz, err) || !x.positions.decode(ps, err)) return false;
+        if (sz.empty()) sz.push_back(0);
+        if (ps.empty()) ps.push_back(0);
+        if (sz.size() != D + 1 || ps.size() != D + 1) {
+            err = "positions/sizes: entry count != distinct_minimizers + 1";
+            return false;
+        }
+        if (sz[D] != x.num_kmers_in_main_index || sz[D] + x.fallback_kmer_order.num_keys != x.nkmers) {
+            err = "k-mer census mismatch: sum(sizes) != num_kmers_in_main_index or + fallback != nkmers";
+            return false;
+        }
+        h.collision_base = x.num_kmers_in_main_index;  // unpartitioned_mphf.cpp:198
+        h.off_upair = w.reserve(((D + LPHQ_PAIR_PER_BLOCK - 1) / LPHQ_PAIR_PER_BLOCK + 1) * sizeof(lphq_plane_block));
+        if (!fill_pair_blocks(w, h.off_upair, sz.data(), ps.data(), D, 0, h.P, err)) return false;
+    }
+    img.resize((img.size() + 255) & ~(size_t)255, 0);
+    h.total_bytes = img.size();
+    memcpy(img.data(), &h, sizeof h);
+    return true;
+}
+
+}  // namespace lphq

@@ -1,0 +1,248 @@
+// kernels.hip -- hand-written gfx950 kernels of the LPHash query path and their launchers.
+//
+//   k_query_packed   random (non-streaming) batch: one lane = one packed k-mer
+//                    (MPHF::operator()(.., streaming=false), partitioned_mphf.hpp:185-195)
+//   k_query_tiles    all windows of a batch of ASCII records, tiled over the concatenated bases;
+//                    bases are 2-bit packed into LDS once per tile (seq_nt4_table, constants.cpp:5-13)
+//   k_pack_kmers     debug::string_to_integer_no_reverse (mphf_utils.hpp:110-116) for chosen windows
+//
+// Wave64, 256-thread workgroups, grids of >= 2048 workgroups where the batch allows so all
+// 256 CUs / 8 XCDs are busy; no inter-workgroup communication, so placement is irrelevant to
+// correctness.
+#include <hip/hip_runtime.h>
+
+#include "device_query.cuh"
+#include "kernels.hpp"
+
+namespace lphq {
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------------------------------
+// random batch over packed k-mers
+// ------------------------------------------------------------------------------------------
+template <int KIND, bool K128, int P>
+__global__ __launch_bounds__(kBlock) void k_query_packed(const lphq_image_header H, const uint8_t* __restrict__ img,
+                                                          const uint64_t* __restrict__ kmers, size_t n, uint64_t* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        uint64_t lo, hi = 0;
+        if (K128) {
+            const ulonglong2 v = ((const ulonglong2*)kmers)[i];
+            lo = v.x;
+            hi = v.y;
+        } else {
+            lo = kmers[i];
+        }
+        out[i] = query_kmer<KIND, K128, P>(img, H, lo, hi);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// ASCII -> 2-bit helpers
+// ------------------------------------------------------------------------------------------
+// seq_nt4_table (constants.cpp:5-13): A/a=0 C/c=1 G/g=2 T/t/U/u=3, everything else 4 (invalid).
+// For the 10 valid characters the code is ((c >> 1) ^ (c >> 2)) & 3.
+__device__ __forceinline__ bool base_valid(uint32_t c) {
+    const uint32_t u = c & 0xDFu;                                                         // fold case
+    const uint32_t B = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20) | (1u << 21);      // A C G T U relative to 0x40
+    return ((u & 0xE0u) == 0x40u) && ((B >> (u & 31u)) & 1u);
+}
+// four characters (first at the lowest byte) -> 8 bits, first base in the highest 2 bits; bad = 4-bit mask
+__device__ __forceinline__ uint32_t pack4(uint32_t x, uint32_t& bad) {
+    bad = 0;
+    uint32_t keep = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool ok = base_valid((x >> (8 * i)) & 0xFFu);
+        bad |= (ok ? 0u : 1u) << i;
+        keep |= (ok ? 0xFFu : 0u) << (8 * i);
+    }
+    const uint32_t t = ((x >> 1) ^ (x >> 2)) & 0x03030303u & keep;  // invalid -> 0 ('A'), mphf_utils.hpp:108
+    return (t * 0x40100401u) >> 24;
+}
+
+template <bool K128>
+__global__ __launch_bounds__(kBlock) void k_pack_kmers(const char* __restrict__ seq, const uint64_t* __restrict__ pos, size_t n, uint32_t k,
+                                                        uint64_t* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint8_t* s = (const uint8_t*)seq + pos[i];
+        uint64_t lo = 0, hi = 0;
+        for (uint32_t j = 0; j < k; ++j) {
+            const uint32_t c = s[j];
+            const uint64_t code = base_valid(c) ? (((c >> 1) ^ (c >> 2)) & 3u) : 0u;
+            if (K128) hi = (hi << 2) | (lo >> 62);
+            lo = (lo << 2) | code;
+        }
+        if (K128) {
+            ((ulonglong2*)out)[i] = make_ulonglong2(lo, hi);
+        } else {
+            out[i] = lo;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// tiles over concatenated records
+// ------------------------------------------------------------------------------------------
+constexpr int kTileW = 2048;                 // window starts per workgroup
+constexpr int kTileBases = kTileW + 64;      // + k-1 (k <= 63) overlap
+constexpr int kTileWords = kTileBases / 16;  // 2-bit packed u32 words (16 bases each, first base in the top bits)
+
+// last r in [lo, hi] with offs[r] <= g   (offs non-decreasing, offs[lo] <= g)
+__device__ __forceinline__ uint32_t find_record(const uint64_t* __restrict__ offs, uint32_t lo, uint32_t hi, uint64_t g) {
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo + 1) / 2;
+        if (offs[mid] <= g) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+// 2k bits starting at base q of the LDS-packed tile
+template <bool K128>
+__device__ __forceinline__ void extract_kmer(const uint32_t* __restrict__ sm, uint32_t q, uint32_t k, uint64_t& lo, uint64_t& hi) {
+    const uint32_t w0 = q >> 4, o = (q & 15u) * 2u;
+    if (K128) {
+        const uint32_t a = sm[w0], b = sm[w0 + 1], c = sm[w0 + 2], d = sm[w0 + 3], e = sm[w0 + 4];
+        // 128-bit big-endian stream starting at bit o of a
+        const uint32_t x0 = o ? ((a << o) | (b >> (32 - o))) : a;
+        const uint32_t x1 = o ? ((b << o) | (c >> (32 - o))) : b;
+        const uint32_t x2 = o ? ((c << o) | (d >> (32 - o))) : c;
+        const uint32_t x3 = o ? ((d << o) | (e >> (32 - o))) : d;
+        const uint64_t H64 = ((uint64_t)x0 << 32) | x1, L64 = ((uint64_t)x2 << 32) | x3;
+        const uint32_t s = 128u - 2u * k;  // 2..126
+        if (s >= 64u) {
+            lo = H64 >> (s - 64u);
+            hi = 0;
+        } else {
+            lo = (L64 >> s) | (H64 << (64u - s));
+            hi = H64 >> s;
+        }
+    } else {
+        const uint32_t a = sm[w0], b = sm[w0 + 1], c = sm[w0 + 2];
+        const uint32_t x0 = o ? ((a << o) | (b >> (32 - o))) : a;
+        const uint32_t x1 = o ? ((b << o) | (c >> (32 - o))) : b;
+        lo = ((((uint64_t)x0 << 32) | x1)) >> (64u - 2u * k);
+        hi = 0;
+    }
+}
+
+// Shared tile prologue: locate the records the tile touches and 2-bit pack its bases into LDS.
+// Coordinates are shifted by `shift` = misalignment of the sequence pointer, so that every 16-byte
+// chunk load is aligned; base g of the batch lives at shifted coordinate g + shift.
+struct TileInfo {
+    uint64_t g0;        // first window start (batch coordinate) of the tile
+    uint32_t rlo, rhi;  // records containing the first / last base the tile can touch
+};
+
+template <bool WANT_BAD>
+__device__ __forceinline__ void load_tile(const uint8_t* __restrict__ seq_al, uint64_t shift, uint64_t total, uint64_t t0 /* shifted, 16-aligned */,
+                                          uint32_t* __restrict__ sm_words, uint32_t* __restrict__ sm_bad) {
+    for (int c = threadIdx.x; c < kTileWords + 1; c += kBlock) {
+        const uint64_t a = t0 + (uint64_t)c * 16u;  // shifted coordinate of the chunk
+        uint32_t word = 0, badm = 0xFFFFu;
+        if (a < shift + total && a + 16u > shift) {
+            const uint4 v = *(const uint4*)(seq_al + a);
+            const uint32_t xs[4] = {v.x, v.y, v.z, v.w};
+            badm = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t b4;
+                const uint32_t p8 = pack4(xs[i], b4);
+                word |= p8 << (24 - 8 * i);
+                badm |= b4 << (4 * i);
+            }
+            if (a < shift || a + 16u > shift + total)  // bytes outside [shift, shift+total) are not bases
+                for (int i = 0; i < 16; ++i)
+                    if (a + i < shift || a + i >= shift + total) badm |= 1u << i;
+        }
+        sm_words[c] = word;
+        if (WANT_BAD) ((uint16_t*)sm_bad)[c] = (uint16_t)badm;
+    }
+}
+
+template <int KIND, bool K128, int P>
+__global__ __launch_bounds__(kBlock) void k_query_tiles_random(const lphq_image_header H, const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
+                                                                uint64_t shift, uint64_t total, const uint64_t* __restrict__ seq_off,
+                                                                const uint64_t* __restrict__ out_off, uint32_t n_records, uint64_t* __restrict__ out) {
+    __shared__ uint32_t sm_words[kTileWords + 8];
+    __shared__ uint32_t sm_rec[2];
+    const uint64_t t0 = (uint64_t)blockIdx.x * kTileW;  // shifted coordinate of the tile's first window start
+    if (threadIdx.x == 0) {
+        const uint64_t gfirst = t0 > shift ? t0 - shift : 0;
+        uint64_t glast = t0 + kTileW + 64 > shift ? t0 + kTileW + 64 - shift : 0;
+        if (glast >= total) glast = total ? total - 1 : 0;
+        sm_rec[0] = find_record(seq_off, 0, n_records - 1, gfirst);
+        sm_rec[1] = find_record(seq_off, 0, n_records - 1, glast);
+    }
+    load_tile<false>(seq_al, shift, total, t0, sm_words, nullptr);
+    for (int c = kTileWords + 1 + threadIdx.x; c < kTileWords + 8; c += kBlock) sm_words[c] = 0;
+    __syncthreads();
+    const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];
+    for (int i = threadIdx.x; i < kTileW; i += kBlock) {
+        const uint64_t a = t0 + i;
+        if (a < shift) continue;
+        const uint64_t g = a - shift;
+        if (g + H.k > total) continue;
+        const uint32_t r = find_record(seq_off, rlo, rhi, g);
+        if (g + H.k > seq_off[r + 1]) continue;  // window would run over the end of its record
+        uint64_t lo, hi;
+        extract_kmer<K128>(sm_words, (uint32_t)i, H.k, lo, hi);
+        out[out_off[r] + (g - seq_off[r])] = query_kmer<KIND, K128, P>(img, H, lo, hi);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static inline int grid_for(size_t n, int per_block, int max_blocks) {
+    size_t b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > (size_t)max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+#define LPHQ_DISPATCH(KERNEL, ...)                                                     \
+    do {                                                                               \
+        const bool k128 = H.kmer_bits == 128;                                          \
+        const bool p6 = H.P == 6;                                                      \
+        if (H.kind == 0) {                                                             \
+            if (k128) { if (p6) KERNEL<0, true, 6> __VA_ARGS__; else KERNEL<0, true, 4> __VA_ARGS__; }   \
+            else      { if (p6) KERNEL<0, false, 6> __VA_ARGS__; else KERNEL<0, false, 4> __VA_ARGS__; } \
+        } else {                                                                       \
+            if (k128) { if (p6) KERNEL<1, true, 6> __VA_ARGS__; else KERNEL<1, true, 4> __VA_ARGS__; }   \
+            else      { if (p6) KERNEL<1, false, 6> __VA_ARGS__; else KERNEL<1, false, 4> __VA_ARGS__; } \
+        }                                                                              \
+    } while (0)
+
+hipError_t launch_query_packed(const lphq_image_header& H, const uint8_t* d_img, const void* d_kmers, size_t n, uint64_t* d_out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const int grid = grid_for(n, kBlock, 256 * 16);
+    LPHQ_DISPATCH(k_query_packed, <<<grid, kBlock, 0, stream>>>(H, d_img, (const uint64_t*)d_kmers, n, d_out));
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_kmers(const lphq_image_header& H, const char* d_seq, const uint64_t* d_pos, size_t n, void* d_kmers, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const int grid = grid_for(n, kBlock, 256 * 16);
+    if (H.kmer_bits == 128) k_pack_kmers<true><<<grid, kBlock, 0, stream>>>(d_seq, d_pos, n, H.k, (uint64_t*)d_kmers);
+    else k_pack_kmers<false><<<grid, kBlock, 0, stream>>>(d_seq, d_pos, n, H.k, (uint64_t*)d_kmers);
+    return hipGetLastError();
+}
+
+hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img, const char* d_seq, uint64_t total_bases, const uint64_t* d_seq_off,
+                                const uint64_t* d_out_off, size_t n_records, uint64_t* d_out, int streaming, hipStream_t stream) {
+    if (n_records == 0 || total_bases < H.k) return hipSuccess;
+    const uint64_t shift = (uint64_t)((uintptr_t)d_seq & 15u);
+    const uint8_t* seq_al = (const uint8_t*)d_seq - shift;
+    const uint64_t span = shift + total_bases;
+    const uint64_t tiles = (span + kTileW - 1) / kTileW;
+    if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    (void)streaming;  // streaming kernel: see launch in a later section
+    LPHQ_DISPATCH(k_query_tiles_random, <<<(int)tiles, kBlock, 0, stream>>>(H, d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out));
+    return hipGetLastError();
+}
+
+}  // namespace lphq
