@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native LPHash query engine.
+
+Workload (BASELINE.json configs[1], "C2"): partitioned LP-MPHF, k=31 m=20, 100 M k-mers; one *step* =
+one batch of 2^28 random positive packed k-mer lookups per GPU (the reference's `streaming == false`
+branch, include/partitioned_mphf.hpp:185-195), inputs and outputs resident in HBM.  `--mode stream`
+measures C3 (all windows of the index FASTA, streaming kernel) instead.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: the index is built once on rank 0, its flat device image is broadcast with RCCL
+(torch.distributed backend "nccl"), and every rank processes its own batch -- no data-path collective
+ => weak scaling; value = lookups of all ranks / max-over-ranks time.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import lphash_amd as L  # noqa: E402
+from lphash_amd.synth import synthetic_records  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def algorithmic_bytes_per_lookup(h, mode, k, W):
+    """bytes of the reference's structures one lookup must touch, each word once at
+    natural width, + the compulsory input/output stream; recomputed from this index's measured type mix."""
+    img = h.image()
+    hdr = np.frombuffer(img[:512].tobytes(), dtype=np.uint64)
+    # lphq_image_header (image_layout.h): u64 magic,total | 8 x u32 | mm_seed,nkmers,D,fallback | n_max | collision_base | off_wt,off_left,off_right,off_none,off_upair | phf mm ...
+    nkmers, n_max, collision_base = int(hdr[7]), int(hdr[10]), int(hdr[11])
+    off_left, off_right, off_none = int(hdr[13]), int(hdr[14]), int(hdr[15])
+    base = W * n_max
+    abs_of = lambda off: int(np.frombuffer(img[off:off + 8].tobytes(), dtype=np.uint64)[0])  # noqa: E731
+    tot_l = abs_of(off_right) - base if off_right else 0
+    tot_r = abs_of(off_none) - base - tot_l if off_none else 0
+    tot_n = collision_base - base - tot_l - tot_r
+    f_max, f_l, f_r, f_n = base / nkmers, tot_l / nkmers, tot_r / nkmers, tot_n / nkmers
+    phf = hdr[17:17 + 3]  # seed, num_keys, table_size of the minimizer PTHash
+    p_free = 1.0 - int(phf[1]) / int(phf[2])
+    chain = 8 + 26 * p_free + 48 + 26 * f_l + 34 * f_r + 60 * f_n
+    kmer_bytes = 8 if k <= 31 else 16
+    mix = {"maximal": round(f_max, 4), "left": round(f_l, 4), "right": round(f_r, 4), "none": round(f_n, 4)}
+    if mode == "random":
+        return kmer_bytes + 8 + chain, chain, mix
+    return 1 + 8 + chain / ((W + 1) / 2.0), chain, mix
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", choices=["random", "stream"], default="random")
+    ap.add_argument("--kmers", type=int, default=100_000_000, help="k-mers in the index (C2: 100 M)")
+    ap.add_argument("--batch-log2", type=int, default=28, help="random mode: 2^x lookups per step per GPU")
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--m", type=int, default=20)
+    ap.add_argument("--kind", choices=["p", "u"], default="p")
+    ap.add_argument("--build-threads", type=int, default=0)
+    ap.add_argument("--cpu-sample-log2", type=int, default=24, help="oracle-timed sample size (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cache-dir", default=os.environ.get("LPHQ_BENCH_CACHE", "/tmp/lphq_bench_cache"))
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the query path has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    k, m = args.k, args.m
+    W = k - m + 1
+    kmer_bits = 64 if k <= 31 else 128
+    kind = L.PARTITIONED if args.kind == "p" else L.UNPARTITIONED
+    cls = L.Mphf if kind == L.PARTITIONED else L.MphfAlt
+    rec_len = 100_000 + k - 1
+    n_records = max(1, args.kmers // 100_000)
+    nk = n_records * 100_000
+
+    # ---- synthetic index set (every rank regenerates it: deterministic, ~1 s per 100 M bases) ----
+    t0 = time.time()
+    flat, recs = synthetic_records(seed=1, n_records=n_records, length=rec_len)
+    log(f"[bench r{rank}] generated {n_records} records x {rec_len} bases in {time.time() - t0:.1f}s")
+
+    # ---- index: built once (rank 0), cached on local disk, image broadcast over RCCL ----
+    os.makedirs(args.cache_dir, exist_ok=True)
+    path = os.path.join(args.cache_dir, f"synth_seed1_{args.kind}_k{k}_m{m}_n{nk}_b{kmer_bits}.lph")
+    build_s = None
+    if rank == 0:
+        if not os.path.exists(path):
+            t0 = time.time()
+            tmp = path + f".tmp{os.getpid()}"
+            L.build(recs, k, m, tmp, kind=kind, kmer_bits=kmer_bits, threads=args.build_threads or min(os.cpu_count() or 8, 64))
+            os.replace(tmp, path)
+            build_s = time.time() - t0
+            log(f"[bench] built index over {nk} k-mers in {build_s:.1f}s -> {path} ({os.path.getsize(path)} bytes)")
+        t0 = time.time()
+        h = cls.load(path, kmer_bits=kmer_bits, device=local_rank)
+        log(f"[bench] loaded + attached in {time.time() - t0:.1f}s: {h.get_kmer_count()} k-mers, {h.get_minimizer_L0()} minimizers, "
+            f"{h.info.fallback_kmers} fallback k-mers, image {h.info.image_bytes / 1e6:.1f} MB")
+        assert h.get_kmer_count() == nk, "synthetic set has duplicate k-mers?"
+    bcast_s = None
+    if world > 1:
+        nbytes = torch.zeros(1, dtype=torch.int64, device=dev)
+        if rank == 0:
+            nbytes[0] = h.info.image_bytes
+        dist.broadcast(nbytes, src=0)
+        image_t = torch.empty(int(nbytes.item()), dtype=torch.uint8, device=dev)
+        if rank == 0:
+            p, n = h.device_image()
+            ctypes_src = (ctypes.c_char * 0)  # noqa: F841
+            src = torch.from_numpy(h.image()).to(dev)  # staging copy of the image in a torch tensor for the collective
+            image_t.copy_(src)
+            del src
+        torch.cuda.synchronize()
+        t0 = time.time()
+        dist.broadcast(image_t, src=0)  # RCCL over xGMI: the only collective of the whole job
+        torch.cuda.synchronize()
+        bcast_s = time.time() - t0
+        if rank != 0:
+            h = cls.from_device_image(image_t.data_ptr(), image_t.numel(), local_rank)
+        log(f"[bench r{rank}] image broadcast {image_t.numel() / 1e6:.1f} MB in {bcast_s * 1e3:.1f} ms")
+
+    stream = torch.cuda.current_stream().cuda_stream
+    d_seq = torch.from_numpy(flat).to(dev)
+    total_bases = int(d_seq.numel())
+
+    # ---- per-rank batch, resident in HBM before the timed region ----
+    if args.mode == "random":
+        Q = 1 << args.batch_log2
+        g = torch.Generator(device=dev)
+        g.manual_seed(2 + rank)
+        rec_i = torch.randint(0, n_records, (Q,), generator=g, device=dev, dtype=torch.int64)
+        off_i = torch.randint(0, 100_000, (Q,), generator=g, device=dev, dtype=torch.int64)
+        d_pos = rec_i * rec_len + off_i
+        del rec_i, off_i
+        d_kmers = torch.empty(Q * (kmer_bits // 64), dtype=torch.int64, device=dev)
+        h.pack_kmers(d_seq.data_ptr(), d_pos.data_ptr(), Q, d_kmers.data_ptr(), stream)
+        d_out = torch.empty(Q, dtype=torch.int64, device=dev)
+        units = Q
+
+        def step():
+            h.query_packed(d_kmers.data_ptr(), Q, d_out.data_ptr(), stream)
+    else:
+        seq_off = torch.arange(0, n_records + 1, dtype=torch.int64, device=dev) * rec_len
+        out_off = torch.arange(0, n_records + 1, dtype=torch.int64, device=dev) * (rec_len - k + 1)
+        units = n_records * (rec_len - k + 1)
+        d_out = torch.empty(units, dtype=torch.int64, device=dev)
+
+        def step():
+            h.query_records(d_seq.data_ptr(), total_bases, seq_off.data_ptr(), n_records, d_out.data_ptr(), out_off.data_ptr(), True, stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()  # HIP events on the stream the kernel is launched on (torch's current stream)
+        step()
+        b.record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    # ---- parity of what was just measured + CPU baseline (oracle = checker, rank 0, N=1 only) ----
+    cpu = None
+    parity = None
+    if rank == 0 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orc
+
+        o = orc.Index(path, orc.PARTITIONED if kind == L.PARTITIONED else orc.UNPARTITIONED, kmer_bits)
+        S = min(1 << args.cpu_sample_log2, units)
+        if args.mode == "random":
+            sample = d_kmers[: S * (kmer_bits // 64)].cpu().numpy().view(np.uint64)
+            t0 = time.perf_counter()
+            exp = o.query_packed(sample)
+            cpu_s = time.perf_counter() - t0
+            got = d_out[:S].cpu().numpy().view(np.uint64)
+            what = f"first 2^{int(np.log2(S))} probes of the timed batch, oracle random branch, single thread"
+        else:
+            nrec_s = max(1, min(n_records, S // (rec_len - k + 1)))
+            t0 = time.perf_counter()
+            exp = np.concatenate([o(recs[i], True) for i in range(nrec_s)])
+            cpu_s = time.perf_counter() - t0
+            S = len(exp)
+            got = d_out[:S].cpu().numpy().view(np.uint64)
+            what = f"first {nrec_s} records of the batch, oracle streaming branch, single thread"
+        parity = bool(np.array_equal(got, exp))
+        cpu = {"value": S / cpu_s, "unit": "k-mer lookups/s", "cores": 1, "kind": "port", "sample": what}
+        if args.mode == "random" and world == 1:
+            full = d_out.cpu().numpy().view(np.uint64)
+            parity = parity and bool(full.max() < nk)  # positive probes: every code is a valid slot
+        log(f"[bench] cpu oracle: {S / cpu_s / 1e6:.2f} M lookups/s on {S} units; GPU == oracle on the sample: {parity}")
+        assert parity, "GPU results differ from the oracle"
+
+    if rank == 0:
+        bpl, chain, mix = algorithmic_bytes_per_lookup(h, args.mode, k, W) if kind == L.PARTITIONED else (None, None, None)
+        value = world * units * args.steps / elapsed
+        out = {
+            "metric": "k-mer lookups/sec (whole node), k=31 partitioned MPHF" if args.mode == "random" else "k-mer lookups/sec (whole node), streaming",
+            "value": value,
+            "unit": "k-mer lookups/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": ("C2: partitioned" if kind == L.PARTITIONED else "C5: unpartitioned")
+                + f" LP-MPHF k={k} m={m}, {nk} k-mers (SplitMix64 seed 1, {n_records} records x {rec_len} bases); "
+                + (f"2^{args.batch_log2} random positive packed k-mer lookups per GPU per step" if args.mode == "random"
+                   else "all windows of the index records per step, streaming kernel"),
+                "k": k, "m": m, "kmers": nk, "units_per_step_per_gpu": units, "kmer_bits": kmer_bits,
+                "index_image_bytes": int(h.info.image_bytes), "type_mix": mix,
+            },
+            "kernel_ms": kernel_ms,
+            "parity_vs_oracle": parity,
+        }
+        if bpl is not None:
+            achieved = bpl * units / (kernel_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                               "traffic": None, "bytes_per_lookup": bpl, "kernel": "k_query_packed" if args.mode == "random" else "k_query_tiles_stream"}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        if build_s is not None:
+            out["index_build_s"] = build_s
+        if bcast_s is not None:
+            out["image_broadcast_ms"] = bcast_s * 1e3
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

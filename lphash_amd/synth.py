@@ -1,0 +1,34 @@
+"""Deterministic synthetic inputs (SplitMix64 -> 2 bits per base), shared by bench.py and the tests.
+
+The reference ships no generator; SURVEY.md section 8(d) fixes this one: forward strand only
+(the reference is non-canonical, src/partitioned_mphf.cpp:34), equal-length records.
+"""
+import numpy as np
+
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def splitmix64(x):
+    """Vectorised SplitMix64 finaliser over a uint64 array of counters."""
+    with np.errstate(over="ignore"):
+        z = (x + np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def random_bases(seed, n):
+    """n ASCII bases as a uint8 array; base i is bits (2*(i%32)) of splitmix64(seed * 2^40 + i//32)."""
+    nw = (n + 31) // 32
+    with np.errstate(over="ignore"):
+        ctr = np.arange(nw, dtype=np.uint64) + (np.uint64(seed) << np.uint64(40))
+    w = splitmix64(ctr)
+    shifts = (np.arange(32, dtype=np.uint64) * np.uint64(2))[None, :]
+    codes = ((w[:, None] >> shifts) & np.uint64(3)).astype(np.uint8).reshape(-1)[:n]
+    return _ACGT[codes]
+
+
+def synthetic_records(seed, n_records, length):
+    """n_records records of `length` bases each, as one contiguous uint8 array + the list of bytes views."""
+    flat = random_bases(seed, n_records * length)
+    return flat, [flat[i * length:(i + 1) * length].tobytes() for i in range(n_records)]
