@@ -16,7 +16,6 @@ Multi-GPU: the index is built once on rank 0, its flat device image is broadcast
 Rank 0 prints ONE JSON line.
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -128,20 +127,11 @@ def main():
         assert h.get_kmer_count() == nk, "synthetic set has duplicate k-mers?"
     bcast_s = None
     if world > 1:
-        nbytes = torch.zeros(1, dtype=torch.int64, device=dev)
-        if rank == 0:
-            nbytes[0] = h.info.image_bytes
-        dist.broadcast(nbytes, src=0)
-        image_t = torch.empty(int(nbytes.item()), dtype=torch.uint8, device=dev)
-        if rank == 0:
-            p, n = h.device_image()
-            ctypes_src = (ctypes.c_char * 0)  # noqa: F841
-            src = torch.from_numpy(h.image()).to(dev)  # staging copy of the image in a torch tensor for the collective
-            image_t.copy_(src)
-            del src
+        from lphash_amd.dist import broadcast_image
+
         torch.cuda.synchronize()
         t0 = time.time()
-        dist.broadcast(image_t, src=0)  # RCCL over xGMI: the only collective of the whole job
+        image_t = broadcast_image(h.image() if rank == 0 else None, dist, dev, src=0)  # RCCL over xGMI: the only collective of the job
         torch.cuda.synchronize()
         bcast_s = time.time() - t0
         if rank != 0:

@@ -86,9 +86,11 @@ __global__ __launch_bounds__(kBlock) void k_pack_kmers(const char* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // tiles over concatenated records
 // ------------------------------------------------------------------------------------------
-constexpr int kTileW = 2048;                 // window starts per workgroup
-constexpr int kTileBases = kTileW + 64;      // + k-1 (k <= 63) overlap
-constexpr int kTileWords = kTileBases / 16;  // 2-bit packed u32 words (16 bases each, first base in the top bits)
+constexpr int kTileW = 2048;  // window starts per workgroup, random-over-records kernel
+constexpr int kStreamTileW = 1024;  // window starts per workgroup, streaming kernel (LDS ~19 KB -> 8 workgroups / CU)
+// 2-bit packed u32 words (16 bases each, first base in the top bits) for TW window starts + k-1 (k <= 63) overlap
+constexpr int tile_words(int tw) { return (tw + 64) / 16; }
+constexpr int kTileWords = tile_words(kTileW);
 
 // last r in [lo, hi] with offs[r] <= g   (offs non-decreasing, offs[lo] <= g)
 __device__ __forceinline__ uint32_t find_record(const uint64_t* __restrict__ offs, uint32_t lo, uint32_t hi, uint64_t g) {
@@ -137,10 +139,10 @@ struct TileInfo {
     uint32_t rlo, rhi;  // records containing the first / last base the tile can touch
 };
 
-template <bool WANT_BAD>
+template <bool WANT_BAD, int NWORDS>
 __device__ __forceinline__ void load_tile(const uint8_t* __restrict__ seq_al, uint64_t shift, uint64_t total, uint64_t t0 /* shifted, 16-aligned */,
                                           uint32_t* __restrict__ sm_words, uint32_t* __restrict__ sm_bad) {
-    for (int c = threadIdx.x; c < kTileWords + 1; c += kBlock) {
+    for (int c = threadIdx.x; c < NWORDS + 1; c += kBlock) {
         const uint64_t a = t0 + (uint64_t)c * 16u;  // shifted coordinate of the chunk
         uint32_t word = 0, badm = 0xFFFFu;
         if (a < shift + total && a + 16u > shift) {
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_random(const lphq_image_
         sm_rec[0] = find_record(seq_off, 0, n_records - 1, gfirst);
         sm_rec[1] = find_record(seq_off, 0, n_records - 1, glast);
     }
-    load_tile<false>(seq_al, shift, total, t0, sm_words, nullptr);
+    load_tile<false, kTileWords>(seq_al, shift, total, t0, sm_words, nullptr);
     for (int c = kTileWords + 1 + threadIdx.x; c < kTileWords + 8; c += kBlock) sm_words[c] = 0;
     __syncthreads();
     const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];
@@ -191,6 +193,179 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_random(const lphq_image_
         uint64_t lo, hi;
         extract_kmer<K128>(sm_words, (uint32_t)i, H.k, lo, hi);
         out[out_off[r] + (g - seq_off[r])] = query_kmer<KIND, K128, P>(img, H, lo, hi);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// streaming kernel: MPHF::operator()(.., streaming=true)   include/partitioned_mphf.hpp:78-184
+// ------------------------------------------------------------------------------------------
+// The reference walks a record base by base with a ring buffer of W = k-m+1 minimizer hashes and
+// only calls query() when the minimizer changes (one call per super-k-mer); consecutive k-mers of a
+// super-k-mer get hval +- 1.  Because the closed forms of query() are linear in the offset p of the
+// minimizer (SURVEY section 8a note 3), the same codes come out position-parallel:
+//   A  bases of the tile -> 2-bit words + bad-base bitmask in LDS
+//   B  one MurmurHash2_64 per m-mer position (partitioned_mphf.hpp:116), all lanes
+//   C  van Herk / Gil-Werman sliding minimum: per block of B <= W positions the leftmost prefix / suffix
+//      arg-minima; a window's leftmost minimum = best of <= 5 block terms (ties keep the left one,
+//      as the strict `>` comparisons of partitioned_mphf.hpp:122,150-163 do)
+//   D  windows whose minimizer position differs from their left neighbour's are super-k-mer leaders;
+//      they are compacted into an LDS queue so the gather chain runs with dense lanes
+//   E  leaders: PTHash + wavelet block + plane block -> (base, mode) stored by minimizer position
+//   F  every window: hval = base +- p (or the per-k-mer fallback lookup for colliding minimizers,
+//      partitioned_mphf.hpp:133-135)
+// Windows holding a non-ACGT base get LPHQ_INVALID (the reference emits nothing for them).
+template <int KIND, bool K128, int P>
+__global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const lphq_image_header H, const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
+                                                                uint64_t shift, uint64_t total, const uint64_t* __restrict__ seq_off,
+                                                                const uint64_t* __restrict__ out_off, uint32_t n_records, uint64_t* __restrict__ out) {
+    constexpr int TW = kStreamTileW, NW = tile_words(TW), NPOS_MAX = TW + 64, WPL = TW / kBlock;
+    __shared__ uint64_t sm_hash[NPOS_MAX];  // phase B-C: minimizer hash per m-mer position; phase E-F: leader's base
+    __shared__ uint32_t sm_words[NW + 8];
+    __shared__ uint32_t sm_bad[(NW + 8) / 2 + 2];
+    __shared__ uint16_t sm_S[NPOS_MAX], sm_P[NPOS_MAX];
+    __shared__ uint16_t sm_q[TW], sm_queue[TW];
+    __shared__ uint8_t sm_mode[NPOS_MAX];
+    __shared__ uint32_t sm_rec[2], sm_count;
+    const uint32_t k = H.k, m = H.m, W = H.W;
+    const uint64_t t0 = (uint64_t)blockIdx.x * TW;
+    if (threadIdx.x == 0) {
+        const uint64_t gfirst = t0 > shift ? t0 - shift : 0;
+        uint64_t glast = t0 + TW + 64 > shift ? t0 + TW + 64 - shift : 0;
+        if (glast >= total) glast = total ? total - 1 : 0;
+        sm_rec[0] = find_record(seq_off, 0, n_records - 1, gfirst);
+        sm_rec[1] = find_record(seq_off, 0, n_records - 1, glast);
+        sm_count = 0;
+    }
+    for (int c = threadIdx.x; c < (NW + 8) / 2 + 2; c += kBlock) sm_bad[c] = 0xFFFFFFFFu;
+    __syncthreads();
+    load_tile<true, NW>(seq_al, shift, total, t0, sm_words, sm_bad);
+    for (int c = NW + 1 + threadIdx.x; c < NW + 8; c += kBlock) sm_words[c] = 0;
+    __syncthreads();
+
+    // ---- B: hashes of the m-mers starting at local positions [0, TW + W - 1) ----
+    const uint32_t NPOS = TW + W - 1;
+    const uint64_t mm_seedx = murmur_seedx(H.mm_seed);
+    for (uint32_t j = threadIdx.x; j < NPOS; j += kBlock) {
+        uint64_t lo, hi;
+        extract_kmer<false>(sm_words, j, m, lo, hi);
+        sm_hash[j] = murmur8(lo, mm_seedx);
+    }
+    __syncthreads();
+
+    // ---- C1: per block of B positions, leftmost prefix / suffix arg-minima ----
+    const uint32_t nsplit = (W + 15) / 16;           // 1..4
+    const uint32_t B = (W + nsplit - 1) / nsplit;    // block length <= 16, B <= W
+    const uint32_t NBLK = (NPOS + B - 1) / B;
+    for (uint32_t b = threadIdx.x; b < NBLK; b += kBlock) {
+        const uint32_t s = b * B, e = min(s + B, NPOS);
+        uint64_t mh = sm_hash[s];
+        uint32_t mp = s;
+        sm_P[s] = (uint16_t)s;
+        for (uint32_t j = s + 1; j < e; ++j) {
+            const uint64_t h = sm_hash[j];
+            if (h < mh) {
+                mh = h;
+                mp = j;
+            }
+            sm_P[j] = (uint16_t)mp;
+        }
+        mh = sm_hash[e - 1];
+        mp = e - 1;
+        sm_S[e - 1] = (uint16_t)mp;
+        for (uint32_t j = e - 1; j-- > s;) {
+            const uint64_t h = sm_hash[j];
+            if (h <= mh) {
+                mh = h;
+                mp = j;
+            }
+            sm_S[j] = (uint16_t)mp;
+        }
+    }
+    __syncthreads();
+
+    // ---- C2: per window, the leftmost minimum over its W m-mer positions ----
+    const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];
+    uint64_t oidx[WPL];  // output slot of this lane's windows (~0: not a window of any record)
+    const uint64_t kmask = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
+#pragma unroll
+    for (int t = 0; t < WPL; ++t) {
+        const uint32_t i = threadIdx.x + t * kBlock;
+        const uint64_t a = t0 + i;
+        oidx[t] = ~0ull;
+        uint16_t qv = 0xFFFEu;  // not a window
+        if (a >= shift && a - shift + k <= total) {
+            const uint64_t g = a - shift;
+            const uint32_t r = find_record(seq_off, rlo, rhi, g);
+            if (g + k <= seq_off[r + 1]) {
+                oidx[t] = out_off[r] + (g - seq_off[r]);
+                // any non-ACGT base in [i, i+k) ?
+                const uint32_t w0 = i >> 5, o = i & 31u;
+                uint64_t x = ((((uint64_t)sm_bad[w0 + 1]) << 32) | sm_bad[w0]) >> o;
+                if (o) x |= ((uint64_t)sm_bad[w0 + 2]) << (64u - o);
+                if (x & kmask) {
+                    qv = 0xFFFFu;  // window holds an invalid base
+                } else {
+                    const uint32_t jl = i + W - 1, b0 = i / B, bl = jl / B;
+                    uint32_t q = sm_S[i];
+                    uint64_t hq = sm_hash[q];
+                    for (uint32_t b = b0 + 1; b < bl; ++b) {
+                        const uint32_t c = sm_S[b * B];
+                        const uint64_t hc = sm_hash[c];
+                        if (hc < hq) {
+                            hq = hc;
+                            q = c;
+                        }
+                    }
+                    if (bl > b0) {
+                        const uint32_t c = sm_P[jl];
+                        if (sm_hash[c] < hq) q = c;
+                    }
+                    qv = (uint16_t)q;
+                }
+            }
+        }
+        sm_q[i] = qv;
+    }
+    __syncthreads();
+
+    // ---- D: leaders -> queue ----
+#pragma unroll
+    for (int t = 0; t < WPL; ++t) {
+        const uint32_t i = threadIdx.x + t * kBlock;
+        const uint16_t qv = sm_q[i];
+        if (qv < 0xFFFEu && (i == 0 || sm_q[i - 1] != qv)) sm_queue[atomicAdd(&sm_count, 1u)] = qv;
+    }
+    __syncthreads();
+
+    // ---- E: one lookup per super-k-mer, dense lanes ----
+    const uint32_t nlead = sm_count;
+    for (uint32_t x = threadIdx.x; x < nlead; x += kBlock) {
+        const uint32_t q = sm_queue[x];
+        uint64_t mm, hi;
+        extract_kmer<false>(sm_words, q, m, mm, hi);
+        const LookupCtx c = lookup_ctx<KIND, K128, P>(img, H, mm);
+        sm_hash[q] = c.base;
+        sm_mode[q] = (uint8_t)c.mode;
+    }
+    __syncthreads();
+
+    // ---- F: every window ----
+#pragma unroll
+    for (int t = 0; t < WPL; ++t) {
+        if (oidx[t] == ~0ull) continue;
+        const uint32_t i = threadIdx.x + t * kBlock;
+        const uint32_t q = sm_q[i];
+        uint64_t hval = ~0ull;  // LPHQ_INVALID
+        if (q < 0xFFFEu) {
+            LookupCtx c;
+            c.base = sm_hash[q];
+            c.mode = sm_mode[q];
+            uint64_t lo = 0, hi = 0;
+            if (c.mode == 2u) extract_kmer<K128>(sm_words, i, k, lo, hi);
+            hval = finish_hval<K128>(img, H, c, lo, hi, q - i);
+        }
+        out[oidx[t]] = hval;
     }
 }
 
@@ -238,10 +413,13 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
     const uint64_t shift = (uint64_t)((uintptr_t)d_seq & 15u);
     const uint8_t* seq_al = (const uint8_t*)d_seq - shift;
     const uint64_t span = shift + total_bases;
-    const uint64_t tiles = (span + kTileW - 1) / kTileW;
+    const uint64_t tw = streaming ? kStreamTileW : kTileW;
+    const uint64_t tiles = (span + tw - 1) / tw;
     if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    (void)streaming;  // streaming kernel: see launch in a later section
-    LPHQ_DISPATCH(k_query_tiles_random, <<<(int)tiles, kBlock, 0, stream>>>(H, d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out));
+    if (streaming)
+        LPHQ_DISPATCH(k_query_tiles_stream, <<<(int)tiles, kBlock, 0, stream>>>(H, d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out));
+    else
+        LPHQ_DISPATCH(k_query_tiles_random, <<<(int)tiles, kBlock, 0, stream>>>(H, d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out));
     return hipGetLastError();
 }
 

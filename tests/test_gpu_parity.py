@@ -1,0 +1,224 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle -- bit-exact, integer work.
+
+Sizes: seeded inputs the oracle finishes in seconds, the committed golden fixtures, and larger runs checked
+through size-independent properties (bijection onto [0, n), streaming == random, order-independent checksum)."""
+import glob
+import os
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import lphash_amd as L  # noqa: E402
+import orc  # noqa: E402
+from lphash_amd.synth import synthetic_records  # noqa: E402
+from util import dedup_records, pack_kmers, random_records  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def torch_dev():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a device; the product has no CPU fallback"
+    return torch, torch.device("cuda", 0)
+
+
+def golden_cases():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(ROOT, "tests", "golden", "*.lph")))
+
+
+def split(flat, off):
+    return [flat[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_golden_fixtures(name, golden_dir):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    cls = L.Mphf if int(z["kind"]) == 0 else L.MphfAlt
+    h = cls.load(os.path.join(golden_dir, name + ".lph"), kmer_bits=int(z["kmer_bits"]), device=0)
+    queries = [bytes(q) for q in split(z["queries"], z["q_off"])]
+    for q, s, r in zip(queries, split(z["streaming"], z["s_off"]), split(z["random"], z["r_off"])):
+        assert np.array_equal(h(q, streaming=True), s)
+        assert np.array_equal(h(q, streaming=False), r)
+
+
+CONFIGS = [(31, 20, 64, 0), (31, 20, 128, 0), (31, 15, 128, 0), (63, 20, 128, 0), (63, 17, 128, 0), (31, 20, 64, 1), (15, 9, 64, 0), (31, 31, 64, 0),
+           (21, 8, 64, 0), (21, 8, 64, 1), (47, 17, 128, 1), (33, 5, 128, 0), (9, 1, 64, 1), (63, 32, 128, 0), (20, 4, 64, 0)]
+
+
+@pytest.mark.parametrize("k,m,bits,kind", CONFIGS)
+def test_contig_queries_match_oracle(tmp_path, k, m, bits, kind):
+    """MPHF::operator()(contig, len, streaming) for members, non-members, ragged and too-short records."""
+    recs = dedup_records(random_records(k * 131 + m, 16, max(k - 2, 1), 6000 if k > 12 else 300), k)
+    path = str(tmp_path / "t.lph")
+    L.build(recs, k, m, path, kind=kind, kmer_bits=bits, threads=8)
+    o = orc.Index(path, kind, bits)
+    h = (L.Mphf if kind == 0 else L.MphfAlt).load(path, kmer_bits=bits, device=0)
+    assert h.get_kmer_count() == o.nkmers
+    queries = recs + random_records(7, 4, 1, 4000) + [b"", recs[0][: k - 1], recs[0][:k], recs[0].lower()]
+    for q in queries:
+        exp_r, exp_s = o(q, False), o(q, True)
+        assert np.array_equal(h(q, streaming=False), exp_r)
+        assert np.array_equal(h(q, streaming=True), exp_s)
+        assert np.array_equal(exp_r, exp_s)  # ACGT-only input: the two reference passes agree
+
+
+@pytest.mark.parametrize("k,m,bits,kind", [(31, 20, 64, 0), (63, 20, 128, 0), (31, 20, 64, 1), (21, 8, 64, 0), (47, 17, 128, 1)])
+def test_packed_batch_and_pack_kernel(tmp_path, k, m, bits, kind):
+    torch, dev = torch_dev()
+    recs = random_records(k + 17 * m, 6, 500, 5000)
+    path = str(tmp_path / "t.lph")
+    L.build(recs, k, m, path, kind=kind, kmer_bits=bits, threads=8)
+    o = orc.Index(path, kind, bits)
+    h = (L.Mphf if kind == 0 else L.MphfAlt).load(path, kmer_bits=bits, device=0)
+    seq = b"".join(recs) + random_records(3, 1, 3000, 3000)[0]  # windows across record joins are non-members
+    pos = np.arange(0, len(seq) - k + 1, dtype=np.int64)
+    pk = pack_kmers(seq, pos, k, bits)
+    d_s = torch.from_numpy(np.frombuffer(seq, dtype=np.uint8).copy()).to(dev)
+    d_p = torch.from_numpy(pos).to(dev)
+    d_k = torch.empty(len(pk), dtype=torch.int64, device=dev)
+    h.pack_kmers(d_s.data_ptr(), d_p.data_ptr(), len(pos), d_k.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_k.cpu().numpy().view(np.uint64), pk)
+    d_o = torch.empty(len(pos), dtype=torch.int64, device=dev)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        h.query_packed(d_k.data_ptr(), len(pos), d_o.data_ptr(), s.cuda_stream)
+    s.synchronize()
+    assert np.array_equal(d_o.cpu().numpy().view(np.uint64), o.query_packed(pk))
+    h.query_packed(d_k.data_ptr(), 0, d_o.data_ptr())  # empty batch is a no-op
+
+
+def run_records(h, torch, dev, recs, k, streaming, misalign=0):
+    lens = np.array([len(r) for r in recs], dtype=np.int64)
+    seq_off = np.concatenate([[0], np.cumsum(lens)])
+    nwin = np.maximum(lens - k + 1, 0)
+    out_off = np.concatenate([[0], np.cumsum(nwin)])
+    flat = np.frombuffer(b"".join(recs), dtype=np.uint8)
+    buf = torch.zeros(len(flat) + 64, dtype=torch.uint8, device=dev)
+    buf[misalign:misalign + len(flat)] = torch.from_numpy(flat.copy()).to(dev)
+    d_so, d_oo = torch.from_numpy(seq_off).to(dev), torch.from_numpy(out_off).to(dev)
+    d_out = torch.full((int(out_off[-1]) + 1,), -7, dtype=torch.int64, device=dev)
+    h.query_records(buf.data_ptr() + misalign, len(flat), d_so.data_ptr(), len(recs), d_out.data_ptr(), d_oo.data_ptr(), streaming)
+    torch.cuda.synchronize()
+    res = d_out.cpu().numpy().view(np.uint64)
+    assert res[-1] == np.uint64(2**64 - 7)  # nothing written past the last slot
+    return [res[out_off[i]:out_off[i + 1]] for i in range(len(recs))]
+
+
+@pytest.mark.parametrize("k,m,bits,kind", [(31, 20, 64, 0), (63, 20, 128, 0), (31, 20, 64, 1), (21, 8, 64, 0)])
+def test_record_batches_ragged_empty_and_misaligned(tmp_path, k, m, bits, kind):
+    """Batches of many records on device: empty, shorter-than-k and tile-straddling records, any pointer alignment."""
+    torch, dev = torch_dev()
+    recs = random_records(99 + k, 40, 400, 3000)
+    path = str(tmp_path / "t.lph")
+    L.build(recs, k, m, path, kind=kind, kmer_bits=bits, threads=8)
+    o = orc.Index(path, kind, bits)
+    h = (L.Mphf if kind == 0 else L.MphfAlt).load(path, kmer_bits=bits, device=0)
+    batch = [b"", recs[0], recs[1][: k - 1], b"", recs[2][:k], recs[3]] + recs[4:] + random_records(5, 30, 1, 200) + [b""]
+    exp = [o(r, False) for r in batch]
+    for streaming in (False, True):
+        for mis in (0, 1, 7, 15):
+            got = run_records(h, torch, dev, batch, k, streaming, mis)
+            for g, e in zip(got, exp):
+                assert np.array_equal(g, e)
+
+
+def test_non_acgt_bases(tmp_path):
+    """Defined behaviour outside the reference's clean-input contract (SURVEY section 8a note 4): random mode reads a
+    non-ACGT base as 'A' (mphf_utils.hpp:108) and still emits; streaming emits one code per fully valid window."""
+    k, m = 31, 20
+    recs = random_records(42, 6, 500, 2000)
+    path = str(tmp_path / "t.lph")
+    L.build(recs, k, m, path, kmer_bits=64, threads=4)
+    o = orc.Index(path, 0, 64)
+    h = L.Mphf.load(path, kmer_bits=64, device=0)
+    rng = np.random.default_rng(0)
+    for r in recs:
+        q = bytearray(r)
+        for p in rng.integers(0, len(q), 5):
+            q[p] = ord("N")
+        q[0] = ord("R")
+        q[-1] = ord("-")
+        q[len(q) // 2] = ord("u")  # U/u are valid (seq_nt4_table maps them to 3)
+        q = bytes(q)
+        exp_r = o(q, False)
+        assert np.array_equal(h(q, streaming=False), exp_r)
+        bad = np.array([c not in b"ACGTUacgtu" for c in q])
+        csum = np.concatenate([[0], np.cumsum(bad)])
+        valid = (csum[k:] - csum[:-k]) == 0
+        assert np.array_equal(h(q, streaming=True), exp_r[valid])
+
+
+def test_device_image_handle_and_concurrent_callers(tmp_path):
+    """lphq_open_device_image over a copy of the image (what a non-root rank does after the RCCL broadcast) and
+    several host threads querying one index at once."""
+    torch, dev = torch_dev()
+    recs = random_records(11, 10, 1000, 4000)
+    path = str(tmp_path / "t.lph")
+    L.build(recs, 31, 20, path, kmer_bits=64, threads=4)
+    o = orc.Index(path, 0, 64)
+    h0 = L.Mphf.load(path, kmer_bits=64, device=0)
+    t = torch.from_numpy(h0.image()).to(dev)
+    h = L.Mphf.from_device_image(t.data_ptr(), t.numel(), 0)
+    assert h.get_kmer_count() == h0.get_kmer_count() and h.info.device == 0
+    exp = [o(r, False) for r in recs]
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                for streaming in (True, False):
+                    if not np.array_equal(h(recs[i], streaming=streaming), exp[i]):
+                        errs.append(i)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(recs))]
+    [t_.start() for t_ in ths]
+    [t_.join() for t_ in ths]
+    assert not errs
+
+
+@pytest.mark.parametrize("kind,k,m,bits", [(0, 31, 20, 64), (1, 31, 20, 64), (0, 63, 20, 128)])
+def test_large_index_properties(tmp_path, kind, k, m, bits):
+    """10 M k-mers (too many for a full oracle pass in a test): the device codes are a bijection onto [0, n) in
+    streaming AND random mode, both modes agree, and a sampled slice equals the oracle."""
+    torch, dev = torch_dev()
+    n_rec, L_rec = 100, 100_000 + k - 1
+    flat, recs = synthetic_records(seed=3, n_records=n_rec, length=L_rec)
+    path = str(tmp_path / "big.lph")
+    L.build(recs, k, m, path, kind=kind, kmer_bits=bits, threads=0)
+    h = (L.Mphf if kind == 0 else L.MphfAlt).load(path, kmer_bits=bits, device=0)
+    n = n_rec * 100_000
+    assert h.get_kmer_count() == n
+    d_seq = torch.from_numpy(flat).to(dev)
+    seq_off = torch.arange(0, n_rec + 1, dtype=torch.int64, device=dev) * L_rec
+    out_off = torch.arange(0, n_rec + 1, dtype=torch.int64, device=dev) * 100_000
+    outs = []
+    for streaming in (True, False):
+        d_out = torch.empty(n, dtype=torch.int64, device=dev)
+        h.query_records(d_seq.data_ptr(), int(d_seq.numel()), seq_off.data_ptr(), n_rec, d_out.data_ptr(), out_off.data_ptr(), streaming)
+        torch.cuda.synchronize()
+        assert int(d_out.min()) == 0 and int(d_out.max()) == n - 1
+        assert int(torch.unique(d_out).numel()) == n  # bijection: every slot exactly once
+        outs.append(d_out)
+    assert torch.equal(outs[0], outs[1])
+    o = orc.Index(path, kind, bits)
+    for i in (0, 37, n_rec - 1):
+        assert np.array_equal(outs[0][i * 100_000:(i + 1) * 100_000].cpu().numpy().view(np.uint64), o(recs[i], True))
+    # packed random batch with repeats: same multiset of codes as the gathered positions
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    Q = 1 << 22
+    win = torch.randint(0, n, (Q,), generator=g, device=dev, dtype=torch.int64)
+    pos = (win // 100_000) * L_rec + win % 100_000
+    d_k = torch.empty(Q * (bits // 64), dtype=torch.int64, device=dev)
+    h.pack_kmers(d_seq.data_ptr(), pos.data_ptr(), Q, d_k.data_ptr())
+    d_o = torch.empty(Q, dtype=torch.int64, device=dev)
+    h.query_packed(d_k.data_ptr(), Q, d_o.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(d_o, outs[0][win])

@@ -1,0 +1,127 @@
+"""CPU tests of the product's host side: C-ABI surface, loader + cross-checks, flat image, index builder
+(byte-identical to the oracle's restatement of the reference build path), error behaviour.  No compute calls:
+the query path only exists on the GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import lphash_amd as L
+import orc
+from lphash_amd import _lib
+from util import random_records
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "lphq.h")).read()
+    declared = set(re.findall(r"\b(lphq_[a-z_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\b(lphq_[a-z_]+)\b", nm))
+    assert declared <= exported, declared - exported
+
+
+def test_no_torch_types_and_no_oracle_in_the_product():
+    """The product must not link/import the oracle or expose torch types (the C ABI is plain pointers/sizes)."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "lphash_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip", ".cuh")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "lph_oracle" not in src and "liblphoracle" not in src and "import orc" not in src, f
+    header = open(os.path.join(ROOT, "include", "lphq.h")).read()
+    assert "torch" not in header and "at::" not in header
+    ldd = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in ldd and "torch" not in ldd
+
+
+def golden(name):
+    return os.path.join(ROOT, "tests", "golden", name)
+
+
+@pytest.mark.parametrize("name,cls,bits", [("p_k31_m20_b64", L.Mphf, 64), ("p_k63_m20_b128", L.Mphf, 128), ("u_k31_m20_b64", L.MphfAlt, 64),
+                                           ("p_k21_m8_b64_fallback", L.Mphf, 64), ("u_k21_m8_b64_fallback", L.MphfAlt, 64)])
+def test_loader_reads_golden_files(name, cls, bits):
+    z = np.load(golden(name + ".npz"))
+    h = cls.load(golden(name + ".lph"), kmer_bits=bits)
+    assert (h.k, h.m, h.kmer_bits) == (int(z["k"]), int(z["m"]), bits)
+    assert h.get_kmer_count() == int(z["nkmers"]) and h.get_minimizer_L0() == int(z["distinct_minimizers"])
+    assert h.info.fallback_kmers == int(z["fallback_keys"])
+    assert h.info.file_bytes == os.path.getsize(golden(name + ".lph")) and h.info.device == -1
+    img = h.image()
+    assert img.size == h.info.image_bytes and img.size % 256 == 0
+    assert bytes(img[:8]) == b"LPQIMG01" and int(np.frombuffer(img[8:16].tobytes(), dtype=np.uint64)[0]) == img.size
+    # same bytes through lphq_open_memory
+    h2 = cls.from_bytes(open(golden(name + ".lph"), "rb").read(), kmer_bits=bits)
+    assert np.array_equal(h2.image(), img)
+
+
+def test_loader_errors(tmp_path):
+    good = open(golden("p_k31_m20_b64.lph"), "rb").read()
+    with pytest.raises(L.LphqError) as e:
+        L.Mphf.load(str(tmp_path / "missing.lph"), kmer_bits=64)
+    assert e.value.code == _lib.ERR_IO
+    for bad, why in ((good[:-9], "truncated"), (good + b"\0" * 8, "trailing"), (good[:40], "header only")):
+        with pytest.raises(L.LphqError) as e:
+            L.Mphf.from_bytes(bad, kmer_bits=64)
+        assert e.value.code == _lib.ERR_FORMAT, why
+    with pytest.raises(L.LphqError) as e:  # a query-p file opened as query-u
+        L.MphfAlt.from_bytes(good, kmer_bits=64)
+    assert e.value.code == _lib.ERR_FORMAT
+    with pytest.raises(L.LphqError) as e:
+        L.Mphf.from_bytes(good, kmer_bits=32)
+    assert e.value.code == _lib.ERR_ARG
+    k63 = open(golden("p_k63_m20_b128.lph"), "rb").read()
+    with pytest.raises(L.LphqError) as e:  # k=63 does not fit a 64-bit kmer_t (constants.hpp:16)
+        L.Mphf.from_bytes(k63, kmer_bits=64)
+    assert e.value.code == _lib.ERR_FORMAT
+    # a flipped redundant field must be caught, not silently mis-hash
+    corrupt = bytearray(good)
+    corrupt[2 + 8 * 7 + 8 * 3] ^= 0x10  # low byte of m_M inside minimizer_order
+    with pytest.raises(L.LphqError) as e:
+        L.Mphf.from_bytes(bytes(corrupt), kmer_bits=64)
+    assert e.value.code == _lib.ERR_FORMAT
+
+
+def test_queries_fail_loudly_without_a_device():
+    import torch
+
+    h = L.Mphf.load(golden("p_k31_m20_b64.lph"), kmer_bits=64)
+    with pytest.raises(L.LphqError) as e:  # not attached: no CPU fallback exists
+        h(b"ACGT" * 20, streaming=False)
+    assert e.value.code == _lib.ERR_STATE
+    if not torch.cuda.is_available():
+        with pytest.raises(L.LphqError) as e:
+            h.attach(0)
+        assert e.value.code == _lib.ERR_NO_DEVICE
+
+
+@pytest.mark.parametrize("k,m,bits,kind", [(31, 20, 64, 0), (31, 15, 128, 0), (63, 20, 128, 0), (31, 20, 64, 1), (15, 9, 64, 0), (31, 31, 64, 0),
+                                           (21, 8, 64, 0), (21, 8, 64, 1), (47, 17, 128, 1), (33, 5, 128, 0)])
+def test_builder_is_byte_identical_to_the_oracle_build(tmp_path, k, m, bits, kind):
+    """Product builder (position-parallel, multi-threaded) vs the oracle's line-by-line restatement of
+    from_string / classify / build_inverted_index / get_colliding_kmers: same bytes, for any thread count."""
+    recs = random_records(1234 + k + m, 14, max(k - 3, 1), 3000)  # includes records shorter than k
+    po, pp = str(tmp_path / "o.lph"), str(tmp_path / "p.lph")
+    try:
+        orc.build(recs, k, m, po, kind=kind, kmer_bits=bits)
+    except RuntimeError:
+        pytest.skip("duplicate k-mers in this random input")
+    for threads in (1, 3, 8):
+        L.build(recs, k, m, pp, kind=kind, kmer_bits=bits, threads=threads)
+        assert open(po, "rb").read() == open(pp, "rb").read()
+
+
+def test_builder_argument_errors(tmp_path):
+    recs = random_records(1, 2, 100, 200)
+    out = str(tmp_path / "x.lph")
+    for kw in (dict(k=32, m=20, kmer_bits=64), dict(k=31, m=32), dict(k=31, m=0), dict(k=31, m=20, c=2.0), dict(k=31, m=20, c=11.0),
+               dict(k=64, m=20, kmer_bits=128)):
+        kw.setdefault("kmer_bits", 64)
+        with pytest.raises(L.LphqError) as e:
+            L.build(recs, out_path=out, **kw)
+        assert e.value.code == _lib.ERR_ARG

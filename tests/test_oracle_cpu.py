@@ -1,0 +1,129 @@
+"""CPU tests of the oracle (oracle/lph_oracle.c): golden fixtures, the reference's own --check properties
+(bijection, range, streaming == random; build.cpp:53-70, mphf_utils.hpp:51-100) and known-answer checks of the
+pieces that do not depend on PTHash."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from util import random_records
+
+M64 = (1 << 64) - 1
+
+
+def murmur64a_py(data: bytes, seed: int) -> int:
+    """Independent restatement of the public MurmurHash64A (Appleby), used to cross-check the C one."""
+    m, r = 0xC6A4A7935BD1E995, 47
+    h = (seed ^ (len(data) * m)) & M64
+    nblocks = len(data) // 8
+    for i in range(nblocks):
+        k = int.from_bytes(data[8 * i:8 * i + 8], "little")
+        k = (k * m) & M64
+        k ^= k >> r
+        k = (k * m) & M64
+        h ^= k
+        h = (h * m) & M64
+    tail = data[8 * nblocks:]
+    if tail:
+        h ^= int.from_bytes(tail, "little")
+        h = (h * m) & M64
+    h ^= h >> r
+    h = (h * m) & M64
+    h ^= h >> r
+    return h
+
+
+def test_murmur64a_known_answers_and_cross_check():
+    assert orc.lib.orc_murmur64a(b"", 0, 0) == 0  # h = 0 ^ (0*m) -> stays 0 through the finaliser
+    rng = np.random.default_rng(5)
+    for n in list(range(0, 24)) + [31, 64, 100]:
+        for _ in range(5):
+            data = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+            seed = int(rng.integers(0, 2**63)) * 2 + int(rng.integers(0, 2))
+            assert orc.lib.orc_murmur64a(data, n, seed) == murmur64a_py(data, seed)
+
+
+def golden_cases():
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(here, "*.lph")))
+
+
+def split(flat, off):
+    return [flat[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_oracle_matches_golden(name, golden_dir):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    ix = orc.Index(os.path.join(golden_dir, name + ".lph"), int(z["kind"]), int(z["kmer_bits"]))
+    assert (ix.k, ix.m, ix.nkmers, ix.distinct_minimizers, ix.fallback_keys) == (
+        int(z["k"]), int(z["m"]), int(z["nkmers"]), int(z["distinct_minimizers"]), int(z["fallback_keys"]))
+    queries = [bytes(q) for q in split(z["queries"], z["q_off"])]
+    for q, s, r in zip(queries, split(z["streaming"], z["s_off"]), split(z["random"], z["r_off"])):
+        assert np.array_equal(ix(q, True), s)
+        assert np.array_equal(ix(q, False), r)
+
+
+def test_golden_set_is_not_empty():
+    assert len(golden_cases()) >= 6
+
+
+@pytest.mark.parametrize("k,m,bits,kind", [(31, 20, 64, 0), (31, 20, 128, 0), (63, 20, 128, 0), (31, 20, 64, 1), (15, 9, 64, 0),
+                                           (31, 31, 64, 0), (21, 8, 64, 0), (21, 8, 64, 1), (33, 5, 128, 0), (9, 1, 64, 1)])
+def test_check_properties(tmp_path, k, m, bits, kind):
+    """The reference's --check: random-mode codes are a bijection onto [0, n) and streaming == random."""
+    recs = random_records(k * 97 + m, 12, k, 2500)
+    kmers = set()
+    keep = []
+    for r in recs:  # the format requires duplicate-free k-mer sets: drop records that would add a duplicate
+        ks = [r[i:i + k] for i in range(len(r) - k + 1)]
+        if len(set(ks)) == len(ks) and not (set(ks) & kmers):
+            kmers |= set(ks)
+            keep.append(r)
+    path = str(tmp_path / "t.lph")
+    orc.build(keep, k, m, path, kind=kind, kmer_bits=bits)
+    ix = orc.Index(path, kind, bits)
+    assert ix.nkmers == len(kmers)
+    codes = []
+    for r in keep:
+        a, b = ix(r, True), ix(r, False)
+        assert len(a) == len(b) == len(r) - k + 1 and np.array_equal(a, b)
+        codes.append(b)
+    codes = np.concatenate(codes)
+    assert len(np.unique(codes)) == len(codes) and int(codes.max()) == ix.nkmers - 1
+
+
+def test_short_and_empty_records(tmp_path):
+    recs = random_records(3, 4, 100, 300)
+    path = str(tmp_path / "t.lph")
+    orc.build(recs, 31, 20, path)
+    ix = orc.Index(path, 0, 64)
+    for s in (True, False):
+        assert len(ix(b"", s)) == 0
+        assert len(ix(recs[0][:30], s)) == 0
+        assert len(ix(recs[0][:31], s)) == 1
+
+
+def test_query_packed_equals_contig_random(tmp_path):
+    from util import pack_kmers
+
+    for k, m, bits in ((31, 20, 64), (47, 17, 128)):
+        recs = random_records(k, 3, 200, 600)
+        path = str(tmp_path / f"t{k}.lph")
+        orc.build(recs, k, m, path, kmer_bits=bits)
+        ix = orc.Index(path, 0, bits)
+        r = recs[1]
+        pk = pack_kmers(r, range(len(r) - k + 1), k, bits)
+        assert np.array_equal(ix.query_packed(pk), ix(r, False))
+
+
+def test_load_rejects_garbage(tmp_path, golden_dir):
+    data = open(os.path.join(golden_dir, "p_k31_m20_b64.lph"), "rb").read()
+    p = tmp_path / "trunc.lph"
+    p.write_bytes(data[:-7])
+    with pytest.raises(RuntimeError):
+        orc.Index(str(p), 0, 64)
+    with pytest.raises(RuntimeError):
+        orc.Index(os.path.join(golden_dir, "p_k31_m20_b64.lph"), 1, 64)  # wrong kind

@@ -23,3 +23,15 @@ def pack_kmers(seq: bytes, positions, k, kmer_bits):
         out[i, 0] = v & 0xFFFFFFFFFFFFFFFF
         out[i, 1] = v >> 64
     return out[:, 0].copy() if kmer_bits == 64 else out.reshape(-1).copy()
+
+
+def dedup_records(recs, k):
+    """Keep only records that do not repeat a k-mer (inside themselves or of an earlier kept record): the index
+    format requires duplicate-free k-mer sets (README.md:112-116 of the reference)."""
+    seen, keep = set(), []
+    for r in recs:
+        ks = [r[i:i + k] for i in range(len(r) - k + 1)]
+        if len(set(ks)) == len(ks) and not (set(ks) & seen):
+            seen |= set(ks)
+            keep.append(r)
+    return keep
