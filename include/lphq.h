@@ -111,6 +111,10 @@ int lphq_query_records(const lphq_index* idx, const char* d_seq, size_t total_ba
 /* Pack windows of d_seq into kmer_t values: out[i] = string_to_integer_no_reverse(d_seq + d_pos[i], k). */
 int lphq_pack_kmers(const lphq_index* idx, const char* d_seq, const uint64_t* d_pos, size_t n, void* d_kmers, void* stream);
 
+/* Number of codes != LPHQ_INVALID in d_codes[0..n) (what vector.size() of the reference's streaming pass
+ * would be).  Synchronous: waits for the default stream. */
+int lphq_count_valid(const lphq_index* idx, const uint64_t* d_codes, size_t n, uint64_t* count);
+
 /* ---- host-buffer convenience: mirrors MPHF::operator()(contig, length, streaming) ----
  * Copies the record to the device, runs the GPU path, copies the codes back and (streaming
  * only) drops invalid windows, so *n_out is what the reference's vector.size() would be for
@@ -122,8 +126,18 @@ int lphq_query_contig(const lphq_index* idx, const char* contig, size_t length, 
  * In-memory build of a partitioned / unpartitioned LP-MPHF over the k-mers of the records
  * (src/partitioned_mphf.cpp:33-145, src/unpartitioned_mphf.cpp:23-136) and essentials::save
  * (src/build.cpp:28).  Host-side, multi-threaded. threads <= 0: all cores. */
+typedef struct lphq_build_stats {
+    uint64_t num_kmers;             /* nkmers                                               */
+    uint64_t num_records;           /* records read (total_contigs before the reference's --) */
+    uint64_t num_super_kmers;       /* all_minimizers.size()   (partitioned_mphf.cpp:82)     */
+    uint64_t distinct_minimizers;   /* unique_mms.size()                                     */
+    uint64_t colliding_super_kmers; /* coll_ids.size()         (partitioned_mphf.cpp:108)    */
+    uint64_t fallback_kmers;        /* k-mers handed to the fallback MPHF                    */
+    uint64_t file_bytes;            /* size of the serialized function                       */
+} lphq_build_stats;
 int lphq_build(const char* const* records, const size_t* lengths, size_t n_records, int k, int m,
-               uint64_t mm_seed, double c, int kind, int kmer_bits, int threads, const char* out_path);
+               uint64_t mm_seed, double c, int kind, int kmer_bits, int threads, const char* out_path,
+               lphq_build_stats* stats /* may be NULL */);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,11 @@ class Info(C.Structure):
     ]
 
 
+class BuildStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("num_kmers", "num_records", "num_super_kmers", "distinct_minimizers",
+                                          "colliding_super_kmers", "fallback_kmers", "file_bytes")]
+
+
 # every symbol include/lphq.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "lphq_last_error": (C.c_char_p, []),
@@ -46,10 +51,11 @@ SIGNATURES = {
     "lphq_query_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_void_p]),
     "lphq_pack_kmers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "lphq_count_valid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "lphq_query_contig": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
                                     C.POINTER(C.c_size_t)]),
     "lphq_build": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int, C.c_uint64,
-                             C.c_double, C.c_int, C.c_int, C.c_int, C.c_char_p]),
+                             C.c_double, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(BuildStats)]),
 }
 
 

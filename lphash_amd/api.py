@@ -27,8 +27,10 @@ def build(records, k, m, out_path, kind=PARTITIONED, kmer_bits=None, mm_seed=42,
     n = len(records)
     arr = (C.c_char_p * n)(*records)
     lens = (C.c_size_t * n)(*[len(r) for r in records])
+    stats = _lib.BuildStats()
     check(lib.lphq_build(arr, lens, n, int(k), int(m), int(mm_seed), float(c), int(kind), int(kmer_bits), int(threads),
-                         str(out_path).encode()))
+                         str(out_path).encode(), C.byref(stats)))
+    return {name: getattr(stats, name) for name, _ in stats._fields_}
 
 
 class _MphfBase:

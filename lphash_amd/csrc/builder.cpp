@@ -587,7 +587,7 @@ using namespace lphq;
 namespace lphq { void set_last_error(const std::string& s); }  // capi.cpp
 
 extern "C" int lphq_build(const char* const* records, const size_t* lengths, size_t n_records, int k_, int m_, uint64_t mm_seed, double c, int kind,
-                          int kmer_bits, int threads, const char* out_path) {
+                          int kmer_bits, int threads, const char* out_path, lphq_build_stats* stats) {
     auto fail = [&](int code, const std::string& msg) {
         set_last_error(msg);
         return code;
@@ -643,6 +643,7 @@ extern "C" int lphq_build(const char* const* records, const size_t* lengths, siz
     uint64_t nkmers = 0;
     for (const Run& r : runs) nkmers += r.size;
     (void)nkmers_upper;
+    const uint64_t n_super_kmers = runs.size();
 
     // ---- Part 2: classify (src/minimizer.cpp:5-50) + PTHash over the distinct minimizers -------------
     parallel_sort_by_key(runs, threads, 2 * m, [](const Run& r) { return r.mm; });
@@ -828,5 +829,14 @@ extern "C" int lphq_build(const char* const* records, const size_t* lengths, siz
     size_t put = fwrite(w.buf.data(), 1, w.buf.size(), fo);
     fclose(fo);
     if (put != w.buf.size()) return fail(LPHQ_ERR_IO, std::string("short write on ") + out_path);
+    if (stats) {
+        stats->num_kmers = nkmers;
+        stats->num_records = n_records;
+        stats->num_super_kmers = n_super_kmers;
+        stats->distinct_minimizers = D;
+        stats->colliding_super_kmers = colliding.size();
+        stats->fallback_kmers = x.fallback_kmer_order.num_keys;
+        stats->file_bytes = w.buf.size();
+    }
     return LPHQ_OK;
 }

@@ -243,6 +243,21 @@ extern "C" int lphq_pack_kmers(const lphq_index* idx, const char* d_seq, const u
     return LPHQ_OK;
 }
 
+extern "C" int lphq_count_valid(const lphq_index* cidx, const uint64_t* d_codes, size_t n, uint64_t* count) {
+    lphq_index* idx = const_cast<lphq_index*>(cidx);
+    REQUIRE_ATTACHED(idx);
+    if (!count || (n && !d_codes)) return fail(LPHQ_ERR_ARG, "null argument");
+    *count = 0;
+    if (n == 0) return LPHQ_OK;
+    DeviceGuard g(idx->device);
+    std::lock_guard<std::mutex> lk(idx->scratch_mu);
+    if (!idx->d_offs) HIP_TRY(hipMalloc((void**)&idx->d_offs, 4 * sizeof(uint64_t)));
+    HIP_TRY(hipMemsetAsync(idx->d_offs, 0, 8, nullptr));
+    HIP_TRY(launch_count_valid(d_codes, n, (unsigned long long*)idx->d_offs, nullptr));
+    HIP_TRY(hipMemcpy(count, idx->d_offs, 8, hipMemcpyDeviceToHost));
+    return LPHQ_OK;
+}
+
 extern "C" int lphq_query_contig(const lphq_index* cidx, const char* contig, size_t length, int streaming, uint64_t* out, size_t cap, size_t* n_out) {
     lphq_index* idx = const_cast<lphq_index*>(cidx);
     REQUIRE_ATTACHED(idx);

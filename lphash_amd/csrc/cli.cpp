@@ -1,0 +1,348 @@
+// cli.cpp -- `lphash` command line, drop-in for the reference driver (src/lphash.cpp:21-35):
+//   lphash query-p|query-u -i <mphf> -q <fasta|fastq[.gz]>      src/query.cpp:14-88
+//   lphash build-p|build-u -i <fasta[.gz]> -k K -m M [-s seed] [-t threads] [-o out] [-c c] [--check] [--verbose]
+//                                                               src/build.cpp:10-70, src/parser_build.cpp:7-92
+// Same flags, same CSV on stdout, same exit codes (1 usage/parse error, 2 cannot open the query file).
+// Extra flags (all optional, defaults keep the reference behaviour): --kmer-bits 64|128 (the reference's
+// compile-time kmer_t, default 128 like include/compile_constants.tpd:1; 64 reproduces a `uint64_t` build),
+// --device N, --batch-mb N.  The work itself runs on the GPU through the C ABI (include/lphq.h).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../include/lphq.h"
+#include "fastx.hpp"
+
+namespace {
+
+int help(const char* arg0) {
+    std::cerr << "LP-Hash: (L)ocality (P)reserving Minimal Perfect (Hash)ing of k-mers\n\n";
+    std::cerr << "Usage: " << arg0 << " <tool> ...\n\n";
+    std::cerr << "Available tools:\n";
+    std::cerr << "  build-p      build a partitioned LP-MPHF\n";
+    std::cerr << "  build-u      build an unpartitioned LP-MPHF\n";
+    std::cerr << "  query-p      query a partitioned LP-MPHF\n";
+    std::cerr << "  query-u      query an unpartitioned LP-MPHF\n";
+    return 1;
+}
+
+struct Args {
+    std::vector<std::pair<std::string, std::string>> kv;
+    std::vector<std::string> flags;
+    bool help = false, bad = false;
+    const std::string* get(const std::string& k) const {
+        for (auto& p : kv)
+            if (p.first == k) return &p.second;
+        return nullptr;
+    }
+    bool has(const std::string& f) const {
+        for (auto& x : flags)
+            if (x == f) return true;
+        return false;
+    }
+};
+Args parse(int argc, char** argv, const std::vector<std::string>& valued, const std::vector<std::string>& boolean) {
+    Args a;
+    for (int i = 1; i < argc; ++i) {
+        std::string s = argv[i];
+        if (s == "-h" || s == "--help") {
+            a.help = true;
+            continue;
+        }
+        bool known = false;
+        for (auto& v : valued)
+            if (s == v) {
+                known = true;
+                if (i + 1 >= argc) a.bad = true;
+                else a.kv.emplace_back(s, argv[++i]);
+            }
+        for (auto& b : boolean)
+            if (s == b) {
+                known = true;
+                a.flags.push_back(s);
+            }
+        if (!known) a.bad = true;
+    }
+    return a;
+}
+
+struct DeviceBatch {
+    char* d_seq = nullptr;
+    uint64_t* d_offs = nullptr;  // seq offsets then out offsets
+    uint64_t* d_out = nullptr;
+    size_t seq_cap = 0, rec_cap = 0, out_cap = 0;
+    bool ensure(size_t bases, size_t recs, size_t outs) {
+        if (bases + 64 > seq_cap) {
+            if (d_seq) (void)hipFree(d_seq);
+            seq_cap = (bases + 64) * 5 / 4;
+            if (hipMalloc((void**)&d_seq, seq_cap) != hipSuccess) return false;
+        }
+        if (2 * (recs + 1) > rec_cap) {
+            if (d_offs) (void)hipFree(d_offs);
+            rec_cap = 2 * (recs + 1) * 5 / 4;
+            if (hipMalloc((void**)&d_offs, rec_cap * 8) != hipSuccess) return false;
+        }
+        if (outs + 1 > out_cap) {
+            if (d_out) (void)hipFree(d_out);
+            out_cap = (outs + 1) * 5 / 4;
+            if (hipMalloc((void**)&d_out, out_cap * 8) != hipSuccess) return false;
+        }
+        return true;
+    }
+};
+
+// One pass of src/query.cpp:48-56 / :68-76 over the whole file, batched: returns false if the file cannot be opened.
+bool query_pass(lphq_index* idx, const lphq_info& info, const std::string& path, int streaming, size_t batch_bases, DeviceBatch& db,
+                uint64_t& total_kmers, uint64_t& elapsed_us, std::string& err) {
+    lphq::FastxReader rd(path.c_str());
+    if (!rd.ok()) return false;
+    auto t0 = std::chrono::high_resolution_clock::now();
+    std::string seq, flat;
+    std::vector<uint64_t> offs, out_offs;
+    total_kmers = 0;
+    auto flush = [&]() -> bool {
+        const size_t n = offs.size();
+        if (n == 0) return true;
+        std::vector<uint64_t> all(2 * (n + 1));
+        uint64_t so = 0, oo = 0;
+        for (size_t i = 0; i < n; ++i) {
+            all[i] = so;
+            all[n + 1 + i] = oo;
+            so += offs[i];
+            oo += offs[i] >= info.k ? offs[i] - info.k + 1 : 0;
+        }
+        all[n] = so;
+        all[2 * n + 1] = oo;
+        if (oo) {
+            if (!db.ensure(so, n, oo)) {
+                err = "device allocation failed";
+                return false;
+            }
+            if (hipMemcpy(db.d_seq, flat.data(), so, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(db.d_offs, all.data(), all.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+                err = "host to device copy failed";
+                return false;
+            }
+            if (lphq_query_records(idx, db.d_seq, so, db.d_offs, n, db.d_out, db.d_offs + n + 1, streaming, nullptr) != LPHQ_OK) {
+                err = lphq_last_error();
+                return false;
+            }
+            uint64_t valid = 0;
+            if (lphq_count_valid(idx, db.d_out, oo, &valid) != LPHQ_OK) {  // synchronises; hashes.size() of the reference
+                err = lphq_last_error();
+                return false;
+            }
+            total_kmers += valid;
+        }
+        flat.clear();
+        offs.clear();
+        return true;
+    };
+    while (rd.next(seq)) {
+        flat += seq;
+        offs.push_back(seq.size());
+        if (flat.size() >= batch_bases && !flush()) return true;
+    }
+    if (!flush()) return true;
+    auto t1 = std::chrono::high_resolution_clock::now();
+    elapsed_us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count();
+    return true;
+}
+
+int query_main(int kind, int argc, char** argv) {
+    Args a = parse(argc, argv, {"-i", "-q", "--kmer-bits", "--device", "--batch-mb"}, {});
+    if (a.help || a.bad || !a.get("-i") || !a.get("-q")) {
+        std::cerr << "Usage: " << argv[0] << " [-h,--help] -i mphf -q query_filename [--kmer-bits 64|128] [--device N] [--batch-mb N]\n\n"
+                  << " -i mphf\n\tREQUIRED: LP-Hash MPHF saved on disk.\n\n"
+                  << " -q query_filename\n\tREQUIRED: Must be a FASTA file (.fa/fasta extension) compressed with gzip (.gz) or not.\n\n"
+                  << " --kmer-bits\n\tk-mer word width the MPHF was built with (the reference's compile-time kmer_t): 128 (default) or 64.\n";
+        return 1;  // ParseError -> 1, src/query.cpp:31-33
+    }
+    const std::string mphf_filename = *a.get("-i"), query_filename = *a.get("-q");
+    const int kmer_bits = a.get("--kmer-bits") ? std::atoi(a.get("--kmer-bits")->c_str()) : 128;
+    const int device = a.get("--device") ? std::atoi(a.get("--device")->c_str()) : 0;
+    const size_t batch_bases = (size_t)(a.get("--batch-mb") ? std::atol(a.get("--batch-mb")->c_str()) : 512) << 20;
+    lphq_index* idx = nullptr;
+    if (lphq_open(mphf_filename.c_str(), kind, kmer_bits, &idx) != LPHQ_OK || lphq_attach(idx, device) != LPHQ_OK) {
+        std::cerr << "[Error] " << lphq_last_error() << "\n";  // the reference dies in essentials::load here
+        if (idx) lphq_close(idx);
+        return 2;
+    }
+    lphq_info info;
+    lphq_get_info(idx, &info);
+    (void)hipSetDevice(device);
+    DeviceBatch db;
+    uint64_t total_on = 0, total_off = 0, t_on = 0, t_off = 0;
+    std::string err;
+    for (int pass = 0; pass < 2; ++pass) {
+        bool opened = query_pass(idx, info, query_filename, pass == 0, batch_bases, db, pass == 0 ? total_on : total_off, pass == 0 ? t_on : t_off, err);
+        if (!opened) {
+            std::cerr << "Unable to open the input file " << query_filename << "\n";
+            lphq_close(idx);
+            return 2;  // src/query.cpp:43-46
+        }
+        if (!err.empty()) {
+            std::cerr << "[Error] " << err << "\n";
+            lphq_close(idx);
+            return 3;
+        }
+    }
+    // src/query.cpp:83-86
+    std::cout << query_filename << "," << mphf_filename << "," << total_on << "," << static_cast<double>(t_on * 1000) / total_on << ","
+              << static_cast<double>(t_off * 1000) / total_off << std::endl;
+    lphq_close(idx);
+    return 0;
+}
+
+int build_main(int kind, int argc, char** argv) {
+    Args a = parse(argc, argv, {"-i", "-k", "-m", "-s", "-t", "-o", "-d", "-c", "--max-memory", "--kmer-bits", "--device"}, {"--check", "--verbose"});
+    if (a.help || a.bad || !a.get("-i") || !a.get("-k") || !a.get("-m")) {
+        std::cerr << "Usage: " << argv[0]
+                  << " [-h,--help] -i input_filename -k k -m m [-s seed] [-t threads] [-o output_filename] [-d tmp_dirname] [-c c] "
+                     "[--max-memory max-memory] [--check] [--verbose] [--kmer-bits 64|128]\n";
+        if (!a.help) std::cerr << "Unable to parse the arguments\n";
+        return 2;  // ParseError -> 2, src/build.cpp:14-16
+    }
+    const std::string input = *a.get("-i");
+    const int k = std::atoi(a.get("-k")->c_str()), m = std::atoi(a.get("-m")->c_str());
+    const int kmer_bits = a.get("--kmer-bits") ? std::atoi(a.get("--kmer-bits")->c_str()) : 128;
+    const uint64_t seed = a.get("-s") ? std::strtoull(a.get("-s")->c_str(), nullptr, 10) : 42;  // constants::default_seed
+    const int threads = a.get("-t") ? std::atoi(a.get("-t")->c_str()) : 1;                      // constants::default_num_threads
+    const double c = a.get("-c") ? std::atof(a.get("-c")->c_str()) : 3.0;                       // constants::c
+    const bool verbose = a.has("--verbose"), check = a.has("--check");
+    // OptionError -> 3, src/build.cpp:17-20, parser_build.cpp:64-88
+    if (kmer_bits != 64 && kmer_bits != 128) {
+        std::cerr << "--kmer-bits must be 64 or 128" << std::endl;
+        return 3;
+    }
+    if (k > kmer_bits / 2 - 1) {
+        std::cerr << "k cannot be larger than " << kmer_bits / 2 - 1 << std::endl;
+        return 3;
+    }
+    if (m > k) {
+        std::cerr << "m cannot be larger than k" << std::endl;
+        return 3;
+    }
+    if (c > 10.0 || c < 3.0) {
+        std::cerr << "3.0 <= c <= 10.0" << std::endl;
+        return 3;
+    }
+    auto t0 = std::chrono::high_resolution_clock::now();
+    std::vector<std::string> recs;
+    {
+        lphq::FastxReader rd(input.c_str());
+        if (!rd.ok()) {
+            std::cerr << "Unable to open the input file " << input << "\n";
+            return 4;  // the reference throws std::runtime_error here (partitioned_mphf.cpp:66-67)
+        }
+        std::string seq;
+        while (rd.next(seq)) recs.push_back(seq);
+    }
+    std::vector<const char*> ptrs(recs.size());
+    std::vector<size_t> lens(recs.size());
+    for (size_t i = 0; i < recs.size(); ++i) {
+        ptrs[i] = recs[i].data();
+        lens[i] = recs[i].size();
+    }
+    std::string out = a.get("-o") ? *a.get("-o") : "";
+    const bool temp_out = out.empty();
+    if (temp_out) out = "/tmp/lphash_build_" + std::to_string((long)getpid()) + ".lph";
+    lphq_build_stats st;
+    if (verbose) std::cerr << "Part 1-4: super-k-mers, minimizer MPHF, inverted index, fallback MPHF\n";
+    if (lphq_build(ptrs.data(), lens.data(), recs.size(), k, m, seed, c, kind, kmer_bits, threads, out.c_str(), &st) != LPHQ_OK) {
+        std::cerr << "[Error] " << lphq_last_error() << "\n";
+        return 4;
+    }
+    // partitioned_mphf.cpp:138-144 (the last field is the serialized size: the reference's num_bits() adds
+    // sizeof(pthash::build_configuration), which has no counterpart here)
+    const uint64_t total_contigs = st.num_records > 0 ? st.num_records - 1 : 0;
+    std::cout << input << "," << k << "," << m << "," << static_cast<double>(st.colliding_super_kmers) / st.distinct_minimizers << ","
+              << 2.0 / ((k - m + 1) + 1) << "," << static_cast<double>(st.num_super_kmers) / st.num_kmers << ","
+              << static_cast<double>(total_contigs) / st.num_kmers << "," << static_cast<double>(st.file_bytes * 8) / st.num_kmers << "\n";
+    auto t1 = std::chrono::high_resolution_clock::now();
+    std::cerr << "function built in " << std::chrono::duration_cast<std::chrono::seconds>(t1 - t0).count() << " [sec]" << std::endl;
+    int rc = 0;
+    if (check) {  // src/build.cpp:53-70 on the GPU path: collisions/range, streaming == random, perfection
+        std::cerr << "Checking...\n";
+        const int device = a.get("--device") ? std::atoi(a.get("--device")->c_str()) : 0;
+        lphq_index* idx = nullptr;
+        if (lphq_open(out.c_str(), kind, kmer_bits, &idx) != LPHQ_OK || lphq_attach(idx, device) != LPHQ_OK) {
+            std::cerr << "[Error] " << lphq_last_error() << "\n";
+            if (idx) lphq_close(idx);
+            return 4;
+        }
+        lphq_info info;
+        lphq_get_info(idx, &info);
+        std::cerr << "[Info] Loaded " << info.file_bytes * 8 << " bits\n";
+        std::vector<uint64_t> population((st.num_kmers + 63) / 64, 0);
+        bool good = true;
+        std::vector<uint64_t> a_codes, b_codes;
+        for (size_t i = 0; i < recs.size() && good; ++i) {
+            if (lens[i] < (size_t)k) continue;
+            const size_t nw = lens[i] - k + 1;
+            a_codes.resize(nw);
+            b_codes.resize(nw);
+            size_t na = 0, nb = 0;
+            if (lphq_query_contig(idx, ptrs[i], lens[i], 0, a_codes.data(), nw, &na) != LPHQ_OK ||
+                lphq_query_contig(idx, ptrs[i], lens[i], 1, b_codes.data(), nw, &nb) != LPHQ_OK) {
+                std::cerr << "[Error] " << lphq_last_error() << "\n";
+                good = false;
+                break;
+            }
+            for (size_t j = 0; j < na && good; ++j) {
+                const uint64_t hsh = a_codes[j];
+                if (hsh >= st.num_kmers) {
+                    std::cerr << "[Error] overflow : " << hsh << " > " << st.num_kmers << std::endl;
+                    good = false;
+                } else if ((population[hsh >> 6] >> (hsh & 63)) & 1) {
+                    std::cerr << "[Error] collision at position (hash) : " << hsh << std::endl;
+                    good = false;
+                } else
+                    population[hsh >> 6] |= 1ULL << (hsh & 63);
+            }
+            if (good && (na != nb || std::memcmp(a_codes.data(), b_codes.data(), na * 8) != 0)) {
+                std::cerr << "[Error] different hashes, maybe there were some Ns in the input (not supported as of now)\n";
+                good = false;
+            }
+        }
+        if (good) {
+            bool perfect = true;
+            for (uint64_t i = 0; i < st.num_kmers; ++i)
+                if (!((population[i >> 6] >> (i & 63)) & 1)) perfect = false;
+            if (!perfect) {
+                std::cerr << "[Error] Not all k-mers have been marked by a hash" << std::endl;
+                rc = 5;
+            } else
+                std::cerr << "[Info] Everything is ok\n";
+        } else
+            rc = 5;
+        lphq_close(idx);
+    }
+    if (verbose) {
+        std::cerr << "Statistics:\n";
+        std::cerr << "Total number of k-mers: " << st.num_kmers << "\n";
+        std::cerr << "Total number of k-mers belonging to ambiguous minimizers: " << st.fallback_kmers << "\n";
+        std::cerr << "xi = " << static_cast<double>(st.fallback_kmers) / st.num_kmers << "\n";
+        std::cerr << "Total size in bits : " << st.file_bytes * 8 << "\n";
+        std::cerr << "\tequivalent to : " << static_cast<double>(st.file_bytes * 8) / st.num_kmers << " bits/k-mer\n";
+    }
+    if (temp_out) std::remove(out.c_str());
+    return rc;
+}
+
+}  // namespace
+
+int main(int argc, char* argv[]) {
+    if (argc < 2) return help(argv[0]);
+    const std::string tool = argv[1];
+    if (tool == "build-p") return build_main(LPHQ_PARTITIONED, argc - 1, argv + 1);
+    if (tool == "build-u") return build_main(LPHQ_UNPARTITIONED, argc - 1, argv + 1);
+    if (tool == "query-p") return query_main(LPHQ_PARTITIONED, argc - 1, argv + 1);
+    if (tool == "query-u") return query_main(LPHQ_UNPARTITIONED, argc - 1, argv + 1);
+    std::cerr << "Unsupported tool '" << tool << "'." << std::endl;
+    return help(argv[0]);
+}

@@ -1,0 +1,95 @@
+// fastx.hpp -- FASTA/FASTQ(.gz) record reader with the record semantics of the reference's kseq
+// (external/kseq.h:192-240): a header starts at any '>' or '@' once the previous record is complete; the
+// sequence is every following line, concatenated, until a line that starts with '>', '@' or '+'; '\r' before
+// '\n' is dropped; a FASTQ quality string must have the length of the sequence or reading stops.
+#pragma once
+#include <zlib.h>
+
+#include <string>
+#include <vector>
+
+namespace lphq {
+
+class FastxReader {
+public:
+    explicit FastxReader(const char* path) : fp_(gzopen(path, "r")), buf_(1 << 22) {
+        if (fp_) gzbuffer(fp_, 1 << 20);
+    }
+    ~FastxReader() {
+        if (fp_) gzclose(fp_);
+    }
+    bool ok() const { return fp_ != nullptr; }
+
+    // Next record's sequence into seq; false at end of input or on a malformed FASTQ record (kseq_read < 0).
+    bool next(std::string& seq) {
+        int c;
+        if (last_char_ == 0) {
+            while ((c = getc()) >= 0 && c != '>' && c != '@') {
+            }
+            if (c < 0) return false;
+            last_char_ = c;
+        }
+        seq.clear();
+        // name up to the first white space, then the rest of the header line (comment)
+        while ((c = getc()) >= 0 && c != ' ' && c != '\t' && c != '\n' && c != '\v' && c != '\f' && c != '\r') {
+        }
+        if (c < 0) return false;  // header without a line end: kseq returns EOF here
+        if (c != '\n') skip_line();
+        while ((c = getc()) >= 0 && c != '>' && c != '+' && c != '@') {
+            if (c == '\n') continue;
+            seq.push_back((char)c);
+            append_line(seq);
+        }
+        if (c == '>' || c == '@') last_char_ = c;
+        if (c != '+') return true;  // FASTA
+        skip_line();
+        size_t qlen = 0;
+        bool eof = false;
+        while (qlen < seq.size() && !eof) qlen += count_line(eof);
+        last_char_ = 0;
+        return qlen == seq.size();
+    }
+
+private:
+    int getc() {
+        if (pos_ >= end_) {
+            if (eof_) return -1;
+            int n = gzread(fp_, buf_.data(), (unsigned)buf_.size());
+            pos_ = 0;
+            end_ = n > 0 ? (size_t)n : 0;
+            if (n <= 0) {
+                eof_ = true;
+                return -1;
+            }
+        }
+        return (unsigned char)buf_[pos_++];
+    }
+    void skip_line() {
+        int c;
+        while ((c = getc()) >= 0 && c != '\n') {
+        }
+    }
+    void append_line(std::string& s) {
+        int c;
+        while ((c = getc()) >= 0 && c != '\n') s.push_back((char)c);
+        if (s.size() > 1 && s.back() == '\r') s.pop_back();
+    }
+    size_t count_line(bool& eof) {
+        int c, last = 0;
+        size_t n = 0;
+        while ((c = getc()) >= 0 && c != '\n') {
+            ++n;
+            last = c;
+        }
+        if (c < 0) eof = true;
+        if (n > 1 && last == '\r') --n;
+        return n;
+    }
+    gzFile fp_;
+    std::vector<char> buf_;
+    size_t pos_ = 0, end_ = 0;
+    bool eof_ = false;
+    int last_char_ = 0;
+};
+
+}  // namespace lphq

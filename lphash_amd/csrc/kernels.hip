@@ -370,6 +370,17 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const lphq_image_
 }
 
 // ------------------------------------------------------------------------------------------
+// number of valid codes (size of the reference's result vector for a streaming pass)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_count_valid(const uint64_t* __restrict__ codes, size_t n, unsigned long long* __restrict__ count) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    unsigned long long c = 0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) c += codes[i] != ~0ull;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 static inline int grid_for(size_t n, int per_block, int max_blocks) {
@@ -404,6 +415,12 @@ hipError_t launch_pack_kmers(const lphq_image_header& H, const char* d_seq, cons
     const int grid = grid_for(n, kBlock, 256 * 16);
     if (H.kmer_bits == 128) k_pack_kmers<true><<<grid, kBlock, 0, stream>>>(d_seq, d_pos, n, H.k, (uint64_t*)d_kmers);
     else k_pack_kmers<false><<<grid, kBlock, 0, stream>>>(d_seq, d_pos, n, H.k, (uint64_t*)d_kmers);
+    return hipGetLastError();
+}
+
+hipError_t launch_count_valid(const uint64_t* d_codes, size_t n, unsigned long long* d_count, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    k_count_valid<<<grid_for(n, kBlock * 8, 256 * 8), kBlock, 0, stream>>>(d_codes, n, d_count);
     return hipGetLastError();
 }
 

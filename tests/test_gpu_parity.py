@@ -222,3 +222,39 @@ def test_large_index_properties(tmp_path, kind, k, m, bits):
     h.query_packed(d_k.data_ptr(), Q, d_o.data_ptr())
     torch.cuda.synchronize()
     assert torch.equal(d_o, outs[0][win])
+
+
+def test_cli_query_end_to_end(tmp_path):
+    """`lphash build-p --check` then `lphash query-p` on a FASTA.gz: 5-field CSV of src/query.cpp:83-86, exit codes."""
+    import gzip
+    import subprocess
+
+    exe = os.path.join(ROOT, "lphash_amd", "lphash")
+    recs = random_records(5, 20, 50, 5000)
+    fa = tmp_path / "idx.fa.gz"
+    with gzip.open(fa, "wb") as f:
+        for i, rec in enumerate(recs):
+            f.write(b">r%d\n%s\n" % (i, rec))
+    fq = tmp_path / "q.fastq"
+    with open(fq, "wb") as f:
+        for i, rec in enumerate(recs[:7]):
+            f.write(b"@q%d\n%s\n+\n%s\n" % (i, rec, b"I" * len(rec)))
+    lph = tmp_path / "x.lph"
+    r = subprocess.run([exe, "build-p", "-i", str(fa), "-k", "31", "-m", "20", "-o", str(lph), "--kmer-bits", "64", "-t", "8", "--check"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "Everything is ok" in r.stderr, r.stderr
+    for q, nrec in ((fa, recs), (fq, recs[:7])):
+        r = subprocess.run([exe, "query-p", "-i", str(lph), "-q", str(q), "--kmer-bits", "64"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        f = r.stdout.strip().split(",")
+        assert len(f) == 5 and f[0] == str(q) and f[1] == str(lph)
+        assert int(f[2]) == sum(max(0, len(x) - 30) for x in nrec) and float(f[3]) > 0 and float(f[4]) > 0
+    r = subprocess.run([exe, "query-p", "-i", str(lph), "-q", str(tmp_path / "missing.fa"), "--kmer-bits", "64"], capture_output=True, text=True)
+    assert r.returncode == 2 and "Unable to open the input file" in r.stderr
+    # a query-u file through query-p is rejected, not mis-hashed
+    lpu = tmp_path / "u.lph"
+    subprocess.run([exe, "build-u", "-i", str(fa), "-k", "31", "-m", "20", "-o", str(lpu), "--kmer-bits", "64"], check=True, capture_output=True)
+    r = subprocess.run([exe, "query-p", "-i", str(lpu), "-q", str(fa), "--kmer-bits", "64"], capture_output=True, text=True)
+    assert r.returncode == 2
+    r = subprocess.run([exe, "query-u", "-i", str(lpu), "-q", str(fa), "--kmer-bits", "64"], capture_output=True, text=True)
+    assert r.returncode == 0 and int(r.stdout.split(",")[2]) == sum(max(0, len(x) - 30) for x in recs)

@@ -125,3 +125,34 @@ def test_builder_argument_errors(tmp_path):
         with pytest.raises(L.LphqError) as e:
             L.build(recs, out_path=out, **kw)
         assert e.value.code == _lib.ERR_ARG
+
+
+def test_cli_usage_and_build(tmp_path):
+    """`lphash` CLI: usage/exit codes of src/lphash.cpp:21-35, build-p writes the same bytes as the library call."""
+    import gzip
+
+    exe = os.path.join(ROOT, "lphash_amd", "lphash")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "Available tools" in r.stderr and "query-p" in r.stderr
+    r = subprocess.run([exe, "frobnicate"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Unsupported tool 'frobnicate'." in r.stderr
+    r = subprocess.run([exe, "query-p", "-i", "x.lph"], capture_output=True, text=True)  # -q missing -> ParseError -> 1
+    assert r.returncode == 1
+    recs = random_records(77, 9, 40, 3000)
+    fa = tmp_path / "in.fa.gz"
+    with gzip.open(fa, "wb") as f:
+        for i, rec in enumerate(recs):
+            f.write(b">rec%d some comment\n" % i)
+            for j in range(0, len(rec), 70):  # multi-line FASTA, CRLF on some lines
+                f.write(rec[j:j + 70] + (b"\r\n" if (i + j) % 3 == 0 else b"\n"))
+    out = tmp_path / "cli.lph"
+    r = subprocess.run([exe, "build-p", "-i", str(fa), "-k", "31", "-m", "20", "-o", str(out), "--kmer-bits", "64", "-t", "4"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    fields = r.stdout.strip().split(",")
+    assert fields[0] == str(fa) and fields[1:3] == ["31", "20"] and len(fields) == 8
+    lib_out = tmp_path / "lib.lph"
+    L.build(recs, 31, 20, str(lib_out), kmer_bits=64, threads=2)
+    assert out.read_bytes() == lib_out.read_bytes()
+    r = subprocess.run([exe, "build-p", "-i", str(fa), "-k", "33", "-m", "20", "--kmer-bits", "64"], capture_output=True, text=True)
+    assert r.returncode == 3 and "k cannot be larger than 31" in r.stderr  # OptionError -> 3, src/build.cpp:17-20
