@@ -250,10 +250,18 @@ def main():
             "kernel_ms": kernel_ms,
             "parity_vs_oracle": parity,
         }
+        traffic = None
+        try:  # HBM bytes per launch from the committed PMC passes of this exact workload (never measured inside this run)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            key = f"{args.mode}|{args.kind}|k{k}|m{m}|n{nk}|b{args.batch_log2 if args.mode == 'random' else 0}"
+            if key in tj:
+                traffic = tj[key]["bytes_per_unit"] * units
+        except (OSError, ValueError, KeyError):
+            pass
         if bpl is not None:
             achieved = bpl * units / (kernel_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                               "traffic": None, "bytes_per_lookup": bpl, "kernel": "k_query_packed" if args.mode == "random" else "k_query_tiles_stream"}
+                               "traffic": traffic, "bytes_per_lookup": bpl, "kernel": "k_query_packed" if args.mode == "random" else "k_query_tiles_stream"}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if build_s is not None:
