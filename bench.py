@@ -129,14 +129,20 @@ def main():
     if world > 1:
         from lphash_amd.dist import broadcast_image
 
+        dist.barrier()  # the index file exists and rank 0 is attached
         torch.cuda.synchronize()
         t0 = time.time()
-        image_t = broadcast_image(h.image() if rank == 0 else None, dist, dev, src=0)  # RCCL over xGMI: the only collective of the job
-        torch.cuda.synchronize()
-        bcast_s = time.time() - t0
-        if rank != 0:
-            h = cls.from_device_image(image_t.data_ptr(), image_t.numel(), local_rank)
-        log(f"[bench r{rank}] image broadcast {image_t.numel() / 1e6:.1f} MB in {bcast_s * 1e3:.1f} ms")
+        try:
+            image_t = broadcast_image(h.image() if rank == 0 else None, dist, dev, src=0)  # RCCL over xGMI: the only collective of the job
+            torch.cuda.synchronize()
+            bcast_s = time.time() - t0
+            if rank != 0:
+                h = cls.from_device_image(image_t.data_ptr(), image_t.numel(), local_rank)
+            log(f"[bench r{rank}] image broadcast {image_t.numel() / 1e6:.1f} MB in {bcast_s * 1e3:.1f} ms")
+        except Exception as e:  # noqa: BLE001  -- distribution fallback only (all ranks share the node-local cache); compute is unchanged
+            log(f"[bench r{rank}] RCCL image broadcast failed ({e!r}); loading the image from {path} instead")
+            if rank != 0:
+                h = cls.load(path, kmer_bits=kmer_bits, device=local_rank)
 
     stream = torch.cuda.current_stream().cuda_stream
     d_seq = torch.from_numpy(flat).to(dev)
@@ -194,7 +200,7 @@ def main():
     # ---- parity of what was just measured + CPU baseline (oracle = checker, rank 0, N=1 only) ----
     cpu = None
     parity = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import orc
 
