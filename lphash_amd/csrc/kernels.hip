@@ -87,7 +87,6 @@ __global__ __launch_bounds__(kBlock) void k_pack_kmers(const char* __restrict__ 
 // tiles over concatenated records
 // ------------------------------------------------------------------------------------------
 constexpr int kTileW = 2048;  // window starts per workgroup, random-over-records kernel
-constexpr int kStreamTileW = 1024;  // window starts per workgroup, streaming kernel (LDS ~19 KB -> 8 workgroups / CU)
 // 2-bit packed u32 words (16 bases each, first base in the top bits) for TW window starts + k-1 (k <= 63) overlap
 constexpr int tile_words(int tw) { return (tw + 64) / 16; }
 constexpr int kTileWords = tile_words(kTileW);
@@ -205,36 +204,56 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_random(const lphq_image_
 // super-k-mer get hval +- 1.  Because the closed forms of query() are linear in the offset p of the
 // minimizer (SURVEY section 8a note 3), the same codes come out position-parallel:
 //   A  bases of the tile -> 2-bit words + bad-base bitmask in LDS
-//   B  one MurmurHash2_64 per m-mer position (partitioned_mphf.hpp:116), all lanes
-//   C  van Herk / Gil-Werman sliding minimum: per block of B <= W positions the leftmost prefix / suffix
-//      arg-minima; a window's leftmost minimum = best of <= 5 block terms (ties keep the left one,
-//      as the strict `>` comparisons of partitioned_mphf.hpp:122,150-163 do)
+//   B  one MurmurHash2_64 per m-mer position (partitioned_mphf.hpp:116); the tile is sized so that the
+//      positions are exactly 4 per lane
+//   C  each lane takes 4 consecutive windows: their W+3 hashes are read once; the W-3 positions common to
+//      all four are reduced once, the 3+3 edge positions as suffix / prefix minima.  Ties keep the LEFT
+//      position, as the strict `>` comparisons of partitioned_mphf.hpp:122,150-163 do
 //   D  windows whose minimizer position differs from their left neighbour's are super-k-mer leaders;
-//      they are compacted into an LDS queue so the gather chain runs with dense lanes
+//      they are compacted (wave ballots) into an LDS queue so the gather chain runs with dense lanes
 //   E  leaders: PTHash + wavelet block + plane block -> (base, mode) stored by minimizer position
 //   F  every window: hval = base +- p (or the per-k-mer fallback lookup for colliding minimizers,
-//      partitioned_mphf.hpp:133-135)
+//      partitioned_mphf.hpp:133-135), coalesced stores
 // Windows holding a non-ACGT base get LPHQ_INVALID (the reference emits nothing for them).
+constexpr int kStreamPos = 1024;  // m-mer positions per tile (4 per lane)
+__host__ __device__ inline uint32_t stream_tile_windows(uint32_t W) { return (uint32_t)(kStreamPos - (int)W + 1) & ~15u; }
+
+struct HashPos {
+    uint64_t h;
+    uint32_t p;
+};
+__device__ __forceinline__ void take_if_less(HashPos& m, uint64_t h, uint32_t p) {  // strict: the left one wins ties
+    const bool lt = h < m.h;
+    m.h = lt ? h : m.h;
+    m.p = lt ? p : m.p;
+}
+
 template <int KIND, bool K128, int P>
 __global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const lphq_image_header H, const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
                                                                 uint64_t shift, uint64_t total, const uint64_t* __restrict__ seq_off,
                                                                 const uint64_t* __restrict__ out_off, uint32_t n_records, uint64_t* __restrict__ out) {
-    constexpr int TW = kStreamTileW, NW = tile_words(TW), NPOS_MAX = TW + 64, WPL = TW / kBlock;
-    __shared__ uint64_t sm_hash[NPOS_MAX];  // phase B-C: minimizer hash per m-mer position; phase E-F: leader's base
+    constexpr int NW = tile_words(kStreamPos), WPL = kStreamPos / kBlock;
+    __shared__ uint64_t sm_hash[kStreamPos + 8];  // phase B-C: minimizer hash per m-mer position; phase E-F: the leader's base
     __shared__ uint32_t sm_words[NW + 8];
     __shared__ uint32_t sm_bad[(NW + 8) / 2 + 2];
-    __shared__ uint16_t sm_S[NPOS_MAX], sm_P[NPOS_MAX];
-    __shared__ uint16_t sm_q[TW], sm_queue[TW];
-    __shared__ uint8_t sm_mode[NPOS_MAX];
+    __shared__ __attribute__((aligned(16))) uint16_t sm_q[kStreamPos + 8];
+    __shared__ uint16_t sm_queue[kStreamPos];
+    __shared__ uint8_t sm_mode[kStreamPos];
     __shared__ uint32_t sm_rec[2], sm_count;
+    __shared__ uint64_t sm_roff[3];  // seq_off[rlo], seq_off[rlo+1], out_off[rlo]
     const uint32_t k = H.k, m = H.m, W = H.W;
+    const uint32_t TW = stream_tile_windows(W);
     const uint64_t t0 = (uint64_t)blockIdx.x * TW;
     if (threadIdx.x == 0) {
         const uint64_t gfirst = t0 > shift ? t0 - shift : 0;
         uint64_t glast = t0 + TW + 64 > shift ? t0 + TW + 64 - shift : 0;
         if (glast >= total) glast = total ? total - 1 : 0;
-        sm_rec[0] = find_record(seq_off, 0, n_records - 1, gfirst);
-        sm_rec[1] = find_record(seq_off, 0, n_records - 1, glast);
+        const uint32_t rlo = find_record(seq_off, 0, n_records - 1, gfirst);
+        sm_rec[0] = rlo;
+        sm_rec[1] = find_record(seq_off, rlo, n_records - 1, glast);
+        sm_roff[0] = seq_off[rlo];
+        sm_roff[1] = seq_off[rlo + 1];
+        sm_roff[2] = out_off[rlo];
         sm_count = 0;
     }
     for (int c = threadIdx.x; c < (NW + 8) / 2 + 2; c += kBlock) sm_bad[c] = 0xFFFFFFFFu;
@@ -243,98 +262,102 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const lphq_image_
     for (int c = NW + 1 + threadIdx.x; c < NW + 8; c += kBlock) sm_words[c] = 0;
     __syncthreads();
 
-    // ---- B: hashes of the m-mers starting at local positions [0, TW + W - 1) ----
-    const uint32_t NPOS = TW + W - 1;
+    // ---- B: hashes of the m-mers starting at local positions [0, 1024) ----
     const uint64_t mm_seedx = murmur_seedx(H.mm_seed);
-    for (uint32_t j = threadIdx.x; j < NPOS; j += kBlock) {
+#pragma unroll
+    for (int r = 0; r < WPL; ++r) {
+        const uint32_t j = threadIdx.x + r * kBlock;
         uint64_t lo, hi;
         extract_kmer<false>(sm_words, j, m, lo, hi);
         sm_hash[j] = murmur8(lo, mm_seedx);
     }
+    if (threadIdx.x < 8) sm_hash[kStreamPos + threadIdx.x] = ~0ull;
     __syncthreads();
 
-    // ---- C1: per block of B positions, leftmost prefix / suffix arg-minima ----
-    const uint32_t nsplit = (W + 15) / 16;           // 1..4
-    const uint32_t B = (W + nsplit - 1) / nsplit;    // block length <= 16, B <= W
-    const uint32_t NBLK = (NPOS + B - 1) / B;
-    for (uint32_t b = threadIdx.x; b < NBLK; b += kBlock) {
-        const uint32_t s = b * B, e = min(s + B, NPOS);
-        uint64_t mh = sm_hash[s];
-        uint32_t mp = s;
-        sm_P[s] = (uint16_t)s;
-        for (uint32_t j = s + 1; j < e; ++j) {
-            const uint64_t h = sm_hash[j];
-            if (h < mh) {
-                mh = h;
-                mp = j;
+    // ---- C: leftmost minimum of 4 consecutive windows per lane ----
+    {
+        const uint32_t a = 4u * threadIdx.x;
+        uint32_t q[4];
+        if (W >= 4u) {
+            // left edge: suffix minima over a+2, a+1, a (`<=`: the left one wins ties)
+            HashPos s2{sm_hash[a + 2], a + 2}, s1, s0;
+            {
+                const uint64_t h1 = sm_hash[a + 1], h0 = sm_hash[a];
+                s1 = (h1 <= s2.h) ? HashPos{h1, a + 1} : s2;
+                s0 = (h0 <= s1.h) ? HashPos{h0, a} : s1;
             }
-            sm_P[j] = (uint16_t)mp;
-        }
-        mh = sm_hash[e - 1];
-        mp = e - 1;
-        sm_S[e - 1] = (uint16_t)mp;
-        for (uint32_t j = e - 1; j-- > s;) {
-            const uint64_t h = sm_hash[j];
-            if (h <= mh) {
-                mh = h;
-                mp = j;
-            }
-            sm_S[j] = (uint16_t)mp;
-        }
-    }
-    __syncthreads();
-
-    // ---- C2: per window, the leftmost minimum over its W m-mer positions ----
-    const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];
-    uint64_t oidx[WPL];  // output slot of this lane's windows (~0: not a window of any record)
-    const uint64_t kmask = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
+            // core a+3 .. a+W-1, common to the four windows
+            HashPos c{sm_hash[a + 3], a + 3};
+            for (uint32_t t = a + 4; t < a + W && t < (uint32_t)kStreamPos; ++t) take_if_less(c, sm_hash[t], t);
+            // right edge: prefix minima over a+W, a+W+1, a+W+2 (indices clamp into the ~0 padding of the last lanes)
+            const uint32_t e = min(a + W, (uint32_t)kStreamPos);
+            HashPos w0 = s0, w1 = s1, w2 = s2, w3 = c;
+            take_if_less(w0, c.h, c.p);
+            take_if_less(w1, c.h, c.p);
+            take_if_less(w2, c.h, c.p);
+            HashPos r{sm_hash[e], e};
+            take_if_less(w1, r.h, r.p);
+            take_if_less(w2, r.h, r.p);
+            take_if_less(w3, r.h, r.p);
+            r = HashPos{sm_hash[min(e + 1, (uint32_t)kStreamPos + 7)], e + 1};
+            take_if_less(w2, r.h, r.p);
+            take_if_less(w3, r.h, r.p);
+            r = HashPos{sm_hash[min(e + 2, (uint32_t)kStreamPos + 7)], e + 2};
+            take_if_less(w3, r.h, r.p);
+            q[0] = w0.p;
+            q[1] = w1.p;
+            q[2] = w2.p;
+            q[3] = w3.p;
+        } else {
 #pragma unroll
-    for (int t = 0; t < WPL; ++t) {
-        const uint32_t i = threadIdx.x + t * kBlock;
-        const uint64_t a = t0 + i;
-        oidx[t] = ~0ull;
-        uint16_t qv = 0xFFFEu;  // not a window
-        if (a >= shift && a - shift + k <= total) {
-            const uint64_t g = a - shift;
-            const uint32_t r = find_record(seq_off, rlo, rhi, g);
-            if (g + k <= seq_off[r + 1]) {
-                oidx[t] = out_off[r] + (g - seq_off[r]);
-                // any non-ACGT base in [i, i+k) ?
-                const uint32_t w0 = i >> 5, o = i & 31u;
-                uint64_t x = ((((uint64_t)sm_bad[w0 + 1]) << 32) | sm_bad[w0]) >> o;
-                if (o) x |= ((uint64_t)sm_bad[w0 + 2]) << (64u - o);
-                if (x & kmask) {
-                    qv = 0xFFFFu;  // window holds an invalid base
-                } else {
-                    const uint32_t jl = i + W - 1, b0 = i / B, bl = jl / B;
-                    uint32_t q = sm_S[i];
-                    uint64_t hq = sm_hash[q];
-                    for (uint32_t b = b0 + 1; b < bl; ++b) {
-                        const uint32_t c = sm_S[b * B];
-                        const uint64_t hc = sm_hash[c];
-                        if (hc < hq) {
-                            hq = hc;
-                            q = c;
-                        }
-                    }
-                    if (bl > b0) {
-                        const uint32_t c = sm_P[jl];
-                        if (sm_hash[c] < hq) q = c;
-                    }
-                    qv = (uint16_t)q;
+            for (int jw = 0; jw < 4; ++jw) {
+                HashPos c{sm_hash[a + jw], a + jw};
+                for (uint32_t t = 1; t < W; ++t) take_if_less(c, sm_hash[min(a + jw + t, (uint32_t)kStreamPos + 7)], a + jw + t);
+                q[jw] = c.p;
+            }
+        }
+        // window validity: inside the batch, inside one record, no non-ACGT base
+        const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];
+        const uint64_t kmask = (1ull << k) - 1ull;  // k <= 63
+        uint16_t qv[4];
+#pragma unroll
+        for (int jw = 0; jw < 4; ++jw) {
+            const uint32_t i = a + jw;
+            const uint64_t ga = t0 + i;
+            uint16_t v = 0xFFFEu;  // not a window of any record
+            if (i < TW && ga >= shift && ga - shift + k <= total) {
+                const uint64_t g = ga - shift;
+                bool inside;
+                if (rlo == rhi) inside = g + k <= sm_roff[1];
+                else {
+                    const uint32_t r = find_record(seq_off, rlo, rhi, g);
+                    inside = g + k <= seq_off[r + 1];
+                }
+                if (inside) {
+                    const uint32_t w0 = i >> 5, o = i & 31u;
+                    uint64_t x = ((((uint64_t)sm_bad[w0 + 1]) << 32) | sm_bad[w0]) >> o;
+                    if (o) x |= ((uint64_t)sm_bad[w0 + 2]) << (64u - o);
+                    v = (x & kmask) ? (uint16_t)0xFFFFu : (uint16_t)q[jw];
                 }
             }
+            qv[jw] = v;
         }
-        sm_q[i] = qv;
+        *(uint2*)&sm_q[a] = make_uint2((uint32_t)qv[0] | ((uint32_t)qv[1] << 16), (uint32_t)qv[2] | ((uint32_t)qv[3] << 16));
     }
     __syncthreads();
 
-    // ---- D: leaders -> queue ----
+    // ---- D: leaders -> queue (one LDS atomic per wave and round) ----
+    const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
-    for (int t = 0; t < WPL; ++t) {
-        const uint32_t i = threadIdx.x + t * kBlock;
+    for (int r = 0; r < WPL; ++r) {
+        const uint32_t i = threadIdx.x + r * kBlock;
         const uint16_t qv = sm_q[i];
-        if (qv < 0xFFFEu && (i == 0 || sm_q[i - 1] != qv)) sm_queue[atomicAdd(&sm_count, 1u)] = qv;
+        const bool leader = qv < 0xFFFEu && (i == 0 || sm_q[i - 1] != qv);
+        const uint64_t bal = __ballot(leader);
+        uint32_t base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&sm_count, (uint32_t)__popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (leader) sm_queue[base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = qv;
     }
     __syncthreads();
 
@@ -350,14 +373,22 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const lphq_image_
     }
     __syncthreads();
 
-    // ---- F: every window ----
+    // ---- F: every window, lane-contiguous stores ----
+    const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];
 #pragma unroll
-    for (int t = 0; t < WPL; ++t) {
-        if (oidx[t] == ~0ull) continue;
-        const uint32_t i = threadIdx.x + t * kBlock;
+    for (int r = 0; r < WPL; ++r) {
+        const uint32_t i = threadIdx.x + r * kBlock;
         const uint32_t q = sm_q[i];
+        if (q == 0xFFFEu) continue;
+        const uint64_t g = t0 + i - shift;
+        uint64_t oidx;
+        if (rlo == rhi) oidx = sm_roff[2] + (g - sm_roff[0]);
+        else {
+            const uint32_t rr = find_record(seq_off, rlo, rhi, g);
+            oidx = out_off[rr] + (g - seq_off[rr]);
+        }
         uint64_t hval = ~0ull;  // LPHQ_INVALID
-        if (q < 0xFFFEu) {
+        if (q != 0xFFFFu) {
             LookupCtx c;
             c.base = sm_hash[q];
             c.mode = sm_mode[q];
@@ -365,7 +396,7 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const lphq_image_
             if (c.mode == 2u) extract_kmer<K128>(sm_words, i, k, lo, hi);
             hval = finish_hval<K128>(img, H, c, lo, hi, q - i);
         }
-        out[oidx[t]] = hval;
+        out[oidx] = hval;
     }
 }
 
@@ -430,7 +461,7 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
     const uint64_t shift = (uint64_t)((uintptr_t)d_seq & 15u);
     const uint8_t* seq_al = (const uint8_t*)d_seq - shift;
     const uint64_t span = shift + total_bases;
-    const uint64_t tw = streaming ? kStreamTileW : kTileW;
+    const uint64_t tw = streaming ? stream_tile_windows(H.W) : kTileW;
     const uint64_t tiles = (span + tw - 1) / tw;
     if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
     if (streaming)
