@@ -40,19 +40,10 @@ def log(*a):
 def algorithmic_bytes_per_lookup(h, mode, k, W):
     """bytes of the reference's structures one lookup must touch, each word once at
     natural width, + the compulsory input/output stream; recomputed from this index's measured type mix."""
-    img = h.image()
-    hdr = np.frombuffer(img[:512].tobytes(), dtype=np.uint64)
-    # lphq_image_header (image_layout.h): u64 magic,total | 8 x u32 | mm_seed,nkmers,D,fallback | n_max | collision_base | off_wt,off_left,off_right,off_none,off_upair | phf mm ...
-    nkmers, n_max, collision_base = int(hdr[7]), int(hdr[10]), int(hdr[11])
-    off_left, off_right, off_none = int(hdr[13]), int(hdr[14]), int(hdr[15])
-    base = W * n_max
-    abs_of = lambda off: int(np.frombuffer(img[off:off + 8].tobytes(), dtype=np.uint64)[0])  # noqa: E731
-    tot_l = abs_of(off_right) - base if off_right else 0
-    tot_r = abs_of(off_none) - base - tot_l if off_none else 0
-    tot_n = collision_base - base - tot_l - tot_r
-    f_max, f_l, f_r, f_n = base / nkmers, tot_l / nkmers, tot_r / nkmers, tot_n / nkmers
-    phf = hdr[17:17 + 3]  # seed, num_keys, table_size of the minimizer PTHash
-    p_free = 1.0 - int(phf[1]) / int(phf[2])
+    info = h.info
+    nk = info.num_kmers
+    f_l, f_r, f_max, f_n = (info.kmers_by_type[i] / nk for i in range(4))
+    p_free = 1.0 - info.distinct_minimizers / info.minimizer_table_size
     chain = 8 + 26 * p_free + 48 + 26 * f_l + 34 * f_r + 60 * f_n
     kmer_bytes = 8 if k <= 31 else 16
     mix = {"maximal": round(f_max, 4), "left": round(f_l, 4), "right": round(f_r, 4), "none": round(f_n, 4)}

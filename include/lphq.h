@@ -60,6 +60,10 @@ typedef struct lphq_info {
     uint64_t image_bytes;          /* size of the flat device image                     */
     int32_t device;                /* attached device, -1 if none                       */
     uint32_t reserved;
+    /* census of the partitioned function (0 for unpartitioned): k-mers whose minimizer is LEFT, RIGHT, MAXIMAL,
+     * NONE (include/quartet_wtree.hpp:7); with fallback_kmers they add up to num_kmers */
+    uint64_t kmers_by_type[4];
+    uint64_t minimizer_table_size; /* PTHash table_size of minimizer_order (>= distinct_minimizers) */
 } lphq_info;
 
 /* Thread-local text of the last error raised on the calling thread. */

@@ -27,6 +27,7 @@ class Info(C.Structure):
         ("mm_seed", C.c_uint64), ("num_kmers", C.c_uint64), ("distinct_minimizers", C.c_uint64),
         ("fallback_kmers", C.c_uint64), ("file_bytes", C.c_uint64), ("image_bytes", C.c_uint64),
         ("device", C.c_int32), ("reserved", C.c_uint32),
+        ("kmers_by_type", C.c_uint64 * 4), ("minimizer_table_size", C.c_uint64),
     ]
 
 

@@ -129,6 +129,8 @@ extern "C" int lphq_get_info(const lphq_index* idx, lphq_info* info) {
     info->file_bytes = idx->file_bytes;
     info->image_bytes = idx->image_bytes;
     info->device = idx->device;
+    for (int i = 0; i < 4; ++i) info->kmers_by_type[i] = idx->hdr.kmers_by_type[i];
+    info->minimizer_table_size = idx->hdr.mm.table_size;
     return LPHQ_OK;
 }
 

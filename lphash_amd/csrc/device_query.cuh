@@ -80,59 +80,61 @@ __device__ __forceinline__ uint64_t phf_position(const uint8_t* __restrict__ img
 // mask of the first nb bits of a 32-bit word, nb in [0, 32]
 __device__ __forceinline__ uint32_t low_mask(int nb) { return nb >= 32 ? ~0u : (nb <= 0 ? 0u : ((1u << nb) - 1u)); }
 
-// quartet_wtree::rank_of(idx) -> (type, rank of that type before idx)   src/quartet_wtree.cpp:84-99
-// over one 64-B block: 4 cumulative counts + msb/lsb planes of 192 symbols.
-__device__ __forceinline__ void wt_rank_of(const uint8_t* __restrict__ img, uint64_t off_wt, uint32_t h, uint32_t& type, uint32_t& rank) {
-    const uint32_t b = h / LPHQ_WT_PER_BLOCK, j = h - b * LPHQ_WT_PER_BLOCK;
-    const uint4* p = (const uint4*)(img + off_wt) + (size_t)b * 4;
-    const uint4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
-    const uint32_t M[6] = {v1.x, v1.y, v1.z, v1.w, v2.x, v2.y};
-    const uint32_t L[6] = {v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
-    const uint32_t wj = j >> 5, bj = j & 31u;
-    uint32_t mw = 0, lw = 0;
-#pragma unroll
-    for (int t = 0; t < 6; ++t) {
-        mw = (wj == (uint32_t)t) ? M[t] : mw;
-        lw = (wj == (uint32_t)t) ? L[t] : lw;
-    }
-    const uint32_t sm = (mw >> bj) & 1u, sl = (lw >> bj) & 1u;
-    const uint32_t xm = sm ? 0u : ~0u, xl = sl ? 0u : ~0u;
-    uint32_t r = 0;
-#pragma unroll
-    for (int t = 0; t < 6; ++t) r += __popc((M[t] ^ xm) & (L[t] ^ xl) & low_mask((int)j - 32 * t));
-    type = (sm << 1) | sl;
-    const uint32_t c01 = sl ? v0.y : v0.x, c23 = sl ? v0.w : v0.z;
-    rank = (sm ? c23 : c01) + r;
-}
-
-// Single-value plane block (LEFT positions / RIGHT_OR_COLLISION sizes): prefix = global-rank base of
-// entry r (ef_sequence::access / pair().first + (k-m+1)*n_maximal, partitioned_mphf.cpp:299-318),
-// own = stored value r (pair().second - pair().first).
+// quartet_wtree::rank_of (src/quartet_wtree.cpp:84-99) and ef_sequence::{access,pair,diff}
+// (include/ef_sequence.hpp:77-99) fused over ONE 128-B block (image_layout.h: lphq_uni_block).
+// Returns the type of minimizer order h, base = global-rank base of its super-k-mer (the `res.global_rank`
+// terms of src/partitioned_mphf.cpp:297-336, already including (k-m+1)*n_maximal), size and position.
 template <int P>
-__device__ __forceinline__ void lr_lookup(const uint8_t* __restrict__ img, uint64_t off, uint32_t r, uint64_t& prefix, uint32_t& own) {
-    constexpr uint32_t T = LPHQ_LR_T(P), E = LPHQ_LR_PER_BLOCK(P);
-    const uint32_t b = r / E, j = r - b * E;
-    const uint4* p = (const uint4*)(img + off) + (size_t)b * 4;
-    const uint4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
-    const uint32_t w[14] = {v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
-    const uint32_t wj = j >> 5, bj = j & 31u;
-    uint32_t msk[T];
+__device__ __forceinline__ void uni_lookup(const uint8_t* __restrict__ img, uint64_t off_uni, uint32_t W, uint32_t h, uint32_t& type, uint64_t& base,
+                                           uint32_t& size, uint32_t& pos) {
+    constexpr uint32_t T = LPHQ_UNI_T(P), E = LPHQ_UNI_PER_BLOCK(P), NWORDS = (2 + 2 * P) * T, NV = (NWORDS + 3) / 4;
+    const uint32_t b = h / E, j = h % E;
+    const uint4* p = (const uint4*)(img + off_uni) + (size_t)b * 8;
+    const uint4 b01 = p[0], b23 = p[1];
+    uint4 v[NV];
 #pragma unroll
-    for (uint32_t t = 0; t < T; ++t) msk[t] = low_mask((int)j - 32 * (int)t);
-    uint32_t sum = 0;
-    own = 0;
+    for (uint32_t i = 0; i < NV; ++i) v[i] = p[2 + i];
+    uint32_t w[NV * 4];
 #pragma unroll
-    for (int q = 0; q < P; ++q) {
-        uint32_t c = 0, sel = 0;
-#pragma unroll
-        for (uint32_t t = 0; t < T; ++t) {
-            c += __popc(w[q * T + t] & msk[t]);
-            sel = (wj == t) ? w[q * T + t] : sel;
-        }
-        sum += c << q;
-        own |= ((sel >> bj) & 1u) << q;
+    for (uint32_t i = 0; i < NV; ++i) {
+        w[4 * i] = v[i].x;
+        w[4 * i + 1] = v[i].y;
+        w[4 * i + 2] = v[i].z;
+        w[4 * i + 3] = v[i].w;
     }
-    prefix = (((uint64_t)v0.y << 32) | v0.x) + sum;
+    const uint32_t wj = j >> 5, bj = j & 31u;
+    auto pick = [&](uint32_t first) {  // word wj of the plane starting at w[first]
+        uint32_t r = w[first];
+#pragma unroll
+        for (uint32_t t = 1; t < T; ++t) r = (wj == t) ? w[first + t] : r;
+        return r;
+    };
+    const uint32_t sm = (pick(0) >> bj) & 1u, sl = (pick(T) >> bj) & 1u;
+    const uint32_t xm = sm ? 0u : ~0u, xl = sl ? 0u : ~0u;
+    uint32_t mw[T];  // entries before j with the same type
+    uint32_t rank = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < T; ++t) {
+        mw[t] = (w[t] ^ xm) & (w[T + t] ^ xl) & low_mask((int)j - 32 * (int)t);
+        rank += __popc(mw[t]);
+    }
+    uint32_t sum = 0;
+    size = 0;
+    pos = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < (uint32_t)P; ++q) {
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t t = 0; t < T; ++t) c += __popc(w[2 * T + q * T + t] & mw[t]);
+        sum += c << q;
+        size |= ((pick(2 * T + q * T) >> bj) & 1u) << q;
+        pos |= ((pick(2 * T + P * T + q * T) >> bj) & 1u) << q;
+    }
+    type = (sm << 1) | sl;
+    const uint64_t base0 = ((uint64_t)b01.y << 32) | b01.x, base1 = ((uint64_t)b01.w << 32) | b01.z;
+    const uint64_t base2 = ((uint64_t)b23.y << 32) | b23.x, base3 = ((uint64_t)b23.w << 32) | b23.z;
+    const uint64_t blo = sl ? base2 : base1, bhi = sl ? base3 : base0;  // type 0:LEFT->1, 1:RIGHT->2, 2:MAXIMAL->0, 3:NONE->3
+    base = (sm ? bhi : blo) + (type == 2u ? W * rank : sum);
 }
 
 // (size, position) pair block, 32 entries: NONE minimizers (partitioned_mphf.cpp:326-333) and the whole
@@ -201,31 +203,21 @@ __device__ __forceinline__ LookupCtx lookup_ctx(const uint8_t* __restrict__ img,
     LookupCtx c;
     const uint32_t h = (uint32_t)phf_position(img, H.mm, murmur8(mm, murmur_seedx(H.mm.seed)));
     if (KIND == 0) {
-        uint32_t type, rank;
-        wt_rank_of(img, H.off_wt, h, type, rank);
-        if (type == 2u) {  // MAXIMAL: (k-m+1)*rank + p
-            c.base = (uint64_t)H.W * rank;
+        uint32_t type, size, pos;
+        uint64_t base;
+        uni_lookup<P>(img, H.off_uni, H.W, h, type, base, size, pos);
+        if (type == 2u || type == 0u) {  // MAXIMAL: (k-m+1)*rank + p ; LEFT: EF[r] + W*n_max + p
+            c.base = base;
             c.mode = 0;
         } else if (type == 3u) {  // NONE: EF[none_sizes_start+r] + W*n_max + (p1 - p)
-            uint64_t prefix;
-            uint32_t size, pos;
-            pair_lookup<P>(img, H.off_none, rank, prefix, size, pos);
-            c.base = prefix + pos;
+            c.base = base + pos;
             c.mode = 1;
-        } else {  // LEFT / RIGHT_OR_COLLISION share the block format
-            uint64_t prefix;
-            uint32_t own;
-            lr_lookup<P>(img, type ? H.off_right : H.off_left, rank, prefix, own);
-            if (type == 0u) {  // LEFT: EF[r] + W*n_max + p
-                c.base = prefix;
-                c.mode = 0;
-            } else if (own == 0u) {  // collision: EF[none_pos_start] + W*n_max + fallback(kmer)
-                c.base = H.collision_base;
-                c.mode = 2;
-            } else {  // RIGHT: val1 + W*n_max + (k - m - p)
-                c.base = prefix + (H.k - H.m);
-                c.mode = 1;
-            }
+        } else if (size == 0u) {  // collision: EF[none_pos_start] + W*n_max + fallback(kmer)
+            c.base = H.collision_base;
+            c.mode = 2;
+        } else {  // RIGHT: val1 + W*n_max + (k - m - p)
+            c.base = base + (H.k - H.m);
+            c.mode = 1;
         }
     } else {
         uint64_t prefix;

@@ -90,26 +90,6 @@ bool build_phf(const SinglePhf& f, ImageWriter& w, lphq_phf_desc& d, const char*
     return true;
 }
 
-// single-value plane blocks: value j of block b sits at bit j%32 of word p*T + j/32, plane p
-bool fill_lr_blocks(ImageWriter& w, uint64_t off, const uint64_t* prefix /* prefix[i] = sum of values before entry i, n+1 long */, uint64_t n,
-                    uint64_t base, uint32_t P, std::string& err) {
-    const uint32_t T = LPHQ_LR_T(P), E = LPHQ_LR_PER_BLOCK(P);
-    uint64_t nblocks = (n + E - 1) / E;
-    for (uint64_t b = 0; b < nblocks; ++b) {
-        lphq_plane_block* blk = w.at<lphq_plane_block>(off) + b;
-        blk->abs = base + prefix[b * E];
-        for (uint32_t j = 0; j < E && b * E + j < n; ++j) {
-            uint64_t v = prefix[b * E + j + 1] - prefix[b * E + j];
-            if (v >> P) {
-                err = "stored value does not fit the plane width (value > k-m+1?)";
-                return false;
-            }
-            for (uint32_t p = 0; p < P; ++p)
-                if ((v >> p) & 1) blk->w[p * T + (j >> 5)] |= 1u << (j & 31);
-        }
-    }
-    return true;
-}
 // pair blocks: size planes w[0..P), position planes w[P..2P), 32 entries
 bool fill_pair_blocks(ImageWriter& w, uint64_t off, const uint64_t* size_prefix, const uint64_t* pos_prefix, uint64_t n, uint64_t base, uint32_t P,
                       std::string& err) {
@@ -175,28 +155,56 @@ bool build_image(const LphFile& x, std::vector<uint8_t>& img, std::string& err) 
         }
         h.collision_base = vals[nps] + base;  // sizes_and_positions.access(none_pos_start) + W*n_maximal, partitioned_mphf.cpp:309-311
 
-        // wavelet blocks
-        uint64_t nwt = (D + LPHQ_WT_PER_BLOCK - 1) / LPHQ_WT_PER_BLOCK;
-        h.off_wt = w.reserve((nwt ? nwt : 1) * sizeof(lphq_wt_block));
-        uint32_t cnt[4] = {0, 0, 0, 0};
-        uint64_t i_lr = 0, i_mn = 0;
+        // fused blocks, in minimizer order (src/partitioned_mphf.cpp:183-267 builds the four arrays in this order)
+        const uint32_t T = LPHQ_UNI_T(h.P), E = LPHQ_UNI_PER_BLOCK(h.P), P = h.P;
+        const uint64_t nblk = (D + E - 1) / E;
+        h.off_uni = w.reserve((nblk + 1) * sizeof(lphq_uni_block));
+        uint64_t n_max_seen = 0, i_l = 0, i_r = 0, i_n = 0, i_lr = 0, i_mn = 0;
         for (uint64_t i = 0; i < D; ++i) {
-            lphq_wt_block* blk = w.at<lphq_wt_block>(h.off_wt) + i / LPHQ_WT_PER_BLOCK;
-            uint32_t j = (uint32_t)(i % LPHQ_WT_PER_BLOCK);
-            if (j == 0) memcpy(blk->cnt, cnt, sizeof cnt);
-            bool msb = x.root.bv.get(i);
-            bool lsb = msb ? x.max_none.bv.get(i_mn++) : x.left_right.bv.get(i_lr++);
-            if (msb) blk->msb[j >> 5] |= 1u << (j & 31);
-            if (lsb) blk->lsb[j >> 5] |= 1u << (j & 31);
-            cnt[(msb ? 2 : 0) | (lsb ? 1 : 0)]++;  // LEFT=0 RIGHT_OR_COLLISION=1 MAXIMAL=2 NONE=3, quartet_wtree.hpp:7
+            lphq_uni_block* blk = w.at<lphq_uni_block>(h.off_uni) + i / E;
+            const uint32_t j = (uint32_t)(i % E);
+            if (j == 0) {
+                blk->base[0] = (uint64_t)h.W * n_max_seen;
+                blk->base[1] = base + vals[i_l];
+                blk->base[2] = base + vals[rcs + i_r];
+                blk->base[3] = base + vals[nss + i_n];
+            }
+            const bool msb = x.root.bv.get(i);
+            const bool lsb = msb ? x.max_none.bv.get(i_mn++) : x.left_right.bv.get(i_lr++);
+            uint64_t size = 0, pos = 0;
+            if (!msb && !lsb) {  // LEFT
+                size = vals[i_l + 1] - vals[i_l];
+                ++i_l;
+            } else if (!msb && lsb) {  // RIGHT_OR_COLLISION
+                size = vals[rcs + i_r + 1] - vals[rcs + i_r];
+                ++i_r;
+            } else if (msb && !lsb) {  // MAXIMAL
+                ++n_max_seen;
+            } else {  // NONE
+                size = vals[nss + i_n + 1] - vals[nss + i_n];
+                pos = vals[nps + i_n + 1] - vals[nps + i_n];
+                ++i_n;
+            }
+            if ((size >> P) || (pos >> P)) {
+                err = "stored size/position does not fit the plane width (value > k-m+1?)";
+                return false;
+            }
+            const uint32_t wi = j >> 5, bit = 1u << (j & 31);
+            if (msb) blk->w[wi] |= bit;
+            if (lsb) blk->w[T + wi] |= bit;
+            for (uint32_t q = 0; q < P; ++q) {
+                if ((size >> q) & 1) blk->w[2 * T + q * T + wi] |= bit;
+                if ((pos >> q) & 1) blk->w[2 * T + P * T + q * T + wi] |= bit;
+            }
         }
-        const uint32_t E = LPHQ_LR_PER_BLOCK(h.P);
-        h.off_left = w.reserve(((n_left + E - 1) / E + 1) * sizeof(lphq_plane_block));
-        if (!fill_lr_blocks(w, h.off_left, vals.data(), n_left, base, h.P, err)) return false;
-        h.off_right = w.reserve(((n_right + E - 1) / E + 1) * sizeof(lphq_plane_block));
-        if (!fill_lr_blocks(w, h.off_right, vals.data() + rcs, n_right, base, h.P, err)) return false;
-        h.off_none = w.reserve(((n_none + LPHQ_PAIR_PER_BLOCK - 1) / LPHQ_PAIR_PER_BLOCK + 1) * sizeof(lphq_plane_block));
-        if (!fill_pair_blocks(w, h.off_none, vals.data() + nss, vals.data() + nps, n_none, base, h.P, err)) return false;
+        if (i_l != n_left || i_r != n_right || i_n != n_none || n_max_seen != x.n_maximal) {
+            err = "wavelet tree census does not match the region starts";
+            return false;
+        }
+        h.kmers_by_type[0] = vals[rcs];
+        h.kmers_by_type[1] = vals[nss] - vals[rcs];
+        h.kmers_by_type[2] = base;
+        h.kmers_by_type[3] = vals[nps] - vals[nss];
         // consistency: every k-mer is counted exactly once (maximal + EF sizes + fallback)
         if (base + vals[nps] + x.fallback_kmer_order.num_keys != x.nkmers) {
             err = "k-mer census mismatch: W*n_maximal + sum(sizes) + fallback != nkmers";

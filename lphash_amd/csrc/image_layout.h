@@ -9,12 +9,16 @@
  *                   by hp[code] = MurmurHash2_64(pilot, seed), saving one hash per lookup
  *                   (single_phf::position hashes the pilot on every call).
  *   free slots      PTHash's Elias-Fano -> plain u32 table (one load instead of a select).
- *   quartet_wtree   three rank9 bit vectors (2 levels x {bits word, rank pair} = 4 lines)
- *                   -> one 64-B block per 192 minimizers: 4 cumulative type counts + the msb and
- *                   lsb bit planes.  rank_of() = one line + 6 masked popcounts.
- *   ef_sequence     Elias-Fano prefix sums (select + low bits = 3-4 lines, twice for NONE)
- *                   -> per-type 64-B "plane blocks": u64 absolute prefix + bit planes of the
- *                   small stored values; prefix/own value = one line + masked popcounts.
+ *   quartet_wtree + ef_sequence (partitioned)
+ *                   three rank9 bit vectors (2 levels x {bits word, rank pair} = 4 lines) and the
+ *                   Elias-Fano prefix sums (select + low bits = 3-4 lines, twice for NONE)
+ *                   -> ONE 128-B block per 64 (k-m+1 <= 15) or 32 minimizers, indexed by the minimizer
+ *                   order: the four per-type global-rank bases at the block start, the msb/lsb type
+ *                   planes, and bit planes of the stored size / position values.  type, rank and
+ *                   prefix sum of a lookup = one line + masked popcounts.  (Beyond L2 the fetch
+ *                   granule is the 128-B line, profiles/r01_microbench2.txt, so 128 B cost what 16 B do.)
+ *   ef_sequence x2 (unpartitioned)
+ *                   -> 64-B "pair blocks": u64 prefix of sizes + size / position planes of 32 minimizers.
  *
  * All offsets are byte offsets from the image base; sections are 256-B aligned.
  */
@@ -24,11 +28,10 @@
 #include <stdint.h>
 
 #define LPHQ_IMAGE_MAGIC 0x3130474d4951504cULL /* "LPQIMG01" */
-#define LPHQ_WT_PER_BLOCK 192u                 /* minimizers per wavelet block              */
 #define LPHQ_PAIR_PER_BLOCK 32u                /* entries per (size,pos) pair block         */
-/* single-value plane blocks: P planes x T words, P*T <= 14 */
-#define LPHQ_LR_T(P) ((P) == 4 ? 3u : 2u)
-#define LPHQ_LR_PER_BLOCK(P) (32u * LPHQ_LR_T(P))
+/* fused block: T words per plane, 2 type planes + P size planes + P position planes, (2 + 2P) * T <= 24 words */
+#define LPHQ_UNI_T(P) ((P) == 4 ? 2u : 1u)
+#define LPHQ_UNI_PER_BLOCK(P) (32u * LPHQ_UNI_T(P))
 
 /* 2-by-1 division by an invariant 32-bit divisor (Moeller & Granlund 2011, Alg. 4) */
 typedef struct lphq_divisor {
@@ -57,18 +60,24 @@ typedef struct lphq_image_header {
     uint64_t mm_seed, nkmers, distinct_minimizers, fallback_kmers;
     uint64_t n_maximal;
     uint64_t collision_base; /* partitioned: EF[none_pos_start] + W*n_maximal ; unpartitioned: num_kmers_in_main_index */
-    uint64_t off_wt;         /* wt_block[]                                                  */
-    uint64_t off_left, off_right, off_none; /* plane blocks (absolute bases already include W*n_maximal and region starts) */
+    uint64_t off_uni;        /* partitioned: lphq_uni_block[] indexed by minimizer order / LPHQ_UNI_PER_BLOCK(P) */
     uint64_t off_upair;      /* unpartitioned: pair blocks indexed by minimizer order       */
+    uint64_t kmers_by_type[4]; /* k-mers under LEFT, RIGHT, MAXIMAL, NONE minimizers (census, for reporting) */
     lphq_phf_desc mm, fb;
 } lphq_image_header;
 
-/* 64-B wavelet block: symbols j = 0..191 of minimizers [192*b, 192*b+192) */
-typedef struct lphq_wt_block {
-    uint32_t cnt[4];  /* # of LEFT, RIGHT_OR_COLLISION, MAXIMAL, NONE before this block     */
-    uint32_t msb[6];  /* bit j%32 of msb[j/32] = root bit (1: MAXIMAL/NONE)                  */
-    uint32_t lsb[6];  /* bit of the child vector (left_right or max_none)                   */
-} lphq_wt_block;
+/* 128-B fused block of minimizers [E*b, E*b+E), E = LPHQ_UNI_PER_BLOCK(P), T = LPHQ_UNI_T(P):
+ *   base[0] = (k-m+1) * #MAXIMAL before the block                         (MAXIMAL: base + W*rank_in_block + p)
+ *   base[1] = W*n_maximal + sum of LEFT values before the block           (EF[r] + W*n_maximal)
+ *   base[2] = W*n_maximal + all LEFT + RIGHT sizes before the block       (pair(rcs+r).first + W*n_maximal)
+ *   base[3] = W*n_maximal + all LEFT + all RIGHT + NONE sizes before      (EF[nss+r] + W*n_maximal)
+ *   w[0..T) msb plane, w[T..2T) lsb plane (type = msb<<1|lsb, quartet_wtree.hpp:7),
+ *   w[2T + q*T + t] bit plane q of the stored size (LEFT: p1+1, RIGHT: size or 0 = collision, NONE: size),
+ *   w[2T + P*T + q*T + t] bit plane q of the NONE position p1. */
+typedef struct lphq_uni_block {
+    uint64_t base[4];
+    uint32_t w[24];
+} lphq_uni_block;
 
 /* 64-B plane block: abs = global-rank base of the first entry; planes of the per-entry values */
 typedef struct lphq_plane_block {

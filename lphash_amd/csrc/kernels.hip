@@ -11,6 +11,8 @@
 // correctness.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "device_query.cuh"
 #include "kernels.hpp"
 
@@ -97,6 +99,22 @@ __device__ __forceinline__ uint32_t find_record(const uint64_t* __restrict__ off
         const uint32_t mid = lo + (hi - lo + 1) / 2;
         if (offs[mid] <= g) lo = mid;
         else hi = mid - 1;
+    }
+    return lo;
+}
+
+// Same result, found by one wave in ~log64(n) rounds: 64 probes per round instead of a 1-load-per-step chain
+// (every lane of the calling wave must pass the same arguments).
+__device__ __forceinline__ uint32_t find_record_wave(const uint64_t* __restrict__ offs, uint32_t n_records, uint64_t g) {
+    uint32_t lo = 0, hi = n_records - 1;
+    const uint32_t lane = threadIdx.x & 63u;
+    while (hi > lo) {
+        const uint32_t step = (hi - lo + 63u) / 64u;
+        const uint64_t idx = (uint64_t)lo + (uint64_t)(lane + 1u) * step;
+        const bool ok = idx <= hi && offs[idx] <= g;  // monotone in the lane: offs is non-decreasing
+        const uint32_t cnt = (uint32_t)__popcll(__ballot(ok));
+        lo += cnt * step;
+        hi = min(hi, lo + step - 1u);
     }
     return lo;
 }
@@ -231,7 +249,8 @@ __device__ __forceinline__ void take_if_less(HashPos& m, uint64_t h, uint32_t p)
 template <int KIND, bool K128, int P>
 __global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const lphq_image_header H, const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
                                                                 uint64_t shift, uint64_t total, const uint64_t* __restrict__ seq_off,
-                                                                const uint64_t* __restrict__ out_off, uint32_t n_records, uint64_t* __restrict__ out) {
+                                                                const uint64_t* __restrict__ out_off, uint32_t n_records, uint64_t* __restrict__ out,
+                                                                uint32_t stop_after /* profiling aid: 0 = run everything */) {
     constexpr int NW = tile_words(kStreamPos), WPL = kStreamPos / kBlock;
     __shared__ uint64_t sm_hash[kStreamPos + 8];  // phase B-C: minimizer hash per m-mer position; phase E-F: the leader's base
     __shared__ uint32_t sm_words[NW + 8];
@@ -244,23 +263,26 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const lphq_image_
     const uint32_t k = H.k, m = H.m, W = H.W;
     const uint32_t TW = stream_tile_windows(W);
     const uint64_t t0 = (uint64_t)blockIdx.x * TW;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 128) {  // wave 0 locates the record of the first base the tile can touch, wave 1 that of the last
         const uint64_t gfirst = t0 > shift ? t0 - shift : 0;
         uint64_t glast = t0 + TW + 64 > shift ? t0 + TW + 64 - shift : 0;
         if (glast >= total) glast = total ? total - 1 : 0;
-        const uint32_t rlo = find_record(seq_off, 0, n_records - 1, gfirst);
-        sm_rec[0] = rlo;
-        sm_rec[1] = find_record(seq_off, rlo, n_records - 1, glast);
-        sm_roff[0] = seq_off[rlo];
-        sm_roff[1] = seq_off[rlo + 1];
-        sm_roff[2] = out_off[rlo];
-        sm_count = 0;
+        const uint32_t r = find_record_wave(seq_off, n_records, threadIdx.x < 64 ? gfirst : glast);
+        if (threadIdx.x == 0) {
+            sm_rec[0] = r;
+            sm_roff[0] = seq_off[r];
+            sm_roff[1] = seq_off[r + 1];
+            sm_roff[2] = out_off[r];
+            sm_count = 0;
+        }
+        if (threadIdx.x == 64) sm_rec[1] = r;
     }
     for (int c = threadIdx.x; c < (NW + 8) / 2 + 2; c += kBlock) sm_bad[c] = 0xFFFFFFFFu;
     __syncthreads();
     load_tile<true, NW>(seq_al, shift, total, t0, sm_words, sm_bad);
     for (int c = NW + 1 + threadIdx.x; c < NW + 8; c += kBlock) sm_words[c] = 0;
     __syncthreads();
+    if (stop_after == 1u) return;
 
     // ---- B: hashes of the m-mers starting at local positions [0, 1024) ----
     const uint64_t mm_seedx = murmur_seedx(H.mm_seed);
@@ -273,6 +295,7 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const lphq_image_
     }
     if (threadIdx.x < 8) sm_hash[kStreamPos + threadIdx.x] = ~0ull;
     __syncthreads();
+    if (stop_after == 2u) return;
 
     // ---- C: leftmost minimum of 4 consecutive windows per lane ----
     {
@@ -345,6 +368,7 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const lphq_image_
         *(uint2*)&sm_q[a] = make_uint2((uint32_t)qv[0] | ((uint32_t)qv[1] << 16), (uint32_t)qv[2] | ((uint32_t)qv[3] << 16));
     }
     __syncthreads();
+    if (stop_after == 3u) return;
 
     // ---- D: leaders -> queue (one LDS atomic per wave and round) ----
     const uint32_t lane = threadIdx.x & 63u;
@@ -360,6 +384,7 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const lphq_image_
         if (leader) sm_queue[base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = qv;
     }
     __syncthreads();
+    if (stop_after == 4u) return;
 
     // ---- E: one lookup per super-k-mer, dense lanes ----
     const uint32_t nlead = sm_count;
@@ -372,6 +397,7 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const lphq_image_
         sm_mode[q] = (uint8_t)c.mode;
     }
     __syncthreads();
+    if (stop_after == 5u) return;
 
     // ---- F: every window, lane-contiguous stores ----
     const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];
@@ -464,8 +490,10 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
     const uint64_t tw = streaming ? stream_tile_windows(H.W) : kTileW;
     const uint64_t tiles = (span + tw - 1) / tw;
     if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    if (streaming)
-        LPHQ_DISPATCH(k_query_tiles_stream, <<<(int)tiles, kBlock, 0, stream>>>(H, d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out));
+    if (streaming) {
+        static const uint32_t stop_after = getenv("LPHQ_PROFILE_STREAM_STOP") ? (uint32_t)atoi(getenv("LPHQ_PROFILE_STREAM_STOP")) : 0u;  // phase timing only
+        LPHQ_DISPATCH(k_query_tiles_stream, <<<(int)tiles, kBlock, 0, stream>>>(H, d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, stop_after));
+    }
     else
         LPHQ_DISPATCH(k_query_tiles_random, <<<(int)tiles, kBlock, 0, stream>>>(H, d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out));
     return hipGetLastError();

@@ -17,15 +17,19 @@ def splitmix64(x):
         return z ^ (z >> np.uint64(31))
 
 
-def random_bases(seed, n):
+def random_bases(seed, n, chunk_words=1 << 22):
     """n ASCII bases as a uint8 array; base i is bits (2*(i%32)) of splitmix64(seed * 2^40 + i//32)."""
     nw = (n + 31) // 32
-    with np.errstate(over="ignore"):
-        ctr = np.arange(nw, dtype=np.uint64) + (np.uint64(seed) << np.uint64(40))
-    w = splitmix64(ctr)
+    out = np.empty(nw * 32, dtype=np.uint8)
     shifts = (np.arange(32, dtype=np.uint64) * np.uint64(2))[None, :]
-    codes = ((w[:, None] >> shifts) & np.uint64(3)).astype(np.uint8).reshape(-1)[:n]
-    return _ACGT[codes]
+    for a in range(0, nw, chunk_words):
+        b = min(nw, a + chunk_words)
+        with np.errstate(over="ignore"):
+            ctr = np.arange(a, b, dtype=np.uint64) + (np.uint64(seed) << np.uint64(40))
+        w = splitmix64(ctr)
+        codes = ((w[:, None] >> shifts) & np.uint64(3)).astype(np.uint8).reshape(-1)
+        out[a * 32:b * 32] = _ACGT[codes]
+    return out[:n]
 
 
 def synthetic_records(seed, n_records, length):

@@ -31,8 +31,8 @@ __global__ __launch_bounds__(256) void k_abl(const lphq_image_header H, const ui
         else if (MODE == 1) { uint64_t mm; uint32_t p; minimizer_of<false>(lo, 0, H.k, H.m, H.W, murmur_seedx(H.mm_seed), mm, p); r = mm ^ p; }
         else if (MODE == 2) { uint64_t mm = mms[i]; LookupCtx c = lookup_ctx<0, false, 4>(img, H, mm >> 8); r = finish_hval<false>(img, H, c, lo, 0, (uint32_t)mm & 255u); }
         else if (MODE == 3) { uint64_t mm = mms[i]; r = phf_position(img, H.mm, murmur8(mm >> 8, murmur_seedx(H.mm.seed))); }
-        else if (MODE == 4) { uint64_t mm = mms[i]; uint32_t t, rk; wt_rank_of(img, H.off_wt, (uint32_t)((mm >> 8) % H.distinct_minimizers), t, rk); r = t + rk; }
-        else if (MODE == 5) { uint64_t mm = mms[i]; uint32_t h = (uint32_t)phf_position(img, H.mm, murmur8(mm >> 8, murmur_seedx(H.mm.seed))); uint32_t t, rk; wt_rank_of(img, H.off_wt, h, t, rk); r = t + rk; }
+        else if (MODE == 4) { uint64_t mm = mms[i]; uint32_t t, sz, ps; uint64_t bs; uni_lookup<4>(img, H.off_uni, H.W, (uint32_t)((mm >> 8) % H.distinct_minimizers), t, bs, sz, ps); r = t + bs + sz + ps; }
+        else if (MODE == 5) { uint64_t mm = mms[i]; uint32_t h = (uint32_t)phf_position(img, H.mm, murmur8(mm >> 8, murmur_seedx(H.mm.seed))); uint32_t t, sz, ps; uint64_t bs; uni_lookup<4>(img, H.off_uni, H.W, h, t, bs, sz, ps); r = t + bs + sz + ps; }
         else { uint64_t mm; uint32_t p; minimizer_of<false>(lo, 0, H.k, H.m, H.W, murmur_seedx(H.mm_seed), mm, p); r = (mm << 8) | p; }
         out[i] = r;
     }
@@ -58,7 +58,7 @@ int main(int argc, char** argv) {
     k_abl<6><<<4096, 256>>>(H, (const uint8_t*)dimg, k, mm, n, mm);  // precompute (mm<<8|p)
     CK(hipDeviceSynchronize());
     for (int grid : {2048, 4096, 8192}) {
-        printf("grid %d: full %.3f ms | hashonly %.3f | lookup(given mm) %.3f | phf %.3f | wt %.3f | phf+wt %.3f   (n=2^27)\n", grid,
+        printf("grid %d: full %.3f ms | hashonly %.3f | lookup(given mm) %.3f | phf %.3f | block %.3f | phf+block %.3f   (n=2^27)\n", grid,
                run<0>(H, (const uint8_t*)dimg, k, mm, n, out, grid), run<1>(H, (const uint8_t*)dimg, k, mm, n, out, grid), run<2>(H, (const uint8_t*)dimg, k, mm, n, out, grid),
                run<3>(H, (const uint8_t*)dimg, k, mm, n, out, grid), run<4>(H, (const uint8_t*)dimg, k, mm, n, out, grid), run<5>(H, (const uint8_t*)dimg, k, mm, n, out, grid));
     }
