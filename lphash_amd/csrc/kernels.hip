@@ -24,6 +24,7 @@ constexpr int kBlock = 256;
 // random batch over packed k-mers
 // ------------------------------------------------------------------------------------------
 template <int KIND, bool K128, int P>
+// (header by value here: measured 2 % faster than reading it from the image, the opposite of the tile kernels)
 __global__ __launch_bounds__(kBlock) void k_query_packed(const lphq_image_header H, const uint8_t* __restrict__ img,
                                                           const uint64_t* __restrict__ kmers, size_t n, uint64_t* __restrict__ out) {
     const size_t stride = (size_t)gridDim.x * kBlock;
@@ -183,9 +184,10 @@ __device__ __forceinline__ void load_tile(const uint8_t* __restrict__ seq_al, ui
 }
 
 template <int KIND, bool K128, int P>
-__global__ __launch_bounds__(kBlock) void k_query_tiles_random(const lphq_image_header H, const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
+__global__ __launch_bounds__(kBlock) void k_query_tiles_random(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
                                                                 uint64_t shift, uint64_t total, const uint64_t* __restrict__ seq_off,
                                                                 const uint64_t* __restrict__ out_off, uint32_t n_records, uint64_t* __restrict__ out) {
+    const lphq_image_header& H = *(const lphq_image_header*)img;
     __shared__ uint32_t sm_words[kTileWords + 8];
     __shared__ uint32_t sm_rec[2];
     const uint64_t t0 = (uint64_t)blockIdx.x * kTileW;  // shifted coordinate of the tile's first window start
@@ -247,10 +249,11 @@ __device__ __forceinline__ void take_if_less(HashPos& m, uint64_t h, uint32_t p)
 }
 
 template <int KIND, bool K128, int P>
-__global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const lphq_image_header H, const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
+__global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
                                                                 uint64_t shift, uint64_t total, const uint64_t* __restrict__ seq_off,
                                                                 const uint64_t* __restrict__ out_off, uint32_t n_records, uint64_t* __restrict__ out,
                                                                 uint32_t stop_after /* profiling aid: 0 = run everything */) {
+    const lphq_image_header& H = *(const lphq_image_header*)img;  // read from the image: 77 SGPRs instead of 112 -> 8 workgroups / CU (+11 %)
     constexpr int NW = tile_words(kStreamPos), WPL = kStreamPos / kBlock;
     __shared__ uint64_t sm_hash[kStreamPos + 8];  // phase B-C: minimizer hash per m-mer position; phase E-F: the leader's base
     __shared__ uint32_t sm_words[NW + 8];
@@ -492,10 +495,10 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
     if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
     if (streaming) {
         static const uint32_t stop_after = getenv("LPHQ_PROFILE_STREAM_STOP") ? (uint32_t)atoi(getenv("LPHQ_PROFILE_STREAM_STOP")) : 0u;  // phase timing only
-        LPHQ_DISPATCH(k_query_tiles_stream, <<<(int)tiles, kBlock, 0, stream>>>(H, d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, stop_after));
+        LPHQ_DISPATCH(k_query_tiles_stream, <<<(int)tiles, kBlock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, stop_after));
     }
     else
-        LPHQ_DISPATCH(k_query_tiles_random, <<<(int)tiles, kBlock, 0, stream>>>(H, d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out));
+        LPHQ_DISPATCH(k_query_tiles_random, <<<(int)tiles, kBlock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out));
     return hipGetLastError();
 }
 
