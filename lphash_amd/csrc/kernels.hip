@@ -157,10 +157,10 @@ struct TileInfo {
     uint32_t rlo, rhi;  // records containing the first / last base the tile can touch
 };
 
-template <bool WANT_BAD, int NWORDS>
+template <bool WANT_BAD, int NWORDS, int BLOCK = kBlock>
 __device__ __forceinline__ void load_tile(const uint8_t* __restrict__ seq_al, uint64_t shift, uint64_t total, uint64_t t0 /* shifted, 16-aligned */,
                                           uint32_t* __restrict__ sm_words, uint32_t* __restrict__ sm_bad) {
-    for (int c = threadIdx.x; c < NWORDS + 1; c += kBlock) {
+    for (int c = threadIdx.x; c < NWORDS + 1; c += BLOCK) {
         const uint64_t a = t0 + (uint64_t)c * 16u;  // shifted coordinate of the chunk
         uint32_t word = 0, badm = 0xFFFFu;
         if (a < shift + total && a + 16u > shift) {
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_random(const uint8_t* __
 //   F  every window: hval = base +- p (or the per-k-mer fallback lookup for colliding minimizers,
 //      partitioned_mphf.hpp:133-135), coalesced stores
 // Windows holding a non-ACGT base get LPHQ_INVALID (the reference emits nothing for them).
-constexpr int kStreamPos = 1024;  // m-mer positions per tile (4 per lane)
-__host__ __device__ inline uint32_t stream_tile_windows(uint32_t W) { return (uint32_t)(kStreamPos - (int)W + 1) & ~15u; }
+constexpr int kStreamBlockDefault = 256;  // threads per workgroup of the streaming kernel; 4 m-mer positions per lane
+__host__ __device__ inline uint32_t stream_tile_windows(uint32_t W, int npos) { return (uint32_t)(npos - (int)W + 1) & ~15u; }
 
 struct HashPos {
     uint64_t h;
@@ -248,23 +248,31 @@ __device__ __forceinline__ void take_if_less(HashPos& m, uint64_t h, uint32_t p)
     m.p = lt ? p : m.p;
 }
 
-template <int KIND, bool K128, int P>
-__global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
+// hash slot of m-mer position i: lane l owns positions 4l..4l+3 and reads up to 4l+W+2; storing position i at
+// (i % 4) * (BLOCK + 2) + i / 4 makes both the writes and the W+3 reads of consecutive lanes hit consecutive
+// 8-byte slots (no LDS bank conflicts; the plain layout was 4-way conflicted: profiles/r01_stream_phase_counters.txt)
+template <int BLOCK>
+__device__ __forceinline__ uint32_t hslot(uint32_t i) { return (i & 3u) * (uint32_t)(BLOCK + 2) + (i >> 2); }
+
+template <int KIND, bool K128, int P, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
                                                                 uint64_t shift, uint64_t total, const uint64_t* __restrict__ seq_off,
                                                                 const uint64_t* __restrict__ out_off, uint32_t n_records, uint64_t* __restrict__ out,
                                                                 uint32_t stop_after /* profiling aid: 0 = run everything */) {
     const lphq_image_header& H = *(const lphq_image_header*)img;  // read from the image: 77 SGPRs instead of 112 -> 8 workgroups / CU (+11 %)
-    constexpr int NW = tile_words(kStreamPos), WPL = kStreamPos / kBlock;
-    __shared__ uint64_t sm_hash[kStreamPos + 8];  // phase B-C: minimizer hash per m-mer position; phase E-F: the leader's base
+    constexpr int kStreamPos = 4 * BLOCK, NW = tile_words(kStreamPos), WPL = 4;
+    constexpr int NBADW = (NW + 8) / 2 + 2;       // 32-bit words of the bad-base bitmask (1 bit per base)
+    constexpr int NDW = (NW + 1) * 4;             // dwords of sequence (4 bases each) the tile loads
+    __shared__ uint64_t sm_hash[4 * (BLOCK + 2)];  // phase B-C: minimizer hash per m-mer position (hslot order); phase E-F: the leader's base
     __shared__ uint32_t sm_words[NW + 8];
-    __shared__ uint32_t sm_bad[(NW + 8) / 2 + 2];
+    __shared__ uint32_t sm_bad[NBADW];
     __shared__ __attribute__((aligned(16))) uint16_t sm_q[kStreamPos + 8];
     __shared__ uint16_t sm_queue[kStreamPos];
     __shared__ uint8_t sm_mode[kStreamPos];
     __shared__ uint32_t sm_rec[2], sm_count;
     __shared__ uint64_t sm_roff[3];  // seq_off[rlo], seq_off[rlo+1], out_off[rlo]
     const uint32_t k = H.k, m = H.m, W = H.W;
-    const uint32_t TW = stream_tile_windows(W);
+    const uint32_t TW = stream_tile_windows(W, kStreamPos);
     const uint64_t t0 = (uint64_t)blockIdx.x * TW;
     if (threadIdx.x < 128) {  // wave 0 locates the record of the first base the tile can touch, wave 1 that of the last
         const uint64_t gfirst = t0 > shift ? t0 - shift : 0;
@@ -280,23 +288,45 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const uint8_t* __
         }
         if (threadIdx.x == 64) sm_rec[1] = r;
     }
-    for (int c = threadIdx.x; c < (NW + 8) / 2 + 2; c += kBlock) sm_bad[c] = 0xFFFFFFFFu;
+    // ---- A: 4 bases per lane -> one byte of the 2-bit stream + 4 bits of the bad-base mask ----
+    for (int c = threadIdx.x; c < NBADW; c += BLOCK) sm_bad[c] = (c < NDW / 8) ? 0u : 0xFFFFFFFFu;
+    for (int c = NW + 1 + threadIdx.x; c < NW + 8; c += BLOCK) sm_words[c] = 0;
     __syncthreads();
-    load_tile<true, NW>(seq_al, shift, total, t0, sm_words, sm_bad);
-    for (int c = NW + 1 + threadIdx.x; c < NW + 8; c += kBlock) sm_words[c] = 0;
+    for (int d = threadIdx.x; d < NDW; d += BLOCK) {
+        const uint64_t a = t0 + (uint64_t)d * 4u;  // shifted coordinate of the dword
+        uint32_t p8 = 0, b4 = 0xFu;
+        if (a < shift + total && a + 4u > shift) {
+            p8 = pack4(*(const uint32_t*)(seq_al + a), b4);
+            if (a < shift || a + 4u > shift + total)  // bytes outside [shift, shift+total) are not bases
+                for (int i = 0; i < 4; ++i)
+                    if (a + i < shift || a + i >= shift + total) b4 |= 1u << i;
+        }
+        ((uint8_t*)sm_words)[(d & ~3) + (3 - (d & 3))] = (uint8_t)p8;  // first base in the top bits of each 32-bit word
+        if (b4) atomicOr(&sm_bad[d >> 3], b4 << (4 * (d & 7)));
+    }
     __syncthreads();
     if (stop_after == 1u) return;
 
-    // ---- B: hashes of the m-mers starting at local positions [0, 1024) ----
-    const uint64_t mm_seedx = murmur_seedx(H.mm_seed);
+    // ---- B: hashes of the m-mers starting at local positions 4*lane .. 4*lane+3 ----
+    {
+        const uint64_t mm_seedx = murmur_seedx(H.mm_seed);
+        const uint32_t a = 4u * threadIdx.x;
+        // 2m + 6 <= 70 bits starting at base a (a % 4 == 0, so the bit offset within the first word is a multiple of 8)
+        const uint32_t w0 = a >> 4, o = (a & 15u) * 2u;
+        const uint32_t x0 = sm_words[w0], x1 = sm_words[w0 + 1], x2 = sm_words[w0 + 2], x3 = sm_words[w0 + 3];
+        const uint64_t A64 = ((uint64_t)x0 << 32) | x1, C64 = ((uint64_t)x2 << 32) | x3;
+        const uint64_t s0 = o ? ((A64 << o) | ((uint64_t)x2 >> (32 - o))) : A64;  // bits [0, 64) of the stream at base a
+        const uint64_t s1 = o ? (C64 << o) : C64;                                  // bits [64, 128): only the top 6 are needed
+        const uint32_t sh = 64u - 2u * m;
+        const uint64_t mask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
 #pragma unroll
-    for (int r = 0; r < WPL; ++r) {
-        const uint32_t j = threadIdx.x + r * kBlock;
-        uint64_t lo, hi;
-        extract_kmer<false>(sm_words, j, m, lo, hi);
-        sm_hash[j] = murmur8(lo, mm_seedx);
+        for (uint32_t r = 0; r < 4; ++r) {
+            // m-mer r = bits [2r, 2r + 2m) of (s0 : s1)
+            const uint64_t v = r == 0 ? (s0 >> sh) : (((s0 << (2 * r)) | (s1 >> (64 - 2 * r))) >> sh);
+            sm_hash[r * (BLOCK + 2) + threadIdx.x] = murmur8(v & mask, mm_seedx);
+        }
+        if (threadIdx.x < 8) sm_hash[hslot<BLOCK>(kStreamPos + threadIdx.x)] = ~0ull;
     }
-    if (threadIdx.x < 8) sm_hash[kStreamPos + threadIdx.x] = ~0ull;
     __syncthreads();
     if (stop_after == 2u) return;
 
@@ -304,31 +334,32 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const uint8_t* __
     {
         const uint32_t a = 4u * threadIdx.x;
         uint32_t q[4];
+        auto HS = [&](uint32_t i) { return sm_hash[hslot<BLOCK>(min(i, (uint32_t)kStreamPos + 7u))]; };
         if (W >= 4u) {
             // left edge: suffix minima over a+2, a+1, a (`<=`: the left one wins ties)
-            HashPos s2{sm_hash[a + 2], a + 2}, s1, s0;
+            HashPos s2{HS(a + 2), a + 2}, s1, s0;
             {
-                const uint64_t h1 = sm_hash[a + 1], h0 = sm_hash[a];
+                const uint64_t h1 = HS(a + 1), h0 = HS(a);
                 s1 = (h1 <= s2.h) ? HashPos{h1, a + 1} : s2;
                 s0 = (h0 <= s1.h) ? HashPos{h0, a} : s1;
             }
             // core a+3 .. a+W-1, common to the four windows
-            HashPos c{sm_hash[a + 3], a + 3};
-            for (uint32_t t = a + 4; t < a + W && t < (uint32_t)kStreamPos; ++t) take_if_less(c, sm_hash[t], t);
+            HashPos c{HS(a + 3), a + 3};
+            for (uint32_t t = a + 4; t < a + W && t < (uint32_t)kStreamPos; ++t) take_if_less(c, HS(t), t);
             // right edge: prefix minima over a+W, a+W+1, a+W+2 (indices clamp into the ~0 padding of the last lanes)
             const uint32_t e = min(a + W, (uint32_t)kStreamPos);
             HashPos w0 = s0, w1 = s1, w2 = s2, w3 = c;
             take_if_less(w0, c.h, c.p);
             take_if_less(w1, c.h, c.p);
             take_if_less(w2, c.h, c.p);
-            HashPos r{sm_hash[e], e};
+            HashPos r{HS(e), e};
             take_if_less(w1, r.h, r.p);
             take_if_less(w2, r.h, r.p);
             take_if_less(w3, r.h, r.p);
-            r = HashPos{sm_hash[min(e + 1, (uint32_t)kStreamPos + 7)], e + 1};
+            r = HashPos{HS(e + 1), e + 1};
             take_if_less(w2, r.h, r.p);
             take_if_less(w3, r.h, r.p);
-            r = HashPos{sm_hash[min(e + 2, (uint32_t)kStreamPos + 7)], e + 2};
+            r = HashPos{HS(e + 2), e + 2};
             take_if_less(w3, r.h, r.p);
             q[0] = w0.p;
             q[1] = w1.p;
@@ -337,14 +368,20 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const uint8_t* __
         } else {
 #pragma unroll
             for (int jw = 0; jw < 4; ++jw) {
-                HashPos c{sm_hash[a + jw], a + jw};
-                for (uint32_t t = 1; t < W; ++t) take_if_less(c, sm_hash[min(a + jw + t, (uint32_t)kStreamPos + 7)], a + jw + t);
+                HashPos c{HS(a + jw), a + jw};
+                for (uint32_t t = 1; t < W; ++t) take_if_less(c, HS(a + jw + t), a + jw + t);
                 q[jw] = c.p;
             }
         }
-        // window validity: inside the batch, inside one record, no non-ACGT base
+        // window validity: inside the batch, inside one record, no non-ACGT base in [i, i+k)
         const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];
         const uint64_t kmask = (1ull << k) - 1ull;  // k <= 63
+        // bad-base bits [a, a + 96): a % 4 == 0, windows a..a+3 need bits up to a + 3 + 62
+        const uint32_t bw = a >> 5, bo = a & 31u;
+        const uint32_t b0 = sm_bad[bw], b1 = sm_bad[bw + 1], b2 = sm_bad[bw + 2], b3 = sm_bad[bw + 3];
+        const uint64_t blo = bo ? (((((uint64_t)b1 << 32) | b0) >> bo) | ((uint64_t)b2 << (64u - bo))) : ((((uint64_t)b1) << 32) | b0);
+        const uint32_t bhi = bo ? (uint32_t)(((((uint64_t)b3 << 32) | b2) >> bo)) : b2;
+        const uint64_t end1 = sm_roff[1];
         uint16_t qv[4];
 #pragma unroll
         for (int jw = 0; jw < 4; ++jw) {
@@ -354,15 +391,13 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const uint8_t* __
             if (i < TW && ga >= shift && ga - shift + k <= total) {
                 const uint64_t g = ga - shift;
                 bool inside;
-                if (rlo == rhi) inside = g + k <= sm_roff[1];
+                if (rlo == rhi) inside = g + k <= end1;
                 else {
                     const uint32_t r = find_record(seq_off, rlo, rhi, g);
                     inside = g + k <= seq_off[r + 1];
                 }
                 if (inside) {
-                    const uint32_t w0 = i >> 5, o = i & 31u;
-                    uint64_t x = ((((uint64_t)sm_bad[w0 + 1]) << 32) | sm_bad[w0]) >> o;
-                    if (o) x |= ((uint64_t)sm_bad[w0 + 2]) << (64u - o);
+                    const uint64_t x = jw ? ((blo >> jw) | ((uint64_t)bhi << (64 - jw))) : blo;
                     v = (x & kmask) ? (uint16_t)0xFFFFu : (uint16_t)q[jw];
                 }
             }
@@ -377,7 +412,7 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const uint8_t* __
     const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
     for (int r = 0; r < WPL; ++r) {
-        const uint32_t i = threadIdx.x + r * kBlock;
+        const uint32_t i = threadIdx.x + r * BLOCK;
         const uint16_t qv = sm_q[i];
         const bool leader = qv < 0xFFFEu && (i == 0 || sm_q[i - 1] != qv);
         const uint64_t bal = __ballot(leader);
@@ -391,12 +426,12 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const uint8_t* __
 
     // ---- E: one lookup per super-k-mer, dense lanes ----
     const uint32_t nlead = sm_count;
-    for (uint32_t x = threadIdx.x; x < nlead; x += kBlock) {
+    for (uint32_t x = threadIdx.x; x < nlead; x += BLOCK) {
         const uint32_t q = sm_queue[x];
         uint64_t mm, hi;
         extract_kmer<false>(sm_words, q, m, mm, hi);
         const LookupCtx c = lookup_ctx<KIND, K128, P>(img, H, mm);
-        sm_hash[q] = c.base;
+        sm_hash[hslot<BLOCK>(q)] = c.base;
         sm_mode[q] = (uint8_t)c.mode;
     }
     __syncthreads();
@@ -406,7 +441,7 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const uint8_t* __
     const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];
 #pragma unroll
     for (int r = 0; r < WPL; ++r) {
-        const uint32_t i = threadIdx.x + r * kBlock;
+        const uint32_t i = threadIdx.x + r * BLOCK;
         const uint32_t q = sm_q[i];
         if (q == 0xFFFEu) continue;
         const uint64_t g = t0 + i - shift;
@@ -419,7 +454,7 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_stream(const uint8_t* __
         uint64_t hval = ~0ull;  // LPHQ_INVALID
         if (q != 0xFFFFu) {
             LookupCtx c;
-            c.base = sm_hash[q];
+            c.base = sm_hash[hslot<BLOCK>(q)];
             c.mode = sm_mode[q];
             uint64_t lo = 0, hi = 0;
             if (c.mode == 2u) extract_kmer<K128>(sm_words, i, k, lo, hi);
@@ -463,6 +498,19 @@ static inline int grid_for(size_t n, int per_block, int max_blocks) {
         }                                                                              \
     } while (0)
 
+#define LPHQ_DISPATCH_B(KERNEL, B, ...)                                                \
+    do {                                                                               \
+        const bool k128 = H.kmer_bits == 128;                                          \
+        const bool p6 = H.P == 6;                                                      \
+        if (H.kind == 0) {                                                             \
+            if (k128) { if (p6) KERNEL<0, true, 6, B> __VA_ARGS__; else KERNEL<0, true, 4, B> __VA_ARGS__; }   \
+            else      { if (p6) KERNEL<0, false, 6, B> __VA_ARGS__; else KERNEL<0, false, 4, B> __VA_ARGS__; } \
+        } else {                                                                       \
+            if (k128) { if (p6) KERNEL<1, true, 6, B> __VA_ARGS__; else KERNEL<1, true, 4, B> __VA_ARGS__; }   \
+            else      { if (p6) KERNEL<1, false, 6, B> __VA_ARGS__; else KERNEL<1, false, 4, B> __VA_ARGS__; } \
+        }                                                                              \
+    } while (0)
+
 hipError_t launch_query_packed(const lphq_image_header& H, const uint8_t* d_img, const void* d_kmers, size_t n, uint64_t* d_out, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const int grid = grid_for(n, kBlock, 256 * 16);
@@ -490,12 +538,16 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
     const uint64_t shift = (uint64_t)((uintptr_t)d_seq & 15u);
     const uint8_t* seq_al = (const uint8_t*)d_seq - shift;
     const uint64_t span = shift + total_bases;
-    const uint64_t tw = streaming ? stream_tile_windows(H.W) : kTileW;
+    static const int sblock = getenv("LPHQ_STREAM_BLOCK") ? atoi(getenv("LPHQ_STREAM_BLOCK")) : kStreamBlockDefault;  // tuning aid
+    const uint64_t tw = streaming ? stream_tile_windows(H.W, 4 * sblock) : kTileW;
     const uint64_t tiles = (span + tw - 1) / tw;
     if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
     if (streaming) {
         static const uint32_t stop_after = getenv("LPHQ_PROFILE_STREAM_STOP") ? (uint32_t)atoi(getenv("LPHQ_PROFILE_STREAM_STOP")) : 0u;  // phase timing only
-        LPHQ_DISPATCH(k_query_tiles_stream, <<<(int)tiles, kBlock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, stop_after));
+#define LPHQ_STREAM_LAUNCH(B) LPHQ_DISPATCH_B(k_query_tiles_stream, B, <<<(int)tiles, B, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, stop_after))
+        if (sblock == 128) LPHQ_STREAM_LAUNCH(128);
+        else if (sblock == 512) LPHQ_STREAM_LAUNCH(512);
+        else LPHQ_STREAM_LAUNCH(256);
     }
     else
         LPHQ_DISPATCH(k_query_tiles_random, <<<(int)tiles, kBlock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out));
