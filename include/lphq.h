@@ -143,6 +143,12 @@ int lphq_build(const char* const* records, const size_t* lengths, size_t n_recor
                uint64_t mm_seed, double c, int kind, int kmer_bits, int threads, const char* out_path,
                lphq_build_stats* stats /* may be NULL */);
 
+/* Same function, same bytes written, with the PTHash pilot search (95 % of the CPU build time) run on HIP device
+ * `device` (speculative search of a window of buckets + in-order commit, lphash_amd/csrc/search.hip).  device < 0: CPU. */
+int lphq_build_device(const char* const* records, const size_t* lengths, size_t n_records, int k, int m,
+                      uint64_t mm_seed, double c, int kind, int kmer_bits, int threads, int device, const char* out_path,
+                      lphq_build_stats* stats /* may be NULL */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,8 @@ SIGNATURES = {
                                     C.POINTER(C.c_size_t)]),
     "lphq_build": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int, C.c_uint64,
                              C.c_double, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(BuildStats)]),
+    "lphq_build_device": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int, C.c_uint64,
+                                    C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(BuildStats)]),
 }
 
 

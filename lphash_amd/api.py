@@ -18,9 +18,10 @@ from . import _lib
 from ._lib import PARTITIONED, UNPARTITIONED, LphqError, check, lib
 
 
-def build(records, k, m, out_path, kind=PARTITIONED, kmer_bits=None, mm_seed=42, c=3.0, threads=0):
+def build(records, k, m, out_path, kind=PARTITIONED, kmer_bits=None, mm_seed=42, c=3.0, threads=0, device=None):
     """`lphash build-p|build-u -i ... -k k -m m -s seed -c c -t threads -o out_path` over in-memory records
-    (src/build.cpp:10-51).  records: iterable of bytes, one per FASTA/FASTQ record (what kseq_read yields)."""
+    (src/build.cpp:10-51).  records: iterable of bytes, one per FASTA/FASTQ record (what kseq_read yields).
+    device: HIP ordinal for the PTHash pilot search (None = CPU search); the file written is the same."""
     records = [bytes(r) for r in records]
     if kmer_bits is None:
         kmer_bits = 64 if k <= 31 else 128
@@ -28,8 +29,8 @@ def build(records, k, m, out_path, kind=PARTITIONED, kmer_bits=None, mm_seed=42,
     arr = (C.c_char_p * n)(*records)
     lens = (C.c_size_t * n)(*[len(r) for r in records])
     stats = _lib.BuildStats()
-    check(lib.lphq_build(arr, lens, n, int(k), int(m), int(mm_seed), float(c), int(kind), int(kmer_bits), int(threads),
-                         str(out_path).encode(), C.byref(stats)))
+    check(lib.lphq_build_device(arr, lens, n, int(k), int(m), int(mm_seed), float(c), int(kind), int(kmer_bits), int(threads),
+                                -1 if device is None else int(device), str(out_path).encode(), C.byref(stats)))
     return {name: getattr(stats, name) for name, _ in stats._fields_}
 
 

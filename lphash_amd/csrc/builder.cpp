@@ -14,6 +14,7 @@
 // does not depend on the thread count.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -24,6 +25,7 @@
 
 #include "../../include/lphq.h"
 #include "lph_format.hpp"
+#include "search.hpp"
 
 namespace lphq {
 namespace {
@@ -282,9 +284,16 @@ void dict_encode(Dictionary& d, const uint64_t* v, uint64_t n) {  // pthash::dic
     cv_build(d.dict, dict);
 }
 
-bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed, double c, double alpha, int threads, std::string& err) {
+bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed, double c, double alpha, int threads, int device, std::string& err) {
     f = SinglePhf();
     f.seed = seed;
+    const bool verbose = getenv("LPHQ_BUILD_VERBOSE") != nullptr;
+    auto tprev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        auto now = std::chrono::steady_clock::now();
+        if (verbose) fprintf(stderr, "[lphq_build]   pthash: %-34s %8.3f s\n", what, std::chrono::duration<double>(now - tprev).count());
+        tprev = now;
+    };
     const uint64_t n = hashes.size();
     f.num_keys = n;
     if (n == 0) return true;  // all-zero function; the reference never builds one
@@ -358,77 +367,88 @@ bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed,
     uint64_t n_nonempty = num_buckets;
     while (n_nonempty && bstart[order[n_nonempty - 1] + 1] == bstart[order[n_nonempty - 1]]) --n_nonempty;
 
+    lap("group hashes by bucket, order");
     // search
     std::vector<uint64_t> pilots(num_buckets, 0);
-    std::vector<std::atomic<uint64_t>> taken(words_for(table_size) + 1);
-    for (auto& x : taken) x.store(0, std::memory_order_relaxed);
-    const uint64_t HP_CACHE = 1ull << 20;
-    std::vector<uint64_t> hp_cache(HP_CACHE);
-    parallel_for(HP_CACHE >> 12, threads, [&](size_t t) {
-        for (uint64_t p = t << 12; p < (t + 1) << 12; ++p) hp_cache[p] = murmur64a_u64(p, seed);
-    });
-    std::atomic<uint64_t> next_commit{0};
-    const u128 M = f.M;
-    auto is_taken = [&](uint64_t p) { return (taken[p >> 6].load(std::memory_order_relaxed) >> (p & 63)) & 1; };
-    const int T = std::max(1, threads);
-    auto worker = [&](int tid) {
-        std::vector<uint64_t> pos(max_size ? max_size : 1);
-        for (uint64_t oi = (uint64_t)tid; oi < n_nonempty; oi += (uint64_t)T) {
-            const uint32_t b = order[oi];
-            const uint64_t* keys = hs.data() + bstart[b];
-            const uint64_t s = bstart[b + 1] - bstart[b];
-            uint64_t pilot = 0;
-            bool my_turn = false;
-            for (;;) {
-                // first pilot (>= current) whose positions are free under the bits visible now
-                for (;; ++pilot) {
-                    const uint64_t hp = pilot < HP_CACHE ? hp_cache[pilot] : murmur64a_u64(pilot, seed);
-                    uint64_t j = 0;
-                    for (; j < s; ++j) {
-                        const uint64_t p = fastmod_u64(keys[j] ^ hp, M, table_size);
-                        if (is_taken(p)) break;
-                        pos[j] = p;
-                    }
-                    if (j < s) continue;
-                    bool d2 = false;
-                    for (uint64_t a = 1; a < s && !d2; ++a)
-                        for (uint64_t q = 0; q < a; ++q)
-                            if (pos[a] == pos[q]) {
-                                d2 = true;
-                                break;
-                            }
-                    if (!d2) break;
-                }
-                if (my_turn) break;  // searched under the exact table: done
-                while (next_commit.load(std::memory_order_acquire) != oi) std::this_thread::yield();
-                my_turn = true;
-                bool still_free = true;
-                for (uint64_t j = 0; j < s; ++j)
-                    if (is_taken(pos[j])) {
-                        still_free = false;
-                        break;
-                    }
-                if (still_free) break;
-                // else: keep scanning from this pilot, now under the exact table
-            }
-            for (uint64_t j = 0; j < s; ++j) taken[pos[j] >> 6].fetch_or(1ULL << (pos[j] & 63), std::memory_order_relaxed);
-            pilots[b] = pilot;
-            next_commit.store(oi + 1, std::memory_order_release);
-        }
-    };
-    if (T == 1) {
-        worker(0);
+    std::vector<uint64_t> taken_plain;  // bit p of word p/64: table position p is occupied
+    if (device >= 0 && n >= 4096) {  // pilot search on the GPU (search.hip): same first-fit result, ~50x faster
+        if (!gpu_pilot_search(device, hs, bstart, order, n_nonempty, table_size, seed, pilots, taken_plain, err)) return false;
     } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < T; ++t) pool.emplace_back(worker, t);
-        for (auto& th : pool) th.join();
+        std::vector<std::atomic<uint64_t>> taken(words_for(table_size) + 1);
+        for (auto& x : taken) x.store(0, std::memory_order_relaxed);
+        const uint64_t HP_CACHE = 1ull << 20;
+        std::vector<uint64_t> hp_cache(HP_CACHE);
+        parallel_for(HP_CACHE >> 12, threads, [&](size_t t) {
+            for (uint64_t p = t << 12; p < (t + 1) << 12; ++p) hp_cache[p] = murmur64a_u64(p, seed);
+        });
+        std::atomic<uint64_t> next_commit{0};
+        const u128 M = f.M;
+        auto is_taken = [&](uint64_t p) { return (taken[p >> 6].load(std::memory_order_relaxed) >> (p & 63)) & 1; };
+        const int T = std::max(1, threads);
+        auto worker = [&](int tid) {
+            std::vector<uint64_t> pos(max_size ? max_size : 1);
+            for (uint64_t oi = (uint64_t)tid; oi < n_nonempty; oi += (uint64_t)T) {
+                const uint32_t b = order[oi];
+                const uint64_t* keys = hs.data() + bstart[b];
+                const uint64_t s = bstart[b + 1] - bstart[b];
+                uint64_t pilot = 0;
+                bool my_turn = false;
+                for (;;) {
+                    // first pilot (>= current) whose positions are free under the bits visible now
+                    for (;; ++pilot) {
+                        const uint64_t hp = pilot < HP_CACHE ? hp_cache[pilot] : murmur64a_u64(pilot, seed);
+                        uint64_t j = 0;
+                        for (; j < s; ++j) {
+                            const uint64_t p = fastmod_u64(keys[j] ^ hp, M, table_size);
+                            if (is_taken(p)) break;
+                            pos[j] = p;
+                        }
+                        if (j < s) continue;
+                        bool d2 = false;
+                        for (uint64_t a = 1; a < s && !d2; ++a)
+                            for (uint64_t q = 0; q < a; ++q)
+                                if (pos[a] == pos[q]) {
+                                    d2 = true;
+                                    break;
+                                }
+                        if (!d2) break;
+                    }
+                    if (my_turn) break;  // searched under the exact table: done
+                    while (next_commit.load(std::memory_order_acquire) != oi) std::this_thread::yield();
+                    my_turn = true;
+                    bool still_free = true;
+                    for (uint64_t j = 0; j < s; ++j)
+                        if (is_taken(pos[j])) {
+                            still_free = false;
+                            break;
+                        }
+                    if (still_free) break;
+                    // else: keep scanning from this pilot, now under the exact table
+                }
+                for (uint64_t j = 0; j < s; ++j) taken[pos[j] >> 6].fetch_or(1ULL << (pos[j] & 63), std::memory_order_relaxed);
+                pilots[b] = pilot;
+                next_commit.store(oi + 1, std::memory_order_release);
+            }
+        };
+        if (T == 1) {
+            worker(0);
+        } else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < T; ++t) pool.emplace_back(worker, t);
+            for (auto& th : pool) th.join();
+        }
+        taken_plain.resize(taken.size());
+        for (size_t i = 0; i < taken.size(); ++i) taken_plain[i] = taken[i].load(std::memory_order_relaxed);
     }
+    auto is_taken = [&](uint64_t p) { return (taken_plain[p >> 6] >> (p & 63)) & 1; };
+    lap(device >= 0 && n >= 4096 ? "pilot search (GPU)" : "pilot search (CPU)");
 
     // dual<dictionary, dictionary>::encode: front = first 0.3 * num_buckets pilots
     const uint64_t front_size = (uint64_t)((double)num_buckets * 0.3);
     dict_encode(f.front, pilots.data(), front_size);
     dict_encode(f.back, pilots.data() + front_size, num_buckets - front_size);
 
+    lap("dictionary encode");
     // minimal: fill_free_slots + ef_sequence<false>::encode
     if (n < table_size) {
         std::vector<uint64_t> fs;
@@ -452,6 +472,7 @@ bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed,
         }
         ef_encode(f.free_slots, fs.size(), fs.back(), false, [&](uint64_t i) { return fs[i]; });
     }
+    lap("free slots");
     return true;
 }
 
@@ -586,8 +607,8 @@ using namespace lphq;
 
 namespace lphq { void set_last_error(const std::string& s); }  // capi.cpp
 
-extern "C" int lphq_build(const char* const* records, const size_t* lengths, size_t n_records, int k_, int m_, uint64_t mm_seed, double c, int kind,
-                          int kmer_bits, int threads, const char* out_path, lphq_build_stats* stats) {
+static int build_impl(const char* const* records, const size_t* lengths, size_t n_records, int k_, int m_, uint64_t mm_seed, double c, int kind,
+                      int kmer_bits, int threads, int device, const char* out_path, lphq_build_stats* stats) {
     auto fail = [&](int code, const std::string& msg) {
         set_last_error(msg);
         return code;
@@ -601,6 +622,13 @@ extern "C" int lphq_build(const char* const* records, const size_t* lengths, siz
     if (c < 3.0 || c > 10.0) return fail(LPHQ_ERR_ARG, "3.0 <= c <= 10.0");  // parser_build.cpp:78-81
     if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
     const uint32_t k = (uint32_t)k_, m = (uint32_t)m_, W = k - m + 1;
+    const bool verbose = getenv("LPHQ_BUILD_VERBOSE") != nullptr;
+    auto tprev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        auto now = std::chrono::steady_clock::now();
+        if (verbose) fprintf(stderr, "[lphq_build] %-44s %8.3f s\n", what, std::chrono::duration<double>(now - tprev).count());
+        tprev = now;
+    };
     const double alpha = 0.94;       // partitioned_mphf.cpp:48
     const uint64_t pthash_seed = 1;  // constants::default_pthash_seed
 
@@ -640,6 +668,7 @@ extern "C" int lphq_build(const char* const* records, const size_t* lengths, siz
             std::vector<Run>().swap(chunk_runs[ci]);
         }
     }
+    lap("part 1: super-k-mer runs");
     uint64_t nkmers = 0;
     for (const Run& r : runs) nkmers += r.size;
     (void)nkmers_upper;
@@ -647,6 +676,7 @@ extern "C" int lphq_build(const char* const* records, const size_t* lengths, siz
 
     // ---- Part 2: classify (src/minimizer.cpp:5-50) + PTHash over the distinct minimizers -------------
     parallel_sort_by_key(runs, threads, 2 * m, [](const Run& r) { return r.mm; });
+    lap("part 2: sort runs by minimizer");
     std::vector<Triplet> uniq;
     std::vector<uint64_t> uniq_mm;
     std::vector<std::pair<uint64_t, uint32_t>> colliding;  // (first window, size) of every super-k-mer of a repeated minimizer
@@ -666,6 +696,7 @@ extern "C" int lphq_build(const char* const* records, const size_t* lengths, siz
     }
     std::vector<Run>().swap(runs);
     const uint64_t D = uniq.size();
+    lap("part 2: classify");
 
     LphFile x;
     x.kind = kind;
@@ -681,8 +712,9 @@ extern "C" int lphq_build(const char* const* records, const size_t* lengths, siz
         parallel_for((D + 65535) / 65536, threads, [&](size_t t) {
             for (size_t i = t * 65536, e = std::min<size_t>(D, i + 65536); i < e; ++i) hashes[i] = murmur64a_u64(uniq_mm[i], pthash_seed);
         });
-        if (!phf_build(x.minimizer_order, hashes, pthash_seed, c, alpha, threads, err)) return fail(LPHQ_ERR_FORMAT, err);
+        if (!phf_build(x.minimizer_order, hashes, pthash_seed, c, alpha, threads, device, err)) return fail(LPHQ_ERR_FORMAT, err);
     }
+    lap("part 2: PTHash over minimizers");
 
     // ---- Part 3: order by the minimizer MPHF (a bijection onto [0, D): direct placement) ---------------
     std::vector<Triplet> by_order(D);
@@ -707,6 +739,7 @@ extern "C" int lphq_build(const char* const* records, const size_t* lengths, siz
     }
     std::vector<Triplet>().swap(uniq);
     std::vector<uint64_t>().swap(uniq_mm);
+    lap("part 3: order by minimizer MPHF");
 
     if (kind == LPHQ_PARTITIONED) {  // build_inverted_index, src/partitioned_mphf.cpp:163-268
         bv_init(x.root.bv, D);
@@ -775,6 +808,7 @@ extern "C" int lphq_build(const char* const* records, const size_t* lengths, siz
         x.num_kmers_in_main_index = size_sum;
     }
     std::vector<Triplet>().swap(by_order);
+    lap("part 3: inverted index (wavelet tree, EF)");
 
     // ---- Part 4: fallback PTHash over the k-mers of repeated minimizers, in input order ----------------
     {
@@ -796,9 +830,10 @@ extern "C" int lphq_build(const char* const* records, const size_t* lengths, siz
                 fh.push_back(h);
             }
         }
-        if (!phf_build(x.fallback_kmer_order, fh, pthash_seed, c, alpha, threads, err)) return fail(LPHQ_ERR_FORMAT, err);
+        if (!phf_build(x.fallback_kmer_order, fh, pthash_seed, c, alpha, threads, device, err)) return fail(LPHQ_ERR_FORMAT, err);
     }
 
+    lap("part 4: fallback MPHF");
     // ---- essentials::save ----------------------------------------------------------------------------
     Writer w;
     w.raw(&x.k, 1);
@@ -829,6 +864,7 @@ extern "C" int lphq_build(const char* const* records, const size_t* lengths, siz
     size_t put = fwrite(w.buf.data(), 1, w.buf.size(), fo);
     fclose(fo);
     if (put != w.buf.size()) return fail(LPHQ_ERR_IO, std::string("short write on ") + out_path);
+    lap("save");
     if (stats) {
         stats->num_kmers = nkmers;
         stats->num_records = n_records;
@@ -839,4 +875,15 @@ extern "C" int lphq_build(const char* const* records, const size_t* lengths, siz
         stats->file_bytes = w.buf.size();
     }
     return LPHQ_OK;
+}
+
+extern "C" int lphq_build(const char* const* records, const size_t* lengths, size_t n_records, int k, int m, uint64_t mm_seed, double c, int kind,
+                          int kmer_bits, int threads, const char* out_path, lphq_build_stats* stats) {
+    return build_impl(records, lengths, n_records, k, m, mm_seed, c, kind, kmer_bits, threads, -1, out_path, stats);
+}
+
+extern "C" int lphq_build_device(const char* const* records, const size_t* lengths, size_t n_records, int k, int m, uint64_t mm_seed, double c, int kind,
+                                 int kmer_bits, int threads, int device, const char* out_path, lphq_build_stats* stats) {
+    if (device < 0) return build_impl(records, lengths, n_records, k, m, mm_seed, c, kind, kmer_bits, threads, -1, out_path, stats);
+    return build_impl(records, lengths, n_records, k, m, mm_seed, c, kind, kmer_bits, threads, device, out_path, stats);
 }

@@ -199,11 +199,11 @@ int query_main(int kind, int argc, char** argv) {
 }
 
 int build_main(int kind, int argc, char** argv) {
-    Args a = parse(argc, argv, {"-i", "-k", "-m", "-s", "-t", "-o", "-d", "-c", "--max-memory", "--kmer-bits", "--device"}, {"--check", "--verbose"});
+    Args a = parse(argc, argv, {"-i", "-k", "-m", "-s", "-t", "-o", "-d", "-c", "--max-memory", "--kmer-bits", "--device"}, {"--check", "--verbose", "--cpu"});
     if (a.help || a.bad || !a.get("-i") || !a.get("-k") || !a.get("-m")) {
         std::cerr << "Usage: " << argv[0]
                   << " [-h,--help] -i input_filename -k k -m m [-s seed] [-t threads] [-o output_filename] [-d tmp_dirname] [-c c] "
-                     "[--max-memory max-memory] [--check] [--verbose] [--kmer-bits 64|128]\n";
+                     "[--max-memory max-memory] [--check] [--verbose] [--kmer-bits 64|128] [--device N] [--cpu]\n";
         if (!a.help) std::cerr << "Unable to parse the arguments\n";
         return 2;  // ParseError -> 2, src/build.cpp:14-16
     }
@@ -253,7 +253,14 @@ int build_main(int kind, int argc, char** argv) {
     if (temp_out) out = "/tmp/lphash_build_" + std::to_string((long)getpid()) + ".lph";
     lphq_build_stats st;
     if (verbose) std::cerr << "Part 1-4: super-k-mers, minimizer MPHF, inverted index, fallback MPHF\n";
-    if (lphq_build(ptrs.data(), lens.data(), recs.size(), k, m, seed, c, kind, kmer_bits, threads, out.c_str(), &st) != LPHQ_OK) {
+    // construction is not the query path: the pilot search runs on the GPU when one is usable, else on the CPU (same file)
+    int build_device = a.has("--cpu") ? -1 : (a.get("--device") ? std::atoi(a.get("--device")->c_str()) : 0);
+    if (build_device >= 0) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || build_device >= ndev) build_device = -1;
+    }
+    if (verbose) std::cerr << "PTHash pilot search on " << (build_device >= 0 ? "GPU " + std::to_string(build_device) : std::string("the CPU")) << "\n";
+    if (lphq_build_device(ptrs.data(), lens.data(), recs.size(), k, m, seed, c, kind, kmer_bits, threads, build_device, out.c_str(), &st) != LPHQ_OK) {
         std::cerr << "[Error] " << lphq_last_error() << "\n";
         return 4;
     }

@@ -258,3 +258,17 @@ def test_cli_query_end_to_end(tmp_path):
     assert r.returncode == 2
     r = subprocess.run([exe, "query-u", "-i", str(lpu), "-q", str(fa), "--kmer-bits", "64"], capture_output=True, text=True)
     assert r.returncode == 0 and int(r.stdout.split(",")[2]) == sum(max(0, len(x) - 30) for x in recs)
+
+
+@pytest.mark.parametrize("k,m,bits,kind,nrec,rlen", [(31, 20, 64, 0, 40, 30_000), (63, 20, 128, 0, 30, 40_000), (31, 20, 64, 1, 40, 30_000), (21, 8, 64, 0, 20, 20_000),
+                                                     (31, 15, 128, 0, 50, 60_000)])
+def test_gpu_pilot_search_build_is_byte_identical(tmp_path, k, m, bits, kind, nrec, rlen):
+    """lphq_build_device (PTHash pilot search on the GPU: speculative window + in-order commit) must write exactly the
+    file the sequential first-fit search writes."""
+    _, recs = synthetic_records(seed=11 + k, n_records=nrec, length=rlen)
+    recs = dedup_records(recs, k) if k < 25 else recs
+    pc, pg = str(tmp_path / "cpu.lph"), str(tmp_path / "gpu.lph")
+    sc = L.build(recs, k, m, pc, kind=kind, kmer_bits=bits, threads=8)
+    sg = L.build(recs, k, m, pg, kind=kind, kmer_bits=bits, threads=8, device=0)
+    assert sc == sg
+    assert open(pc, "rb").read() == open(pg, "rb").read()
