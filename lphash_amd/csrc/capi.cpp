@@ -72,12 +72,18 @@ extern "C" int lphq_open_memory(const void* buf, size_t len, int kind, int kmer_
     if (kmer_bits != 64 && kmer_bits != 128) return fail(LPHQ_ERR_ARG, "kmer_bits must be 64 or 128");
     LphFile file;
     std::string err;
-    if (!parse_lph((const uint8_t*)buf, len, kind, kmer_bits, file, err)) return fail(LPHQ_ERR_FORMAT, err);
-    lphq_index* idx = new (std::nothrow) lphq_index();
-    if (!idx) return fail(LPHQ_ERR_ARG, "out of memory");
-    if (!build_image(file, idx->image, err)) {
+    lphq_index* idx = nullptr;
+    try {  // no exception may cross the C ABI (a hostile length field could otherwise surface as std::bad_alloc)
+        if (!parse_lph((const uint8_t*)buf, len, kind, kmer_bits, file, err)) return fail(LPHQ_ERR_FORMAT, err);
+        idx = new (std::nothrow) lphq_index();
+        if (!idx) return fail(LPHQ_ERR_ARG, "out of memory");
+        if (!build_image(file, idx->image, err)) {
+            delete idx;
+            return fail(err.find("beyond the device layout") != std::string::npos ? LPHQ_ERR_UNSUPPORTED : LPHQ_ERR_FORMAT, err);
+        }
+    } catch (const std::exception& e) {
         delete idx;
-        return fail(err.find("beyond the device layout") != std::string::npos ? LPHQ_ERR_UNSUPPORTED : LPHQ_ERR_FORMAT, err);
+        return fail(LPHQ_ERR_FORMAT, std::string("malformed file: ") + e.what());
     }
     memcpy(&idx->hdr, idx->image.data(), sizeof idx->hdr);
     idx->file_bytes = file.bytes_read;

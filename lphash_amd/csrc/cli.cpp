@@ -97,7 +97,7 @@ struct DeviceBatch {
 
 // One pass of src/query.cpp:48-56 / :68-76 over the whole file, batched: returns false if the file cannot be opened.
 bool query_pass(lphq_index* idx, const lphq_info& info, const std::string& path, int streaming, size_t batch_bases, DeviceBatch& db,
-                uint64_t& total_kmers, uint64_t& elapsed_us, std::string& err) {
+                uint64_t& total_kmers, uint64_t& elapsed_us, std::string& err, FILE* sink) {
     lphq::FastxReader rd(path.c_str());
     if (!rd.ok()) return false;
     auto t0 = std::chrono::high_resolution_clock::now();
@@ -137,6 +137,20 @@ bool query_pass(lphq_index* idx, const lphq_info& info, const std::string& path,
                 return false;
             }
             total_kmers += valid;
+            if (sink) {  // result sink: the reference discards the codes (src/query.cpp:54); here they can be kept (raw little-endian u64)
+                std::vector<uint64_t> codes(oo);
+                if (hipMemcpy(codes.data(), db.d_out, oo * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+                    err = "device to host copy failed";
+                    return false;
+                }
+                size_t nv = 0;
+                for (size_t i = 0; i < oo; ++i)
+                    if (codes[i] != LPHQ_INVALID) codes[nv++] = codes[i];
+                if (fwrite(codes.data(), 8, nv, sink) != nv) {
+                    err = "cannot write the output file";
+                    return false;
+                }
+            }
         }
         flat.clear();
         offs.clear();
@@ -154,9 +168,9 @@ bool query_pass(lphq_index* idx, const lphq_info& info, const std::string& path,
 }
 
 int query_main(int kind, int argc, char** argv) {
-    Args a = parse(argc, argv, {"-i", "-q", "--kmer-bits", "--device", "--batch-mb"}, {});
+    Args a = parse(argc, argv, {"-i", "-q", "--kmer-bits", "--device", "--batch-mb", "--output"}, {});
     if (a.help || a.bad || !a.get("-i") || !a.get("-q")) {
-        std::cerr << "Usage: " << argv[0] << " [-h,--help] -i mphf -q query_filename [--kmer-bits 64|128] [--device N] [--batch-mb N]\n\n"
+        std::cerr << "Usage: " << argv[0] << " [-h,--help] -i mphf -q query_filename [--kmer-bits 64|128] [--device N] [--batch-mb N] [--output codes.u64]\n\n"
                   << " -i mphf\n\tREQUIRED: LP-Hash MPHF saved on disk.\n\n"
                   << " -q query_filename\n\tREQUIRED: Must be a FASTA file (.fa/fasta extension) compressed with gzip (.gz) or not.\n\n"
                   << " --kmer-bits\n\tk-mer word width the MPHF was built with (the reference's compile-time kmer_t): 128 (default) or 64.\n";
@@ -178,8 +192,15 @@ int query_main(int kind, int argc, char** argv) {
     DeviceBatch db;
     uint64_t total_on = 0, total_off = 0, t_on = 0, t_off = 0;
     std::string err;
+    FILE* sink = nullptr;
+    if (a.get("--output") && !(sink = fopen(a.get("--output")->c_str(), "wb"))) {
+        std::cerr << "Unable to open the output file " << *a.get("--output") << "\n";
+        lphq_close(idx);
+        return 2;
+    }
     for (int pass = 0; pass < 2; ++pass) {
-        bool opened = query_pass(idx, info, query_filename, pass == 0, batch_bases, db, pass == 0 ? total_on : total_off, pass == 0 ? t_on : t_off, err);
+        bool opened = query_pass(idx, info, query_filename, pass == 0, batch_bases, db, pass == 0 ? total_on : total_off, pass == 0 ? t_on : t_off, err,
+                                 pass == 0 ? sink : nullptr);
         if (!opened) {
             std::cerr << "Unable to open the input file " << query_filename << "\n";
             lphq_close(idx);
@@ -191,6 +212,7 @@ int query_main(int kind, int argc, char** argv) {
             return 3;
         }
     }
+    if (sink) fclose(sink);
     // src/query.cpp:83-86
     std::cout << query_filename << "," << mphf_filename << "," << total_on << "," << static_cast<double>(t_on * 1000) / total_on << ","
               << static_cast<double>(t_off * 1000) / total_off << std::endl;

@@ -125,12 +125,13 @@ bool check_cv(const CompactVector& c, const char* what, std::string& err) {
     CHECK(c.width <= 64, "compact_vector width %llu", (unsigned long long)c.width);
     uint64_t mask = c.width == 64 ? ~0ULL : ((1ULL << c.width) - 1);
     CHECK(c.mask == mask, "compact_vector mask does not match width %llu", (unsigned long long)c.width);
-    CHECK(c.bits.size() >= words_for(c.size * c.width), "compact_vector too short");
+    CHECK(c.width == 0 || c.size <= (uint64_t)c.bits.size() * 64 / c.width, "compact_vector too short");
     return true;
 }
 bool check_ef(const EliasFano& e, const char* what, std::string& err) {
     if (!check_bv(e.high, what, err) || !check_cv(e.low, what, err)) return false;
     CHECK(e.low.width < 64, "elias-fano low width %llu", (unsigned long long)e.low.width);
+    CHECK(e.low.size <= e.high.size, "elias-fano: more values than high bits");
     return true;
 }
 uint64_t popcount_bv(const BitVector& b) {
@@ -162,8 +163,10 @@ bool check_phf(const SinglePhf& f, const char* what, std::string& err) {
           (unsigned long long)(f.front.ranks.size + f.back.ranks.size), (unsigned long long)(f.num_dense + f.num_sparse));
     CHECK(f.free_slots.size() == f.table_size - f.num_keys, "free slots: %llu entries for %llu holes", (unsigned long long)f.free_slots.size(),
           (unsigned long long)(f.table_size - f.num_keys));
-    for (const Dictionary* d : {&f.front, &f.back})
+    for (const Dictionary* d : {&f.front, &f.back}) {
+        CHECK(d->ranks.size == 0 || (d->ranks.width >= 1 && d->dict.width >= 1), "zero-width pilot dictionary");
         for (uint64_t i = 0; i < d->ranks.size; ++i) CHECK(d->ranks.access(i) < d->dict.size, "pilot codeword out of range");
+    }
     return true;
 }
 

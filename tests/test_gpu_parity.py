@@ -251,6 +251,12 @@ def test_cli_query_end_to_end(tmp_path):
         assert int(f[2]) == sum(max(0, len(x) - 30) for x in nrec) and float(f[3]) > 0 and float(f[4]) > 0
     r = subprocess.run([exe, "query-p", "-i", str(lph), "-q", str(tmp_path / "missing.fa"), "--kmer-bits", "64"], capture_output=True, text=True)
     assert r.returncode == 2 and "Unable to open the input file" in r.stderr
+    # result sink: --output keeps the codes of the streaming pass (the reference discards them, src/query.cpp:54)
+    sink = tmp_path / "codes.u64"
+    r = subprocess.run([exe, "query-p", "-i", str(lph), "-q", str(fa), "--kmer-bits", "64", "--output", str(sink)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    o = orc.Index(str(lph), 0, 64)
+    assert np.array_equal(np.fromfile(sink, dtype=np.uint64), np.concatenate([o(x, True) for x in recs]))
     # a query-u file through query-p is rejected, not mis-hashed
     lpu = tmp_path / "u.lph"
     subprocess.run([exe, "build-u", "-i", str(fa), "-k", "31", "-m", "20", "-o", str(lpu), "--kmer-bits", "64"], check=True, capture_output=True)

@@ -156,3 +156,32 @@ def test_cli_usage_and_build(tmp_path):
     assert out.read_bytes() == lib_out.read_bytes()
     r = subprocess.run([exe, "build-p", "-i", str(fa), "-k", "33", "-m", "20", "--kmer-bits", "64"], capture_output=True, text=True)
     assert r.returncode == 3 and "k cannot be larger than 31" in r.stderr  # OptionError -> 3, src/build.cpp:17-20
+
+
+def test_loader_fuzz_never_crashes():
+    """Random corruptions of valid files must either load (and then describe a self-consistent function: the image builder
+    re-derives every table) or be rejected with LPHQ_ERR_FORMAT/UNSUPPORTED -- never crash or hang the host side."""
+    rng = np.random.default_rng(123)
+    outcomes = {"ok": 0, "rejected": 0}
+    for name, cls, bits in (("p_k31_m20_b64", L.Mphf, 64), ("u_k21_m8_b64_fallback", L.MphfAlt, 64), ("p_k63_m20_b128", L.Mphf, 128)):
+        good = bytearray(open(golden(name + ".lph"), "rb").read())
+        for trial in range(150):
+            bad = bytearray(good)
+            mode = trial % 3
+            if mode == 0:  # flip a few bits
+                for _ in range(int(rng.integers(1, 4))):
+                    bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+            elif mode == 1:  # overwrite an aligned u64 with a wild value
+                off = int(rng.integers(0, len(bad) - 8))
+                bad[off:off + 8] = int(rng.integers(0, 2**63)).to_bytes(8, "little")
+            else:  # truncate or extend
+                cut = int(rng.integers(1, len(bad)))
+                bad = bad[:cut] if trial % 2 else bad + bytes(rng.integers(0, 256, 16, dtype=np.uint8))
+            try:
+                h = cls.from_bytes(bytes(bad), kmer_bits=bits)
+                assert h.info.image_bytes > 0
+                outcomes["ok"] += 1
+            except L.LphqError as e:
+                assert e.code in (_lib.ERR_FORMAT, _lib.ERR_UNSUPPORTED, _lib.ERR_ARG), e
+                outcomes["rejected"] += 1
+    assert outcomes["rejected"] > 100  # the cross-checks do catch most corruptions
