@@ -69,8 +69,9 @@ __device__ __forceinline__ uint64_t phf_position(const uint8_t* __restrict__ img
     const uint64_t bit = bi * width;
     const uint64_t dw = bit >> 5;
     const uint32_t sh = (uint32_t)bit & 31u;
-    const uint32_t lo = ranks[dw], hi = ranks[dw + 1];
-    const uint32_t code = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & (width >= 32 ? ~0u : ((1u << width) - 1u));
+    struct __attribute__((packed, aligned(4))) u64a4 { uint64_t v; };  // one 8-byte request at 4-byte alignment (gfx950 allows it)
+    const uint64_t two = ((const u64a4*)(ranks + dw))->v;
+    const uint32_t code = (uint32_t)(two >> sh) & (width >= 32 ? ~0u : ((1u << width) - 1u));
     const uint64_t hp = ((const uint64_t*)(img + (front ? f.off_front_hp : f.off_back_hp)))[code];
     uint64_t p = mod_u64(x ^ hp, f.div_table);
     if (p >= f.num_keys) p = ((const uint32_t*)(img + f.off_free))[p - f.num_keys];

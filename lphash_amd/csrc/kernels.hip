@@ -513,7 +513,8 @@ static inline int grid_for(size_t n, int per_block, int max_blocks) {
 
 hipError_t launch_query_packed(const lphq_image_header& H, const uint8_t* d_img, const void* d_kmers, size_t n, uint64_t* d_out, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    const int grid = grid_for(n, kBlock, 256 * 16);
+    static const int max_blocks = getenv("LPHQ_PACKED_GRID") ? atoi(getenv("LPHQ_PACKED_GRID")) : (1 << 30);  // one k-mer per thread measured best (sweep: profiles/r01_packed_grid_sweep.txt); grid-stride beyond 2^30 blocks
+    const int grid = grid_for(n, kBlock, max_blocks);
     LPHQ_DISPATCH(k_query_packed, <<<grid, kBlock, 0, stream>>>(H, d_img, (const uint64_t*)d_kmers, n, d_out));
     return hipGetLastError();
 }
