@@ -68,11 +68,19 @@ __device__ __forceinline__ uint32_t pack4(uint32_t x, uint32_t& bad) {
 template <bool K128>
 __global__ __launch_bounds__(kBlock) void k_pack_kmers(const char* __restrict__ seq, const uint64_t* __restrict__ pos, size_t n, uint32_t k,
                                                         uint64_t* __restrict__ out) {
+    struct __attribute__((packed, aligned(1))) u32a1 { uint32_t v; };  // 4 bases per (unaligned) load instead of 1
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const uint8_t* s = (const uint8_t*)seq + pos[i];
         uint64_t lo = 0, hi = 0;
-        for (uint32_t j = 0; j < k; ++j) {
+        uint32_t j = 0;
+        for (; j + 4 <= k; j += 4) {
+            uint32_t bad;
+            const uint64_t p8 = pack4(((const u32a1*)(s + j))->v, bad);  // non-ACGT -> 0 ('A'), mphf_utils.hpp:108
+            if (K128) hi = (hi << 8) | (lo >> 56);
+            lo = (lo << 8) | p8;
+        }
+        for (; j < k; ++j) {
             const uint32_t c = s[j];
             const uint64_t code = base_valid(c) ? (((c >> 1) ^ (c >> 2)) & 3u) : 0u;
             if (K128) hi = (hi << 2) | (lo >> 62);

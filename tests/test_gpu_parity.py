@@ -183,15 +183,16 @@ def test_device_image_handle_and_concurrent_callers(tmp_path):
     assert not errs
 
 
-@pytest.mark.parametrize("kind,k,m,bits", [(0, 31, 20, 64), (1, 31, 20, 64), (0, 63, 20, 128)])
-def test_large_index_properties(tmp_path, kind, k, m, bits):
-    """10 M k-mers (too many for a full oracle pass in a test): the device codes are a bijection onto [0, n) in
-    streaming AND random mode, both modes agree, and a sampled slice equals the oracle."""
+@pytest.mark.parametrize("kind,k,m,bits,n_rec", [(0, 31, 20, 64, 1000), (1, 31, 20, 64, 100), (0, 63, 20, 128, 100)])
+def test_large_index_properties(tmp_path, kind, k, m, bits, n_rec):
+    """10 M k-mers, and BASELINE.json's full C2 size (100 M k-mers, k=31 m=20) for the partitioned function -- too many for
+    a full oracle pass in a test: the device codes are a bijection onto [0, n) in streaming AND random mode, both modes
+    agree, and sampled records equal the oracle."""
     torch, dev = torch_dev()
-    n_rec, L_rec = 100, 100_000 + k - 1
-    flat, recs = synthetic_records(seed=3, n_records=n_rec, length=L_rec)
+    L_rec = 100_000 + k - 1
+    flat, recs = synthetic_records(seed=3 if n_rec == 100 else 1, n_records=n_rec, length=L_rec)
     path = str(tmp_path / "big.lph")
-    L.build(recs, k, m, path, kind=kind, kmer_bits=bits, threads=0)
+    L.build(recs, k, m, path, kind=kind, kmer_bits=bits, threads=0, device=0)
     h = (L.Mphf if kind == 0 else L.MphfAlt).load(path, kmer_bits=bits, device=0)
     n = n_rec * 100_000
     assert h.get_kmer_count() == n
