@@ -79,7 +79,8 @@ typedef struct lphq_uni_block {
     uint32_t w[24];
 } lphq_uni_block;
 
-/* 64-B plane block: abs = global-rank base of the first entry; planes of the per-entry values */
+/* 64-B pair block of the unpartitioned function, 32 minimizers: abs = sum of the sizes before the block (sizes.pair().first),
+ * w[q] = bit plane q of the size, w[P + q] = bit plane q of the position p1 */
 typedef struct lphq_plane_block {
     uint64_t abs;
     uint32_t w[14];

@@ -1,14 +1,17 @@
 // kernels.hip -- hand-written gfx950 kernels of the LPHash query path and their launchers.
 //
-//   k_query_packed   random (non-streaming) batch: one lane = one packed k-mer
-//                    (MPHF::operator()(.., streaming=false), partitioned_mphf.hpp:185-195)
-//   k_query_tiles    all windows of a batch of ASCII records, tiled over the concatenated bases;
-//                    bases are 2-bit packed into LDS once per tile (seq_nt4_table, constants.cpp:5-13)
-//   k_pack_kmers     debug::string_to_integer_no_reverse (mphf_utils.hpp:110-116) for chosen windows
+//   k_query_packed        random (non-streaming) batch: one lane = one packed k-mer
+//                         (MPHF::operator()(.., streaming=false), partitioned_mphf.hpp:185-195)
+//   k_query_tiles_stream  all windows of a batch of ASCII records, tiled over the concatenated bases: one minimizer hash
+//                         per base, one lookup per super-k-mer (MPHF::operator()(.., streaming=true), partitioned_mphf.hpp:78-184)
+//   k_query_tiles_random  the same batch shape with every window doing the full random lookup
+//   k_pack_kmers          debug::string_to_integer_no_reverse (mphf_utils.hpp:110-116) for chosen windows
+//   k_count_valid         size of the reference's result vector for a streaming pass
 //
-// Wave64, 256-thread workgroups, grids of >= 2048 workgroups where the batch allows so all
-// 256 CUs / 8 XCDs are busy; no inter-workgroup communication, so placement is irrelevant to
-// correctness.
+// Wave64, 256-thread workgroups, one k-mer per lane / one tile per workgroup, so grids are >> 256 workgroups and all
+// 256 CUs / 8 XCDs are busy; no inter-workgroup communication, so placement is irrelevant to correctness.
+// Environment variables read once by the launchers are profiling / tuning aids only (LPHQ_PROFILE_STREAM_STOP,
+// LPHQ_STREAM_BLOCK, LPHQ_PACKED_GRID); defaults are the measured best (profiles/).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -157,14 +160,9 @@ __device__ __forceinline__ void extract_kmer(const uint32_t* __restrict__ sm, ui
     }
 }
 
-// Shared tile prologue: locate the records the tile touches and 2-bit pack its bases into LDS.
-// Coordinates are shifted by `shift` = misalignment of the sequence pointer, so that every 16-byte
-// chunk load is aligned; base g of the batch lives at shifted coordinate g + shift.
-struct TileInfo {
-    uint64_t g0;        // first window start (batch coordinate) of the tile
-    uint32_t rlo, rhi;  // records containing the first / last base the tile can touch
-};
-
+// Tile prologue of the random-over-records kernel: 16 bases per lane -> one 2-bit packed word (+ bad-base mask).
+// Coordinates are shifted by `shift` = misalignment of the sequence pointer, so that every 16-byte chunk load is aligned;
+// base g of the batch lives at shifted coordinate g + shift.
 template <bool WANT_BAD, int NWORDS, int BLOCK = kBlock>
 __device__ __forceinline__ void load_tile(const uint8_t* __restrict__ seq_al, uint64_t shift, uint64_t total, uint64_t t0 /* shifted, 16-aligned */,
                                           uint32_t* __restrict__ sm_words, uint32_t* __restrict__ sm_bad) {
