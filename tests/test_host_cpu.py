@@ -185,3 +185,29 @@ def test_loader_fuzz_never_crashes():
                 assert e.code in (_lib.ERR_FORMAT, _lib.ERR_UNSUPPORTED, _lib.ERR_ARG), e
                 outcomes["rejected"] += 1
     assert outcomes["rejected"] > 100  # the cross-checks do catch most corruptions
+
+
+def test_fastx_reader_record_semantics(tmp_path):
+    """The CLI's reader must yield the records kseq_read yields (external/kseq.h:192-240): multi-line FASTA and FASTQ,
+    '>'/'@' headers with comments, blank lines, CRLF, quality lines starting with '@', a last line without newline, gz.
+    Observed through `lphash build-p`: its file must equal the library build over the hand-written expected records."""
+    import gzip
+
+    exe = os.path.join(ROOT, "lphash_amd", "lphash")
+    r = random_records(4242, 12, 80, 400)
+    fa = b"garbage before the first header\n>r0 comment here\n" + r[0][:50] + b"\n" + r[0][50:] + b"\n\n>r1\r\n" + r[1] + b"\r\n>empty\n>r2\tx\n"
+    fa += r[2][:10] + b"\n" + r[2][10:300].lower() + b"\n" + r[2][300:] + b"\n>r3\n" + r[3]  # no trailing newline
+    fq = b"@q4 desc\n" + r[4] + b"\n+\n" + b"@" * len(r[4]) + b"\n@q5\n" + r[5][:40] + b"\n" + r[5][40:] + b"\n+q5\n" + b"I" * 40 + b"\n" + b"@" + b"I" * (len(r[5]) - 41)
+    fq += b"\n@q6\n" + r[6] + b"\n+\n" + b"#" * len(r[6]) + b"\n"
+    cases = [("a.fa", fa, [r[0], r[1], b"", r[2][:10] + r[2][10:300].lower() + r[2][300:], r[3]]), ("b.fq", fq, [r[4], r[5], r[6]]),
+             ("c.fa.gz", gzip.compress(b">x\n" + r[7] + b"\n>y\n" + r[8] + b"\n"), [r[7], r[8]]),
+             ("d.fq", b"@t\n" + r[9] + b"\n+\n" + b"I" * (len(r[9]) - 3) + b"\n@u\n" + r[10] + b"\n+\n" + b"I" * len(r[10]) + b"\n", [])]  # truncated quality: kseq stops (-2)
+    for name, data, expected in cases:
+        p = tmp_path / name
+        p.write_bytes(data)
+        out = tmp_path / (name + ".lph")
+        res = subprocess.run([exe, "build-p", "-i", str(p), "-k", "31", "-m", "20", "-o", str(out), "--kmer-bits", "64", "--cpu"], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+        ref = tmp_path / (name + ".ref.lph")
+        L.build(expected, 31, 20, str(ref), kmer_bits=64, threads=2)
+        assert out.read_bytes() == ref.read_bytes(), name
