@@ -5,6 +5,7 @@
 #pragma once
 #include <zlib.h>
 
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -64,24 +65,38 @@ private:
         }
         return (unsigned char)buf_[pos_++];
     }
-    void skip_line() {
-        int c;
-        while ((c = getc()) >= 0 && c != '\n') {
+    // Rest of the current line, a buffer span at a time (memchr): visit(ptr, len) per span; returns false at end of input.
+    template <typename Visit>
+    bool rest_of_line(Visit visit) {
+        for (;;) {
+            if (pos_ >= end_) {
+                int c = getc();  // refill
+                if (c < 0) return false;
+                --pos_;
+            }
+            const char* p = buf_.data() + pos_;
+            const char* nl = (const char*)memchr(p, '\n', end_ - pos_);
+            const size_t n = nl ? (size_t)(nl - p) : end_ - pos_;
+            visit(p, n);
+            pos_ += n + (nl ? 1 : 0);
+            if (nl) return true;
         }
     }
+    void skip_line() {
+        rest_of_line([](const char*, size_t) {});
+    }
     void append_line(std::string& s) {
-        int c;
-        while ((c = getc()) >= 0 && c != '\n') s.push_back((char)c);
+        rest_of_line([&](const char* p, size_t n) { s.append(p, n); });
         if (s.size() > 1 && s.back() == '\r') s.pop_back();
     }
     size_t count_line(bool& eof) {
-        int c, last = 0;
         size_t n = 0;
-        while ((c = getc()) >= 0 && c != '\n') {
-            ++n;
-            last = c;
-        }
-        if (c < 0) eof = true;
+        int last = 0;
+        if (!rest_of_line([&](const char* p, size_t len) {
+                n += len;
+                if (len) last = (unsigned char)p[len - 1];
+            }))
+            eof = true;
         if (n > 1 && last == '\r') --n;
         return n;
     }
