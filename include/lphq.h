@@ -107,7 +107,9 @@ int lphq_query_packed(const lphq_index* idx, const void* d_kmers, size_t n, uint
  * d_out[d_out_offsets[r] + i] for window i.  d_out_offsets[r+1]-d_out_offsets[r] must be
  * max(0, len_r - k + 1).  streaming != 0: one minimizer hash per base, super-k-mer leaders do the
  * lookup (the reference's streaming branch, include/partitioned_mphf.hpp:78-184); windows holding
- * a non-ACGT base get LPHQ_INVALID.  streaming == 0: every window does the full random lookup
+ * a non-ACGT base get LPHQ_INVALID (a NON-member k-mer can also evaluate to 2^64-1 through the
+ * reference's wrapping arithmetic; callers that query non-members and need to tell the two apart
+ * derive validity from the bases, as lphq_query_contig does).  streaming == 0: every window does the full random lookup
  * with non-ACGT bases read as 'A' (include/mphf_utils.hpp:108). */
 int lphq_query_records(const lphq_index* idx, const char* d_seq, size_t total_bases, const uint64_t* d_seq_offsets,
                        size_t n_records, uint64_t* d_out, const uint64_t* d_out_offsets, int streaming, void* stream);
@@ -121,7 +123,8 @@ int lphq_count_valid(const lphq_index* idx, const uint64_t* d_codes, size_t n, u
 
 /* ---- host-buffer convenience: mirrors MPHF::operator()(contig, length, streaming) ----
  * Copies the record to the device, runs the GPU path, copies the codes back and (streaming
- * only) drops invalid windows, so *n_out is what the reference's vector.size() would be for
+ * only) drops the windows that hold a non-ACGT base -- decided from the input bases, not from the
+ * LPHQ_INVALID sentinel -- so *n_out is what the reference's vector.size() would be for
  * ACGT input.  length < k yields 0 codes in both modes. */
 int lphq_query_contig(const lphq_index* idx, const char* contig, size_t length, int streaming,
                       uint64_t* out, size_t cap, size_t* n_out);

@@ -382,6 +382,10 @@ bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed,
             for (uint64_t p = t << 12; p < (t + 1) << 12; ++p) hp_cache[p] = murmur64a_u64(p, seed);
         });
         std::atomic<uint64_t> next_commit{0};
+        std::atomic<bool> gave_up{false};
+        // XOR displacement keeps the low bits of a hash: with a tiny table whose size has a power-of-two factor a bucket can
+        // be unplaceable for every pilot (PTHash itself would spin forever there); give up instead of hanging
+        const uint64_t kPilotCap = 1ull << 28;
         const u128 M = f.M;
         auto is_taken = [&](uint64_t p) { return (taken[p >> 6].load(std::memory_order_relaxed) >> (p & 63)) & 1; };
         const int T = std::max(1, threads);
@@ -396,6 +400,10 @@ bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed,
                 for (;;) {
                     // first pilot (>= current) whose positions are free under the bits visible now
                     for (;; ++pilot) {
+                        if (pilot >= kPilotCap || gave_up.load(std::memory_order_relaxed)) {
+                            gave_up.store(true);
+                            break;
+                        }
                         const uint64_t hp = pilot < HP_CACHE ? hp_cache[pilot] : murmur64a_u64(pilot, seed);
                         uint64_t j = 0;
                         for (; j < s; ++j) {
@@ -413,8 +421,9 @@ bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed,
                                 }
                         if (!d2) break;
                     }
-                    if (my_turn) break;  // searched under the exact table: done
-                    while (next_commit.load(std::memory_order_acquire) != oi) std::this_thread::yield();
+                    if (my_turn || gave_up.load()) break;  // searched under the exact table: done
+                    while (next_commit.load(std::memory_order_acquire) != oi && !gave_up.load(std::memory_order_relaxed)) std::this_thread::yield();
+                    if (gave_up.load()) break;
                     my_turn = true;
                     bool still_free = true;
                     for (uint64_t j = 0; j < s; ++j)
@@ -424,6 +433,10 @@ bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed,
                         }
                     if (still_free) break;
                     // else: keep scanning from this pilot, now under the exact table
+                }
+                if (gave_up.load()) {
+                    next_commit.store(n_nonempty, std::memory_order_release);
+                    return;
                 }
                 for (uint64_t j = 0; j < s; ++j) taken[pos[j] >> 6].fetch_or(1ULL << (pos[j] & 63), std::memory_order_relaxed);
                 pilots[b] = pilot;
@@ -436,6 +449,11 @@ bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed,
             std::vector<std::thread> pool;
             for (int t = 0; t < T; ++t) pool.emplace_back(worker, t);
             for (auto& th : pool) th.join();
+        }
+        if (gave_up.load()) {
+            err = "pthash search: no pilot below 2^28 for some bucket (degenerate tiny key set: XOR displacement cannot separate keys that share "
+                  "their low bits when the table size has a power-of-two factor; the reference's PTHash does not terminate on it either)";
+            return false;
         }
         taken_plain.resize(taken.size());
         for (size_t i = 0; i < taken.size(); ++i) taken_plain[i] = taken[i].load(std::memory_order_relaxed);

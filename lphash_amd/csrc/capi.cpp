@@ -301,10 +301,28 @@ extern "C" int lphq_query_contig(const lphq_index* cidx, const char* contig, siz
     HIP_TRY(hipMemcpyAsync(out, idx->d_out, nwin * 8, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
     size_t n = nwin;
-    if (streaming) {  // drop windows holding a non-ACGT base (the reference emits nothing for them)
-        n = 0;
-        for (size_t i = 0; i < nwin; ++i)
-            if (out[i] != LPHQ_INVALID) out[n++] = out[i];
+    if (streaming) {
+        // Drop windows holding a non-ACGT base (the reference emits nothing for them).  Validity is taken from the input, not
+        // from the LPHQ_INVALID sentinel: a non-member k-mer's wrapped arithmetic may legitimately produce 2^64-1.
+        auto valid_base = [](unsigned char ch) {
+            switch (ch) {
+                case 'A': case 'a': case 'C': case 'c': case 'G': case 'g': case 'T': case 't': case 'U': case 'u': return true;
+                default: return false;
+            }
+        };
+        size_t last_bad = (size_t)-1;  // position of the last invalid base seen
+        bool any_bad = false;
+        for (size_t i = 0; i < length && !any_bad; ++i) any_bad = !valid_base((unsigned char)contig[i]);
+        if (any_bad) {
+            n = 0;
+            for (size_t i = 0; i < length; ++i) {
+                if (!valid_base((unsigned char)contig[i])) last_bad = i;
+                if (i + 1 >= k) {  // window ending at base i starts at i + 1 - k
+                    const size_t w = i + 1 - k;
+                    if (last_bad == (size_t)-1 || last_bad < w) out[n++] = out[w];
+                }
+            }
+        }
     }
     *n_out = n;
     return LPHQ_OK;

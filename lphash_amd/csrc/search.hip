@@ -29,7 +29,7 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr uint32_t kNoOwner = 0xFFFFFFFFu;
-constexpr uint64_t kPilotCap = 1ull << 32;  // a bucket with a duplicated hash would never succeed: give up here
+constexpr uint64_t kPilotCap = 1ull << 28;  // unplaceable bucket (duplicate hash, or degenerate tiny table: see builder.cpp): give up here
 
 struct SearchArgs {
     const uint64_t* hs;       // hashes grouped by bucket
@@ -240,7 +240,7 @@ bool gpu_pilot_search(int device, const std::vector<uint64_t>& hs, const std::ve
             uint32_t flags[3];
             HIP_OK(hipMemcpy(flags, d_flags, sizeof flags, hipMemcpyDeviceToHost));
             if (flags[1]) {
-                err = "pthash seed failure: no pilot below 2^32 for some bucket (duplicate key in the input?)";
+                err = "pthash search: no pilot below 2^28 for some bucket (duplicate key in the input, or a degenerate tiny key set)";
                 goto done;
             }
             const uint32_t in_window = std::min(a.n_commit, flags[2]);

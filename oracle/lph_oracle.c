@@ -834,6 +834,11 @@ static int phf_build(phf* f, const uint64_t* hashes, uint64_t n, uint64_t seed, 
         if (s == 0) break;
         const bh_t* keys = bh + bstart[b];
         for (uint64_t pilot = 0;; ++pilot) {
+            if (pilot >> 28) { /* unplaceable bucket: PTHash itself would not terminate (see lphash_amd/csrc/builder.cpp) */
+                FAIL("pthash search: no pilot below 2^28 for some bucket (degenerate tiny key set)");
+                free(bh); free(bstart); free(order); free(pilots); free(taken); free(pos); free(hp_cache);
+                return -1;
+            }
             uint64_t hp = pilot < HP_CACHE ? hp_cache[pilot] : hash_u64(pilot, seed);
             uint64_t j = 0;
             for (; j < s; ++j) {
