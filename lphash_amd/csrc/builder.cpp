@@ -460,6 +460,14 @@ bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed,
     }
     auto is_taken = [&](uint64_t p) { return (taken_plain[p >> 6] >> (p & 63)) & 1; };
     lap(device >= 0 && n >= 4096 ? "pilot search (GPU)" : "pilot search (CPU)");
+    {  // the search must have placed every key exactly once: everything below relies on it (free-slot fill, minimality)
+        uint64_t ones = 0;
+        for (uint64_t p = 0; p < table_size; ++p) ones += is_taken(p);
+        if (ones != n) {
+            err = "pthash search: internal error (occupied slots != keys)";
+            return false;
+        }
+    }
 
     // dual<dictionary, dictionary>::encode: front = first 0.3 * num_buckets pilots
     const uint64_t front_size = (uint64_t)((double)num_buckets * 0.3);
@@ -475,9 +483,13 @@ bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed,
         for (;;) {
             while (last_free_slot < n && is_taken(last_free_slot)) ++last_free_slot;
             if (last_free_slot == n) break;
-            while (!is_taken(next_used_slot)) {
+            while (next_used_slot < table_size && !is_taken(next_used_slot)) {
                 fs.push_back(last_free_slot);
                 ++next_used_slot;
+            }
+            if (next_used_slot >= table_size) {  // cannot happen when exactly n slots are occupied (checked above)
+                err = "pthash: inconsistent slot bitmap";
+                return false;
             }
             fs.push_back(last_free_slot);
             last_valid_free_slot = last_free_slot;

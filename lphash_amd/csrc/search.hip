@@ -222,14 +222,15 @@ bool gpu_pilot_search(int device, const std::vector<uint64_t>& hs, const std::ve
         a.div.shift = (uint32_t)__builtin_clz((uint32_t)table_size);
         a.div.dn = (uint32_t)table_size << a.div.shift;
         a.div.inv = (uint32_t)(~(uint64_t)0 / a.div.dn - (1ull << 32));
-        a.max_steps = getenv("LPHQ_SEARCH_STEPS") ? (uint32_t)atoi(getenv("LPHQ_SEARCH_STEPS")) : 32u;          // tuning aids
-        const uint32_t kLookAhead = getenv("LPHQ_SEARCH_LOOKAHEAD") ? (uint32_t)atoi(getenv("LPHQ_SEARCH_LOOKAHEAD")) : 16384u;
+        // tuning aids, clamped to sane ranges (an unclamped look-ahead below the commit window once committed unsearched buckets)
+        a.max_steps = getenv("LPHQ_SEARCH_STEPS") ? (uint32_t)std::min(1024, std::max(1, atoi(getenv("LPHQ_SEARCH_STEPS")))) : 32u;
+        const uint32_t kLookAhead = getenv("LPHQ_SEARCH_LOOKAHEAD") ? (uint32_t)std::min(1 << 20, std::max(8192, atoi(getenv("LPHQ_SEARCH_LOOKAHEAD")))) : 16384u;
         uint64_t base = 0, rounds = 0, idle_rounds = 0;
         uint32_t window = 1024;
         while (base < n_nonempty) {
             a.base = (uint32_t)base;
             a.n_search = (uint32_t)std::min<uint64_t>(kLookAhead, n_nonempty - base);
-            a.n_commit = (uint32_t)std::min<uint64_t>(window, n_nonempty - base);
+            a.n_commit = std::min((uint32_t)std::min<uint64_t>(window, n_nonempty - base), a.n_search);  // only searched buckets may commit
             const uint32_t flags_init[3] = {0xFFFFFFFFu, 0, 0xFFFFFFFFu};
             HIP_OK(hipMemcpyAsync(d_flags, flags_init, sizeof flags_init, hipMemcpyHostToDevice, nullptr));
             k_search<<<(int)((a.n_search * (uint64_t)kWave + 255) / 256), 256>>>(a);
@@ -266,6 +267,14 @@ bool gpu_pilot_search(int device, const std::vector<uint64_t>& hs, const std::ve
         HIP_OK(hipMemcpy(t32.data(), d_taken, taken_u32 * 4, hipMemcpyDeviceToHost));
         taken_words.assign((table_size + 63) / 64 + 1, 0);
         for (size_t i = 0; i + 1 < taken_u32 && i / 2 < taken_words.size(); ++i) taken_words[i / 2] |= (uint64_t)t32[i] << (32 * (i & 1));
+    }
+    {
+        uint64_t ones = 0;
+        for (uint64_t w : taken_words) ones += (uint64_t)__builtin_popcountll(w);
+        if (ones != hs.size()) {
+            err = "gpu pilot search: internal error (occupied slots != keys)";
+            goto done;
+        }
     }
     pilots_by_bucket.assign(nb, 0);
     for (uint64_t oi = 0; oi < n_nonempty; ++oi) pilots_by_bucket[order[oi]] = pilot_by_order[oi];
