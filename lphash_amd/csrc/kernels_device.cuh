@@ -1,0 +1,483 @@
+// kernels_device.cuh -- the gfx950 kernels of the LPHash query path (launchers: kernels.hip).
+//
+//   k_query_packed        random (non-streaming) batch: one lane = one packed k-mer
+//                         (MPHF::operator()(.., streaming=false), partitioned_mphf.hpp:185-195)
+//   k_query_tiles_stream  all windows of a batch of ASCII records, tiled over the concatenated bases: one minimizer hash
+//                         per base, one lookup per super-k-mer (MPHF::operator()(.., streaming=true), partitioned_mphf.hpp:78-184)
+//   k_query_tiles_random  the same batch shape with every window doing the full random lookup
+//   k_pack_kmers          debug::string_to_integer_no_reverse (mphf_utils.hpp:110-116) for chosen windows
+//   k_count_valid         size of the reference's result vector for a streaming pass
+//
+// Wave64, 256-thread workgroups, one k-mer per lane / one tile per workgroup, so grids are >> 256 workgroups and all
+// 256 CUs / 8 XCDs are busy; no inter-workgroup communication, so placement is irrelevant to correctness.
+// Environment variables read once by the launchers are profiling / tuning aids only (LPHQ_PROFILE_STREAM_STOP,
+// LPHQ_STREAM_BLOCK, LPHQ_PACKED_GRID); defaults are the measured best (profiles/).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_query.cuh"
+
+namespace lphq {
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------------------------------
+// random batch over packed k-mers
+// ------------------------------------------------------------------------------------------
+template <int KIND, bool K128, int P>
+// (header by value here: measured 2 % faster than reading it from the image, the opposite of the tile kernels)
+__global__ __launch_bounds__(kBlock) void k_query_packed(const lphq_image_header H, const uint8_t* __restrict__ img,
+                                                          const uint64_t* __restrict__ kmers, size_t n, uint64_t* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        uint64_t lo, hi = 0;
+        if (K128) {
+            const ulonglong2 v = ((const ulonglong2*)kmers)[i];
+            lo = v.x;
+            hi = v.y;
+        } else {
+            lo = kmers[i];
+        }
+        out[i] = query_kmer<KIND, K128, P>(img, H, lo, hi);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// ASCII -> 2-bit helpers
+// ------------------------------------------------------------------------------------------
+// seq_nt4_table (constants.cpp:5-13): A/a=0 C/c=1 G/g=2 T/t/U/u=3, everything else 4 (invalid).
+// For the 10 valid characters the code is ((c >> 1) ^ (c >> 2)) & 3.
+__device__ __forceinline__ bool base_valid(uint32_t c) {
+    const uint32_t u = c & 0xDFu;                                                         // fold case
+    const uint32_t B = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20) | (1u << 21);      // A C G T U relative to 0x40
+    return ((u & 0xE0u) == 0x40u) && ((B >> (u & 31u)) & 1u);
+}
+// four characters (first at the lowest byte) -> 8 bits, first base in the highest 2 bits; bad = 4-bit mask
+__device__ __forceinline__ uint32_t pack4(uint32_t x, uint32_t& bad) {
+    bad = 0;
+    uint32_t keep = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool ok = base_valid((x >> (8 * i)) & 0xFFu);
+        bad |= (ok ? 0u : 1u) << i;
+        keep |= (ok ? 0xFFu : 0u) << (8 * i);
+    }
+    const uint32_t t = ((x >> 1) ^ (x >> 2)) & 0x03030303u & keep;  // invalid -> 0 ('A'), mphf_utils.hpp:108
+    return (t * 0x40100401u) >> 24;
+}
+
+template <bool K128>
+__global__ __launch_bounds__(kBlock) void k_pack_kmers(const char* __restrict__ seq, const uint64_t* __restrict__ pos, size_t n, uint32_t k,
+                                                        uint64_t* __restrict__ out) {
+    struct __attribute__((packed, aligned(1))) u32a1 { uint32_t v; };  // 4 bases per (unaligned) load instead of 1
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint8_t* s = (const uint8_t*)seq + pos[i];
+        uint64_t lo = 0, hi = 0;
+        uint32_t j = 0;
+        for (; j + 4 <= k; j += 4) {
+            uint32_t bad;
+            const uint64_t p8 = pack4(((const u32a1*)(s + j))->v, bad);  // non-ACGT -> 0 ('A'), mphf_utils.hpp:108
+            if (K128) hi = (hi << 8) | (lo >> 56);
+            lo = (lo << 8) | p8;
+        }
+        for (; j < k; ++j) {
+            const uint32_t c = s[j];
+            const uint64_t code = base_valid(c) ? (((c >> 1) ^ (c >> 2)) & 3u) : 0u;
+            if (K128) hi = (hi << 2) | (lo >> 62);
+            lo = (lo << 2) | code;
+        }
+        if (K128) {
+            ((ulonglong2*)out)[i] = make_ulonglong2(lo, hi);
+        } else {
+            out[i] = lo;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// tiles over concatenated records
+// ------------------------------------------------------------------------------------------
+constexpr int kTileW = 2048;  // window starts per workgroup, random-over-records kernel
+// 2-bit packed u32 words (16 bases each, first base in the top bits) for TW window starts + k-1 (k <= 63) overlap
+constexpr int tile_words(int tw) { return (tw + 64) / 16; }
+constexpr int kTileWords = tile_words(kTileW);
+
+// last r in [lo, hi] with offs[r] <= g   (offs non-decreasing, offs[lo] <= g)
+__device__ __forceinline__ uint32_t find_record(const uint64_t* __restrict__ offs, uint32_t lo, uint32_t hi, uint64_t g) {
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo + 1) / 2;
+        if (offs[mid] <= g) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+// Same result, found by one wave in ~log64(n) rounds: 64 probes per round instead of a 1-load-per-step chain
+// (every lane of the calling wave must pass the same arguments).
+__device__ __forceinline__ uint32_t find_record_wave(const uint64_t* __restrict__ offs, uint32_t n_records, uint64_t g) {
+    uint32_t lo = 0, hi = n_records - 1;
+    const uint32_t lane = threadIdx.x & 63u;
+    while (hi > lo) {
+        const uint32_t step = (hi - lo + 63u) / 64u;
+        const uint64_t idx = (uint64_t)lo + (uint64_t)(lane + 1u) * step;
+        const bool ok = idx <= hi && offs[idx] <= g;  // monotone in the lane: offs is non-decreasing
+        const uint32_t cnt = (uint32_t)__popcll(__ballot(ok));
+        lo += cnt * step;
+        hi = min(hi, lo + step - 1u);
+    }
+    return lo;
+}
+
+// 2k bits starting at base q of the LDS-packed tile
+template <bool K128>
+__device__ __forceinline__ void extract_kmer(const uint32_t* __restrict__ sm, uint32_t q, uint32_t k, uint64_t& lo, uint64_t& hi) {
+    const uint32_t w0 = q >> 4, o = (q & 15u) * 2u;
+    if (K128) {
+        const uint32_t a = sm[w0], b = sm[w0 + 1], c = sm[w0 + 2], d = sm[w0 + 3], e = sm[w0 + 4];
+        // 128-bit big-endian stream starting at bit o of a
+        const uint32_t x0 = o ? ((a << o) | (b >> (32 - o))) : a;
+        const uint32_t x1 = o ? ((b << o) | (c >> (32 - o))) : b;
+        const uint32_t x2 = o ? ((c << o) | (d >> (32 - o))) : c;
+        const uint32_t x3 = o ? ((d << o) | (e >> (32 - o))) : d;
+        const uint64_t H64 = ((uint64_t)x0 << 32) | x1, L64 = ((uint64_t)x2 << 32) | x3;
+        const uint32_t s = 128u - 2u * k;  // 2..126
+        if (s >= 64u) {
+            lo = H64 >> (s - 64u);
+            hi = 0;
+        } else {
+            lo = (L64 >> s) | (H64 << (64u - s));
+            hi = H64 >> s;
+        }
+    } else {
+        const uint32_t a = sm[w0], b = sm[w0 + 1], c = sm[w0 + 2];
+        const uint32_t x0 = o ? ((a << o) | (b >> (32 - o))) : a;
+        const uint32_t x1 = o ? ((b << o) | (c >> (32 - o))) : b;
+        lo = ((((uint64_t)x0 << 32) | x1)) >> (64u - 2u * k);
+        hi = 0;
+    }
+}
+
+// Tile prologue of the random-over-records kernel: 16 bases per lane -> one 2-bit packed word (+ bad-base mask).
+// Coordinates are shifted by `shift` = misalignment of the sequence pointer, so that every 16-byte chunk load is aligned;
+// base g of the batch lives at shifted coordinate g + shift.
+template <bool WANT_BAD, int NWORDS, int BLOCK = kBlock>
+__device__ __forceinline__ void load_tile(const uint8_t* __restrict__ seq_al, uint64_t shift, uint64_t total, uint64_t t0 /* shifted, 16-aligned */,
+                                          uint32_t* __restrict__ sm_words, uint32_t* __restrict__ sm_bad) {
+    for (int c = threadIdx.x; c < NWORDS + 1; c += BLOCK) {
+        const uint64_t a = t0 + (uint64_t)c * 16u;  // shifted coordinate of the chunk
+        uint32_t word = 0, badm = 0xFFFFu;
+        if (a < shift + total && a + 16u > shift) {
+            const uint4 v = *(const uint4*)(seq_al + a);
+            const uint32_t xs[4] = {v.x, v.y, v.z, v.w};
+            badm = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t b4;
+                const uint32_t p8 = pack4(xs[i], b4);
+                word |= p8 << (24 - 8 * i);
+                badm |= b4 << (4 * i);
+            }
+            if (a < shift || a + 16u > shift + total)  // bytes outside [shift, shift+total) are not bases
+                for (int i = 0; i < 16; ++i)
+                    if (a + i < shift || a + i >= shift + total) badm |= 1u << i;
+        }
+        sm_words[c] = word;
+        if (WANT_BAD) ((uint16_t*)sm_bad)[c] = (uint16_t)badm;
+    }
+}
+
+template <int KIND, bool K128, int P>
+__global__ __launch_bounds__(kBlock) void k_query_tiles_random(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
+                                                                uint64_t shift, uint64_t total, const uint64_t* __restrict__ seq_off,
+                                                                const uint64_t* __restrict__ out_off, uint32_t n_records, uint64_t* __restrict__ out) {
+    const lphq_image_header& H = *(const lphq_image_header*)img;
+    __shared__ uint32_t sm_words[kTileWords + 8];
+    __shared__ uint32_t sm_rec[2];
+    const uint64_t t0 = (uint64_t)blockIdx.x * kTileW;  // shifted coordinate of the tile's first window start
+    if (threadIdx.x == 0) {
+        const uint64_t gfirst = t0 > shift ? t0 - shift : 0;
+        uint64_t glast = t0 + kTileW + 64 > shift ? t0 + kTileW + 64 - shift : 0;
+        if (glast >= total) glast = total ? total - 1 : 0;
+        sm_rec[0] = find_record(seq_off, 0, n_records - 1, gfirst);
+        sm_rec[1] = find_record(seq_off, 0, n_records - 1, glast);
+    }
+    load_tile<false, kTileWords>(seq_al, shift, total, t0, sm_words, nullptr);
+    for (int c = kTileWords + 1 + threadIdx.x; c < kTileWords + 8; c += kBlock) sm_words[c] = 0;
+    __syncthreads();
+    const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];
+    for (int i = threadIdx.x; i < kTileW; i += kBlock) {
+        const uint64_t a = t0 + i;
+        if (a < shift) continue;
+        const uint64_t g = a - shift;
+        if (g + H.k > total) continue;
+        const uint32_t r = find_record(seq_off, rlo, rhi, g);
+        if (g + H.k > seq_off[r + 1]) continue;  // window would run over the end of its record
+        uint64_t lo, hi;
+        extract_kmer<K128>(sm_words, (uint32_t)i, H.k, lo, hi);
+        out[out_off[r] + (g - seq_off[r])] = query_kmer<KIND, K128, P>(img, H, lo, hi);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// streaming kernel: MPHF::operator()(.., streaming=true)   include/partitioned_mphf.hpp:78-184
+// ------------------------------------------------------------------------------------------
+// The reference walks a record base by base with a ring buffer of W = k-m+1 minimizer hashes and
+// only calls query() when the minimizer changes (one call per super-k-mer); consecutive k-mers of a
+// super-k-mer get hval +- 1.  Because the closed forms of query() are linear in the offset p of the
+// minimizer (SURVEY section 8a note 3), the same codes come out position-parallel:
+//   A  bases of the tile -> 2-bit words + bad-base bitmask in LDS
+//   B  one MurmurHash2_64 per m-mer position (partitioned_mphf.hpp:116); the tile is sized so that the
+//      positions are exactly 4 per lane
+//   C  each lane takes 4 consecutive windows: their W+3 hashes are read once; the W-3 positions common to
+//      all four are reduced once, the 3+3 edge positions as suffix / prefix minima.  Ties keep the LEFT
+//      position, as the strict `>` comparisons of partitioned_mphf.hpp:122,150-163 do
+//   D  windows whose minimizer position differs from their left neighbour's are super-k-mer leaders;
+//      they are compacted (wave ballots) into an LDS queue so the gather chain runs with dense lanes
+//   E  leaders: PTHash + wavelet block + plane block -> (base, mode) stored by minimizer position
+//   F  every window: hval = base +- p (or the per-k-mer fallback lookup for colliding minimizers,
+//      partitioned_mphf.hpp:133-135), coalesced stores
+// Windows holding a non-ACGT base get LPHQ_INVALID (the reference emits nothing for them).
+constexpr int kStreamBlockDefault = 256;  // threads per workgroup of the streaming kernel; 4 m-mer positions per lane
+__host__ __device__ inline uint32_t stream_tile_windows(uint32_t W, int npos) { return (uint32_t)(npos - (int)W + 1) & ~15u; }
+
+struct HashPos {
+    uint64_t h;
+    uint32_t p;
+};
+__device__ __forceinline__ void take_if_less(HashPos& m, uint64_t h, uint32_t p) {  // strict: the left one wins ties
+    const bool lt = h < m.h;
+    m.h = lt ? h : m.h;
+    m.p = lt ? p : m.p;
+}
+
+// hash slot of m-mer position i: lane l owns positions 4l..4l+3 and reads up to 4l+W+2; storing position i at
+// (i % 4) * (BLOCK + 2) + i / 4 makes both the writes and the W+3 reads of consecutive lanes hit consecutive
+// 8-byte slots (no LDS bank conflicts; the plain layout was 4-way conflicted: profiles/r01_stream_phase_counters.txt)
+template <int BLOCK>
+__device__ __forceinline__ uint32_t hslot(uint32_t i) { return (i & 3u) * (uint32_t)(BLOCK + 2) + (i >> 2); }
+
+template <int KIND, bool K128, int P, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
+                                                                uint64_t shift, uint64_t total, const uint64_t* __restrict__ seq_off,
+                                                                const uint64_t* __restrict__ out_off, uint32_t n_records, uint64_t* __restrict__ out,
+                                                                uint32_t stop_after /* profiling aid: 0 = run everything */) {
+    const lphq_image_header& H = *(const lphq_image_header*)img;  // read from the image: 77 SGPRs instead of 112 -> 8 workgroups / CU (+11 %)
+    constexpr int kStreamPos = 4 * BLOCK, NW = tile_words(kStreamPos), WPL = 4;
+    constexpr int NBADW = (NW + 8) / 2 + 2;       // 32-bit words of the bad-base bitmask (1 bit per base)
+    constexpr int NDW = (NW + 1) * 4;             // dwords of sequence (4 bases each) the tile loads
+    __shared__ uint64_t sm_hash[4 * (BLOCK + 2)];  // phase B-C: minimizer hash per m-mer position (hslot order); phase E-F: the leader's base
+    __shared__ uint32_t sm_words[NW + 8];
+    __shared__ uint32_t sm_bad[NBADW];
+    __shared__ __attribute__((aligned(16))) uint16_t sm_q[kStreamPos + 8];
+    __shared__ uint16_t sm_queue[kStreamPos];
+    __shared__ uint8_t sm_mode[kStreamPos];
+    __shared__ uint32_t sm_rec[2], sm_count;
+    __shared__ uint64_t sm_roff[3];  // seq_off[rlo], seq_off[rlo+1], out_off[rlo]
+    const uint32_t k = H.k, m = H.m, W = H.W;
+    const uint32_t TW = stream_tile_windows(W, kStreamPos);
+    const uint64_t t0 = (uint64_t)blockIdx.x * TW;
+    if (threadIdx.x < 128) {  // wave 0 locates the record of the first base the tile can touch, wave 1 that of the last
+        const uint64_t gfirst = t0 > shift ? t0 - shift : 0;
+        uint64_t glast = t0 + TW + 64 > shift ? t0 + TW + 64 - shift : 0;
+        if (glast >= total) glast = total ? total - 1 : 0;
+        const uint32_t r = find_record_wave(seq_off, n_records, threadIdx.x < 64 ? gfirst : glast);
+        if (threadIdx.x == 0) {
+            sm_rec[0] = r;
+            sm_roff[0] = seq_off[r];
+            sm_roff[1] = seq_off[r + 1];
+            sm_roff[2] = out_off[r];
+            sm_count = 0;
+        }
+        if (threadIdx.x == 64) sm_rec[1] = r;
+    }
+    // ---- A: 4 bases per lane -> one byte of the 2-bit stream + 4 bits of the bad-base mask ----
+    for (int c = threadIdx.x; c < NBADW; c += BLOCK) sm_bad[c] = (c < NDW / 8) ? 0u : 0xFFFFFFFFu;
+    for (int c = NW + 1 + threadIdx.x; c < NW + 8; c += BLOCK) sm_words[c] = 0;
+    __syncthreads();
+    for (int d = threadIdx.x; d < NDW; d += BLOCK) {
+        const uint64_t a = t0 + (uint64_t)d * 4u;  // shifted coordinate of the dword
+        uint32_t p8 = 0, b4 = 0xFu;
+        if (a < shift + total && a + 4u > shift) {
+            p8 = pack4(*(const uint32_t*)(seq_al + a), b4);
+            if (a < shift || a + 4u > shift + total)  // bytes outside [shift, shift+total) are not bases
+                for (int i = 0; i < 4; ++i)
+                    if (a + i < shift || a + i >= shift + total) b4 |= 1u << i;
+        }
+        ((uint8_t*)sm_words)[(d & ~3) + (3 - (d & 3))] = (uint8_t)p8;  // first base in the top bits of each 32-bit word
+        if (b4) atomicOr(&sm_bad[d >> 3], b4 << (4 * (d & 7)));
+    }
+    __syncthreads();
+    if (stop_after == 1u) return;
+
+    // ---- B: hashes of the m-mers starting at local positions 4*lane .. 4*lane+3 ----
+    {
+        const uint64_t mm_seedx = murmur_seedx(H.mm_seed);
+        const uint32_t a = 4u * threadIdx.x;
+        // 2m + 6 <= 70 bits starting at base a (a % 4 == 0, so the bit offset within the first word is a multiple of 8)
+        const uint32_t w0 = a >> 4, o = (a & 15u) * 2u;
+        const uint32_t x0 = sm_words[w0], x1 = sm_words[w0 + 1], x2 = sm_words[w0 + 2], x3 = sm_words[w0 + 3];
+        const uint64_t A64 = ((uint64_t)x0 << 32) | x1, C64 = ((uint64_t)x2 << 32) | x3;
+        const uint64_t s0 = o ? ((A64 << o) | ((uint64_t)x2 >> (32 - o))) : A64;  // bits [0, 64) of the stream at base a
+        const uint64_t s1 = o ? (C64 << o) : C64;                                  // bits [64, 128): only the top 6 are needed
+        const uint32_t sh = 64u - 2u * m;
+        const uint64_t mask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+            // m-mer r = bits [2r, 2r + 2m) of (s0 : s1)
+            const uint64_t v = r == 0 ? (s0 >> sh) : (((s0 << (2 * r)) | (s1 >> (64 - 2 * r))) >> sh);
+            sm_hash[r * (BLOCK + 2) + threadIdx.x] = murmur8(v & mask, mm_seedx);
+        }
+        if (threadIdx.x < 8) sm_hash[hslot<BLOCK>(kStreamPos + threadIdx.x)] = ~0ull;
+    }
+    __syncthreads();
+    if (stop_after == 2u) return;
+
+    // ---- C: leftmost minimum of 4 consecutive windows per lane ----
+    {
+        const uint32_t a = 4u * threadIdx.x;
+        uint32_t q[4];
+        auto HS = [&](uint32_t i) { return sm_hash[hslot<BLOCK>(min(i, (uint32_t)kStreamPos + 7u))]; };
+        if (W >= 4u) {
+            // left edge: suffix minima over a+2, a+1, a (`<=`: the left one wins ties)
+            HashPos s2{HS(a + 2), a + 2}, s1, s0;
+            {
+                const uint64_t h1 = HS(a + 1), h0 = HS(a);
+                s1 = (h1 <= s2.h) ? HashPos{h1, a + 1} : s2;
+                s0 = (h0 <= s1.h) ? HashPos{h0, a} : s1;
+            }
+            // core a+3 .. a+W-1, common to the four windows
+            HashPos c{HS(a + 3), a + 3};
+            for (uint32_t t = a + 4; t < a + W && t < (uint32_t)kStreamPos; ++t) take_if_less(c, HS(t), t);
+            // right edge: prefix minima over a+W, a+W+1, a+W+2 (indices clamp into the ~0 padding of the last lanes)
+            const uint32_t e = min(a + W, (uint32_t)kStreamPos);
+            HashPos w0 = s0, w1 = s1, w2 = s2, w3 = c;
+            take_if_less(w0, c.h, c.p);
+            take_if_less(w1, c.h, c.p);
+            take_if_less(w2, c.h, c.p);
+            HashPos r{HS(e), e};
+            take_if_less(w1, r.h, r.p);
+            take_if_less(w2, r.h, r.p);
+            take_if_less(w3, r.h, r.p);
+            r = HashPos{HS(e + 1), e + 1};
+            take_if_less(w2, r.h, r.p);
+            take_if_less(w3, r.h, r.p);
+            r = HashPos{HS(e + 2), e + 2};
+            take_if_less(w3, r.h, r.p);
+            q[0] = w0.p;
+            q[1] = w1.p;
+            q[2] = w2.p;
+            q[3] = w3.p;
+        } else {
+#pragma unroll
+            for (int jw = 0; jw < 4; ++jw) {
+                HashPos c{HS(a + jw), a + jw};
+                for (uint32_t t = 1; t < W; ++t) take_if_less(c, HS(a + jw + t), a + jw + t);
+                q[jw] = c.p;
+            }
+        }
+        // window validity: inside the batch, inside one record, no non-ACGT base in [i, i+k)
+        const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];
+        const uint64_t kmask = (1ull << k) - 1ull;  // k <= 63
+        // bad-base bits [a, a + 96): a % 4 == 0, windows a..a+3 need bits up to a + 3 + 62
+        const uint32_t bw = a >> 5, bo = a & 31u;
+        const uint32_t b0 = sm_bad[bw], b1 = sm_bad[bw + 1], b2 = sm_bad[bw + 2], b3 = sm_bad[bw + 3];
+        const uint64_t blo = bo ? (((((uint64_t)b1 << 32) | b0) >> bo) | ((uint64_t)b2 << (64u - bo))) : ((((uint64_t)b1) << 32) | b0);
+        const uint32_t bhi = bo ? (uint32_t)(((((uint64_t)b3 << 32) | b2) >> bo)) : b2;
+        const uint64_t end1 = sm_roff[1];
+        uint16_t qv[4];
+#pragma unroll
+        for (int jw = 0; jw < 4; ++jw) {
+            const uint32_t i = a + jw;
+            const uint64_t ga = t0 + i;
+            uint16_t v = 0xFFFEu;  // not a window of any record
+            if (i < TW && ga >= shift && ga - shift + k <= total) {
+                const uint64_t g = ga - shift;
+                bool inside;
+                if (rlo == rhi) inside = g + k <= end1;
+                else {
+                    const uint32_t r = find_record(seq_off, rlo, rhi, g);
+                    inside = g + k <= seq_off[r + 1];
+                }
+                if (inside) {
+                    const uint64_t x = jw ? ((blo >> jw) | ((uint64_t)bhi << (64 - jw))) : blo;
+                    v = (x & kmask) ? (uint16_t)0xFFFFu : (uint16_t)q[jw];
+                }
+            }
+            qv[jw] = v;
+        }
+        *(uint2*)&sm_q[a] = make_uint2((uint32_t)qv[0] | ((uint32_t)qv[1] << 16), (uint32_t)qv[2] | ((uint32_t)qv[3] << 16));
+    }
+    __syncthreads();
+    if (stop_after == 3u) return;
+
+    // ---- D: leaders -> queue (one LDS atomic per wave and round) ----
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int r = 0; r < WPL; ++r) {
+        const uint32_t i = threadIdx.x + r * BLOCK;
+        const uint16_t qv = sm_q[i];
+        const bool leader = qv < 0xFFFEu && (i == 0 || sm_q[i - 1] != qv);
+        const uint64_t bal = __ballot(leader);
+        uint32_t base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&sm_count, (uint32_t)__popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (leader) sm_queue[base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = qv;
+    }
+    __syncthreads();
+    if (stop_after == 4u) return;
+
+    // ---- E: one lookup per super-k-mer, dense lanes ----
+    const uint32_t nlead = sm_count;
+    for (uint32_t x = threadIdx.x; x < nlead; x += BLOCK) {
+        const uint32_t q = sm_queue[x];
+        uint64_t mm, hi;
+        extract_kmer<false>(sm_words, q, m, mm, hi);
+        const LookupCtx c = lookup_ctx<KIND, K128, P>(img, H, mm);
+        sm_hash[hslot<BLOCK>(q)] = c.base;
+        sm_mode[q] = (uint8_t)c.mode;
+    }
+    __syncthreads();
+    if (stop_after == 5u) return;
+
+    // ---- F: every window, lane-contiguous stores ----
+    const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];
+#pragma unroll
+    for (int r = 0; r < WPL; ++r) {
+        const uint32_t i = threadIdx.x + r * BLOCK;
+        const uint32_t q = sm_q[i];
+        if (q == 0xFFFEu) continue;
+        const uint64_t g = t0 + i - shift;
+        uint64_t oidx;
+        if (rlo == rhi) oidx = sm_roff[2] + (g - sm_roff[0]);
+        else {
+            const uint32_t rr = find_record(seq_off, rlo, rhi, g);
+            oidx = out_off[rr] + (g - seq_off[rr]);
+        }
+        uint64_t hval = ~0ull;  // LPHQ_INVALID
+        if (q != 0xFFFFu) {
+            LookupCtx c;
+            c.base = sm_hash[hslot<BLOCK>(q)];
+            c.mode = sm_mode[q];
+            uint64_t lo = 0, hi = 0;
+            if (c.mode == 2u) extract_kmer<K128>(sm_words, i, k, lo, hi);
+            hval = finish_hval<K128>(img, H, c, lo, hi, q - i);
+        }
+        out[oidx] = hval;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// number of valid codes (size of the reference's result vector for a streaming pass)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_count_valid(const uint64_t* __restrict__ codes, size_t n, unsigned long long* __restrict__ count) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    unsigned long long c = 0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) c += codes[i] != ~0ull;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+
+
+}  // namespace lphq

@@ -1,0 +1,76 @@
+// TEST INFRASTRUCTURE ONLY.  The product's kernels (lphash_amd/csrc/kernels_device.cuh) compiled for the host and run by the
+// fiber emulator, with the launch geometry of lphash_amd/csrc/kernels.hip restated here.
+#include <cstring>
+
+#include "kernels_device.cuh"  // -Itests/emu resolves <hip/hip_runtime.h> to the stub
+
+using namespace lphq;
+
+#define EMU_DISPATCH(CALL_B)                                                                    \
+    do {                                                                                        \
+        const bool k128 = H.kmer_bits == 128, p6 = H.P == 6;                                    \
+        if (H.kind == 0) {                                                                      \
+            if (k128) { if (p6) { CALL_B(0, true, 6); } else { CALL_B(0, true, 4); } }          \
+            else      { if (p6) { CALL_B(0, false, 6); } else { CALL_B(0, false, 4); } }        \
+        } else {                                                                                \
+            if (k128) { if (p6) { CALL_B(1, true, 6); } else { CALL_B(1, true, 4); } }          \
+            else      { if (p6) { CALL_B(1, false, 6); } else { CALL_B(1, false, 4); } }        \
+        }                                                                                       \
+    } while (0)
+
+static bool header(const uint8_t* img, size_t nbytes, lphq_image_header& H) {
+    if (nbytes < sizeof H) return false;
+    memcpy(&H, img, sizeof H);
+    return H.magic == LPHQ_IMAGE_MAGIC && H.total_bytes == nbytes;
+}
+
+extern "C" int emu_kernel_query_packed(const uint8_t* img, size_t nbytes, const uint64_t* kmers, size_t n, uint64_t* out) {
+    lphq_image_header H;
+    if (!header(img, nbytes, H)) return 1;
+    const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+#define CALL(KIND, K128, P) emu::launch(grid, kBlock, [&] { k_query_packed<KIND, K128, P>(H, img, kmers, n, out); })
+    EMU_DISPATCH(CALL);
+#undef CALL
+    return 0;
+}
+
+// seq must be 16-byte aligned minus `misalign` (the caller passes base + misalign), padded with >= 64 readable bytes
+extern "C" int emu_kernel_query_records(const uint8_t* img, size_t nbytes, const char* seq, uint64_t total, const uint64_t* seq_off, const uint64_t* out_off,
+                                        uint32_t n_records, uint64_t* out, int streaming, int block) {
+    lphq_image_header H;
+    if (!header(img, nbytes, H)) return 1;
+    if (n_records == 0 || total < H.k) return 0;
+    const uint64_t shift = (uint64_t)((uintptr_t)seq & 15u);
+    const uint8_t* seq_al = (const uint8_t*)seq - shift;
+    const uint64_t span = shift + total;
+    if (streaming) {
+        const uint64_t tw = stream_tile_windows(H.W, 4 * block);
+        const unsigned tiles = (unsigned)((span + tw - 1) / tw);
+#define CALL(KIND, K128, P)                                                                                                                             \
+    do {                                                                                                                                                \
+        if (block == 128) emu::launch(tiles, 128, [&] { k_query_tiles_stream<KIND, K128, P, 128>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0u); }); \
+        else emu::launch(tiles, 256, [&] { k_query_tiles_stream<KIND, K128, P, 256>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0u); });              \
+    } while (0)
+        EMU_DISPATCH(CALL);
+#undef CALL
+    } else {
+        const unsigned tiles = (unsigned)((span + kTileW - 1) / kTileW);
+#define CALL(KIND, K128, P) emu::launch(tiles, kBlock, [&] { k_query_tiles_random<KIND, K128, P>(img, seq_al, shift, total, seq_off, out_off, n_records, out); })
+        EMU_DISPATCH(CALL);
+#undef CALL
+    }
+    return 0;
+}
+
+extern "C" int emu_kernel_pack_kmers(const char* seq, const uint64_t* pos, size_t n, uint32_t k, int k128, uint64_t* out) {
+    const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+    if (k128) emu::launch(grid, kBlock, [&] { k_pack_kmers<true>(seq, pos, n, k, out); });
+    else emu::launch(grid, kBlock, [&] { k_pack_kmers<false>(seq, pos, n, k, out); });
+    return 0;
+}
+
+extern "C" int emu_kernel_count_valid(const uint64_t* codes, size_t n, unsigned long long* count) {
+    *count = 0;
+    emu::launch((unsigned)((n + kBlock * 8 - 1) / (kBlock * 8)), kBlock, [&] { k_count_valid(codes, n, count); });
+    return 0;
+}

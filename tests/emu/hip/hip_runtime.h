@@ -1,12 +1,53 @@
-// TEST INFRASTRUCTURE ONLY: the handful of HIP names lphash_amd/csrc/device_query.cuh needs, so that the very same device
-// functions can be compiled for the host (g++) and checked against the oracle without a GPU (tests/test_emu_cpu.py).
+// TEST INFRASTRUCTURE ONLY: a host stand-in for the few HIP names the product's device sources use, so that the very same
+// device functions (lphash_amd/csrc/device_query.cuh) and kernels (kernels_device.cuh) can be compiled with g++ and checked
+// against the oracle without a GPU (tests/test_emu_cpu.py).  Workgroups are emulated by cooperative fibers (emu_runtime.hpp):
+// 64-lane waves, __syncthreads, __ballot/__any/__shfl, LDS = function-local statics, one workgroup at a time.
 // Not a product path: nothing under lphash_amd/ includes or links this.
 #pragma once
+#include <cstddef>
 #include <cstdint>
+
+#include "../emu_runtime.hpp"
+
 #define __device__
 #define __host__
+#define __global__
 #define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+
 struct uint4 {
     uint32_t x, y, z, w;
 };
+struct uint2 {
+    uint32_t x, y;
+};
+struct ulonglong2 {
+    unsigned long long x, y;
+};
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+static inline ulonglong2 make_ulonglong2(unsigned long long x, unsigned long long y) { return ulonglong2{x, y}; }
+
 static inline int __popc(uint32_t v) { return __builtin_popcount(v); }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+static inline uint32_t min(uint32_t a, uint32_t b) { return a < b ? a : b; }
+static inline uint64_t min(uint64_t a, uint64_t b) { return a < b ? a : b; }
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline uint32_t max(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
+#define threadIdx (emu::thread_idx())
+#define blockIdx (emu::g_block_idx)
+#define gridDim (emu::g_grid_dim)
+
+static inline void __syncthreads() { emu::sync_block(); }
+static inline unsigned long long __ballot(int pred) { return emu::ballot(pred != 0); }
+static inline int __any(int pred) { return emu::ballot(pred != 0) != 0; }
+template <typename T>
+static inline T __shfl(T v, int src, int = 64) { return (T)emu::shfl((uint64_t)v, src); }
+template <typename T>
+static inline T __shfl_down(T v, unsigned delta, int = 64) { return (T)emu::shfl_down((uint64_t)v, delta); }
+// one OS thread runs all fibers, so plain read-modify-write is atomic
+static inline unsigned int atomicAdd(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o + v; return o; }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
+static inline unsigned int atomicOr(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o | v; return o; }

@@ -89,3 +89,105 @@ def test_device_chain_larger_index(emu, tmp_path):
     got = emu_query(emu, h, pk, len(pk))
     assert np.array_equal(got, o.query_packed(pk))
     assert got.max() < h.get_kmer_count()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the kernels themselves (kernels_device.cuh) under the wave64 fiber emulator
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def emuk(emu):
+    emu.emu_kernel_query_packed.restype = C.c_int
+    emu.emu_kernel_query_packed.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    emu.emu_kernel_query_records.restype = C.c_int
+    emu.emu_kernel_query_records.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_int]
+    emu.emu_kernel_pack_kmers.restype = C.c_int
+    emu.emu_kernel_pack_kmers.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_void_p]
+    emu.emu_kernel_count_valid.restype = C.c_int
+    emu.emu_kernel_count_valid.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_ulonglong)]
+    return emu
+
+
+def emu_records(lib, h, recs, k, streaming, misalign=0, block=256):
+    """lphq_query_records as kernels.hip launches it, on the emulator; returns one code array per record."""
+    img = h.image()
+    lens = np.array([len(r) for r in recs], dtype=np.uint64)
+    seq_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    nwin = np.where(lens >= k, lens - np.uint64(k) + np.uint64(1), np.uint64(0)).astype(np.uint64)
+    out_off = np.concatenate([[0], np.cumsum(nwin)]).astype(np.uint64)
+    flat = np.frombuffer(b"".join(recs), dtype=np.uint8)
+    raw = np.full(len(flat) + 256, ord("#"), dtype=np.uint8)  # margins: the tile loader reads whole aligned 16-byte chunks
+    base = (-raw.ctypes.data) % 16 + 64 + misalign
+    raw[base:base + len(flat)] = flat
+    out = np.full(int(out_off[-1]) + 1, 0xDEAD, dtype=np.uint64)
+    rc = lib.emu_kernel_query_records(img.ctypes.data, img.size, raw.ctypes.data + base, len(flat), seq_off.ctypes.data, out_off.ctypes.data, len(recs),
+                                      out.ctypes.data, 1 if streaming else 0, block)
+    assert rc == 0 and out[-1] == 0xDEAD
+    return [out[int(out_off[i]):int(out_off[i + 1])] for i in range(len(recs))]
+
+
+@pytest.mark.parametrize("k,m,bits,kind", [(31, 20, 64, 0), (63, 20, 128, 0), (31, 20, 64, 1), (21, 8, 64, 0), (47, 17, 128, 1), (31, 31, 64, 0), (15, 9, 64, 0), (9, 7, 64, 0),
+                                           (63, 32, 128, 0), (33, 5, 128, 0)])
+def test_tile_kernels_on_the_emulator(emuk, tmp_path, k, m, bits, kind):
+    """k_query_tiles_stream / k_query_tiles_random over ragged multi-record batches: members, non-members, records shorter than
+    k, empty records, tile-straddling records, every pointer alignment class, both workgroup sizes."""
+    recs = dedup_records(random_records(k * 19 + m, 14 if k > 12 else 60, k, 2600 if k > 12 else k + 12), k)
+    assert len(recs) >= 4
+    path = str(tmp_path / "t.lph")
+    L.build(recs, k, m, path, kind=kind, kmer_bits=bits, threads=4)
+    o = orc.Index(path, kind, bits)
+    h = (L.Mphf if kind == 0 else L.MphfAlt).load(path, kmer_bits=bits)
+    batch = [b"", recs[0], recs[1][: k - 1], b"", recs[2][:k]] + recs[3:] + random_records(3, 6, 1, 1500) + [b""]
+    exp = [o(r, False) for r in batch]
+    for streaming, mis, block in ((True, 0, 256), (True, 5, 256), (True, 15, 128), (False, 0, 256), (False, 9, 256)):
+        got = emu_records(emuk, h, batch, k, streaming, mis, block)
+        for g, e in zip(got, exp):
+            assert np.array_equal(g, e), (streaming, mis, block)
+
+
+def test_tile_kernels_non_acgt_on_the_emulator(emuk, tmp_path):
+    k, m = 31, 20
+    recs = random_records(42, 5, 400, 1800)
+    path = str(tmp_path / "t.lph")
+    L.build(recs, k, m, path, kmer_bits=64, threads=4)
+    o = orc.Index(path, 0, 64)
+    h = L.Mphf.load(path, kmer_bits=64)
+    rng = np.random.default_rng(0)
+    batch = []
+    for r in recs:
+        q = bytearray(r)
+        for p in rng.integers(0, len(q), 4):
+            q[p] = ord("N")
+        q[0], q[-1], q[len(q) // 2] = ord("R"), ord("-"), ord("u")
+        batch.append(bytes(q))
+    got_s = emu_records(emuk, h, batch, k, True)
+    got_r = emu_records(emuk, h, batch, k, False)
+    for q, gs, gr in zip(batch, got_s, got_r):
+        exp = o(q, False)  # random mode reads a non-ACGT base as 'A' (mphf_utils.hpp:108)
+        assert np.array_equal(gr, exp)
+        bad = np.array([c not in b"ACGTUacgtu" for c in q])
+        csum = np.concatenate([[0], np.cumsum(bad)])
+        valid = (csum[k:] - csum[:-k]) == 0
+        assert np.array_equal(gs[valid], exp[valid]) and np.all(gs[~valid] == np.uint64(L.INVALID))
+        cnt = C.c_ulonglong()
+        gs = np.ascontiguousarray(gs)
+        assert emuk.emu_kernel_count_valid(gs.ctypes.data, len(gs), C.byref(cnt)) == 0 and cnt.value == int(valid.sum())
+
+
+@pytest.mark.parametrize("k,m,bits,kind", [(31, 20, 64, 0), (63, 20, 128, 0), (21, 8, 64, 1)])
+def test_packed_and_pack_kernels_on_the_emulator(emuk, tmp_path, k, m, bits, kind):
+    recs = dedup_records(random_records(k + 3 * m, 8, 200, 1500), k)
+    path = str(tmp_path / "t.lph")
+    L.build(recs, k, m, path, kind=kind, kmer_bits=bits, threads=4)
+    o = orc.Index(path, kind, bits)
+    h = (L.Mphf if kind == 0 else L.MphfAlt).load(path, kmer_bits=bits)
+    seq = b"".join(recs) + b"NNACGTNacgtu" + random_records(8, 1, 700, 700)[0]
+    pos = np.arange(0, len(seq) - k + 1, dtype=np.uint64)
+    pk = pack_kmers(seq, [int(p) for p in pos], k, bits)
+    raw = np.frombuffer(seq + b"\0" * 16, dtype=np.uint8).copy()
+    got_pk = np.zeros_like(pk)
+    assert emuk.emu_kernel_pack_kmers(raw.ctypes.data, pos.ctypes.data, len(pos), k, 1 if bits == 128 else 0, got_pk.ctypes.data) == 0
+    assert np.array_equal(got_pk, pk)
+    img = h.image()
+    out = np.empty(len(pos), dtype=np.uint64)
+    assert emuk.emu_kernel_query_packed(img.ctypes.data, img.size, pk.ctypes.data, len(pos), out.ctypes.data) == 0
+    assert np.array_equal(out, o.query_packed(pk))
