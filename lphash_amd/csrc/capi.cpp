@@ -52,6 +52,8 @@ static int fail_hip(hipError_t e, const char* what) {
         if (e_ != hipSuccess) return fail_hip(e_, #call); \
     } while (0)
 
+static bool header_is_consistent(const lphq_image_header& h, size_t nbytes, std::string& why);
+
 struct DeviceGuard {  // make idx->device current for the duration of a call
     int prev = -1;
     bool ok = true;
@@ -86,6 +88,13 @@ extern "C" int lphq_open_memory(const void* buf, size_t len, int kind, int kmer_
         return fail(LPHQ_ERR_FORMAT, std::string("malformed file: ") + e.what());
     }
     memcpy(&idx->hdr, idx->image.data(), sizeof idx->hdr);
+    {
+        std::string why;
+        if (!header_is_consistent(idx->hdr, idx->image.size(), why)) {  // self-check of the image builder
+            delete idx;
+            return fail(LPHQ_ERR_FORMAT, "internal: image builder produced an inconsistent header: " + why);
+        }
+    }
     idx->file_bytes = file.bytes_read;
     idx->image_bytes = idx->image.size();
     *out = idx;
@@ -154,6 +163,40 @@ extern "C" int lphq_image_copy(const lphq_index* idx, void* host_dst, size_t cap
     return LPHQ_OK;
 }
 
+// Every section a kernel may read must lie inside the image: guards lphq_open_device_image against a foreign / stale buffer.
+static bool header_is_consistent(const lphq_image_header& h, size_t nbytes, std::string& why) {
+    auto inside = [&](uint64_t off, uint64_t bytes) { return off >= sizeof(lphq_image_header) && off <= nbytes && bytes <= nbytes - off; };
+    auto phf_ok = [&](const lphq_phf_desc& f, const char* name) {
+        if (f.num_keys == 0) return true;
+        const uint64_t nb = f.num_dense + f.num_sparse;
+        bool ok = f.table_size >= f.num_keys && f.table_size <= 0xFFFFFFFFull && f.front_size <= nb && f.front_width >= 1 && f.front_width <= 32 &&
+                  f.back_width >= 1 && f.back_width <= 32 && f.div_table.d64 == f.table_size && f.div_dense.d64 == f.num_dense &&
+                  f.div_sparse.d64 == f.num_sparse && f.num_dense > 0 && f.num_sparse > 0 &&
+                  inside(f.off_front_ranks, (f.front_size * f.front_width + 7) / 8 + 8) &&
+                  inside(f.off_back_ranks, ((nb - f.front_size) * f.back_width + 7) / 8 + 8) && inside(f.off_front_hp, (uint64_t)f.n_front_dict * 8) &&
+                  inside(f.off_back_hp, (uint64_t)f.n_back_dict * 8) && inside(f.off_free, (f.table_size - f.num_keys) * 4);
+        if (!ok) why = std::string(name) + " descriptor points outside the image";
+        return ok;
+    };
+    if (h.kind > 1 || (h.kmer_bits != 64 && h.kmer_bits != 128) || h.k < 1 || h.k > h.kmer_bits / 2 - 1 || h.m < 1 || h.m > h.k || h.m > 32 ||
+        h.W != h.k - h.m + 1 || h.P != (h.W <= 15 ? 4u : 6u) || h.distinct_minimizers > 0xFFFFFFFFull || h.mm.num_keys != h.distinct_minimizers) {
+        why = "inconsistent scalar fields";
+        return false;
+    }
+    if (!phf_ok(h.mm, "minimizer_order") || !phf_ok(h.fb, "fallback_kmer_order")) return false;
+    if (h.kind == LPHQ_PARTITIONED) {
+        const uint64_t E = LPHQ_UNI_PER_BLOCK(h.P);
+        if (!inside(h.off_uni, ((h.distinct_minimizers + E - 1) / E + 1) * sizeof(lphq_uni_block))) {
+            why = "fused blocks lie outside the image";
+            return false;
+        }
+    } else if (!inside(h.off_upair, ((h.distinct_minimizers + LPHQ_PAIR_PER_BLOCK - 1) / LPHQ_PAIR_PER_BLOCK + 1) * sizeof(lphq_plane_block))) {
+        why = "pair blocks lie outside the image";
+        return false;
+    }
+    return true;
+}
+
 static int check_device(int device) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -201,6 +244,13 @@ extern "C" int lphq_open_device_image(const void* d_image, size_t nbytes, int de
     if (idx->hdr.magic != LPHQ_IMAGE_MAGIC || idx->hdr.total_bytes != nbytes) {
         delete idx;
         return fail(LPHQ_ERR_FORMAT, "not a flat LPHQ image (magic/size mismatch)");
+    }
+    {
+        std::string why;
+        if (!header_is_consistent(idx->hdr, nbytes, why)) {
+            delete idx;
+            return fail(LPHQ_ERR_FORMAT, "flat LPHQ image rejected: " + why);
+        }
     }
     idx->d_image = (uint8_t*)d_image;
     idx->owns_device_image = false;
