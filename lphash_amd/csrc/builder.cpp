@@ -388,7 +388,11 @@ bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed,
         const uint64_t kPilotCap = 1ull << 28;
         const u128 M = f.M;
         auto is_taken = [&](uint64_t p) { return (taken[p >> 6].load(std::memory_order_relaxed) >> (p & 63)) & 1; };
-        const int T = std::max(1, threads);
+        // The CPU search is sequential: the speculative in-order-commit pool below never beat one thread (1.05 us/key on 64
+        // threads = sequential speed), and a CPU port of the GPU's window/claim/commit scheme got slower with every thread
+        // added (profiles/r01_builder_stages.txt).  The parallel search is the GPU's (search.hip).
+        const int T = 1;
+        (void)threads;
         auto worker = [&](int tid) {
             std::vector<uint64_t> pos(max_size ? max_size : 1);
             for (uint64_t oi = (uint64_t)tid; oi < n_nonempty; oi += (uint64_t)T) {
