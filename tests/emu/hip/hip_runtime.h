@@ -51,3 +51,4 @@ static inline T __shfl_down(T v, unsigned delta, int = 64) { return (T)emu::shfl
 static inline unsigned int atomicAdd(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o + v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 static inline unsigned int atomicOr(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o | v; return o; }
+static inline unsigned int atomicMin(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = v < o ? v : o; return o; }

@@ -191,3 +191,45 @@ def test_packed_and_pack_kernels_on_the_emulator(emuk, tmp_path, k, m, bits, kin
     out = np.empty(len(pos), dtype=np.uint64)
     assert emuk.emu_kernel_query_packed(img.ctypes.data, img.size, pk.ctypes.data, len(pos), out.ctypes.data) == 0
     assert np.array_equal(out, o.query_packed(pk))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GPU pilot search of the index builder (search_device.cuh kernels + search_rounds.hpp round loop) on the emulator
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_keys,look_ahead,steps,seed", [(3000, 16384, 32, 1), (3500, 16384, 4, 2), (2500, 8192, 1, 3), (800, 100, 1000000, 4), (7000, 16384, 32, 5)])
+def test_gpu_pilot_search_on_the_emulator(emuk, n_keys, look_ahead, steps, seed):
+    """Speculative window + claim/validate/commit must give exactly the sequential first-fit pilots and bitmap, for any step
+    budget and for (clamped) out-of-range look-ahead values -- the configuration that once committed unsearched buckets."""
+    lib = emuk
+    lib.emu_pilot_search.restype = C.c_int
+    lib.emu_pilot_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                     C.POINTER(C.c_uint64)]
+    lib.ref_pilot_search.restype = C.c_int
+    lib.ref_pilot_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(seed)
+    hashes = rng.integers(0, 2**63, n_keys, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n_keys, dtype=np.uint64)
+    hashes = np.unique(hashes)
+    n = len(hashes)
+    table_size = int(n / 0.94)
+    if table_size & (table_size - 1) == 0:
+        table_size += 1
+    nb = int(np.ceil(3.0 * n / np.log2(n)))
+    # skewed buckets like PTHash's: 60 % of the keys in the first 30 % of the buckets
+    dense = max(1, int(0.3 * nb))
+    r = rng.random(n)
+    bucket = np.where(r < 0.6, rng.integers(0, dense, n), rng.integers(dense, nb, n)).astype(np.int64)
+    perm = np.argsort(bucket, kind="stable")
+    hs = np.ascontiguousarray(hashes[perm])
+    counts = np.bincount(bucket, minlength=nb)
+    bstart = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint32)
+    order = np.array(sorted(range(nb), key=lambda b: (-counts[b], b)), dtype=np.uint32)
+    n_nonempty = int((counts > 0).sum())
+    words = (table_size + 63) // 64 * 2 + 2
+    p_emu, p_ref = np.zeros(n_nonempty, dtype=np.uint64), np.zeros(n_nonempty, dtype=np.uint64)
+    t_emu, t_ref = np.zeros(words, dtype=np.uint32), np.zeros(words, dtype=np.uint32)
+    rounds = C.c_uint64()
+    assert lib.ref_pilot_search(hs.ctypes.data, bstart.ctypes.data, order.ctypes.data, n_nonempty, table_size, 1, p_ref.ctypes.data, t_ref.ctypes.data) == 0
+    assert lib.emu_pilot_search(hs.ctypes.data, bstart.ctypes.data, order.ctypes.data, n_nonempty, table_size, 1, look_ahead, steps, p_emu.ctypes.data,
+                                t_emu.ctypes.data, C.byref(rounds)) == 0
+    assert np.array_equal(p_emu, p_ref) and np.array_equal(t_emu, t_ref)
+    assert int(np.unpackbits(t_emu.view(np.uint8)).sum()) == n and rounds.value >= 1
