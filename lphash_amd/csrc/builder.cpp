@@ -371,9 +371,18 @@ bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed,
     // search
     std::vector<uint64_t> pilots(num_buckets, 0);
     std::vector<uint64_t> taken_plain;  // bit p of word p/64: table position p is occupied
-    if (device >= 0 && n >= 4096) {  // pilot search on the GPU (search.hip): same first-fit result, ~50x faster
-        if (!gpu_pilot_search(device, hs, bstart, order, n_nonempty, table_size, seed, pilots, taken_plain, err)) return false;
-    } else {
+    bool searched = false;
+    if (device >= 0 && n >= 4096) {  // pilot search on the GPU (search.hip): same first-fit result, ~16x faster
+        searched = gpu_pilot_search(device, hs, bstart, order, n_nonempty, table_size, seed, pilots, taken_plain, err);
+        const bool used_gpu = searched;
+    if (!searched) {  // construction is not the query path: finish on the CPU, loudly
+            fprintf(stderr, "[lphq_build] WARNING: GPU pilot search failed (%s); falling back to the sequential CPU search\n", err.c_str());
+            std::fill(pilots.begin(), pilots.end(), 0);
+            taken_plain.clear();
+            err.clear();
+        }
+    }
+    if (!searched) {
         std::vector<std::atomic<uint64_t>> taken(words_for(table_size) + 1);
         for (auto& x : taken) x.store(0, std::memory_order_relaxed);
         const uint64_t HP_CACHE = 1ull << 20;
@@ -463,7 +472,7 @@ bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed,
         for (size_t i = 0; i < taken.size(); ++i) taken_plain[i] = taken[i].load(std::memory_order_relaxed);
     }
     auto is_taken = [&](uint64_t p) { return (taken_plain[p >> 6] >> (p & 63)) & 1; };
-    lap(device >= 0 && n >= 4096 ? "pilot search (GPU)" : "pilot search (CPU)");
+    lap(used_gpu ? "pilot search (GPU)" : "pilot search (CPU)");
     {  // the search must have placed every key exactly once: everything below relies on it (free-slot fill, minimality)
         uint64_t ones = 0;
         for (uint64_t p = 0; p < table_size; ++p) ones += is_taken(p);

@@ -103,7 +103,7 @@ bool gpu_pilot_search(int device, const std::vector<uint64_t>& hs, const std::ve
             void launch_validate(const SearchArgs& x, int g) { k_validate<<<g, 256>>>(x); }
             void launch_commit(const SearchArgs& x, int g) { k_commit<<<g, 256>>>(x); }
         } dev{d_flags};
-        const uint32_t steps = getenv("LPHQ_SEARCH_STEPS") ? (uint32_t)std::max(1, atoi(getenv("LPHQ_SEARCH_STEPS"))) : 32u;                    // tuning aids
+        const uint32_t steps = getenv("LPHQ_SEARCH_STEPS") ? (uint32_t)std::max(1, atoi(getenv("LPHQ_SEARCH_STEPS"))) : 16u;                    // tuning aids (16 steps x 256 pilots measured best)
         const uint32_t look_ahead = getenv("LPHQ_SEARCH_LOOKAHEAD") ? (uint32_t)std::max(1, atoi(getenv("LPHQ_SEARCH_LOOKAHEAD"))) : 16384u;
         uint64_t rounds = 0;
         if (!run_rounds(dev, a, n_nonempty, look_ahead, steps, err, &rounds)) goto done;

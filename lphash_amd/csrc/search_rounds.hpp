@@ -44,7 +44,7 @@ bool run_rounds(Dev& dev, SearchArgs a, uint64_t n_nonempty, uint32_t look_ahead
             err = "gpu pilot search: cannot reset the round flags";
             return false;
         }
-        dev.launch_search(a, (int)((a.n_search * (uint64_t)kWave + 255) / 256));
+        dev.launch_search(a, (int)a.n_search);  // one workgroup per bucket
         const int grid = (int)((a.n_commit * (uint64_t)kWave + 255) / 256);
         dev.launch_claim(a, grid);
         dev.launch_validate(a, grid);
@@ -63,7 +63,7 @@ bool run_rounds(Dev& dev, SearchArgs a, uint64_t n_nonempty, uint32_t look_ahead
         base += committed;
         ++rounds;
         idle_rounds = committed ? 0 : idle_rounds + 1;
-        if (idle_rounds > (kPilotCap / kWave) / a.max_steps + 16) {
+        if (idle_rounds > (kPilotCap / 256) / a.max_steps + 16) {
             err = "gpu pilot search: no progress";
             return false;
         }

@@ -76,6 +76,14 @@ void sync_block() {
         while (bar_gen == g) yield();
     }
 }
+bool sync_block_or(bool pred) {
+    static bool acc[2];
+    const unsigned g = bar_gen;
+    if (bar_arrived == 0) acc[g & 1] = false;  // first arrival of this barrier instance; the buffer's previous readers are done
+    acc[g & 1] = acc[g & 1] || pred;
+    sync_block();
+    return acc[g & 1];
+}
 unsigned long long ballot(bool pred) {
     return wave_op(pred ? 1 : 0, [](const uint64_t* vals, uint64_t part, unsigned) {
         unsigned long long m = 0;

@@ -10,6 +10,7 @@ struct Dim3 {
 extern Dim3 g_block_idx, g_grid_dim;
 const Dim3& thread_idx();
 void sync_block();                          // __syncthreads
+bool sync_block_or(bool pred);              // __syncthreads_or
 unsigned long long ballot(bool pred);       // active lanes = lanes of the wave that have not returned
 uint64_t shfl(uint64_t v, int src_lane);
 uint64_t shfl_down(uint64_t v, unsigned delta);

@@ -41,6 +41,7 @@ static inline uint32_t max(uint32_t a, uint32_t b) { return a > b ? a : b; }
 #define gridDim (emu::g_grid_dim)
 
 static inline void __syncthreads() { emu::sync_block(); }
+static inline int __syncthreads_or(int pred) { return emu::sync_block_or(pred != 0); }
 static inline unsigned long long __ballot(int pred) { return emu::ballot(pred != 0); }
 static inline int __any(int pred) { return emu::ballot(pred != 0) != 0; }
 template <typename T>
