@@ -374,14 +374,14 @@ bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed,
     bool searched = false;
     if (device >= 0 && n >= 4096) {  // pilot search on the GPU (search.hip): same first-fit result, ~16x faster
         searched = gpu_pilot_search(device, hs, bstart, order, n_nonempty, table_size, seed, pilots, taken_plain, err);
-        const bool used_gpu = searched;
-    if (!searched) {  // construction is not the query path: finish on the CPU, loudly
+        if (!searched) {  // construction is not the query path: finish on the CPU, loudly
             fprintf(stderr, "[lphq_build] WARNING: GPU pilot search failed (%s); falling back to the sequential CPU search\n", err.c_str());
             std::fill(pilots.begin(), pilots.end(), 0);
             taken_plain.clear();
             err.clear();
         }
     }
+    const bool used_gpu = searched;
     if (!searched) {
         std::vector<std::atomic<uint64_t>> taken(words_for(table_size) + 1);
         for (auto& x : taken) x.store(0, std::memory_order_relaxed);
