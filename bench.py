@@ -67,8 +67,12 @@ def main():
     ap.add_argument("--cpu-build", action="store_true", help="run the PTHash pilot search of the index build on the CPU")
     ap.add_argument("--cpu-sample-log2", type=int, default=24, help="oracle-timed sample size (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stream-pipeline", action="store_true",
+                    help="stream mode: use the opt-in software-pipelined kernel (sets LPHQ_STREAM_PIPELINE=1; see kernels_stream_pipe.cuh)")
     ap.add_argument("--cache-dir", default=os.environ.get("LPHQ_BENCH_CACHE", "/tmp/lphq_bench_cache"))
     args = ap.parse_args()
+    if args.stream_pipeline:
+        os.environ["LPHQ_STREAM_PIPELINE"] = "1"  # read by the launcher at its first streaming launch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -276,7 +280,7 @@ def main():
         if bpl is not None:
             achieved = bpl * units / (kernel_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                               "traffic": traffic, "bytes_per_lookup": bpl, "kernel": "k_query_packed" if args.mode == "random" else "k_query_tiles_stream"}
+                               "traffic": traffic, "bytes_per_lookup": bpl, "kernel": "k_query_packed" if args.mode == "random" else ("k_query_tiles_stream_pipe" if os.environ.get("LPHQ_STREAM_PIPELINE", "0") not in ("", "0") else "k_query_tiles_stream")}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if cpu_all is not None:

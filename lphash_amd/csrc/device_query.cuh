@@ -37,8 +37,11 @@ __device__ __forceinline__ uint32_t div_step(uint32_t r, uint32_t u, uint32_t dn
 }
 // Exact a % d.  pthash fastmod::fastmod_u64(a, M, d) is the exact remainder for all 64-bit a, d; the
 // 128-bit M of the file is replaced by a 32-bit reciprocal when d < 2^32 (always, for < 4 G keys).
+// WIDE = false drops the >= 2^32 divisor path (a software 64-bit division: ~450 instructions and ~15 VGPRs per inlined
+// copy); only for callers that checked d != 0 on the host (launch_query_records does for the pipelined kernel).
+template <bool WIDE = true>
 __device__ __forceinline__ uint64_t mod_u64(uint64_t a, uint32_t d, uint32_t dn, uint32_t inv, uint32_t shift, uint64_t d64) {
-    if (d) {
+    if (!WIDE || d) {
         uint32_t u2 = (uint32_t)((a >> 32) >> (32 - shift));
         uint32_t u1 = (uint32_t)((a << shift) >> 32);
         uint32_t u0 = (uint32_t)(a << shift);
@@ -48,34 +51,63 @@ __device__ __forceinline__ uint64_t mod_u64(uint64_t a, uint32_t d, uint32_t dn,
     }
     return d64 ? a % d64 : 0;
 }
-__device__ __forceinline__ uint64_t mod_u64(uint64_t a, const lphq_divisor& dv) { return mod_u64(a, dv.d, dv.dn, dv.inv, dv.shift, dv.d64); }
+template <bool WIDE = true>
+__device__ __forceinline__ uint64_t mod_u64(uint64_t a, const lphq_divisor& dv) { return mod_u64<WIDE>(a, dv.d, dv.dn, dv.inv, dv.shift, dv.d64); }
 
 // pthash::single_phf<..., dictionary_dictionary, true>::position(hash)  (SURVEY Appendix A):
 //   bucket = skew_bucketer(hash); pilot = dict[ranks[bucket]]; p = (hash ^ H(pilot)) mod table_size;
 //   p < num_keys ? p : free_slots[p - num_keys]
 // Device layout: hp[code] = H(pilot) precomputed; free_slots is a plain u32 table.
-__device__ __forceinline__ uint64_t phf_position(const uint8_t* __restrict__ img, const lphq_phf_desc& f, uint64_t x) {
-    if (f.num_keys == 0) return 0;  // empty function: unreachable for well-formed files
+// The chain is three dependent gathers; it is written as issue / consume stages so that a caller can put other work
+// between a stage's load and the next stage's use of it (the pipelined streaming kernel does; phf_position() is the
+// stages back to back).
+struct PhfRank {       // where the codeword of a bucket sits
+    uint32_t sh;       // bit offset of the codeword within the two dwords loaded by phf_load_code
+    uint32_t width;    // codeword width
+    bool front;        // front (dense-bucket) or back dictionary
+};
+template <bool WIDE = true>
+__device__ __forceinline__ uint64_t phf_load_code(const uint8_t* __restrict__ img, const lphq_phf_desc& f, uint64_t x, PhfRank& rk) {
     const uint64_t T = 0x9999999999999800ULL;  // uint64_t(0.6 * UINT64_MAX), skew_bucketer
     const bool dense = x < T;
-    uint64_t b = mod_u64(x, dense ? f.div_dense.d : f.div_sparse.d, dense ? f.div_dense.dn : f.div_sparse.dn,
-                         dense ? f.div_dense.inv : f.div_sparse.inv, dense ? f.div_dense.shift : f.div_sparse.shift,
-                         dense ? f.div_dense.d64 : f.div_sparse.d64);
+    // Both alternatives are read into (scalar) registers first and the VALUES are selected: `dense ? f.a : f.b` on
+    // the fields themselves selects the ADDRESS, and with the descriptor in memory (tile kernels) that is a per-lane
+    // vector load of a header field at the head of the gather chain.
+    const lphq_divisor dd = f.div_dense, ds = f.div_sparse;
+    uint64_t b = mod_u64<WIDE>(x, dense ? dd.d : ds.d, dense ? dd.dn : ds.dn, dense ? dd.inv : ds.inv, dense ? dd.shift : ds.shift,
+                               WIDE ? (dense ? dd.d64 : ds.d64) : 0);
     if (!dense) b += f.num_dense;
     const bool front = b < f.front_size;
     const uint64_t bi = front ? b : b - f.front_size;
-    const uint32_t width = front ? f.front_width : f.back_width;
-    const uint32_t* ranks = (const uint32_t*)(img + (front ? f.off_front_ranks : f.off_back_ranks));
+    const uint32_t fw = f.front_width, bw = f.back_width;
+    const uint64_t fo = f.off_front_ranks, bo = f.off_back_ranks;
+    const uint32_t width = front ? fw : bw;
+    const uint32_t* ranks = (const uint32_t*)(img + (front ? fo : bo));
     const uint64_t bit = bi * width;
     const uint64_t dw = bit >> 5;
-    const uint32_t sh = (uint32_t)bit & 31u;
+    rk.sh = (uint32_t)bit & 31u;
+    rk.width = width;
+    rk.front = front;
     struct __attribute__((packed, aligned(4))) u64a4 { uint64_t v; };  // one 8-byte request at 4-byte alignment (gfx950 allows it)
-    const uint64_t two = ((const u64a4*)(ranks + dw))->v;
-    const uint32_t code = (uint32_t)(two >> sh) & (width >= 32 ? ~0u : ((1u << width) - 1u));
-    const uint64_t hp = ((const uint64_t*)(img + (front ? f.off_front_hp : f.off_back_hp)))[code];
-    uint64_t p = mod_u64(x ^ hp, f.div_table);
+    return ((const u64a4*)(ranks + dw))->v;
+}
+__device__ __forceinline__ uint64_t phf_load_hp(const uint8_t* __restrict__ img, const lphq_phf_desc& f, uint64_t two, const PhfRank& rk) {
+    const uint32_t code = (uint32_t)(two >> rk.sh) & (rk.width >= 32 ? ~0u : ((1u << rk.width) - 1u));
+    const uint64_t fo = f.off_front_hp, bo = f.off_back_hp;
+    return ((const uint64_t*)(img + (rk.front ? fo : bo)))[code];
+}
+template <bool WIDE = true>
+__device__ __forceinline__ uint64_t phf_finish(const uint8_t* __restrict__ img, const lphq_phf_desc& f, uint64_t x, uint64_t hp) {
+    uint64_t p = mod_u64<WIDE>(x ^ hp, f.div_table);
     if (p >= f.num_keys) p = ((const uint32_t*)(img + f.off_free))[p - f.num_keys];
     return p;
+}
+template <bool WIDE = true>
+__device__ __forceinline__ uint64_t phf_position(const uint8_t* __restrict__ img, const lphq_phf_desc& f, uint64_t x) {
+    if (f.num_keys == 0) return 0;  // empty function: unreachable for well-formed files
+    PhfRank rk;
+    const uint64_t two = phf_load_code<WIDE>(img, f, x, rk);
+    return phf_finish<WIDE>(img, f, x, phf_load_hp(img, f, two, rk));
 }
 
 // mask of the first nb bits of a 32-bit word, nb in [0, 32]
@@ -86,22 +118,31 @@ __device__ __forceinline__ uint32_t low_mask(int nb) { return nb >= 32 ? ~0u : (
 // Returns the type of minimizer order h, base = global-rank base of its super-k-mer (the `res.global_rank`
 // terms of src/partitioned_mphf.cpp:297-336, already including (k-m+1)*n_maximal), size and position.
 template <int P>
-__device__ __forceinline__ void uni_lookup(const uint8_t* __restrict__ img, uint64_t off_uni, uint32_t W, uint32_t h, uint32_t& type, uint64_t& base,
-                                           uint32_t& size, uint32_t& pos) {
-    constexpr uint32_t T = LPHQ_UNI_T(P), E = LPHQ_UNI_PER_BLOCK(P), NWORDS = (2 + 2 * P) * T, NV = (NWORDS + 3) / 4;
-    const uint32_t b = h / E, j = h % E;
-    const uint4* p = (const uint4*)(img + off_uni) + (size_t)b * 8;
-    const uint4 b01 = p[0], b23 = p[1];
+struct UniRegs {  // one fused block in registers
+    static constexpr uint32_t T = LPHQ_UNI_T(P), E = LPHQ_UNI_PER_BLOCK(P), NWORDS = (2 + 2 * P) * T, NV = (NWORDS + 3) / 4;
+    uint4 b01, b23;
     uint4 v[NV];
+};
+template <int P>
+__device__ __forceinline__ void uni_load(const uint8_t* __restrict__ img, uint64_t off_uni, uint32_t h, UniRegs<P>& r) {
+    const uint4* p = (const uint4*)(img + off_uni) + (size_t)(h / UniRegs<P>::E) * 8;
+    r.b01 = p[0];
+    r.b23 = p[1];
 #pragma unroll
-    for (uint32_t i = 0; i < NV; ++i) v[i] = p[2 + i];
+    for (uint32_t i = 0; i < UniRegs<P>::NV; ++i) r.v[i] = p[2 + i];
+}
+template <int P>
+__device__ __forceinline__ void uni_decode(const UniRegs<P>& r, uint32_t W, uint32_t h, uint32_t& type, uint64_t& base, uint32_t& size, uint32_t& pos) {
+    constexpr uint32_t T = UniRegs<P>::T, E = UniRegs<P>::E, NV = UniRegs<P>::NV;
+    const uint32_t j = h % E;
+    const uint4 b01 = r.b01, b23 = r.b23;
     uint32_t w[NV * 4];
 #pragma unroll
     for (uint32_t i = 0; i < NV; ++i) {
-        w[4 * i] = v[i].x;
-        w[4 * i + 1] = v[i].y;
-        w[4 * i + 2] = v[i].z;
-        w[4 * i + 3] = v[i].w;
+        w[4 * i] = r.v[i].x;
+        w[4 * i + 1] = r.v[i].y;
+        w[4 * i + 2] = r.v[i].z;
+        w[4 * i + 3] = r.v[i].w;
     }
     const uint32_t wj = j >> 5, bj = j & 31u;
     auto pick = [&](uint32_t first) {  // word wj of the plane starting at w[first]
@@ -137,14 +178,30 @@ __device__ __forceinline__ void uni_lookup(const uint8_t* __restrict__ img, uint
     const uint64_t blo = sl ? base2 : base1, bhi = sl ? base3 : base0;  // type 0:LEFT->1, 1:RIGHT->2, 2:MAXIMAL->0, 3:NONE->3
     base = (sm ? bhi : blo) + (type == 2u ? W * rank : sum);
 }
+template <int P>
+__device__ __forceinline__ void uni_lookup(const uint8_t* __restrict__ img, uint64_t off_uni, uint32_t W, uint32_t h, uint32_t& type, uint64_t& base,
+                                           uint32_t& size, uint32_t& pos) {
+    UniRegs<P> r;
+    uni_load<P>(img, off_uni, h, r);
+    uni_decode<P>(r, W, h, type, base, size, pos);
+}
 
 // (size, position) pair block, 32 entries: NONE minimizers (partitioned_mphf.cpp:326-333) and the whole
 // unpartitioned index (sizes.pair + positions.diff, unpartitioned_mphf.cpp:194-204).
+struct PairRegs {
+    uint4 v0, v1, v2, v3;
+};
+__device__ __forceinline__ void pair_load(const uint8_t* __restrict__ img, uint64_t off, uint32_t r, PairRegs& g) {
+    const uint4* p = (const uint4*)(img + off) + (size_t)(r / LPHQ_PAIR_PER_BLOCK) * 4;
+    g.v0 = p[0];
+    g.v1 = p[1];
+    g.v2 = p[2];
+    g.v3 = p[3];
+}
 template <int P>
-__device__ __forceinline__ void pair_lookup(const uint8_t* __restrict__ img, uint64_t off, uint32_t r, uint64_t& prefix, uint32_t& size, uint32_t& pos) {
-    const uint32_t b = r / LPHQ_PAIR_PER_BLOCK, j = r & (LPHQ_PAIR_PER_BLOCK - 1u);
-    const uint4* p = (const uint4*)(img + off) + (size_t)b * 4;
-    const uint4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+__device__ __forceinline__ void pair_decode(const PairRegs& g, uint32_t r, uint64_t& prefix, uint32_t& size, uint32_t& pos) {
+    const uint32_t j = r & (LPHQ_PAIR_PER_BLOCK - 1u);
+    const uint4 v0 = g.v0, v1 = g.v1, v2 = g.v2, v3 = g.v3;
     const uint32_t w[14] = {v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
     const uint32_t msk = (1u << j) - 1u;
     uint32_t sum = 0;
@@ -157,6 +214,12 @@ __device__ __forceinline__ void pair_lookup(const uint8_t* __restrict__ img, uin
         pos |= ((w[P + q] >> j) & 1u) << q;
     }
     prefix = (((uint64_t)v0.y << 32) | v0.x) + sum;
+}
+template <int P>
+__device__ __forceinline__ void pair_lookup(const uint8_t* __restrict__ img, uint64_t off, uint32_t r, uint64_t& prefix, uint32_t& size, uint32_t& pos) {
+    PairRegs g;
+    pair_load(img, off, r, g);
+    pair_decode<P>(g, r, prefix, size, pos);
 }
 
 // fallback_hasher::hash(kmer_t, seed)   include/constants.hpp:56-70
@@ -199,44 +262,53 @@ struct LookupCtx {   // what a streaming follower needs from its super-k-mer lea
     uint64_t base;   // hval = base + sign * p  (collision: base = collision_base, hval = base + fallback(kmer))
     uint32_t mode;   // 0: base + p, 1: base - p, 2: collision
 };
-template <int KIND, bool K128, int P>
-__device__ __forceinline__ LookupCtx lookup_ctx(const uint8_t* __restrict__ img, const lphq_image_header& H, uint64_t mm) {
+// the type-dependent closed forms, from the decoded block entry
+__device__ __forceinline__ LookupCtx ctx_partitioned(const lphq_image_header& H, uint32_t type, uint64_t base, uint32_t size, uint32_t pos) {
     LookupCtx c;
-    const uint32_t h = (uint32_t)phf_position(img, H.mm, murmur8(mm, murmur_seedx(H.mm.seed)));
+    if (type == 2u || type == 0u) {  // MAXIMAL: (k-m+1)*rank + p ; LEFT: EF[r] + W*n_max + p
+        c.base = base;
+        c.mode = 0;
+    } else if (type == 3u) {  // NONE: EF[none_sizes_start+r] + W*n_max + (p1 - p)
+        c.base = base + pos;
+        c.mode = 1;
+    } else if (size == 0u) {  // collision: EF[none_pos_start] + W*n_max + fallback(kmer)
+        c.base = H.collision_base;
+        c.mode = 2;
+    } else {  // RIGHT: val1 + W*n_max + (k - m - p)
+        c.base = base + (H.k - H.m);
+        c.mode = 1;
+    }
+    return c;
+}
+__device__ __forceinline__ LookupCtx ctx_unpartitioned(const lphq_image_header& H, uint64_t prefix, uint32_t size, uint32_t pos) {
+    LookupCtx c;
+    if (size == 0u) {  // num_kmers_in_main_index + fallback(kmer)
+        c.base = H.collision_base;
+        c.mode = 2;
+    } else {  // val1 + p1 - p
+        c.base = prefix + pos;
+        c.mode = 1;
+    }
+    return c;
+}
+template <int KIND, bool K128, int P, bool WIDE = true>
+__device__ __forceinline__ LookupCtx lookup_ctx(const uint8_t* __restrict__ img, const lphq_image_header& H, uint64_t mm) {
+    const uint32_t h = (uint32_t)phf_position<WIDE>(img, H.mm, murmur8(mm, murmur_seedx(H.mm.seed)));
     if (KIND == 0) {
         uint32_t type, size, pos;
         uint64_t base;
         uni_lookup<P>(img, H.off_uni, H.W, h, type, base, size, pos);
-        if (type == 2u || type == 0u) {  // MAXIMAL: (k-m+1)*rank + p ; LEFT: EF[r] + W*n_max + p
-            c.base = base;
-            c.mode = 0;
-        } else if (type == 3u) {  // NONE: EF[none_sizes_start+r] + W*n_max + (p1 - p)
-            c.base = base + pos;
-            c.mode = 1;
-        } else if (size == 0u) {  // collision: EF[none_pos_start] + W*n_max + fallback(kmer)
-            c.base = H.collision_base;
-            c.mode = 2;
-        } else {  // RIGHT: val1 + W*n_max + (k - m - p)
-            c.base = base + (H.k - H.m);
-            c.mode = 1;
-        }
+        return ctx_partitioned(H, type, base, size, pos);
     } else {
         uint64_t prefix;
         uint32_t size, pos;
         pair_lookup<P>(img, H.off_upair, h, prefix, size, pos);
-        if (size == 0u) {  // num_kmers_in_main_index + fallback(kmer)
-            c.base = H.collision_base;
-            c.mode = 2;
-        } else {  // val1 + p1 - p
-            c.base = prefix + pos;
-            c.mode = 1;
-        }
+        return ctx_unpartitioned(H, prefix, size, pos);
     }
-    return c;
 }
-template <bool K128>
+template <bool K128, bool WIDE = true>
 __device__ __forceinline__ uint64_t finish_hval(const uint8_t* __restrict__ img, const lphq_image_header& H, const LookupCtx& c, uint64_t lo, uint64_t hi, uint32_t p) {
-    if (c.mode == 2u) return c.base + phf_position(img, H.fb, fallback_hash<K128>(lo, hi, H.fb.seed));
+    if (c.mode == 2u) return c.base + phf_position<WIDE>(img, H.fb, fallback_hash<K128>(lo, hi, H.fb.seed));
     return c.mode == 0u ? c.base + p : c.base - p;
 }
 

@@ -15,6 +15,8 @@
 #define __forceinline__ inline
 #define __shared__ static
 #define __launch_bounds__(...)
+// optimisation barrier used by kernels_stream_pipe.cuh (the device version names an AMDGPU register class)
+#define LPHQ_OPAQUE_LANE(x) asm volatile("" : "+r"(x))
 
 struct uint4 {
     uint32_t x, y, z, w;
