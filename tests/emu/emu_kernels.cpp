@@ -25,6 +25,8 @@ static bool header(const uint8_t* img, size_t nbytes, lphq_image_header& H) {
     return H.magic == LPHQ_IMAGE_MAGIC && H.total_bytes == nbytes;
 }
 
+extern "C" void emu_set_schedule(int mode, uint64_t seed) { emu::set_schedule(mode, seed); }
+
 extern "C" int emu_kernel_query_packed(const uint8_t* img, size_t nbytes, const uint64_t* kmers, size_t n, uint64_t* out) {
     lphq_image_header H;
     if (!header(img, nbytes, H)) return 1;

@@ -1,11 +1,14 @@
 // TEST INFRASTRUCTURE ONLY: see emu_runtime.hpp.  Fibers are ucontext coroutines scheduled round-robin by one OS thread;
-// a fiber blocked in a barrier or a wave operation yields until its generation counter moves.
+// a fiber blocked in a barrier or a wave operation yields until its generation counter moves.  The order in which the
+// threads of a workgroup run between two synchronisation points is selectable (set_schedule): a kernel without LDS races
+// gives the same result for every order, a missing barrier shows up as a mismatch under the reverse or random order.
 #include "emu_runtime.hpp"
 
 #include <ucontext.h>
 
 #include <cstdio>
 #include <cstdlib>
+#include <utility>
 #include <vector>
 
 namespace emu {
@@ -27,6 +30,8 @@ std::vector<Fiber> fibers;
 std::vector<Wave> waves;
 ucontext_t main_ctx;
 int cur = -1;
+int sched_mode = 0;            // 0: lanes in order, 1: reverse order, 2: a fresh random order at every scheduling pass
+uint64_t sched_state = 1;
 unsigned bar_arrived = 0, bar_gen = 0, alive = 0;
 const std::function<void()>* body_fn = nullptr;
 
@@ -67,6 +72,10 @@ uint64_t wave_op(uint64_t v, Fn result) {
 }  // namespace
 
 const Dim3& thread_idx() { return fibers[cur].tid; }
+void set_schedule(int mode, uint64_t seed) {
+    sched_mode = mode;
+    sched_state = seed ? seed : 1;
+}
 void sync_block() {
     const unsigned g = bar_gen;
     if (++bar_arrived == alive) {
@@ -127,8 +136,18 @@ void launch(unsigned grid, unsigned block, const std::function<void()>& body) {
             makecontext(&f.ctx, trampoline, 0);
         }
         unsigned long spins = 0;
+        std::vector<unsigned> order(block);
+        for (unsigned t = 0; t < block; ++t) order[t] = sched_mode == 1 ? block - 1 - t : t;
         while (alive) {
-            for (unsigned t = 0; t < block; ++t) {
+            if (sched_mode == 2)  // Fisher-Yates with xorshift64: any interleaving of the threads between two synchronisation points
+                for (unsigned t = block; t > 1; --t) {
+                    sched_state ^= sched_state << 13;
+                    sched_state ^= sched_state >> 7;
+                    sched_state ^= sched_state << 17;
+                    std::swap(order[t - 1], order[sched_state % t]);
+                }
+            for (unsigned i = 0; i < block; ++i) {
+                const unsigned t = order[i];
                 if (fibers[t].done) continue;
                 cur = (int)t;
                 swapcontext(&main_ctx, &fibers[t].ctx);

@@ -247,3 +247,25 @@ def test_gpu_pilot_search_on_the_emulator(emuk, n_keys, look_ahead, steps, seed)
                                 t_emu.ctypes.data, C.byref(rounds)) == 0
     assert np.array_equal(p_emu, p_ref) and np.array_equal(t_emu, t_ref)
     assert int(np.unpackbits(t_emu.view(np.uint8)).sum()) == n and rounds.value >= 1
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# LDS-race check: a kernel whose barriers are complete gives the same answer for every order in which the threads of a
+# workgroup run between two synchronisation points (tests/emu/emu_runtime.cpp: set_schedule).  The default order runs lane 0
+# first, so a consumer in a low lane reading what a high lane has not written yet only fails under the other orders.
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode,seed", [(1, 0), (2, 12345), (2, 987654321)])
+def test_kernels_under_other_thread_schedules(emuk, tmp_path, mode, seed):
+    emuk.emu_set_schedule.restype = None
+    emuk.emu_set_schedule.argtypes = [C.c_int, C.c_uint64]
+    emuk.emu_set_schedule(mode, seed)
+    try:
+        test_tile_kernels_on_the_emulator(emuk, tmp_path, 31, 20, 64, 0)   # incl. the pipelined kernel, one workgroup walking all tiles
+        test_tile_kernels_on_the_emulator(emuk, tmp_path, 9, 7, 64, 0)     # W = 3 path, > 256 leaders per tile
+        test_tile_kernels_on_the_emulator(emuk, tmp_path, 47, 17, 128, 1)  # unpartitioned, 128-bit k-mers
+        test_tile_kernels_non_acgt_on_the_emulator(emuk, tmp_path)
+        test_packed_and_pack_kernels_on_the_emulator(emuk, tmp_path, 31, 20, 64, 0)
+        test_gpu_pilot_search_on_the_emulator(emuk, 3000, 16384, 32, 1)
+        test_gpu_pilot_search_on_the_emulator(emuk, 2500, 8192, 1, 3)
+    finally:
+        emuk.emu_set_schedule(0, 0)
