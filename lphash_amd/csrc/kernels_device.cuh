@@ -129,6 +129,36 @@ __device__ __forceinline__ uint32_t find_record_wave(const uint64_t* __restrict_
     return lo;
 }
 
+// Records of a tile cached in LDS.  A streaming tile spans <= 1088 bases, so it touches more than kRecCap records only if
+// they average < 17 bases; such tiles (and nothing else) keep searching the global offset arrays.  Layout of the table:
+// seq_off[rlo .. rlo + n] (n + 1 entries), then from entry kRecCap + 1 on out_off[rlo .. rlo + n - 1].
+constexpr int kRecCap = 64;
+__device__ __forceinline__ void load_record_table(uint64_t* __restrict__ rtab, const uint64_t* __restrict__ seq_off, const uint64_t* __restrict__ out_off,
+                                                  uint32_t rlo, uint32_t rhi, uint32_t tid) {
+    const uint32_t n = rhi - rlo + 1u;
+    if (n > 1u && n <= (uint32_t)kRecCap) {
+        if (tid <= n) rtab[tid] = seq_off[rlo + tid];
+        if (tid < n) rtab[kRecCap + 1 + tid] = out_off[rlo + tid];
+    }
+}
+// record of base g (rlo <= record <= rhi, rlo != rhi): index, first base and end
+__device__ __forceinline__ uint32_t tile_record(const uint64_t* __restrict__ rtab, const uint64_t* __restrict__ seq_off, uint32_t rlo, uint32_t rhi, uint64_t g,
+                                                uint64_t& start, uint64_t& end) {
+    if (rhi - rlo < (uint32_t)kRecCap) {
+        const uint32_t j = find_record(rtab, 0, rhi - rlo, g);
+        start = rtab[j];
+        end = rtab[j + 1];
+        return j;
+    }
+    const uint32_t r = find_record(seq_off, rlo, rhi, g);
+    start = seq_off[r];
+    end = seq_off[r + 1];
+    return r - rlo;
+}
+__device__ __forceinline__ uint64_t tile_record_out(const uint64_t* __restrict__ rtab, const uint64_t* __restrict__ out_off, uint32_t rlo, uint32_t rhi, uint32_t j) {
+    return (rhi - rlo < (uint32_t)kRecCap) ? rtab[kRecCap + 1 + j] : out_off[rlo + j];
+}
+
 // 2k bits starting at base q of the LDS-packed tile
 template <bool K128>
 __device__ __forceinline__ void extract_kmer(const uint32_t* __restrict__ sm, uint32_t q, uint32_t k, uint64_t& lo, uint64_t& hi) {
@@ -275,6 +305,7 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
     __shared__ uint8_t sm_mode[kStreamPos];
     __shared__ uint32_t sm_rec[2], sm_count;
     __shared__ uint64_t sm_roff[3];  // seq_off[rlo], seq_off[rlo+1], out_off[rlo]
+    __shared__ uint64_t sm_rtab[2 * kRecCap + 1];  // multi-record tiles: the tile's slice of seq_off / out_off
     const uint32_t k = H.k, m = H.m, W = H.W;
     const uint32_t TW = stream_tile_windows(W, kStreamPos);
     const uint64_t t0 = (uint64_t)blockIdx.x * TW;
@@ -296,6 +327,7 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
     for (int c = threadIdx.x; c < NBADW; c += BLOCK) sm_bad[c] = (c < NDW / 8) ? 0u : 0xFFFFFFFFu;
     for (int c = NW + 1 + threadIdx.x; c < NW + 8; c += BLOCK) sm_words[c] = 0;
     __syncthreads();
+    if (sm_rec[0] != sm_rec[1]) load_record_table(sm_rtab, seq_off, out_off, sm_rec[0], sm_rec[1], threadIdx.x);
     for (int d = threadIdx.x; d < NDW; d += BLOCK) {
         const uint64_t a = t0 + (uint64_t)d * 4u;  // shifted coordinate of the dword
         uint32_t p8 = 0, b4 = 0xFu;
@@ -397,8 +429,9 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
                 bool inside;
                 if (rlo == rhi) inside = g + k <= end1;
                 else {
-                    const uint32_t r = find_record(seq_off, rlo, rhi, g);
-                    inside = g + k <= seq_off[r + 1];
+                    uint64_t rs, re;
+                    tile_record(sm_rtab, seq_off, rlo, rhi, g, rs, re);
+                    inside = g + k <= re;
                 }
                 if (inside) {
                     const uint64_t x = jw ? ((blo >> jw) | ((uint64_t)bhi << (64 - jw))) : blo;
@@ -452,8 +485,9 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
         uint64_t oidx;
         if (rlo == rhi) oidx = sm_roff[2] + (g - sm_roff[0]);
         else {
-            const uint32_t rr = find_record(seq_off, rlo, rhi, g);
-            oidx = out_off[rr] + (g - seq_off[rr]);
+            uint64_t rs, re;
+            const uint32_t j = tile_record(sm_rtab, seq_off, rlo, rhi, g, rs, re);
+            oidx = tile_record_out(sm_rtab, out_off, rlo, rhi, j) + (g - rs);
         }
         uint64_t hval = ~0ull;  // LPHQ_INVALID
         if (q != 0xFFFFu) {

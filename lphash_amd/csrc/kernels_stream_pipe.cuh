@@ -52,6 +52,7 @@ struct StreamTileLds {  // what phases A-D of a tile leave behind for E-F
     uint16_t q[kPos + 8] __attribute__((aligned(16)));     // per window: minimizer position, 0xFFFF invalid, 0xFFFE no window
     uint16_t queue[kPos];                                  // leaders (their minimizer positions)
     uint64_t roff[3];                                      // seq_off[rlo], seq_off[rlo+1], out_off[rlo]
+    uint64_t rtab[2 * kRecCap + 1];                        // multi-record tiles: the tile's slice of seq_off / out_off
     uint32_t rec[2], count;
     __device__ __forceinline__ void reset(uint32_t tid) {  // state phase A accumulates into
         for (int c = (int)tid; c < NBADW; c += BLOCK) bad[c] = (c < NDW / 8) ? 0u : 0xFFFFFFFFu;
@@ -127,9 +128,11 @@ __device__ __forceinline__ void pipe_pack(StreamTileLds<BLOCK>& t, uint64_t t0, 
 
 // ---- B: hashes of the m-mers starting at local positions 4*lane .. 4*lane+3 ----
 template <int BLOCK>
-__device__ __forceinline__ void pipe_hash(const StreamTileLds<BLOCK>& t, uint64_t* __restrict__ sm_hash, uint32_t m, uint64_t mm_seedx) {
+__device__ __forceinline__ void pipe_hash(StreamTileLds<BLOCK>& t, uint64_t* __restrict__ sm_hash, uint32_t m, uint64_t mm_seedx,
+                                          const uint64_t* __restrict__ seq_off, const uint64_t* __restrict__ out_off) {
     const uint32_t tid = phase_lane();
     constexpr int kPos = 4 * BLOCK;
+    if (t.rec[0] != t.rec[1]) load_record_table(t.rtab, seq_off, out_off, t.rec[0], t.rec[1], tid);  // for C and F (t.rec: visible since A's barrier)
     const uint32_t a = 4u * tid;
     const uint32_t w0 = a >> 4, o = (a & 15u) * 2u;
     const uint32_t x0 = t.words[w0], x1 = t.words[w0 + 1], x2 = t.words[w0 + 2], x3 = t.words[w0 + 3];
@@ -208,8 +211,9 @@ __device__ __forceinline__ void pipe_argmin(StreamTileLds<BLOCK>& t, const uint6
             bool inside;
             if (rlo == rhi) inside = g + k <= end1;
             else {
-                const uint32_t r = find_record(seq_off, rlo, rhi, g);
-                inside = g + k <= seq_off[r + 1];
+                uint64_t rs, re;
+                tile_record(t.rtab, seq_off, rlo, rhi, g, rs, re);
+                inside = g + k <= re;
             }
             if (inside) {
                 const uint64_t x = jw ? ((blo >> jw) | ((uint64_t)bhi << (64 - jw))) : blo;
@@ -255,8 +259,9 @@ __device__ __forceinline__ void pipe_store(const StreamTileLds<BLOCK>& t, const 
         uint64_t oidx;
         if (rlo == rhi) oidx = t.roff[2] + (g - t.roff[0]);
         else {
-            const uint32_t rr = find_record(seq_off, rlo, rhi, g);
-            oidx = out_off[rr] + (g - seq_off[rr]);
+            uint64_t rs, re;
+            const uint32_t j = tile_record(t.rtab, seq_off, rlo, rhi, g, rs, re);
+            oidx = tile_record_out(t.rtab, out_off, rlo, rhi, j) + (g - rs);
         }
         uint64_t hval = ~0ull;  // LPHQ_INVALID
         if (q != 0xFFFFu) {
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(BLOCK, 5) void k_query_tiles_stream_pipe(const uint
         __syncthreads();
         pipe_pack<BLOCK>(sm_tile[0], t0, shift, total, sq, rc);
         __syncthreads();
-        pipe_hash<BLOCK>(sm_tile[0], sm_hash, H.m, murmur_seedx(H.mm_seed));
+        pipe_hash<BLOCK>(sm_tile[0], sm_hash, H.m, murmur_seedx(H.mm_seed), seq_off, out_off);
         __syncthreads();
         pipe_argmin<BLOCK>(sm_tile[0], sm_hash, t0, TW, H.k, H.W, shift, total, seq_off);
         __syncthreads();
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(BLOCK, 5) void k_query_tiles_stream_pipe(const uint
 
         // ---- E2 ----
         const uint64_t hp = phf_load_hp(img, H.mm, two, rk);
-        if (has_next) pipe_hash<BLOCK>(tn, sm_hash, H.m, murmur_seedx(H.mm_seed));
+        if (has_next) pipe_hash<BLOCK>(tn, sm_hash, H.m, murmur_seedx(H.mm_seed), seq_off, out_off);
         __syncthreads();
 
         // ---- E3 ----  (EARLY_BLOCK: the block gather flies over C and D, at the price of ~28 VGPRs held across C;

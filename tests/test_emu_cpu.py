@@ -144,6 +144,8 @@ def test_tile_kernels_on_the_emulator(emuk, tmp_path, k, m, bits, kind):
     o = orc.Index(path, kind, bits)
     h = (L.Mphf if kind == 0 else L.MphfAlt).load(path, kmer_bits=bits)
     batch = [b"", recs[0], recs[1][: k - 1], b"", recs[2][:k]] + recs[3:] + random_records(3, 6, 1, 1500) + [b""]
+    # > 64 records inside one tile (beyond the LDS record table of the streaming kernels), then ~20 records per tile
+    batch += random_records(11, 150, 0, 5) + [recs[0][:k + 2]] + random_records(12, 40, k, k + 20) + [recs[1]]
     exp = [o(r, False) for r in batch]
     for streaming, mis, block in ((True, 0, 256), (True, 5, 256), (True, 15, 128), (False, 0, 256), (False, 9, 256)):
         got = emu_records(emuk, h, batch, k, streaming, mis, block)
