@@ -33,6 +33,7 @@ def main():
         o = orc.Index(path, kind, bits)
         h = (L.Mphf if kind == 0 else L.MphfAlt).load(path, kmer_bits=bits, device=0)
         batch = [b"", recs[0], recs[1][: k - 1], b"", recs[2][:k], recs[3]] + recs[4:] + random_records(5, 30, 1, 200) + [b"", b"ACGTNNNNACGT" * 40]
+        batch += random_records(11, 150, 0, 5) + [recs[0][:k + 2]] + random_records(12, 60, k, k + 20)  # > 64 and ~20 records per tile
         lens = np.array([len(r) for r in batch], dtype=np.int64)
         seq_off = np.concatenate([[0], np.cumsum(lens)])
         nwin = np.maximum(lens - k + 1, 0)

@@ -125,6 +125,7 @@ def test_record_batches_ragged_empty_and_misaligned(tmp_path, k, m, bits, kind):
     o = orc.Index(path, kind, bits)
     h = (L.Mphf if kind == 0 else L.MphfAlt).load(path, kmer_bits=bits, device=0)
     batch = [b"", recs[0], recs[1][: k - 1], b"", recs[2][:k], recs[3]] + recs[4:] + random_records(5, 30, 1, 200) + [b""]
+    batch += random_records(11, 150, 0, 5) + [recs[0][:k + 2]] + random_records(12, 60, k, k + 20)  # > 64 and ~20 records per tile
     exp = [o(r, False) for r in batch]
     for streaming in (False, True):
         for mis in (0, 1, 7, 15):
