@@ -5,17 +5,24 @@
 // Same flags, same CSV on stdout, same exit codes (1 usage/parse error, 2 cannot open the query file).
 // Extra flags (all optional, defaults keep the reference behaviour): --kmer-bits 64|128 (the reference's
 // compile-time kmer_t, default 128 like include/compile_constants.tpd:1; 64 reproduces a `uint64_t` build),
-// --device N, --batch-mb N.  The work itself runs on the GPU through the C ABI (include/lphq.h).
+// --device N, --batch-mb N, --threads N (FASTA parsing threads of the query tools), --pinned (parse into pinned host
+// memory).  The work itself runs on the GPU through the C ABI (include/lphq.h).
+//   lphash records -i <fasta|fastq[.gz]> [-t N] [--serial] [--batch-bytes N] [--min-piece N]
+// is a diagnostic: it prints the record count, base count and a checksum of what the reader yields (tests compare the
+// multi-threaded reader with the serial one through it).
 #include <hip/hip_runtime.h>
 
 #include <chrono>
 #include <cstring>
+#include <future>
 #include <iostream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/lphq.h"
 #include "fastx.hpp"
+#include "fastx_batch.hpp"
 
 namespace {
 
@@ -95,25 +102,61 @@ struct DeviceBatch {
     }
 };
 
+// Parse arenas are kept between the two passes over the query file (streaming, then random): memory that has been touched
+// once is several times cheaper to fill than fresh pages.  Blocks are handed back to the system when the process ends.
+struct ArenaCache {
+    struct Block {
+        void* p;
+        size_t cap;
+        bool in_use;
+    };
+    std::vector<Block> blocks;
+    bool pinned = false;
+    void* get(size_t n) {
+        Block* best = nullptr;
+        for (Block& b : blocks)
+            if (!b.in_use && b.cap >= n && (!best || b.cap < best->cap)) best = &b;
+        if (best) {
+            best->in_use = true;
+            return best->p;
+        }
+        void* p = nullptr;
+        if (pinned) {
+            if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) p = nullptr;
+        } else
+            p = malloc(n);
+        if (p) blocks.push_back({p, n, true});
+        return p;
+    }
+    void put(void* p) {
+        for (Block& b : blocks)
+            if (b.p == p) b.in_use = false;
+    }
+} g_arenas;
+void* arena_alloc(size_t n) { return g_arenas.get(n); }
+void arena_free(void* p) { g_arenas.put(p); }
+int default_parse_threads() { return (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency())); }
+
 // One pass of src/query.cpp:48-56 / :68-76 over the whole file, batched: returns false if the file cannot be opened.
-bool query_pass(lphq_index* idx, const lphq_info& info, const std::string& path, int streaming, size_t batch_bases, DeviceBatch& db,
+bool query_pass(lphq_index* idx, const lphq_info& info, const std::string& path, int streaming, size_t batch_bases, int threads, bool pinned, DeviceBatch& db,
                 uint64_t& total_kmers, uint64_t& elapsed_us, std::string& err, FILE* sink) {
-    lphq::FastxReader rd(path.c_str());
+    g_arenas.pinned = pinned;
+    lphq::FastxBatchReader rd(path.c_str(), threads, &arena_alloc, &arena_free);
     if (!rd.ok()) return false;
     auto t0 = std::chrono::high_resolution_clock::now();
-    std::string seq, flat;
-    std::vector<uint64_t> offs, out_offs;
+    lphq::FastxBatch bufs[2];
+    std::vector<uint64_t> all;
     total_kmers = 0;
-    auto flush = [&]() -> bool {
-        const size_t n = offs.size();
+    auto flush = [&](const lphq::FastxBatch& b) -> bool {
+        const size_t n = b.lens.size();
         if (n == 0) return true;
-        std::vector<uint64_t> all(2 * (n + 1));
+        all.resize(2 * (n + 1));
         uint64_t so = 0, oo = 0;
         for (size_t i = 0; i < n; ++i) {
             all[i] = so;
             all[n + 1 + i] = oo;
-            so += offs[i];
-            oo += offs[i] >= info.k ? offs[i] - info.k + 1 : 0;
+            so += b.lens[i];
+            oo += b.lens[i] >= info.k ? b.lens[i] - info.k + 1 : 0;
         }
         all[n] = so;
         all[2 * n + 1] = oo;
@@ -122,8 +165,15 @@ bool query_pass(lphq_index* idx, const lphq_info& info, const std::string& path,
                 err = "device allocation failed";
                 return false;
             }
-            if (hipMemcpy(db.d_seq, flat.data(), so, hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemcpy(db.d_offs, all.data(), all.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+            size_t at = 0;
+            for (const auto& sg : b.segs) {  // one copy per parsed piece, compacting on the way
+                if (hipMemcpy(db.d_seq + at, sg.p, sg.n, hipMemcpyHostToDevice) != hipSuccess) {
+                    err = "host to device copy failed";
+                    return false;
+                }
+                at += sg.n;
+            }
+            if (hipMemcpy(db.d_offs, all.data(), all.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
                 err = "host to device copy failed";
                 return false;
             }
@@ -152,25 +202,100 @@ bool query_pass(lphq_index* idx, const lphq_info& info, const std::string& path,
                 }
             }
         }
-        flat.clear();
-        offs.clear();
         return true;
     };
-    while (rd.next(seq)) {
-        flat += seq;
-        offs.push_back(seq.size());
-        if (flat.size() >= batch_bases && !flush()) return true;
+    // batch i+1 is parsed (by `threads` threads) while batch i is copied to the device and looked up; the reader keeps
+    // both batches' bases alive (fastx_batch.hpp)
+    auto parse = [&](int i) { return std::async(std::launch::async, [&rd, &bufs, i, batch_bases] { return rd.next(bufs[i], batch_bases); }); };
+    std::future<bool> pending = parse(0);
+    for (int i = 0;; i ^= 1) {
+        if (!pending.get()) break;
+        pending = parse(i ^ 1);
+        if (!flush(bufs[i])) {
+            pending.wait();
+            return true;
+        }
     }
-    if (!flush()) return true;
+    if (!rd.ok()) err = "out of host memory while reading the query file";
     auto t1 = std::chrono::high_resolution_clock::now();
     elapsed_us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count();
     return true;
 }
 
+// diagnostic: what the reader yields (see the file header)
+int records_main(int argc, char** argv) {
+    Args a = parse(argc, argv, {"-i", "-t", "--batch-bytes", "--min-piece", "--passes"}, {"--serial", "--no-hash"});
+    if (a.help || a.bad || !a.get("-i")) {
+        std::cerr << "Usage: " << argv[0] << " -i fastx [-t threads] [--serial] [--no-hash] [--batch-bytes N] [--min-piece N] [--passes N]\n";
+        return 1;
+    }
+    const int threads = a.get("-t") ? std::atoi(a.get("-t")->c_str()) : default_parse_threads();
+    const size_t batch = a.get("--batch-bytes") ? (size_t)std::strtoull(a.get("--batch-bytes")->c_str(), nullptr, 10) : (size_t)512 << 20;
+    const size_t min_piece = a.get("--min-piece") ? (size_t)std::strtoull(a.get("--min-piece")->c_str(), nullptr, 10) : (size_t)1 << 16;
+    const int passes = a.get("--passes") ? std::max(1, std::atoi(a.get("--passes")->c_str())) : 1;  // later passes reuse the (warm) parse arenas
+    uint64_t n_rec = 0, n_bases = 0, h = 0, n_batches = 0, n_parallel = 0;
+    std::chrono::high_resolution_clock::time_point t0;
+    for (int pass = 0; pass < passes; ++pass) {
+    n_rec = n_bases = n_batches = n_parallel = 0;
+    h = 1469598103934665603ull;  // FNV-1a over (length, bases) of every record
+    const bool no_hash = a.has("--no-hash");  // timing of the reader alone
+    auto mix = [&](const void* p, size_t n) {
+        if (no_hash) return;
+        const unsigned char* c = (const unsigned char*)p;
+        for (size_t i = 0; i < n; ++i) h = (h ^ c[i]) * 1099511628211ull;
+    };
+    t0 = std::chrono::high_resolution_clock::now();
+    if (a.has("--serial")) {
+        lphq::FastxReader rd(a.get("-i")->c_str());
+        if (!rd.ok()) return 2;
+        std::string seq;
+        while (rd.next(seq)) {
+            const uint64_t len = seq.size();
+            mix(&len, 8);
+            mix(seq.data(), seq.size());
+            ++n_rec;
+            n_bases += len;
+        }
+    } else {
+        lphq::FastxBatchReader rd(a.get("-i")->c_str(), threads, &arena_alloc, &arena_free, min_piece);
+        if (!rd.ok()) return 2;
+        lphq::FastxBatch b;
+        while (rd.next(b, batch)) {
+            ++n_batches;
+            n_parallel += rd.parallel();
+            size_t si = 0, so = 0;  // walk the segments record by record
+            for (uint64_t len : b.lens) {
+                mix(&len, 8);
+                uint64_t left = len;
+                while (left) {
+                    while (si < b.segs.size() && so == b.segs[si].n) {
+                        ++si;
+                        so = 0;
+                    }
+                    if (si == b.segs.size()) return 5;  // lengths and segments disagree
+                    const size_t take = (size_t)std::min<uint64_t>(left, b.segs[si].n - so);
+                    mix(b.segs[si].p + so, take);
+                    so += take;
+                    left -= take;
+                }
+                ++n_rec;
+                n_bases += len;
+            }
+        }
+        if (!rd.ok()) return 3;
+    }
+    }
+    auto t1 = std::chrono::high_resolution_clock::now();
+    const double sec = std::chrono::duration<double>(t1 - t0).count();
+    std::cout << n_rec << "," << n_bases << "," << h << "," << n_batches << "," << n_parallel << "," << sec << std::endl;
+    return 0;
+}
+
 int query_main(int kind, int argc, char** argv) {
-    Args a = parse(argc, argv, {"-i", "-q", "--kmer-bits", "--device", "--batch-mb", "--output"}, {});
+    Args a = parse(argc, argv, {"-i", "-q", "--kmer-bits", "--device", "--batch-mb", "--output", "--threads"}, {"--pinned"});
     if (a.help || a.bad || !a.get("-i") || !a.get("-q")) {
-        std::cerr << "Usage: " << argv[0] << " [-h,--help] -i mphf -q query_filename [--kmer-bits 64|128] [--device N] [--batch-mb N] [--output codes.u64]\n\n"
+        std::cerr << "Usage: " << argv[0]
+                  << " [-h,--help] -i mphf -q query_filename [--kmer-bits 64|128] [--device N] [--batch-mb N] [--threads N] [--pinned] [--output codes.u64]\n\n"
                   << " -i mphf\n\tREQUIRED: LP-Hash MPHF saved on disk.\n\n"
                   << " -q query_filename\n\tREQUIRED: Must be a FASTA file (.fa/fasta extension) compressed with gzip (.gz) or not.\n\n"
                   << " --kmer-bits\n\tk-mer word width the MPHF was built with (the reference's compile-time kmer_t): 128 (default) or 64.\n";
@@ -179,7 +304,10 @@ int query_main(int kind, int argc, char** argv) {
     const std::string mphf_filename = *a.get("-i"), query_filename = *a.get("-q");
     const int kmer_bits = a.get("--kmer-bits") ? std::atoi(a.get("--kmer-bits")->c_str()) : 128;
     const int device = a.get("--device") ? std::atoi(a.get("--device")->c_str()) : 0;
-    const size_t batch_bases = (size_t)(a.get("--batch-mb") ? std::atol(a.get("--batch-mb")->c_str()) : 512) << 20;
+    // 32 MB batches: the parse arenas stay small and warm, and parsing overlaps the device side (see query_pass)
+    const size_t batch_bases = (size_t)(a.get("--batch-mb") ? std::max(1l, std::atol(a.get("--batch-mb")->c_str())) : 32) << 20;
+    const int threads = a.get("--threads") ? std::max(1, std::atoi(a.get("--threads")->c_str())) : default_parse_threads();
+    const bool pinned = a.has("--pinned");
     lphq_index* idx = nullptr;
     if (lphq_open(mphf_filename.c_str(), kind, kmer_bits, &idx) != LPHQ_OK || lphq_attach(idx, device) != LPHQ_OK) {
         std::cerr << "[Error] " << lphq_last_error() << "\n";  // the reference dies in essentials::load here
@@ -199,8 +327,8 @@ int query_main(int kind, int argc, char** argv) {
         return 2;
     }
     for (int pass = 0; pass < 2; ++pass) {
-        bool opened = query_pass(idx, info, query_filename, pass == 0, batch_bases, db, pass == 0 ? total_on : total_off, pass == 0 ? t_on : t_off, err,
-                                 pass == 0 ? sink : nullptr);
+        bool opened = query_pass(idx, info, query_filename, pass == 0, batch_bases, threads, pinned, db, pass == 0 ? total_on : total_off,
+                                 pass == 0 ? t_on : t_off, err, pass == 0 ? sink : nullptr);
         if (!opened) {
             std::cerr << "Unable to open the input file " << query_filename << "\n";
             lphq_close(idx);
@@ -254,21 +382,31 @@ int build_main(int kind, int argc, char** argv) {
         return 3;
     }
     auto t0 = std::chrono::high_resolution_clock::now();
-    std::vector<std::string> recs;
-    {
-        lphq::FastxReader rd(input.c_str());
-        if (!rd.ok()) {
-            std::cerr << "Unable to open the input file " << input << "\n";
-            return 4;  // the reference throws std::runtime_error here (partitioned_mphf.cpp:66-67)
-        }
-        std::string seq;
-        while (rd.next(seq)) recs.push_back(seq);
+    lphq::FastxBatchReader rd(input.c_str(), std::max(1, threads));
+    if (!rd.ok()) {
+        std::cerr << "Unable to open the input file " << input << "\n";
+        return 4;  // the reference throws std::runtime_error here (partitioned_mphf.cpp:66-67)
     }
-    std::vector<const char*> ptrs(recs.size());
-    std::vector<size_t> lens(recs.size());
-    for (size_t i = 0; i < recs.size(); ++i) {
-        ptrs[i] = recs[i].data();
-        lens[i] = recs[i].size();
+    lphq::FastxBatch whole;  // the whole input as one batch: its segments stay valid while `rd` lives
+    (void)rd.next(whole, ~(size_t)0);
+    if (!rd.ok()) {
+        std::cerr << "[Error] out of host memory while reading " << input << "\n";
+        return 4;
+    }
+    const size_t n_recs = whole.lens.size();
+    std::vector<const char*> ptrs(n_recs);
+    std::vector<size_t> lens(n_recs);
+    {
+        size_t si = 0, so = 0;
+        for (size_t i = 0; i < n_recs; ++i) {  // a record never straddles two segments (segments are whole parsed pieces)
+            while (si < whole.segs.size() && so == whole.segs[si].n) {
+                ++si;
+                so = 0;
+            }
+            lens[i] = (size_t)whole.lens[i];
+            ptrs[i] = si < whole.segs.size() ? whole.segs[si].p + so : "";
+            so += lens[i];
+        }
     }
     std::string out = a.get("-o") ? *a.get("-o") : "";
     const bool temp_out = out.empty();
@@ -282,7 +420,7 @@ int build_main(int kind, int argc, char** argv) {
         if (hipGetDeviceCount(&ndev) != hipSuccess || build_device >= ndev) build_device = -1;
     }
     if (verbose) std::cerr << "PTHash pilot search on " << (build_device >= 0 ? "GPU " + std::to_string(build_device) : std::string("the CPU")) << "\n";
-    if (lphq_build_device(ptrs.data(), lens.data(), recs.size(), k, m, seed, c, kind, kmer_bits, threads, build_device, out.c_str(), &st) != LPHQ_OK) {
+    if (lphq_build_device(ptrs.data(), lens.data(), n_recs, k, m, seed, c, kind, kmer_bits, threads, build_device, out.c_str(), &st) != LPHQ_OK) {
         std::cerr << "[Error] " << lphq_last_error() << "\n";
         return 4;
     }
@@ -310,7 +448,7 @@ int build_main(int kind, int argc, char** argv) {
         std::vector<uint64_t> population((st.num_kmers + 63) / 64, 0);
         bool good = true;
         std::vector<uint64_t> a_codes, b_codes;
-        for (size_t i = 0; i < recs.size() && good; ++i) {
+        for (size_t i = 0; i < n_recs && good; ++i) {
             if (lens[i] < (size_t)k) continue;
             const size_t nw = lens[i] - k + 1;
             a_codes.resize(nw);
@@ -372,6 +510,7 @@ int main(int argc, char* argv[]) {
     if (tool == "build-u") return build_main(LPHQ_UNPARTITIONED, argc - 1, argv + 1);
     if (tool == "query-p") return query_main(LPHQ_PARTITIONED, argc - 1, argv + 1);
     if (tool == "query-u") return query_main(LPHQ_UNPARTITIONED, argc - 1, argv + 1);
+    if (tool == "records") return records_main(argc - 1, argv + 1);
     std::cerr << "Unsupported tool '" << tool << "'." << std::endl;
     return help(argv[0]);
 }

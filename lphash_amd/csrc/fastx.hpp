@@ -20,6 +20,14 @@ public:
         if (fp_) gzclose(fp_);
     }
     bool ok() const { return fp_ != nullptr; }
+    // Restart between records at an (uncompressed) byte offset; the next record is the first one that begins at or after it.
+    bool seek(size_t offset) {
+        if (!fp_ || gzseek(fp_, (z_off_t)offset, SEEK_SET) < 0) return false;
+        pos_ = end_ = 0;
+        eof_ = false;
+        last_char_ = 0;
+        return true;
+    }
 
     // Next record's sequence into seq; false at end of input or on a malformed FASTQ record (kseq_read < 0).
     bool next(std::string& seq) {

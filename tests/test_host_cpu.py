@@ -211,3 +211,58 @@ def test_fastx_reader_record_semantics(tmp_path):
         ref = tmp_path / (name + ".ref.lph")
         L.build(expected, 31, 20, str(ref), kmer_bits=64, threads=2)
         assert out.read_bytes() == ref.read_bytes(), name
+
+
+def test_parallel_fastx_reader_equals_serial(tmp_path):
+    """`lphash records`: the multi-threaded batch reader (fastx_batch.hpp) yields exactly the serial kseq-semantics reader's records
+    -- same count, bases and checksum -- for any batch size, thread count and piece size; FASTQ-looking input makes it fall back."""
+    exe = os.path.join(ROOT, "lphash_amd", "lphash")
+    rng = np.random.default_rng(77)
+
+    def fasta(n, lmin, lmax, width, crlf=False, blank=False, lower=False, headers=True):
+        out = bytearray()
+        for i in range(n):
+            out += b">r%d some comment\tx" % i if headers else b">"
+            out += b"\r\n" if crlf else b"\n"
+            s = bytes(rng.choice(np.frombuffer(b"ACGTacgtNn" if lower else b"ACGT", dtype=np.uint8), int(rng.integers(lmin, lmax + 1))))
+            for j in range(0, len(s), width):
+                out += s[j:j + width] + (b"\r\n" if crlf else b"\n")
+                if blank and rng.integers(0, 5) == 0:
+                    out += b"\n"
+        return bytes(out)
+
+    r = random_records(5, 8, 30, 300)
+    files = {
+        "plain.fa": fasta(300, 0, 900, 60),
+        "crlf.fa": fasta(120, 0, 500, 70, crlf=True),
+        "blank_lower.fa": fasta(200, 1, 400, 33, blank=True, lower=True),
+        "tiny_records.fa": fasta(2000, 0, 3, 80),
+        "one_line_long.fa": fasta(3, 200000, 300000, 1 << 30),
+        "no_trailing_newline.fa": fasta(50, 10, 200, 60)[:-1],
+        "header_only_at_end.fa": fasta(20, 10, 200, 60) + b">last",
+        "header_with_space_at_end.fa": fasta(20, 10, 200, 60) + b">last one",
+        "at_records.fa": b">a\n" + r[0] + b"\n@b\n" + r[1] + b"\n>c\n" + r[2] + b"\n",          # '@' starts a record in kseq
+        "gt_inside_lines.fa": b">a x>y\n" + r[0][:20] + b">" + r[0][20:] + b"\n>b\n" + r[1] + b"\n",  # '>' not at a line start
+        "cr_only_line.fa": b">a\n\r\n" + r[0] + b"\n>b\n" + r[1] + b"\r\n\r\n>c\n",
+        "fastq_after_fasta.fq": fasta(40, 50, 300, 60) + b"@q\n" + r[3] + b"\n+\n" + b">" * len(r[3]) + b"\n>tail\n" + r[4] + b"\n",  # '+' line: must fall back
+        "plus_first.fa": b">a\n+\n" + r[0] + b"\n",
+        "starts_with_garbage.fa": b"junk\n" + fasta(10, 10, 100, 60),
+        "empty.fa": b"",
+        "only_gt.fa": b">",
+    }
+    for name, data in files.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        ser = subprocess.run([exe, "records", "-i", str(p), "--serial"], capture_output=True, text=True)
+        assert ser.returncode == 0, (name, ser.stderr)
+        want = ser.stdout.strip().split(",")[:3]
+        for threads, batch, piece in ((1, 1 << 30, 1 << 16), (4, 1 << 30, 1), (8, 997, 1), (3, 50000, 64), (16, 1, 1)):
+            par = subprocess.run([exe, "records", "-i", str(p), "-t", str(threads), "--batch-bytes", str(batch), "--min-piece", str(piece)],
+                                 capture_output=True, text=True)
+            assert par.returncode == 0, (name, par.stderr)
+            got = par.stdout.strip().split(",")
+            assert got[:3] == want, (name, threads, batch, piece, got, want)
+            if name in ("plain.fa", "tiny_records.fa", "crlf.fa") and data:
+                assert int(got[4]) == int(got[3]) > 0  # every batch came from the multi-threaded path
+            if name in ("plus_first.fa", "starts_with_garbage.fa"):
+                assert int(got[4]) == 0                # ... and none here
