@@ -283,10 +283,79 @@ __device__ __forceinline__ void take_if_less(HashPos& m, uint64_t h, uint32_t p)
 }
 
 // hash slot of m-mer position i: lane l owns positions 4l..4l+3 and reads up to 4l+W+2; storing position i at
-// (i % 4) * (BLOCK + 2) + i / 4 makes both the writes and the W+3 reads of consecutive lanes hit consecutive
-// 8-byte slots (no LDS bank conflicts; the plain layout was 4-way conflicted: profiles/r01_stream_phase_counters.txt)
+// (i % 4) * ROW + i / 4 makes both the writes and the W+3 reads of consecutive lanes hit consecutive 8-byte slots (no LDS
+// bank conflicts; the plain layout was 4-way conflicted: profiles/r01_stream_phase_counters.txt).  ROW = BLOCK + 17: the
+// last lanes read up to position 4*BLOCK + 60 (W <= 62), i.e. 16 columns past the tile; those slots hold ~0 (never a
+// minimum), so no index needs clamping and, for lane l, position 4l + c is at a compile-time offset from column l.
 template <int BLOCK>
-__device__ __forceinline__ uint32_t hslot(uint32_t i) { return (i & 3u) * (uint32_t)(BLOCK + 2) + (i >> 2); }
+constexpr uint32_t hash_row() { return (uint32_t)BLOCK + 17u; }
+template <int BLOCK>
+constexpr uint32_t hash_slots() { return 4u * hash_row<BLOCK>(); }
+template <int BLOCK>
+__device__ __forceinline__ uint32_t hslot(uint32_t i) { return (i & 3u) * hash_row<BLOCK>() + (i >> 2); }
+// ~0 in the slots of positions 4*BLOCK .. 4*BLOCK + 67 (call with every lane; part of phase B)
+template <int BLOCK>
+__device__ __forceinline__ void hash_pad(uint64_t* __restrict__ sm_hash, uint32_t tid) {
+    if (tid < 4u * 17u) sm_hash[(tid / 17u) * hash_row<BLOCK>() + (uint32_t)BLOCK + tid % 17u] = ~0ull;
+}
+
+// Phase C core: leftmost minimum of the 4 consecutive windows starting at local positions a .. a+3, a = 4 * tid, each W
+// positions wide -> q[0..3] (local positions).  Offsets from a are uniform over the wave, so they live in scalar
+// registers and the W-3 positions common to the four windows are read four per step at immediate LDS offsets.
+// Ties keep the LEFT position, as the strict `>` comparisons of partitioned_mphf.hpp:122,150-163 do.
+template <int BLOCK>
+__device__ __forceinline__ void window_argmin4(const uint64_t* __restrict__ sm_hash, uint32_t tid, uint32_t W, uint32_t (&q)[4]) {
+    constexpr uint32_t ROW = hash_row<BLOCK>();
+    const uint64_t* col = sm_hash + tid;  // position a + c: col[(c & 3) * ROW + (c >> 2)]
+    auto H = [&](uint32_t c) { return col[(c & 3u) * ROW + (c >> 2)]; };
+    const uint32_t a = 4u * tid;
+    if (W >= 4u) {
+        // left edge: suffix minima over offsets 2, 1, 0 (`<=`: the left one wins ties)
+        HashPos s2{H(2), 2}, s1, s0;
+        {
+            const uint64_t h1 = H(1), h0 = H(0);
+            s1 = (h1 <= s2.h) ? HashPos{h1, 1} : s2;
+            s0 = (h0 <= s1.h) ? HashPos{h0, 0} : s1;
+        }
+        // core: offsets 3 .. W-1, common to the four windows
+        HashPos c{H(3), 3};
+        uint32_t o = 4;
+        for (; o + 4u <= W; o += 4u) {
+            const uint64_t* p = col + (o >> 2);
+            const uint64_t h0 = p[0], h1 = p[ROW], h2 = p[2 * ROW], h3 = p[3 * ROW];
+            take_if_less(c, h0, o);
+            take_if_less(c, h1, o + 1u);
+            take_if_less(c, h2, o + 2u);
+            take_if_less(c, h3, o + 3u);
+        }
+        for (; o < W; ++o) take_if_less(c, H(o), o);
+        // right edge: prefix minima over offsets W, W+1, W+2
+        HashPos w0 = s0, w1 = s1, w2 = s2, w3 = c;
+        take_if_less(w0, c.h, c.p);
+        take_if_less(w1, c.h, c.p);
+        take_if_less(w2, c.h, c.p);
+        HashPos r{H(W), W};
+        take_if_less(w1, r.h, r.p);
+        take_if_less(w2, r.h, r.p);
+        take_if_less(w3, r.h, r.p);
+        r = HashPos{H(W + 1u), W + 1u};
+        take_if_less(w2, r.h, r.p);
+        take_if_less(w3, r.h, r.p);
+        r = HashPos{H(W + 2u), W + 2u};
+        take_if_less(w3, r.h, r.p);
+        q[0] = a + w0.p;
+        q[1] = a + w1.p;
+        q[2] = a + w2.p;
+        q[3] = a + w3.p;
+    } else {
+#pragma unroll
+        for (uint32_t jw = 0; jw < 4; ++jw) {
+            HashPos c{H(jw), jw};
+            for (uint32_t t = 1; t < W; ++t) take_if_less(c, H(jw + t), jw + t);
+            q[jw] = a + c.p;
+        }
+    }
+}
 
 template <int KIND, bool K128, int P, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
@@ -297,7 +366,7 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
     constexpr int kStreamPos = 4 * BLOCK, NW = tile_words(kStreamPos), WPL = 4;
     constexpr int NBADW = (NW + 8) / 2 + 2;       // 32-bit words of the bad-base bitmask (1 bit per base)
     constexpr int NDW = (NW + 1) * 4;             // dwords of sequence (4 bases each) the tile loads
-    __shared__ uint64_t sm_hash[4 * (BLOCK + 2)];  // phase B-C: minimizer hash per m-mer position (hslot order); phase E-F: the leader's base
+    __shared__ uint64_t sm_hash[hash_slots<BLOCK>()];  // phase B-C: minimizer hash per m-mer position (hslot order); phase E-F: the leader's base
     __shared__ uint32_t sm_words[NW + 8];
     __shared__ uint32_t sm_bad[NBADW];
     __shared__ __attribute__((aligned(16))) uint16_t sm_q[kStreamPos + 8];
@@ -359,9 +428,9 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
         for (uint32_t r = 0; r < 4; ++r) {
             // m-mer r = bits [2r, 2r + 2m) of (s0 : s1)
             const uint64_t v = r == 0 ? (s0 >> sh) : (((s0 << (2 * r)) | (s1 >> (64 - 2 * r))) >> sh);
-            sm_hash[r * (BLOCK + 2) + threadIdx.x] = murmur8(v & mask, mm_seedx);
+            sm_hash[r * hash_row<BLOCK>() + threadIdx.x] = murmur8(v & mask, mm_seedx);
         }
-        if (threadIdx.x < 8) sm_hash[hslot<BLOCK>(kStreamPos + threadIdx.x)] = ~0ull;
+        hash_pad<BLOCK>(sm_hash, threadIdx.x);
     }
     __syncthreads();
     if (stop_after == 2u) return;
@@ -370,45 +439,7 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
     {
         const uint32_t a = 4u * threadIdx.x;
         uint32_t q[4];
-        auto HS = [&](uint32_t i) { return sm_hash[hslot<BLOCK>(min(i, (uint32_t)kStreamPos + 7u))]; };
-        if (W >= 4u) {
-            // left edge: suffix minima over a+2, a+1, a (`<=`: the left one wins ties)
-            HashPos s2{HS(a + 2), a + 2}, s1, s0;
-            {
-                const uint64_t h1 = HS(a + 1), h0 = HS(a);
-                s1 = (h1 <= s2.h) ? HashPos{h1, a + 1} : s2;
-                s0 = (h0 <= s1.h) ? HashPos{h0, a} : s1;
-            }
-            // core a+3 .. a+W-1, common to the four windows
-            HashPos c{HS(a + 3), a + 3};
-            for (uint32_t t = a + 4; t < a + W && t < (uint32_t)kStreamPos; ++t) take_if_less(c, HS(t), t);
-            // right edge: prefix minima over a+W, a+W+1, a+W+2 (indices clamp into the ~0 padding of the last lanes)
-            const uint32_t e = min(a + W, (uint32_t)kStreamPos);
-            HashPos w0 = s0, w1 = s1, w2 = s2, w3 = c;
-            take_if_less(w0, c.h, c.p);
-            take_if_less(w1, c.h, c.p);
-            take_if_less(w2, c.h, c.p);
-            HashPos r{HS(e), e};
-            take_if_less(w1, r.h, r.p);
-            take_if_less(w2, r.h, r.p);
-            take_if_less(w3, r.h, r.p);
-            r = HashPos{HS(e + 1), e + 1};
-            take_if_less(w2, r.h, r.p);
-            take_if_less(w3, r.h, r.p);
-            r = HashPos{HS(e + 2), e + 2};
-            take_if_less(w3, r.h, r.p);
-            q[0] = w0.p;
-            q[1] = w1.p;
-            q[2] = w2.p;
-            q[3] = w3.p;
-        } else {
-#pragma unroll
-            for (int jw = 0; jw < 4; ++jw) {
-                HashPos c{HS(a + jw), a + jw};
-                for (uint32_t t = 1; t < W; ++t) take_if_less(c, HS(a + jw + t), a + jw + t);
-                q[jw] = c.p;
-            }
-        }
+        window_argmin4<BLOCK>(sm_hash, threadIdx.x, W, q);
         // window validity: inside the batch, inside one record, no non-ACGT base in [i, i+k)
         const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];
         const uint64_t kmask = (1ull << k) - 1ull;  // k <= 63

@@ -144,9 +144,9 @@ __device__ __forceinline__ void pipe_hash(StreamTileLds<BLOCK>& t, uint64_t* __r
 #pragma unroll
     for (uint32_t r = 0; r < 4; ++r) {
         const uint64_t v = r == 0 ? (s0 >> sh) : (((s0 << (2 * r)) | (s1 >> (64 - 2 * r))) >> sh);
-        sm_hash[r * (BLOCK + 2) + tid] = murmur8(v & mask, mm_seedx);
+        sm_hash[r * hash_row<BLOCK>() + tid] = murmur8(v & mask, mm_seedx);
     }
-    if (tid < 8) sm_hash[hslot<BLOCK>(kPos + tid)] = ~0ull;
+    hash_pad<BLOCK>(sm_hash, tid);
 }
 
 // ---- C: leftmost minimum of 4 consecutive windows per lane + their validity -> t.q ----
@@ -157,42 +157,7 @@ __device__ __forceinline__ void pipe_argmin(StreamTileLds<BLOCK>& t, const uint6
     constexpr int kPos = 4 * BLOCK;
     const uint32_t a = 4u * tid;
     uint32_t q[4];
-    auto HS = [&](uint32_t i) { return sm_hash[hslot<BLOCK>(min(i, (uint32_t)kPos + 7u))]; };
-    if (W >= 4u) {
-        HashPos s2{HS(a + 2), a + 2}, s1, s0;  // left edge: suffix minima (`<=`: the left one wins ties)
-        {
-            const uint64_t h1 = HS(a + 1), h0 = HS(a);
-            s1 = (h1 <= s2.h) ? HashPos{h1, a + 1} : s2;
-            s0 = (h0 <= s1.h) ? HashPos{h0, a} : s1;
-        }
-        HashPos c{HS(a + 3), a + 3};  // core a+3 .. a+W-1, common to the four windows
-        for (uint32_t i = a + 4; i < a + W && i < (uint32_t)kPos; ++i) take_if_less(c, HS(i), i);
-        const uint32_t e = min(a + W, (uint32_t)kPos);  // right edge: prefix minima
-        HashPos w0 = s0, w1 = s1, w2 = s2, w3 = c;
-        take_if_less(w0, c.h, c.p);
-        take_if_less(w1, c.h, c.p);
-        take_if_less(w2, c.h, c.p);
-        HashPos r{HS(e), e};
-        take_if_less(w1, r.h, r.p);
-        take_if_less(w2, r.h, r.p);
-        take_if_less(w3, r.h, r.p);
-        r = HashPos{HS(e + 1), e + 1};
-        take_if_less(w2, r.h, r.p);
-        take_if_less(w3, r.h, r.p);
-        r = HashPos{HS(e + 2), e + 2};
-        take_if_less(w3, r.h, r.p);
-        q[0] = w0.p;
-        q[1] = w1.p;
-        q[2] = w2.p;
-        q[3] = w3.p;
-    } else {
-#pragma unroll
-        for (int jw = 0; jw < 4; ++jw) {
-            HashPos c{HS(a + jw), a + jw};
-            for (uint32_t i = 1; i < W; ++i) take_if_less(c, HS(a + jw + i), a + jw + i);
-            q[jw] = c.p;
-        }
-    }
+    window_argmin4<BLOCK>(sm_hash, tid, W, q);
     const uint32_t rlo = t.rec[0], rhi = t.rec[1];
     const uint64_t kmask = (1ull << k) - 1ull;  // k <= 63
     const uint32_t bw = a >> 5, bo = a & 31u;
@@ -294,7 +259,7 @@ __global__ __launch_bounds__(BLOCK, 5) void k_query_tiles_stream_pipe(const uint
                                                                         uint32_t n_tiles) {
     using TL = StreamTileLds<BLOCK>;
     constexpr int kPos = TL::kPos;
-    __shared__ uint64_t sm_hash[4 * (BLOCK + 2)];  // B-C of tile i+1: minimizer hashes; E4-F of tile i: the leaders' bases
+    __shared__ uint64_t sm_hash[hash_slots<BLOCK>()];  // B-C of tile i+1: minimizer hashes; E4-F of tile i: the leaders' bases
     __shared__ uint8_t sm_mode[kPos];
     __shared__ TL sm_tile[2];
     const lphq_image_header& H = *(const lphq_image_header*)img;
