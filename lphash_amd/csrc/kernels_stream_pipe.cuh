@@ -131,7 +131,6 @@ template <int BLOCK>
 __device__ __forceinline__ void pipe_hash(StreamTileLds<BLOCK>& t, uint64_t* __restrict__ sm_hash, uint32_t m, uint64_t mm_seedx,
                                           const uint64_t* __restrict__ seq_off, const uint64_t* __restrict__ out_off) {
     const uint32_t tid = phase_lane();
-    constexpr int kPos = 4 * BLOCK;
     if (t.rec[0] != t.rec[1]) load_record_table(t.rtab, seq_off, out_off, t.rec[0], t.rec[1], tid);  // for C and F (t.rec: visible since A's barrier)
     const uint32_t a = 4u * tid;
     const uint32_t w0 = a >> 4, o = (a & 15u) * 2u;
@@ -154,7 +153,6 @@ template <int BLOCK>
 __device__ __forceinline__ void pipe_argmin(StreamTileLds<BLOCK>& t, const uint64_t* __restrict__ sm_hash, uint64_t t0, uint32_t TW, uint32_t k, uint32_t W,
                                             uint64_t shift, uint64_t total, const uint64_t* __restrict__ seq_off) {
     const uint32_t tid = phase_lane();
-    constexpr int kPos = 4 * BLOCK;
     const uint32_t a = 4u * tid;
     uint32_t q[4];
     window_argmin4<BLOCK>(sm_hash, tid, W, q);
