@@ -266,3 +266,36 @@ def test_parallel_fastx_reader_equals_serial(tmp_path):
                 assert int(got[4]) == int(got[3]) > 0  # every batch came from the multi-threaded path
             if name in ("plus_first.fa", "starts_with_garbage.fa"):
                 assert int(got[4]) == 0                # ... and none here
+
+
+def test_parallel_fastx_reader_fuzz(tmp_path):
+    """Random byte soups over the characters that matter to the record state machine ('>', '@', '+', line ends, blanks): whatever the
+    serial reader makes of them, the multi-threaded reader must make the same (it either parses pieces or falls back)."""
+    exe = os.path.join(ROOT, "lphash_amd", "lphash")
+    rng = np.random.default_rng(2024)
+    alphabet = np.frombuffer(b"ACGTacgtN\n\n\n\r>@+ \t", dtype=np.uint8)
+    weights = {
+        "mostly_fasta": [8, 8, 8, 8, 1, 1, 1, 1, 1, 2, 2, 2, .2, .4, .02, .0, .1, .05],
+        "few_plus": [8, 8, 8, 8, 1, 1, 1, 1, 1, 2, 2, 2, .2, .4, .05, .01, .1, .05],
+        "hostile": [2, 2, 2, 2, 1, 1, 1, 1, 1, 3, 3, 3, 1, 2, 1, 1, 1, 1],
+    }
+    n_parallel_batches = 0
+    for name, w in weights.items():
+        pr = np.array(w, dtype=np.float64)
+        pr /= pr.sum()
+        for trial in range(12):
+            body = bytes(rng.choice(alphabet, size=int(rng.integers(1, 6000)), p=pr))
+            data = (b">" if trial % 4 else b"") + body
+            p = tmp_path / f"{name}_{trial}.fa"
+            p.write_bytes(data)
+            ser = subprocess.run([exe, "records", "-i", str(p), "--serial"], capture_output=True, text=True)
+            assert ser.returncode == 0, (name, trial, ser.stderr)
+            want = ser.stdout.strip().split(",")[:3]
+            for threads, batch, piece in ((4, 1 << 30, 1), (8, 257, 1), (3, 1500, 16)):
+                par = subprocess.run([exe, "records", "-i", str(p), "-t", str(threads), "--batch-bytes", str(batch), "--min-piece", str(piece)],
+                                     capture_output=True, text=True)
+                assert par.returncode == 0, (name, trial, par.stderr)
+                got = par.stdout.strip().split(",")
+                assert got[:3] == want, (name, trial, threads, batch, piece, got, want, data[:200])
+                n_parallel_batches += int(got[4])
+    assert n_parallel_batches > 50  # the multi-threaded path did take part
