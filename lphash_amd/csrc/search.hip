@@ -45,7 +45,7 @@ bool gpu_pilot_search(int device, const std::vector<uint64_t>& hs, const std::ve
     bool ok = false;
     int prev = -1;
     uint64_t* d_hs = nullptr;
-    uint32_t *d_bstart = nullptr, *d_order = nullptr, *d_taken = nullptr, *d_owner = nullptr, *d_flags = nullptr;
+    uint32_t *d_bstart = nullptr, *d_order = nullptr, *d_taken = nullptr, *d_owner = nullptr, *d_ctl = nullptr;
     uint64_t* d_pilot = nullptr;
     uint8_t* d_ready = nullptr;
     const size_t nb = bstart.size() - 1;
@@ -71,7 +71,7 @@ bool gpu_pilot_search(int device, const std::vector<uint64_t>& hs, const std::ve
     HIP_OK(hipMalloc((void**)&d_taken, taken_u32 * 4));
     HIP_OK(hipMalloc((void**)&d_owner, table_size * 4));
     HIP_OK(hipMalloc((void**)&d_pilot, pilot_by_order.size() * 8));
-    HIP_OK(hipMalloc((void**)&d_flags, 4 * 4));
+    HIP_OK(hipMalloc((void**)&d_ctl, kCtlWords * 4));
     HIP_OK(hipMalloc((void**)&d_ready, pilot_by_order.size()));
     HIP_OK(hipMemcpy(d_hs, hs.data(), hs.size() * 8, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_bstart, bstart32.data(), bstart32.size() * 4, hipMemcpyHostToDevice));
@@ -79,7 +79,6 @@ bool gpu_pilot_search(int device, const std::vector<uint64_t>& hs, const std::ve
     HIP_OK(hipMemset(d_taken, 0, taken_u32 * 4));
     HIP_OK(hipMemset(d_owner, 0xFF, table_size * 4));
     HIP_OK(hipMemset(d_pilot, 0, pilot_by_order.size() * 8));
-    HIP_OK(hipMemset(d_flags, 0, 16));
     HIP_OK(hipMemset(d_ready, 0, pilot_by_order.size()));
     {
         SearchArgs a;
@@ -91,22 +90,24 @@ bool gpu_pilot_search(int device, const std::vector<uint64_t>& hs, const std::ve
         a.owner = d_owner;
         a.pilot = d_pilot;
         a.ready = d_ready;
-        a.flags = d_flags;
+        a.ctl = d_ctl;
         a.seedx = seed ^ (8ull * LPHQ_MURMUR_M);
         a.div = divisor_u32(table_size);
-        struct HipDev {  // the product backend of search_rounds.hpp: default stream, synchronous flag read-back once per round
-            uint32_t* d_flags;
-            bool set_flags(const uint32_t (&f)[3]) { return hipMemcpyAsync(d_flags, f, sizeof f, hipMemcpyHostToDevice, nullptr) == hipSuccess; }
-            bool get_flags(uint32_t (&f)[3]) { return hipMemcpy(f, d_flags, sizeof f, hipMemcpyDeviceToHost) == hipSuccess; }
+        struct HipDev {  // the product backend of search_rounds.hpp: default stream, one synchronous read-back per batch of rounds
+            uint32_t* d_ctl;
+            bool set_ctl(const uint32_t (&c)[kCtlWords]) { return hipMemcpy(d_ctl, c, sizeof c, hipMemcpyHostToDevice) == hipSuccess; }
+            bool get_ctl(uint32_t (&c)[kCtlWords]) { return hipMemcpy(c, d_ctl, sizeof c, hipMemcpyDeviceToHost) == hipSuccess && hipGetLastError() == hipSuccess; }
             void launch_search(const SearchArgs& x, int g) { k_search<<<g, 256>>>(x); }
             void launch_claim(const SearchArgs& x, int g) { k_claim<<<g, 256>>>(x); }
             void launch_validate(const SearchArgs& x, int g) { k_validate<<<g, 256>>>(x); }
             void launch_commit(const SearchArgs& x, int g) { k_commit<<<g, 256>>>(x); }
-        } dev{d_flags};
+            void launch_advance(const SearchArgs& x) { k_advance<<<1, 64>>>(x); }
+        } dev{d_ctl};
         const uint32_t steps = getenv("LPHQ_SEARCH_STEPS") ? (uint32_t)std::max(1, atoi(getenv("LPHQ_SEARCH_STEPS"))) : 16u;                    // tuning aids (16 steps x 256 pilots measured best)
         const uint32_t look_ahead = getenv("LPHQ_SEARCH_LOOKAHEAD") ? (uint32_t)std::max(1, atoi(getenv("LPHQ_SEARCH_LOOKAHEAD"))) : 16384u;
+        const uint32_t per_sync = getenv("LPHQ_SEARCH_ROUNDS_PER_SYNC") ? (uint32_t)std::max(1, atoi(getenv("LPHQ_SEARCH_ROUNDS_PER_SYNC"))) : 16u;
         uint64_t rounds = 0;
-        if (!run_rounds(dev, a, n_nonempty, look_ahead, steps, err, &rounds)) goto done;
+        if (!run_rounds(dev, a, n_nonempty, look_ahead, steps, per_sync, err, &rounds)) goto done;
         if (getenv("LPHQ_BUILD_VERBOSE")) fprintf(stderr, "[lphq_build] gpu pilot search: %llu buckets in %llu rounds\n", (unsigned long long)n_nonempty, (unsigned long long)rounds);
     }
     HIP_OK(hipMemcpy(pilot_by_order.data(), d_pilot, n_nonempty * 8, hipMemcpyDeviceToHost));
@@ -134,7 +135,7 @@ done:
     if (d_taken) (void)hipFree(d_taken);
     if (d_owner) (void)hipFree(d_owner);
     if (d_pilot) (void)hipFree(d_pilot);
-    if (d_flags) (void)hipFree(d_flags);
+    if (d_ctl) (void)hipFree(d_ctl);
     if (d_ready) (void)hipFree(d_ready);
     if (prev >= 0) (void)hipSetDevice(prev);
     return ok;

@@ -1,4 +1,4 @@
-// search_device.cuh -- kernels of the GPU pilot search (see search.hip for the algorithm; rounds: search_rounds.hpp).
+// search_device.cuh -- kernels of the GPU pilot search (see search.hip for the algorithm; host side of the rounds: search_rounds.hpp).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -12,6 +12,26 @@ constexpr int kWave = 64;
 constexpr uint32_t kNoOwner = 0xFFFFFFFFu;
 constexpr uint64_t kPilotCap = 1ull << 28;  // unplaceable bucket (duplicate hash, or degenerate tiny table: see builder.cpp): give up here
 
+// Round control lives in device memory so that several rounds can be enqueued without a host round trip: every kernel reads
+// its window from it and k_advance (one thread, last kernel of a round) moves the window on.
+enum : uint32_t {
+    kIStar = 0,      // first local index of the commit window that lost a position to an earlier bucket (k_validate)
+    kFailed,         // a bucket ran past kPilotCap
+    kNotReady,       // first local index of the commit window whose bucket is still searching (k_search)
+    kBase,           // first unfinished bucket (order index)
+    kNSearch,        // look-ahead window: buckets [base, base + n_search) are searched
+    kNCommit,        // commit window: buckets [base, base + n_commit) may be committed this round
+    kWindow,         // adaptive commit-window size
+    kDone,           // base reached n_nonempty
+    kRounds,         // rounds executed
+    kIdle,           // consecutive rounds without a commit
+    kStuck,          // kIdle exceeded kMaxIdle
+    kNNonEmpty,      // (constant) buckets to place
+    kLookAhead,      // (constant)
+    kMaxIdle,        // (constant)
+    kCtlWords = 16
+};
+
 struct SearchArgs {
     const uint64_t* hs;       // hashes grouped by bucket
     const uint32_t* bstart;   // bucket -> first hash
@@ -20,14 +40,15 @@ struct SearchArgs {
     uint32_t* owner;          // table_size entries, kNoOwner when unclaimed
     uint64_t* pilot;          // per order index: tentative pilot (ready) or the next pilot to try (not ready)
     uint8_t* ready;           // per order index: 1 = pilot was valid against the bitmap when last checked
-    uint32_t* flags;          // [0] i_star: first conflicting local index, [1] failed, [2] first not-ready local index of the commit window
+    uint32_t* ctl;            // kCtlWords control words (above)
     uint64_t seedx;           // murmur_seedx(seed)
     lphq_divisor div;         // table_size
-    uint32_t base;            // first unfinished bucket (order index)
-    uint32_t n_search;        // look-ahead window: buckets [base, base + n_search) are searched
-    uint32_t n_commit;        // commit window: buckets [base, base + n_commit) may be committed this round
     uint32_t max_steps;       // search steps (256 pilots each) per bucket and round
 };
+__device__ __forceinline__ bool search_over(const uint32_t* ctl) { return (ctl[kDone] | ctl[kFailed] | ctl[kStuck]) != 0u; }
+// k_search itself sets kFailed, so it must not branch on it (the threads of a workgroup could disagree ahead of a barrier);
+// kDone and kStuck only change between kernels
+__device__ __forceinline__ bool search_stopped(const uint32_t* ctl) { return (ctl[kDone] | ctl[kStuck]) != 0u; }
 
 __device__ __forceinline__ uint32_t position(uint64_t h, uint64_t hp, const lphq_divisor& d) { return (uint32_t)mod_u64(h ^ hp, d); }
 __device__ __forceinline__ bool is_taken(const uint32_t* taken, uint32_t p) { return (taken[p >> 5] >> (p & 31u)) & 1u; }
@@ -52,13 +73,14 @@ __device__ bool pilot_ok(const SearchArgs& a, const uint64_t* keys, uint32_t s, 
 __global__ __launch_bounds__(256) void k_search(SearchArgs a) {
     __shared__ uint64_t sm_found[4];
     const uint32_t local = blockIdx.x, lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    if (local >= a.n_search) return;
-    const uint32_t oi = a.base + local, b = a.order[oi];
+    if (search_stopped(a.ctl) || local >= a.ctl[kNSearch]) return;
+    const uint32_t n_commit = a.ctl[kNCommit];
+    const uint32_t oi = a.ctl[kBase] + local, b = a.order[oi];
     const uint64_t* keys = a.hs + a.bstart[b];
     const uint32_t s = a.bstart[b + 1] - a.bstart[b];
     uint64_t start = a.pilot[oi];
     if (a.ready[oi]) {  // tentative pilot: still free?  (uniform over the workgroup)
-        if (local >= a.n_commit) return;
+        if (local >= n_commit) return;
         const uint64_t hp = murmur8(start, a.seedx);
         bool hit = false;
         for (uint32_t j = threadIdx.x; j < s; j += 256) hit |= is_taken(a.taken, position(keys[j], hp, a.div));
@@ -101,22 +123,23 @@ __global__ __launch_bounds__(256) void k_search(SearchArgs a) {
         }
         start += 256;
         if (start >= kPilotCap) {
-            if (threadIdx.x == 0) a.flags[1] = 1;
+            if (threadIdx.x == 0) a.ctl[kFailed] = 1;
             break;
         }
     }
     if (threadIdx.x == 0) {  // not found yet: resume here next round
         a.pilot[oi] = start;
         a.ready[oi] = 0;
-        if (local < a.n_commit) atomicMin(&a.flags[2], local);
+        if (local < n_commit) atomicMin(&a.ctl[kNotReady], local);
     }
 }
 
 #define LPHQ_SEARCH_BUCKET_PROLOGUE()                                                              \
     const uint32_t local = (blockIdx.x * 256u + threadIdx.x) / kWave, lane = threadIdx.x & (kWave - 1); \
-    const uint32_t ncommit = min(a.n_commit, a.flags[2]); /* stop at the first bucket still searching */ \
+    if (search_over(a.ctl)) return;                                                                \
+    const uint32_t ncommit = min(a.ctl[kNCommit], a.ctl[kNotReady]); /* stop at the first bucket still searching */ \
     if (local >= ncommit) return;                                                                  \
-    const uint32_t oi = a.base + local, b = a.order[oi];                                           \
+    const uint32_t oi = a.ctl[kBase] + local, b = a.order[oi];                                     \
     const uint64_t* keys = a.hs + a.bstart[b];                                                     \
     const uint32_t s = a.bstart[b + 1] - a.bstart[b];                                              \
     const uint64_t hp = murmur8(a.pilot[oi], a.seedx)
@@ -132,13 +155,13 @@ __global__ __launch_bounds__(256) void k_validate(SearchArgs a) {
     LPHQ_SEARCH_BUCKET_PROLOGUE();
     bool lost = false;
     for (uint32_t j = lane; j < s; j += kWave) lost |= a.owner[position(keys[j], hp, a.div)] < local;
-    if (__any(lost) && lane == 0) atomicMin(&a.flags[0], local);
+    if (__any(lost) && lane == 0) atomicMin(&a.ctl[kIStar], local);
 }
 
 // buckets before i_star are final: take their positions; everybody releases the owner table
 __global__ __launch_bounds__(256) void k_commit(SearchArgs a) {
     LPHQ_SEARCH_BUCKET_PROLOGUE();
-    const bool final_ = local < a.flags[0];
+    const bool final_ = local < a.ctl[kIStar];
     for (uint32_t j = lane; j < s; j += kWave) {
         const uint32_t p = position(keys[j], hp, a.div);
         a.owner[p] = kNoOwner;
@@ -146,6 +169,41 @@ __global__ __launch_bounds__(256) void k_commit(SearchArgs a) {
     }
 }
 
+// End of a round (one thread): the conflict-free, fully searched prefix of the commit window is final; move the windows on.
+// The commit window adapts to the conflict rate only (a bucket that is still searching stops the prefix too, but a smaller
+// window would not help it): it grows while conflict-free and shrinks when a conflict cut it short.
+__global__ void k_advance(SearchArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t* c = a.ctl;
+    if (search_over(c)) return;
+    const uint32_t n_commit = c[kNCommit], i_star = c[kIStar];
+    const uint32_t in_window = min(n_commit, c[kNotReady]);
+    const uint32_t committed = min(in_window, i_star);
+    const uint32_t base = c[kBase] + committed;
+    uint32_t window = c[kWindow];
+    c[kRounds] += 1u;
+    const uint32_t idle = committed ? 0u : c[kIdle] + 1u;
+    c[kIdle] = idle;
+    if (idle > c[kMaxIdle]) {
+        c[kStuck] = 1u;
+        return;
+    }
+    const bool conflict = i_star < in_window;
+    if (!conflict && window < 8192u) window *= 2u;
+    else if (conflict && committed < n_commit / 4u && window > 256u) window /= 2u;
+    c[kWindow] = window;
+    c[kBase] = base;
+    const uint32_t n = c[kNNonEmpty];
+    if (base >= n) {
+        c[kDone] = 1u;
+        return;
+    }
+    const uint32_t rem = n - base, ns = min(c[kLookAhead], rem);
+    c[kNSearch] = ns;
+    c[kNCommit] = min(min(window, rem), ns);  // only searched buckets may commit
+    c[kIStar] = 0xFFFFFFFFu;
+    c[kNotReady] = 0xFFFFFFFFu;
+}
 
 }  // namespace search
 }  // namespace lphq

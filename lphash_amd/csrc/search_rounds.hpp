@@ -1,9 +1,13 @@
-// search_rounds.hpp -- the round loop of the GPU pilot search, written against a small device backend so that the product
-// (HIP: search.hip) and the CPU emulator of the tests (tests/emu/emu_search.cpp) run the very same control logic.
+// search_rounds.hpp -- host side of the rounds of the GPU pilot search, written against a small device backend so that the
+// product (HIP: search.hip) and the CPU emulator of the tests (tests/emu/emu_search.cpp) run the very same control logic.
+// A round is k_search, k_claim, k_validate, k_commit, k_advance; its windows live in device memory (search_device.cuh), so the
+// host enqueues `rounds_per_sync` rounds back to back and looks at the control words once per batch instead of once per
+// round (C2: ~9 K rounds; the per-round read-back was about half of the search's wall time).
 //
 // Backend Dev provides:
-//   bool set_flags(const uint32_t (&f)[3]);  bool get_flags(uint32_t (&f)[3]);          // [0] i_star, [1] failed, [2] first not-ready
-//   void launch_search(const search::SearchArgs&, int workgroups);  launch_claim / launch_validate / launch_commit  likewise
+//   bool set_ctl(const uint32_t (&c)[kCtlWords]);  bool get_ctl(uint32_t (&c)[kCtlWords]);   // get_ctl synchronises
+//   void launch_search(const search::SearchArgs&, int workgroups);  launch_claim / launch_validate / launch_commit likewise;
+//   void launch_advance(const search::SearchArgs&);
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -29,52 +33,58 @@ inline lphq_divisor divisor_u32(uint64_t d) {  // same reciprocal as image.cpp::
 
 // a: pointers + seedx + div filled in by the caller.  Returns false and sets err on failure; *rounds_out = rounds used.
 template <class Dev>
-bool run_rounds(Dev& dev, SearchArgs a, uint64_t n_nonempty, uint32_t look_ahead, uint32_t max_steps, std::string& err, uint64_t* rounds_out) {
+bool run_rounds(Dev& dev, SearchArgs a, uint64_t n_nonempty, uint32_t look_ahead, uint32_t max_steps, uint32_t rounds_per_sync, std::string& err,
+                uint64_t* rounds_out) {
     // tuning aids are clamped to sane ranges (an unclamped look-ahead below the commit window once committed unsearched buckets)
     a.max_steps = std::min<uint32_t>(1024u, std::max<uint32_t>(1u, max_steps));
     look_ahead = std::min<uint32_t>(1u << 20, std::max<uint32_t>(8192u, look_ahead));
-    uint64_t base = 0, rounds = 0, idle_rounds = 0;
-    uint32_t window = 1024;
-    while (base < n_nonempty) {
-        a.base = (uint32_t)base;
-        a.n_search = (uint32_t)std::min<uint64_t>(look_ahead, n_nonempty - base);
-        a.n_commit = std::min((uint32_t)std::min<uint64_t>(window, n_nonempty - base), a.n_search);  // only searched buckets may commit
-        const uint32_t flags_init[3] = {0xFFFFFFFFu, 0, 0xFFFFFFFFu};
-        if (!dev.set_flags(flags_init)) {
-            err = "gpu pilot search: cannot reset the round flags";
+    rounds_per_sync = std::min<uint32_t>(64u, std::max<uint32_t>(1u, rounds_per_sync));
+    if (rounds_out) *rounds_out = 0;
+    if (n_nonempty == 0) return true;
+    if (n_nonempty > 0xFFFFFFFFull) {
+        err = "gpu pilot search: too many buckets";
+        return false;
+    }
+    uint32_t c[kCtlWords];
+    memset(c, 0, sizeof c);
+    c[kIStar] = c[kNotReady] = 0xFFFFFFFFu;
+    c[kWindow] = 1024u;
+    c[kNNonEmpty] = (uint32_t)n_nonempty;
+    c[kLookAhead] = look_ahead;
+    c[kMaxIdle] = (uint32_t)((kPilotCap / 256) / a.max_steps + 16);
+    c[kNSearch] = (uint32_t)std::min<uint64_t>(look_ahead, n_nonempty);
+    c[kNCommit] = std::min((uint32_t)std::min<uint64_t>(c[kWindow], n_nonempty), c[kNSearch]);
+    if (!dev.set_ctl(c)) {
+        err = "gpu pilot search: cannot initialise the round control words";
+        return false;
+    }
+    // fixed grids (the kernels cut themselves down to the current windows): one workgroup per bucket of the look-ahead window,
+    // one wave per bucket of the largest commit window
+    const int search_grid = (int)std::min<uint64_t>(look_ahead, n_nonempty);
+    const int commit_grid = (int)((std::min<uint64_t>(8192u, n_nonempty) * (uint64_t)kWave + 255) / 256);
+    for (;;) {
+        for (uint32_t r = 0; r < rounds_per_sync; ++r) {
+            dev.launch_search(a, search_grid);
+            dev.launch_claim(a, commit_grid);
+            dev.launch_validate(a, commit_grid);
+            dev.launch_commit(a, commit_grid);
+            dev.launch_advance(a);
+        }
+        if (!dev.get_ctl(c)) {
+            err = "gpu pilot search: cannot read the round control words";
             return false;
         }
-        dev.launch_search(a, (int)a.n_search);  // one workgroup per bucket
-        const int grid = (int)((a.n_commit * (uint64_t)kWave + 255) / 256);
-        dev.launch_claim(a, grid);
-        dev.launch_validate(a, grid);
-        dev.launch_commit(a, grid);
-        uint32_t flags[3];
-        if (!dev.get_flags(flags)) {
-            err = "gpu pilot search: cannot read the round flags";
-            return false;
-        }
-        if (flags[1]) {
+        if (rounds_out) *rounds_out = c[kRounds];
+        if (c[kFailed]) {
             err = "pthash search: no pilot below 2^28 for some bucket (duplicate key in the input, or a degenerate tiny key set)";
             return false;
         }
-        const uint32_t in_window = std::min(a.n_commit, flags[2]);
-        const uint32_t committed = std::min(in_window, flags[0]);
-        base += committed;
-        ++rounds;
-        idle_rounds = committed ? 0 : idle_rounds + 1;
-        if (idle_rounds > (kPilotCap / 256) / a.max_steps + 16) {
+        if (c[kStuck]) {
             err = "gpu pilot search: no progress";
             return false;
         }
-        // adapt the commit window to the conflict rate only (a bucket that is still searching stops the prefix too, but a
-        // smaller window would not help it): grow while conflict-free, shrink when a conflict cut it short
-        const bool conflict = flags[0] < in_window;
-        if (!conflict && window < 8192) window *= 2;
-        else if (conflict && committed < a.n_commit / 4 && window > 256) window /= 2;
+        if (c[kDone]) return true;
     }
-    if (rounds_out) *rounds_out = rounds;
-    return true;
 }
 
 }  // namespace search

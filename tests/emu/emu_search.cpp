@@ -1,5 +1,6 @@
 // TEST INFRASTRUCTURE ONLY.  The product's GPU pilot search -- kernels (lphash_amd/csrc/search_device.cuh) AND round loop
 // (search_rounds.hpp) -- run on the fiber emulator, next to a plain sequential first-fit reference (PTHash v1 search).
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -11,23 +12,33 @@ using namespace lphq::search;
 
 namespace {
 struct EmuDev {  // "device" memory is host memory, a launch is an emulated grid
-    uint32_t* flags;
-    bool set_flags(const uint32_t (&f)[3]) { memcpy(flags, f, sizeof f); return true; }
-    bool get_flags(uint32_t (&f)[3]) { memcpy(f, flags, sizeof f); return true; }
-    void launch_search(const SearchArgs& x, int g) { emu::launch((unsigned)g, 256, [&] { k_search(x); }); }
-    void launch_claim(const SearchArgs& x, int g) { emu::launch((unsigned)g, 256, [&] { k_claim(x); }); }
-    void launch_validate(const SearchArgs& x, int g) { emu::launch((unsigned)g, 256, [&] { k_validate(x); }); }
-    void launch_commit(const SearchArgs& x, int g) { emu::launch((unsigned)g, 256, [&] { k_commit(x); }); }
+    uint32_t* ctl;
+    bool set_ctl(const uint32_t (&c)[kCtlWords]) { memcpy(ctl, c, sizeof c); return true; }
+    bool get_ctl(uint32_t (&c)[kCtlWords]) { memcpy(c, ctl, sizeof c); return true; }
+    // The product launches fixed grids and lets the kernels cut themselves down to the current windows.  An emulated workgroup
+    // costs 256 fiber start-ups even when it exits at once, so the emulator launches the window's workgroups plus ONE beyond it
+    // (the early-exit path still runs) -- it can, because its "device" control words are host memory.
+    unsigned cut(int g, unsigned need) const {
+        const bool over = (ctl[kDone] | ctl[kFailed] | ctl[kStuck]) != 0;
+        return (unsigned)std::min<uint64_t>((uint64_t)g, over ? 1u : (uint64_t)need + 1u);
+    }
+    unsigned commit_wgs() const { return (unsigned)(((uint64_t)ctl[kNCommit] * kWave + 255) / 256); }
+    void launch_search(const SearchArgs& x, int g) { emu::launch(cut(g, ctl[kNSearch]), 256, [&] { k_search(x); }); }
+    void launch_claim(const SearchArgs& x, int g) { emu::launch(cut(g, commit_wgs()), 256, [&] { k_claim(x); }); }
+    void launch_validate(const SearchArgs& x, int g) { emu::launch(cut(g, commit_wgs()), 256, [&] { k_validate(x); }); }
+    void launch_commit(const SearchArgs& x, int g) { emu::launch(cut(g, commit_wgs()), 256, [&] { k_commit(x); }); }
+    void launch_advance(const SearchArgs& x) { emu::launch(1, 64, [&] { k_advance(x); }); }
 };
 uint64_t murmur_u64(uint64_t v, uint64_t seed) { return murmur8(v, seed ^ (8ull * LPHQ_MURMUR_M)); }
 }  // namespace
 
 // returns 0 on success; pilots by processing order; taken = table_size-bit bitmap in u32 words
 extern "C" int emu_pilot_search(const uint64_t* hs, const uint32_t* bstart, const uint32_t* order, uint64_t n_nonempty, uint64_t table_size, uint64_t seed,
-                                uint32_t look_ahead, uint32_t steps, uint64_t* pilot_by_order, uint32_t* taken, uint64_t* rounds) {
+                                uint32_t look_ahead, uint32_t steps, uint32_t rounds_per_sync, uint64_t* pilot_by_order, uint32_t* taken, uint64_t* rounds) {
     std::vector<uint32_t> owner(table_size, kNoOwner);
     std::vector<uint8_t> ready(n_nonempty ? n_nonempty : 1, 0);
-    uint32_t flags[4] = {0, 0, 0, 0};
+    uint32_t ctl[kCtlWords];
+    memset(ctl, 0, sizeof ctl);
     memset(taken, 0, ((table_size + 63) / 64 * 2 + 2) * 4);
     memset(pilot_by_order, 0, n_nonempty * 8);
     SearchArgs a;
@@ -39,12 +50,12 @@ extern "C" int emu_pilot_search(const uint64_t* hs, const uint32_t* bstart, cons
     a.owner = owner.data();
     a.pilot = pilot_by_order;
     a.ready = ready.data();
-    a.flags = flags;
+    a.ctl = ctl;
     a.seedx = seed ^ (8ull * LPHQ_MURMUR_M);
     a.div = divisor_u32(table_size);
-    EmuDev dev{flags};
+    EmuDev dev{ctl};
     std::string err;
-    if (!run_rounds(dev, a, n_nonempty, look_ahead, steps, err, rounds)) return 1;
+    if (!run_rounds(dev, a, n_nonempty, look_ahead, steps, rounds_per_sync, err, rounds)) return 1;
     for (uint32_t o : owner)
         if (o != kNoOwner) return 2;  // every round must release the owner table
     return 0;
