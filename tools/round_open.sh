@@ -6,6 +6,7 @@
 #   2. bench.py: C2 random (headline line, with cpu_baseline), C3 streaming default, C3 streaming pipelined, C5
 #   3. rocprofv3 --kernel-trace --stats of the C2 and C3 commands -> kernel summaries (tools/rocpd_summary.py)
 #   4. tools/stream_pipeline_sweep.sh
+#   5. index build time with the GPU pilot search (1 vs 16 rounds per host read-back) and the byte comparison with the CPU search
 # Copy what is to be judged from gpurun_out/<tag>/ into profiles/ afterwards.
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -42,4 +43,11 @@ done
 step "4. pipeline sweep"
 timeout 1500 bash tools/stream_pipeline_sweep.sh > "$O/sweep_stdout.txt" 2>&1
 cp gpurun_out/stream_pipe_sweep.txt gpurun_out/stream_pipe_sweep_summary.txt "$O/" 2> /dev/null
+step "5. index build: GPU pilot search, 1 vs 16 rounds per host read-back; CPU search for the byte comparison"
+for rps in 1 16; do
+    LPHQ_BUILD_VERBOSE=1 LPHQ_SEARCH_ROUNDS_PER_SYNC=$rps timeout 600 python tools/gpu_build_time.py 1000 31 > "$O/build_rps$rps.txt" 2>&1 || step "build (rounds per sync $rps) failed"
+    grep -E "gpu-search build|gpu pilot search" "$O/build_rps$rps.txt" | tee -a "$O/log.txt"
+done
+timeout 900 python tools/gpu_build_time.py 1000 31 --cpu > "$O/build_cpu_compare.txt" 2>&1 || step "cpu comparison build failed"
+tail -1 "$O/build_cpu_compare.txt" | tee -a "$O/log.txt"
 step "done"
