@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--cpu-build", action="store_true", help="run the PTHash pilot search of the index build on the CPU")
     ap.add_argument("--cpu-sample-log2", type=int, default=24, help="oracle-timed sample size (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nonmember-frac", type=float, default=0.0,
+                    help="random mode: this fraction of the probes are uniformly random k-mers (non-members; SURVEY 8(d) secondary run)")
+    ap.add_argument("--shuffle-records", action="store_true", help="stream mode: the index records in a random order (SURVEY 8(d) variant)")
     ap.add_argument("--stream-pipeline", action="store_true",
                     help="stream mode: use the opt-in software-pipelined kernel (sets LPHQ_STREAM_PIPELINE=1; see kernels_stream_pipe.cuh)")
     ap.add_argument("--cache-dir", default=os.environ.get("LPHQ_BENCH_CACHE", "/tmp/lphq_bench_cache"))
@@ -144,6 +147,10 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     d_seq = torch.from_numpy(flat).to(dev)
     total_bases = int(d_seq.numel())
+    rec_order = None
+    if args.shuffle_records and args.mode == "stream":
+        rec_order = np.random.default_rng(3).permutation(n_records)
+        d_seq = d_seq.view(n_records, rec_len)[torch.from_numpy(rec_order).to(dev)].contiguous().view(-1)
 
     # ---- per-rank batch, resident in HBM before the timed region ----
     if args.mode == "random":
@@ -156,6 +163,21 @@ def main():
         del rec_i, off_i
         d_kmers = torch.empty(Q * (kmer_bits // 64), dtype=torch.int64, device=dev)
         h.pack_kmers(d_seq.data_ptr(), d_pos.data_ptr(), Q, d_kmers.data_ptr(), stream)
+        n_neg = int(Q * min(max(args.nonmember_frac, 0.0), 1.0))
+        if n_neg:  # uniformly random k-mers (members with probability ~nk / 4^k ~ 0), scattered over the batch
+            torch.cuda.synchronize()
+            where = torch.randperm(Q, generator=g, device=dev)[:n_neg]
+            lo_bits = min(2 * k, 64)
+            lo = torch.randint(-(1 << 63), (1 << 63) - 1, (n_neg,), generator=g, device=dev, dtype=torch.int64)
+            if lo_bits < 64:
+                lo &= (1 << lo_bits) - 1
+            if kmer_bits == 64:
+                d_kmers[where] = lo
+            else:
+                hi = torch.randint(0, 1 << max(2 * k - 64, 1), (n_neg,), generator=g, device=dev, dtype=torch.int64) if 2 * k > 64 else torch.zeros_like(lo)
+                d_kmers.view(Q, 2)[where, 0] = lo
+                d_kmers.view(Q, 2)[where, 1] = hi
+            del where, lo
         d_out = torch.empty(Q, dtype=torch.int64, device=dev)
         units = Q
 
@@ -214,7 +236,7 @@ def main():
         else:
             nrec_s = max(1, min(n_records, S // (rec_len - k + 1)))
             t0 = time.perf_counter()
-            exp = np.concatenate([o(recs[i], True) for i in range(nrec_s)])
+            exp = np.concatenate([o(recs[i if rec_order is None else int(rec_order[i])], True) for i in range(nrec_s)])
             cpu_s = time.perf_counter() - t0
             S = len(exp)
             got = d_out[:S].cpu().numpy().view(np.uint64)
@@ -236,7 +258,7 @@ def main():
             parity = parity and bool(np.array_equal(np.concatenate(parts), d_out[:S3].cpu().numpy().view(np.uint64)))
             cpu_all = {"value": S3 / cpu3_s, "unit": "k-mer lookups/s", "cores": nthreads, "kind": "port",
                        "sample": f"first {S3} probes of the timed batch, {nthreads} threads"}
-        if args.mode == "random" and world == 1:
+        if args.mode == "random" and world == 1 and args.nonmember_frac == 0.0:
             full = d_out.cpu().numpy().view(np.uint64)
             parity = parity and bool(full.max() < nk)  # positive probes: every code is a valid slot
         log(f"[bench] cpu oracle: {S / cpu_s / 1e6:.2f} M lookups/s on {S} units; GPU == oracle on the sample: {parity}")
@@ -261,8 +283,10 @@ def main():
             "config": {
                 "workload": ("C2: partitioned" if kind == L.PARTITIONED else "C5: unpartitioned")
                 + f" LP-MPHF k={k} m={m}, {nk} k-mers (SplitMix64 seed 1, {n_records} records x {rec_len} bases); "
-                + (f"2^{args.batch_log2} random positive packed k-mer lookups per GPU per step" if args.mode == "random"
-                   else "all windows of the index records per step, streaming kernel"),
+                + ((f"2^{args.batch_log2} random positive packed k-mer lookups per GPU per step" if args.nonmember_frac == 0.0 else
+                    f"2^{args.batch_log2} random packed k-mer lookups per GPU per step, {args.nonmember_frac:.0%} of them uniformly random non-members")
+                   if args.mode == "random"
+                   else "all windows of the index records per step, streaming kernel" + (", records in shuffled order" if rec_order is not None else "")),
                 "k": k, "m": m, "kmers": nk, "units_per_step_per_gpu": units, "kmer_bits": kmer_bits,
                 "index_image_bytes": int(h.info.image_bytes), "type_mix": mix,
             },
@@ -274,7 +298,8 @@ def main():
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             key = f"{args.mode}|{args.kind}|k{k}|m{m}|n{nk}|b{args.batch_log2 if args.mode == 'random' else 0}"
             pipelined = args.mode == "stream" and os.environ.get("LPHQ_STREAM_PIPELINE", "0") not in ("", "0")
-            if key in tj and not pipelined:  # (no counter pass exists for the opt-in pipelined kernel yet)
+            variant = args.nonmember_frac != 0.0 or rec_order is not None
+            if key in tj and not pipelined and not variant:  # (counter passes exist for the default kernels on the primary workloads only)
                 traffic = tj[key]["bytes_per_unit"] * units
         except (OSError, ValueError, KeyError):
             pass

@@ -3,7 +3,8 @@
 #   gpurun --timeout 3000 -- bash tools/round_open.sh [tag]        (tag defaults to r02; output in gpurun_out/<tag>/)
 # Steps (each under its own `timeout`, failures are recorded and do not stop the rest):
 #   1. python -m pytest tests -m gpu -x -q
-#   2. bench.py: C2 random (headline line, with cpu_baseline), C3 streaming default, C3 streaming pipelined, C5
+#   2. bench.py: C2 random (headline line, with cpu_baseline), C3 streaming default, C3 streaming pipelined, C5, the two
+#      secondary workloads of SURVEY 8(d) (50 % non-member probes; shuffled records) and the HBM copy/read/write probe
 #   3. rocprofv3 --kernel-trace --stats of the C2 and C3 commands -> kernel summaries (tools/rocpd_summary.py)
 #   4. tools/stream_pipeline_sweep.sh
 #   5. index build time with the GPU pilot search (1 vs 16 rounds per host read-back) and the byte comparison with the CPU search
@@ -26,7 +27,11 @@ timeout 900 python bench.py > "$O/bench_c2_random.json" 2> "$O/bench_c2_random.e
 timeout 600 python bench.py --mode stream --no-cpu-baseline > "$O/bench_c3_stream.json" 2> "$O/bench_c3_stream.err" || step "C3 bench failed"
 timeout 600 python bench.py --mode stream --stream-pipeline --no-cpu-baseline > "$O/bench_c3_stream_pipe.json" 2> "$O/bench_c3_stream_pipe.err" || step "C3 pipelined bench failed"
 timeout 600 python bench.py --kind u --no-cpu-baseline > "$O/bench_c5_unpartitioned.json" 2> "$O/bench_c5_unpartitioned.err" || step "C5 bench failed"
+timeout 600 python bench.py --nonmember-frac 0.5 --no-cpu-baseline > "$O/bench_c2_random_half_nonmembers.json" 2> "$O/bench_c2_random_half_nonmembers.err" || step "C2 non-member bench failed"
+timeout 600 python bench.py --mode stream --shuffle-records --no-cpu-baseline > "$O/bench_c3_stream_shuffled.json" 2> "$O/bench_c3_stream_shuffled.err" || step "C3 shuffled bench failed"
+timeout 300 python tools/hbm_copy_probe.py > "$O/hbm_copy_probe.json" 2> "$O/hbm_copy_probe.err" || step "HBM probe failed"
 grep -ho '"value": [0-9.e+]*\|"kernel_ms": [0-9.]*' "$O"/bench_*.json | paste - - | tee -a "$O/log.txt"
+cat "$O/hbm_copy_probe.json" | tee -a "$O/log.txt"
 
 step "3. kernel traces"
 cd /tmp && export TMPDIR=/tmp
