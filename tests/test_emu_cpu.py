@@ -212,7 +212,7 @@ def test_packed_and_pack_kernels_on_the_emulator(emuk, tmp_path, k, m, bits, kin
 # ------------------------------------------------------------------------------------------------------------------
 # GPU pilot search of the index builder (search_device.cuh kernels + search_rounds.hpp round loop) on the emulator
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n_keys,look_ahead,steps,seed", [(3000, 16384, 32, 1), (3500, 16384, 4, 2), (2500, 8192, 1, 3), (800, 100, 1000000, 4), (5000, 16384, 32, 5)])
+@pytest.mark.parametrize("n_keys,look_ahead,steps,seed", [(3000, 16384, 32, 1), (2000, 16384, 4, 2), (2500, 8192, 1, 3), (800, 100, 1000000, 4), (4000, 16384, 32, 5)])
 def test_gpu_pilot_search_on_the_emulator(emuk, n_keys, look_ahead, steps, seed):
     """Speculative window + claim/validate/commit must give exactly the sequential first-fit pilots and bitmap, for any step
     budget and for (clamped) out-of-range look-ahead values -- the configuration that once committed unsearched buckets."""
@@ -269,7 +269,6 @@ def test_kernels_under_other_thread_schedules(emuk, tmp_path, mode, seed):
         test_tile_kernels_on_the_emulator(emuk, tmp_path, 47, 17, 128, 1)  # unpartitioned, 128-bit k-mers
         test_tile_kernels_non_acgt_on_the_emulator(emuk, tmp_path)
         test_packed_and_pack_kernels_on_the_emulator(emuk, tmp_path, 31, 20, 64, 0)
-        test_gpu_pilot_search_on_the_emulator(emuk, 3000, 16384, 32, 1)
-        test_gpu_pilot_search_on_the_emulator(emuk, 2500, 8192, 1, 3)
+        test_gpu_pilot_search_on_the_emulator(emuk, 1500, 16384, 8, 3)
     finally:
         emuk.emu_set_schedule(0, 0)
