@@ -393,12 +393,13 @@ int build_main(int kind, int argc, char** argv) {
         std::cerr << "[Error] out of host memory while reading " << input << "\n";
         return 4;
     }
+    whole.compact();  // one pointer per record below: records must be contiguous (pieces of the parallel reader may split them)
     const size_t n_recs = whole.lens.size();
     std::vector<const char*> ptrs(n_recs);
     std::vector<size_t> lens(n_recs);
     {
         size_t si = 0, so = 0;
-        for (size_t i = 0; i < n_recs; ++i) {  // a record never straddles two segments (segments are whole parsed pieces)
+        for (size_t i = 0; i < n_recs; ++i) {
             while (si < whole.segs.size() && so == whole.segs[si].n) {
                 ++si;
                 so = 0;

@@ -1,14 +1,17 @@
 // fastx_batch.hpp -- batches of FASTA/FASTQ records for the CLI, parsed by several threads when that is safe.
 //
 // The record semantics are kseq's (external/kseq.h:192-240, restated in fastx.hpp).  For a plain (not gzip) file whose
-// first byte is '>', every "\n>" is a record boundary as long as no sequence line starts with '+' (which would open a
-// FASTQ quality string, where '>' and '@' are ordinary characters).  Such a file is mmap'ed, cut at "\n>" boundaries
-// and the pieces are parsed concurrently with the same per-record state machine; a piece that meets a line starting
-// with '+' makes the reader fall back, from the start of the current batch, to the serial FastxReader for the rest of
-// the file, so the records are the serial reader's in every case.  gzip input and files that do not start with '>'
-// take the serial reader from the beginning.
+// first byte is '>', a header is exactly one line, so every later line that does not start with '>' or '@' is a
+// sequence line -- as long as no sequence line starts with '+' (which would open a FASTQ quality string, where '>' and
+// '@' are ordinary characters).  Such a file is mmap'ed; a batch is a run of whole records, cut at ANY line start into
+// pieces that are parsed concurrently with the same per-record state machine (a piece that begins inside a record
+// contributes its leading bases to the record begun in an earlier piece, so one 250-Mbase chromosome is still parsed by
+// all threads).  A piece that meets a line starting with '+' -- or the one case where kseq's '\r' rule would need the
+// length of a record begun elsewhere -- makes the reader fall back, from the start of the current batch, to the serial
+// FastxReader for the rest of the file, so the records are the serial reader's in every case.  gzip input and files
+// that do not start with '>' take the serial reader from the beginning.
 //
-// A batch is a list of segments (the bases of consecutive records, concatenated) plus the record lengths; segments
+// A batch is a list of segments (bases in file order; a record may run across segments) plus the record lengths; segments
 // point into one of two arenas owned by the reader, used alternately, so a batch stays valid while the NEXT one is
 // being parsed (the CLI parses batch i+1 on a helper thread while batch i is on its way to the GPU) and dies with the
 // call after that.  Arenas are allocated once and reused: first-touch page faults of fresh memory cost more than the
@@ -34,16 +37,26 @@ namespace lphq {
 
 struct FastxBatch {
     struct Segment {
-        const char* p;
+        char* p;
         size_t n;
     };
-    std::vector<Segment> segs;    // bases of the batch, in order
+    std::vector<Segment> segs;    // bases of the batch, in order (ascending addresses within one arena)
     std::vector<uint64_t> lens;   // length of every record, in order (sum = total bases of segs)
     size_t bases = 0;
     void clear() {
         segs.clear();
         lens.clear();
         bases = 0;
+    }
+    // one contiguous segment (for consumers that want a pointer per record): slides the segments together in place
+    void compact() {
+        if (segs.size() <= 1) return;
+        char* dst = segs[0].p + segs[0].n;
+        for (size_t i = 1; i < segs.size(); ++i) {
+            memmove(dst, segs[i].p, segs[i].n);
+            dst += segs[i].n;
+        }
+        segs.assign(1, Segment{segs[0].p, (size_t)(dst - segs[0].p)});
     }
 };
 
@@ -105,10 +118,11 @@ public:
 
 private:
     struct Piece {
-        size_t begin, end;   // file span; begin is at a '>' that starts a line
+        size_t begin, end;   // file span; begin is a line start
         char* out;           // output position in the arena (capacity end - begin)
         size_t n = 0;        // bases written
-        std::vector<uint64_t> lens;
+        size_t head = 0;     // of which: bases before the first header of the piece (they belong to the previous piece's last record)
+        std::vector<uint64_t> lens;  // records that BEGIN in this piece
         bool unsafe = false;
     };
 
@@ -146,19 +160,60 @@ private:
         return size_;
     }
 
-    // kseq's record loop over one piece (which starts at a record's '>').
+    // first line start in (from, end]; `end` if the rest holds no line end
+    size_t next_line_start(size_t from, size_t end) const {
+        if (from >= end) return end;
+        const char* q = (const char*)memchr(map_ + from, '\n', end - from);
+        return q ? (size_t)(q - map_) + 1 : end;
+    }
+
+    // Sequence lines from p on, appended at out, until a line that starts a record ('>' / '@') or the end of the piece.
+    // `rec` = where the record's bases begin if that is inside this piece, else nullptr (record begun in an earlier piece).
+    // Returns false if the piece cannot be parsed on its own.
+    bool sequence_lines(size_t& p, size_t e, char*& out, char* rec) const {
+        const char* s = map_;
+        char* const local = rec ? rec : out;
+        while (p < e) {
+            const char c = s[p];
+            if (c == '>' || c == '@') break;  // next record
+            if (c == '+') return false;       // FASTQ quality string ahead
+            if (c == '\n') {
+                ++p;
+                continue;
+            }
+            const char* ln = (const char*)memchr(s + p, '\n', e - p);
+            const size_t n = ln ? (size_t)(ln - (s + p)) : e - p;
+            memcpy(out, s + p, n);
+            out += n;
+            if (out[-1] == '\r') {  // kseq: `\r` before the line end is dropped once the sequence has > 1 characters
+                if (out - local > 1) --out;
+                else if (!rec) return false;  // ... and how long the record is so far is only known to an earlier piece
+            }
+            p += n + (ln ? 1 : 0);
+        }
+        return true;
+    }
+
+    // kseq's record loop over one piece.
     void parse_piece(Piece& pc) const {
         const char* s = map_;
         size_t p = pc.begin;
         const size_t e = pc.end;
         char* out = pc.out;
+        if (p < e && s[p] != '>' && s[p] != '@') {  // the piece begins inside a record
+            if (!sequence_lines(p, e, out, nullptr)) {
+                pc.unsafe = true;
+                return;
+            }
+            pc.head = (size_t)(out - pc.out);
+        }
         while (p < e) {
-            // header: s[p] is '>' or '@'; kseq drops a header that has no line end
+            // header: s[p] is '>' or '@'
             const char* nl = (const char*)memchr(s + p, '\n', e - p);
             if (!nl) {
                 // last header of the file without a line end: the serial reader yields an empty record if the header
                 // holds a white-space character after its first one, and nothing otherwise (fastx.hpp: next())
-                if (pc.end != size_) pc.unsafe = true;  // cannot happen for a piece cut at "\n>" (defensive)
+                if (pc.end != size_) pc.unsafe = true;  // cannot happen: pieces end at line starts (defensive)
                 else
                     for (size_t i = p + 1; i < e; ++i)
                         if (s[i] == ' ' || s[i] == '\t' || s[i] == '\v' || s[i] == '\f' || s[i] == '\r') {
@@ -169,23 +224,9 @@ private:
             }
             p = (size_t)(nl - s) + 1;
             char* rec = out;
-            while (p < e) {
-                const char c = s[p];
-                if (c == '>' || c == '@') break;  // next record
-                if (c == '+') {
-                    pc.unsafe = true;
-                    return;
-                }
-                if (c == '\n') {
-                    ++p;
-                    continue;
-                }
-                const char* ln = (const char*)memchr(s + p, '\n', e - p);
-                const size_t n = ln ? (size_t)(ln - (s + p)) : e - p;
-                memcpy(out, s + p, n);
-                out += n;
-                if (out - rec > 1 && out[-1] == '\r') --out;  // kseq: `\r` before the line end is dropped once the sequence has > 1 characters
-                p += n + (ln ? 1 : 0);
+            if (!sequence_lines(p, e, out, rec)) {
+                pc.unsafe = true;
+                return;
             }
             pc.lens.push_back((uint64_t)(out - rec));
         }
@@ -198,12 +239,12 @@ private:
         // sized for a full batch from the start, so that a short first batch does not cause a second cold allocation
         if (!reserve(std::max(end - off_, std::min(want, size_ - off_)))) return true;
         char* const arena = arenas_[which_].p;
-        // cut [off_, end) into pieces at record starts
+        // cut [off_, end) into pieces at line starts
         const int T = (int)std::min<size_t>((size_t)threads_, std::max<size_t>(1, (end - off_) / min_piece_));
         std::vector<Piece> pieces;
         size_t from = off_;
         for (int t = 1; t <= T && from < end; ++t) {
-            size_t to = t == T ? end : std::min(end, next_record_start(off_ + (end - off_) / T * t));
+            size_t to = t == T ? end : next_line_start(off_ + (end - off_) / T * t, end);
             if (to <= from) continue;
             Piece pc;
             pc.begin = from;
@@ -223,6 +264,10 @@ private:
             if (pc.unsafe) return false;
         for (const Piece& pc : pieces) {
             if (pc.n) b.segs.push_back({pc.out, pc.n});
+            if (pc.head) {
+                if (b.lens.empty()) return false;  // cannot happen: the batch begins with a header (defensive)
+                b.lens.back() += pc.head;
+            }
             b.lens.insert(b.lens.end(), pc.lens.begin(), pc.lens.end());
             b.bases += pc.n;
         }

@@ -238,6 +238,8 @@ def test_parallel_fastx_reader_equals_serial(tmp_path):
         "blank_lower.fa": fasta(200, 1, 400, 33, blank=True, lower=True),
         "tiny_records.fa": fasta(2000, 0, 3, 80),
         "one_line_long.fa": fasta(3, 200000, 300000, 1 << 30),
+        "long_multiline.fa": fasta(2, 150000, 200000, 60),           # records far longer than a piece: pieces begin inside records
+        "long_multiline_crlf.fa": fasta(2, 50000, 80000, 70, crlf=True),
         "no_trailing_newline.fa": fasta(50, 10, 200, 60)[:-1],
         "header_only_at_end.fa": fasta(20, 10, 200, 60) + b">last",
         "header_with_space_at_end.fa": fasta(20, 10, 200, 60) + b">last one",
@@ -299,3 +301,21 @@ def test_parallel_fastx_reader_fuzz(tmp_path):
                 assert got[:3] == want, (name, trial, threads, batch, piece, got, want, data[:200])
                 n_parallel_batches += int(got[4])
     assert n_parallel_batches > 50  # the multi-threaded path did take part
+
+
+def test_cli_build_from_long_records_with_threads(tmp_path):
+    """`lphash build-p -t 8` on records much longer than a parse piece: the reader's pieces begin inside records, the builder needs
+    them contiguous again (FastxBatch::compact) -- the file must equal the library build over the same records."""
+    exe = os.path.join(ROOT, "lphash_amd", "lphash")
+    recs = random_records(31337, 3, 250_000, 400_000)
+    fa = tmp_path / "long.fa"
+    with open(fa, "wb") as f:
+        for i, r in enumerate(recs):
+            f.write(b">contig%d\n" % i)
+            for j in range(0, len(r), 70):
+                f.write(r[j:j + 70] + b"\n")
+    out, ref = tmp_path / "cli.lph", tmp_path / "ref.lph"
+    res = subprocess.run([exe, "build-p", "-i", str(fa), "-k", "31", "-m", "20", "-o", str(out), "--kmer-bits", "64", "--cpu", "-t", "8"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    L.build(recs, 31, 20, str(ref), kmer_bits=64, threads=4)
+    assert out.read_bytes() == ref.read_bytes()
