@@ -2,6 +2,7 @@
 // (external/kseq.h:192-240): a header starts at any '>' or '@' once the previous record is complete; the
 // sequence is every following line, concatenated, until a line that starts with '>', '@' or '+'; '\r' before
 // '\n' is dropped; a FASTQ quality string must have the length of the sequence or reading stops.
+// Pinned against the real kseq.h on crafted and fuzzed inputs (oracle/kseq_dump.c, tests/test_host_cpu.py).
 #pragma once
 #include <zlib.h>
 
@@ -30,36 +31,42 @@ public:
     }
 
     // Next record's sequence into seq; false at end of input or on a malformed FASTQ record (kseq_read < 0).
+    // Operation by operation what kseq_read does (external/kseq.h:192-240), because its corner cases are observable:
+    // a last header without a line end still yields an (empty) record if anything follows the header character; the
+    // '\r' before a line end is dropped only once the string holds more than one character, and not at all when the
+    // line's first character is the last byte of the input; a '+' line always consumes one quality line, even for an
+    // empty sequence.
     bool next(std::string& seq) {
         int c;
-        if (last_char_ == 0) {
+        if (last_char_ == 0) {  // jump to the next header line
             while ((c = getc()) >= 0 && c != '>' && c != '@') {
             }
             if (c < 0) return false;
             last_char_ = c;
-        }
+        }  // else: the first header character was read by the previous call
         seq.clear();
-        // name up to the first white space, then the rest of the header line (comment)
-        while ((c = getc()) >= 0 && c != ' ' && c != '\t' && c != '\n' && c != '\v' && c != '\f' && c != '\r') {
-        }
-        if (c < 0) return false;  // header without a line end: kseq returns EOF here
-        if (c != '\n') skip_line();
+        int delim = 0;
+        if (get_until(kSpace, scratch_, &delim, false) < 0) return false;  // name; nothing at all after the header character: EOF
+        if (delim != '\n') (void)get_until(kLine, scratch_, nullptr, false);  // comment: the rest of the header line
         while ((c = getc()) >= 0 && c != '>' && c != '+' && c != '@') {
-            if (c == '\n') continue;
+            if (c == '\n') continue;  // skip empty lines
             seq.push_back((char)c);
-            append_line(seq);
+            (void)get_until(kLine, seq, nullptr, true);  // the rest of the line
         }
-        if (c == '>' || c == '@') last_char_ = c;
-        if (c != '+') return true;  // FASTA
-        skip_line();
-        size_t qlen = 0;
-        bool eof = false;
-        while (qlen < seq.size() && !eof) qlen += count_line(eof);
-        last_char_ = 0;
-        return qlen == seq.size();
+        if (c == '>' || c == '@') last_char_ = c;  // the first header character has been read
+        if (c != '+') return true;                 // FASTA
+        while ((c = getc()) >= 0 && c != '\n') {  // skip the rest of the '+' line
+        }
+        if (c < 0) return false;  // no quality string (-2)
+        qual_.clear();
+        while (get_until(kLine, qual_, nullptr, true) >= 0 && qual_.size() < seq.size()) {
+        }
+        last_char_ = 0;  // we have not come to the next header line
+        return qual_.size() == seq.size();  // (-2 otherwise: the caller's read loop stops)
     }
 
 private:
+    enum Delim { kSpace, kLine };
     int getc() {
         if (pos_ >= end_) {
             if (eof_) return -1;
@@ -73,41 +80,48 @@ private:
         }
         return (unsigned char)buf_[pos_++];
     }
-    // Rest of the current line, a buffer span at a time (memchr): visit(ptr, len) per span; returns false at end of input.
-    template <typename Visit>
-    bool rest_of_line(Visit visit) {
+    // ks_getuntil2 (external/kseq.h:99-158): append (or assign) the bytes up to the next delimiter -- any isspace()
+    // character for kSpace, '\n' for kLine -- consume the delimiter and report it in *dret (0 if the input ended first).
+    // Returns -1 if the input was already exhausted, else the length of str; for kLine a trailing '\r' is dropped when
+    // str holds more than one character.
+    long get_until(Delim d, std::string& str, int* dret, bool append) {
+        bool gotany = false;
+        if (dret) *dret = 0;
+        if (!append) str.clear();
         for (;;) {
             if (pos_ >= end_) {
-                int c = getc();  // refill
-                if (c < 0) return false;
-                --pos_;
+                if (eof_) break;
+                int n = gzread(fp_, buf_.data(), (unsigned)buf_.size());
+                pos_ = 0;
+                end_ = n > 0 ? (size_t)n : 0;
+                if (n <= 0) {
+                    eof_ = true;
+                    break;
+                }
             }
             const char* p = buf_.data() + pos_;
-            const char* nl = (const char*)memchr(p, '\n', end_ - pos_);
-            const size_t n = nl ? (size_t)(nl - p) : end_ - pos_;
-            visit(p, n);
-            pos_ += n + (nl ? 1 : 0);
-            if (nl) return true;
+            size_t i;
+            if (d == kLine) {
+                const char* nl = (const char*)memchr(p, '\n', end_ - pos_);
+                i = nl ? (size_t)(nl - p) : end_ - pos_;
+            } else {
+                for (i = 0; i < end_ - pos_; ++i) {
+                    const unsigned char ch = (unsigned char)p[i];
+                    if (ch == ' ' || (ch >= '\t' && ch <= '\r')) break;  // isspace() in the C locale
+                }
+            }
+            gotany = true;
+            str.append(p, i);
+            const bool hit = i < end_ - pos_;
+            if (hit && dret) *dret = (unsigned char)p[i];
+            pos_ += i + (hit ? 1 : 0);
+            if (hit) break;
         }
+        if (!gotany) return -1;
+        if (d == kLine && str.size() > 1 && str.back() == '\r') str.pop_back();
+        return (long)str.size();
     }
-    void skip_line() {
-        rest_of_line([](const char*, size_t) {});
-    }
-    void append_line(std::string& s) {
-        rest_of_line([&](const char* p, size_t n) { s.append(p, n); });
-        if (s.size() > 1 && s.back() == '\r') s.pop_back();
-    }
-    size_t count_line(bool& eof) {
-        size_t n = 0;
-        int last = 0;
-        if (!rest_of_line([&](const char* p, size_t len) {
-                n += len;
-                if (len) last = (unsigned char)p[len - 1];
-            }))
-            eof = true;
-        if (n > 1 && last == '\r') --n;
-        return n;
-    }
+    std::string scratch_, qual_;
     gzFile fp_;
     std::vector<char> buf_;
     size_t pos_ = 0, end_ = 0;

@@ -185,7 +185,9 @@ private:
             const size_t n = ln ? (size_t)(ln - (s + p)) : e - p;
             memcpy(out, s + p, n);
             out += n;
-            if (out[-1] == '\r') {  // kseq: `\r` before the line end is dropped once the sequence has > 1 characters
+            // kseq: `\r` before the line end is dropped once the sequence has > 1 characters -- but not when the line's first
+            // character is the last byte of the input (ks_getuntil2 then returns before that rule)
+            if (out[-1] == '\r' && (ln || n > 1)) {
                 if (out - local > 1) --out;
                 else if (!rec) return false;  // ... and how long the record is so far is only known to an earlier piece
             }
@@ -211,15 +213,10 @@ private:
             // header: s[p] is '>' or '@'
             const char* nl = (const char*)memchr(s + p, '\n', e - p);
             if (!nl) {
-                // last header of the file without a line end: the serial reader yields an empty record if the header
-                // holds a white-space character after its first one, and nothing otherwise (fastx.hpp: next())
+                // last header of the file without a line end: kseq still yields an (empty) record, unless the header
+                // character is the very last byte of the input (fastx.hpp: next())
                 if (pc.end != size_) pc.unsafe = true;  // cannot happen: pieces end at line starts (defensive)
-                else
-                    for (size_t i = p + 1; i < e; ++i)
-                        if (s[i] == ' ' || s[i] == '\t' || s[i] == '\v' || s[i] == '\f' || s[i] == '\r') {
-                            pc.lens.push_back(0);
-                            break;
-                        }
+                else if (e - p > 1) pc.lens.push_back(0);
                 break;
             }
             p = (size_t)(nl - s) + 1;

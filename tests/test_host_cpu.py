@@ -319,3 +319,43 @@ def test_cli_build_from_long_records_with_threads(tmp_path):
     assert res.returncode == 0, res.stderr
     L.build(recs, 31, 20, str(ref), kmer_bits=64, threads=4)
     assert out.read_bytes() == ref.read_bytes()
+
+
+KSEQ_DUMP = os.path.join(ROOT, "oracle", "_ref", "kseq_dump")
+
+
+@pytest.mark.skipif(not os.path.exists(KSEQ_DUMP), reason="oracle/_ref/kseq_dump is built only where /root/reference exists (oracle/Makefile)")
+def test_readers_against_the_real_kseq(tmp_path):
+    """Pin: the reference's OWN parser (external/kseq.h, compiled from /root/reference by oracle/Makefile into oracle/_ref/kseq_dump and
+    driven exactly like src/query.cpp:43-56) against the product's serial and multi-threaded readers, on crafted corner cases and on
+    byte soups: record count, base count and checksum of every record must agree."""
+    import gzip
+
+    exe = os.path.join(ROOT, "lphash_amd", "lphash")
+    rng = np.random.default_rng(31)
+    r = random_records(6, 8, 30, 300)
+    crafted = [
+        b">a\n" + r[0] + b"\n>b", b">a\n" + r[0] + b"\n>b x", b">a\n" + r[0] + b"\n>", b">", b">x", b"", b"\n\n", b"junk>a\nAC\n",
+        b">a\nAC\r\n\r\nGT\r", b">a\n\r\nAC\n", b">a\nAC\n\r", b">a\nA\r", b">a\r\nAC\r\r\n\nG\n",
+        b"@q\n" + r[1] + b"\n+\n" + b"I" * len(r[1]) + b"\n@r\n" + r[2] + b"\n+\n" + b"I" * (len(r[2]) - 1) + b"\n",
+        b"@q\n\n+\nIIII\n@r\nAC\n+\nII\n", b"@q\nAC\n+", b"@q\nAC\n+\n", b"@q\nAC\n+\nI\r\nI\n>x\nGG\n", b"@q\nACGT\n+\nII\r\r\n\n>x\nGG\n",
+        b">a b\tc\nAC>GT\n+notqual\nAC\n", b">a\n@b\nAC\n@c\n", gzip.compress(b">z\n" + r[3] + b"\n>y\n" + r[4][:50] + b"\n" + r[4][50:] + b"\n"),
+    ]
+    alphabet = np.frombuffer(b"ACGTacgtN\n\n\n\r>@+ \t", dtype=np.uint8)
+    weights = [[8, 8, 8, 8, 1, 1, 1, 1, 1, 2, 2, 2, .2, .4, .02, .0, .1, .05], [2, 2, 2, 2, 1, 1, 1, 1, 1, 3, 3, 3, 1, 2, 1, 1, 1, 1],
+               [4, 4, 4, 4, 0, 0, 0, 0, 0, 2, 2, 2, .5, .3, .3, .3, .2, .2], [8, 8, 8, 8, 0, 0, 0, 0, 0, 1, 1, 1, 1.5, .05, 0, 0, 0, 0]]
+    soups = []
+    for t in range(120):
+        pr = np.array(weights[t % 4], dtype=np.float64)
+        pr /= pr.sum()
+        body = bytes(rng.choice(alphabet, size=int(rng.integers(0, 2500)), p=pr))
+        soups.append((b">" if t % 3 else (b"@" if t % 2 else b"")) + body)
+    for i, data in enumerate(crafted + soups):
+        p = tmp_path / f"f{i}.fx"
+        p.write_bytes(data)
+        want = subprocess.run([KSEQ_DUMP, str(p)], capture_output=True, text=True).stdout.strip()
+        ser = subprocess.run([exe, "records", "-i", str(p), "--serial"], capture_output=True, text=True).stdout.strip().split(",")[:3]
+        par = subprocess.run([exe, "records", "-i", str(p), "-t", "4", "--min-piece", "1", "--batch-bytes", str(1 + 37 * i)], capture_output=True,
+                             text=True).stdout.strip().split(",")[:3]
+        assert ",".join(ser) == want, (i, "serial", ser, want, data[:120])
+        assert ",".join(par) == want, (i, "parallel", par, want, data[:120])
