@@ -272,3 +272,51 @@ def test_kernels_under_other_thread_schedules(emuk, tmp_path, mode, seed):
         test_gpu_pilot_search_on_the_emulator(emuk, 1500, 16384, 8, 3)
     finally:
         emuk.emu_set_schedule(0, 0)
+
+
+REF_NT4 = "/root/reference/src/constants.cpp"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_NT4), reason="reads the literal of the reference's seq_nt4_table where /root/reference exists")
+def test_base_encoding_against_the_reference_table(emuk, tmp_path):
+    """Pin of SURVEY 8(a) a9: constants::seq_nt4_table (src/constants.cpp:5-13) is read from the reference tree as DATA (256 numbers) and
+    every byte value is pushed through the oracle and through the product's streaming and random kernels (emulator): a byte the table
+    maps to 0..3 must behave exactly like that base, a byte it maps to 4 must void the streaming windows that contain it and read
+    as 'A' in random mode (mphf_utils.hpp:108)."""
+    import re
+
+    text = open(REF_NT4).read()
+    body = text[text.index("seq_nt4_table"):]
+    table = [int(x) for x in re.findall(r"\b\d+\b", body[body.index("{"):body.index("}")])]
+    assert len(table) == 256 and set(table) <= {0, 1, 2, 3, 4}
+    k, m = 31, 20
+    recs = random_records(9001, 3, 300, 500)
+    path = str(tmp_path / "t.lph")
+    L.build(recs, k, m, path, kmer_bits=64, threads=2)
+    o = orc.Index(path, 0, 64)
+    h = L.Mphf.load(path, kmer_bits=64)
+    base = recs[0][:90]
+    pos = 45
+    queries, clean = [], []
+    for c in range(256):
+        q = bytearray(base)
+        q[pos] = c
+        queries.append(bytes(q))
+        q[pos] = b"ACGT"[table[c]] if table[c] < 4 else ord("A")
+        clean.append(bytes(q))
+    got_s = emu_records(emuk, h, queries, k, True)
+    got_r = emu_records(emuk, h, queries, k, False)
+    for c in range(256):
+        exp = o(clean[c], False)
+        assert np.array_equal(got_r[c], exp), c                      # random mode: the table's code, or 'A' for the 4s
+        assert np.array_equal(o(queries[c], False), exp), c          # ... and the oracle's random branch agrees
+        os_ = o(queries[c], True)
+        if table[c] < 4:
+            assert np.array_equal(got_s[c], exp) and np.array_equal(os_, exp), c
+        else:
+            bad = np.zeros(len(base) - k + 1, dtype=bool)
+            bad[max(0, pos - k + 1):pos + 1] = True
+            assert np.all(got_s[c][bad] == np.uint64(L.INVALID)) and np.array_equal(got_s[c][~bad], exp[~bad]), c
+            # (the oracle's streaming branch restates the reference literally, including the spurious extra code its stale min_pos can
+            # emit after a reset -- SURVEY 8(a) note 4(ii) -- so only its count is bounded here)
+            assert int((~bad).sum()) <= len(os_) <= int((~bad).sum()) + 1, c
