@@ -80,7 +80,7 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
     const int sblock = (!pipelined && (sblock_env == 128 || sblock_env == 512)) ? sblock_env : 256;
     const uint64_t tw = streaming ? stream_tile_windows(H.W, 4 * sblock) : kTileW;
     const uint64_t tiles = (span + tw - 1) / tw;
-    if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (tiles > 0x7FFFFFFFull || n_records > 0xFFFFFFFFull) return hipErrorInvalidValue;  // 32-bit tile and record indices in the kernels
     // the pipelined kernel is compiled without the >= 2^32 divisor path (device_query.cuh: mod_u64<WIDE = false>) and without
     // the empty-function early-out of the minimizer PHF
     auto narrow = [](const lphq_phf_desc& f) { return f.num_keys == 0 || (f.div_dense.d != 0 && f.div_sparse.d != 0 && f.div_table.d != 0); };
