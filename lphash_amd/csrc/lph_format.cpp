@@ -39,6 +39,7 @@ struct Reader {
     size_t len, off = 0;
     bool bad = false;
     void raw(void* dst, size_t n) {
+        if (n == 0) return;  // (an empty vector's data() may be null: not a valid memcpy argument even for 0 bytes)
         if (bad || n > len - off) {
             bad = true;
             memset(dst, 0, n);

@@ -1,0 +1,101 @@
+// TEST INFRASTRUCTURE ONLY: the product's host-side sources that need no GPU (loader lph_format.cpp, image builder image.cpp,
+// index builder builder.cpp with the CPU pilot search, the FASTA readers) linked into one executable and compiled with
+// -fsanitize=address,undefined (tests/test_host_cpu.py::test_host_sources_under_sanitizers).  The two symbols that live in the HIP
+// part of the library are stubbed: the GPU pilot search reports "unavailable", errors go to a string.
+//   san_host build <fasta> <k> <m> <kind> <kmer_bits> <threads> <out.lph>     build with the product builder (CPU search)
+//   san_host load  <file.lph> <kind> <kmer_bits>                             parse + cross-check + flat image
+//   san_host fuzz  <file.lph> <kind> <kmer_bits> <n> <seed>                  n corrupted copies through the loader
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../include/lphq.h"
+#include "fastx_batch.hpp"
+#include "image.hpp"
+#include "lph_format.hpp"
+#include "search.hpp"
+
+namespace lphq {
+static std::string g_err;
+void set_last_error(const std::string& e) { g_err = e; }
+bool gpu_pilot_search(int, const std::vector<uint64_t>&, const std::vector<uint64_t>&, const std::vector<uint32_t>&, uint64_t, uint64_t, uint64_t,
+                      std::vector<uint64_t>&, std::vector<uint64_t>&, std::string& err) {
+    err = "no GPU in the sanitizer harness";
+    return false;
+}
+}  // namespace lphq
+
+static std::vector<uint8_t> slurp(const char* p) {
+    std::ifstream f(p, std::ios::binary);
+    return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+static int load(const std::vector<uint8_t>& buf, int kind, int bits, bool verbose) {
+    lphq::LphFile x;
+    std::string err;
+    if (!lphq::parse_lph(buf.data(), buf.size(), kind, bits, x, err)) {
+        if (verbose) fprintf(stderr, "rejected: %s\n", err.c_str());
+        return 1;
+    }
+    std::vector<uint8_t> image;
+    if (!lphq::build_image(x, image, err)) {
+        if (verbose) fprintf(stderr, "image: %s\n", err.c_str());
+        return 2;
+    }
+    if (verbose) printf("ok %zu image bytes\n", image.size());
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 64;
+    const std::string cmd = argv[1];
+    if (cmd == "build" && argc == 9) {
+        lphq::FastxBatchReader rd(argv[2], atoi(argv[7]), nullptr, nullptr, 4096);
+        if (!rd.ok()) return 3;
+        lphq::FastxBatch b;
+        (void)rd.next(b, ~(size_t)0);
+        b.compact();
+        std::vector<const char*> ptrs(b.lens.size());
+        std::vector<size_t> lens(b.lens.size());
+        size_t so = 0;
+        for (size_t i = 0; i < lens.size(); ++i) {
+            lens[i] = (size_t)b.lens[i];
+            ptrs[i] = b.segs.empty() ? "" : b.segs[0].p + so;
+            so += lens[i];
+        }
+        lphq_build_stats st;
+        const int rc = lphq_build(ptrs.data(), lens.data(), lens.size(), atoi(argv[3]), atoi(argv[4]), 42, 3.0, atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), argv[8], &st);
+        if (rc != LPHQ_OK) fprintf(stderr, "build failed (%d): %s\n", rc, lphq::g_err.c_str());
+        return rc == LPHQ_OK ? 0 : 4;
+    }
+    if (cmd == "load" && argc == 5) return load(slurp(argv[2]), atoi(argv[3]), atoi(argv[4]), true);
+    if (cmd == "fuzz" && argc == 7) {
+        const std::vector<uint8_t> good = slurp(argv[2]);
+        uint64_t s = strtoull(argv[6], nullptr, 10) | 1;
+        auto rnd = [&] {
+            s ^= s << 13;
+            s ^= s >> 7;
+            s ^= s << 17;
+            return s;
+        };
+        int ok = 0, rejected = 0;
+        for (int t = 0; t < atoi(argv[5]); ++t) {
+            std::vector<uint8_t> bad = good;
+            switch (rnd() % 4) {
+                case 0: bad.resize(rnd() % (bad.size() + 1)); break;                                        // truncation
+                case 1: for (int j = 0; j < 1 + (int)(rnd() % 8); ++j) bad[rnd() % bad.size()] ^= (uint8_t)(1u << (rnd() % 8)); break;  // bit flips
+                case 2: { const size_t at = rnd() % bad.size() & ~(size_t)7; const uint64_t v = rnd() % 3 ? rnd() : ~0ull >> (rnd() % 64);
+                          if (at + 8 <= bad.size()) memcpy(&bad[at], &v, 8); break; }                         // a wild 64-bit field
+                default: bad.insert(bad.end(), (size_t)(rnd() % 64), (uint8_t)rnd()); break;                 // trailing bytes
+            }
+            if (bad.empty()) continue;
+            (load(bad, atoi(argv[3]), atoi(argv[4]), false) == 0 ? ok : rejected)++;
+        }
+        printf("fuzz: %d accepted, %d rejected\n", ok, rejected);
+        return 0;
+    }
+    return 64;
+}

@@ -359,3 +359,41 @@ def test_readers_against_the_real_kseq(tmp_path):
                              text=True).stdout.strip().split(",")[:3]
         assert ",".join(ser) == want, (i, "serial", ser, want, data[:120])
         assert ",".join(par) == want, (i, "parallel", par, want, data[:120])
+
+
+def test_host_sources_under_sanitizers(tmp_path):
+    """The GPU-free host sources of the product (loader, image builder, index builder with the CPU pilot search, FASTA readers) compiled
+    with -fsanitize=address,undefined (tests/san/san_host.cpp): builds with 1 and 8 threads, loads, and a few hundred corrupted files
+    through the loader must raise no report (a report aborts the harness)."""
+    import shutil
+
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("g++ not available")
+    csrc = os.path.join(ROOT, "lphash_amd", "csrc")
+    exe = str(tmp_path / "san_host")
+    cc = subprocess.run([gxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I" + csrc,
+                         os.path.join(ROOT, "tests", "san", "san_host.cpp"), os.path.join(csrc, "builder.cpp"), os.path.join(csrc, "lph_format.cpp"),
+                         os.path.join(csrc, "image.cpp"), "-o", exe, "-lz", "-lpthread"], capture_output=True, text=True)
+    if cc.returncode != 0 and "sanitize" in cc.stderr:
+        pytest.skip("this g++ has no sanitizer runtime")
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    recs = random_records(808, 30, 300, 6000) + random_records(809, 2, 90_000, 120_000)
+    fa = tmp_path / "in.fa"
+    with open(fa, "wb") as f:
+        for i, r in enumerate(recs):
+            f.write(b">r%d\n" % i)
+            for j in range(0, len(r), 70):
+                f.write(r[j:j + 70] + b"\n")
+    env = dict(os.environ, UBSAN_OPTIONS="print_stacktrace=1", ASAN_OPTIONS="detect_leaks=1")
+    for k, m, kind, bits in ((31, 20, 0, 64), (63, 20, 0, 128), (31, 20, 1, 64)):
+        out = tmp_path / f"o_{k}_{kind}.lph"
+        for threads in (1, 8):
+            r = subprocess.run([exe, "build", str(fa), str(k), str(m), str(kind), str(bits), str(threads), str(out)], capture_output=True, text=True, env=env)
+            assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+        ref = tmp_path / "ref.lph"
+        L.build(recs, k, m, str(ref), kind=kind, kmer_bits=bits, threads=2)
+        assert out.read_bytes() == ref.read_bytes()
+        for cmd in (["load", str(out), str(kind), str(bits)], ["fuzz", str(out), str(kind), str(bits), "150", str(k)]):
+            r = subprocess.run([exe] + cmd, capture_output=True, text=True, env=env)
+            assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
