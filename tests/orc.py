@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_SO = os.path.join(_ROOT, "oracle", "liblphoracle.so")
+_SO = os.environ.get("LPHQ_ORACLE_LIB") or os.path.join(_ROOT, "oracle", "liblphoracle.so")  # override: e.g. a sanitizer build
 
 PARTITIONED, UNPARTITIONED = 0, 1
 
