@@ -155,37 +155,36 @@ void ef_encode(EliasFano& e, uint64_t n, uint64_t u, bool leading_zero, Get get)
     d1_build(e.d1, e.high);
 }
 
-void rs_build(RsBitVector& r) {  // rs_bit_vector::build_indices(false), rs_bit_vector.hpp:120-157
-    const std::vector<uint64_t>& bits = r.bv.bits;
-    std::vector<uint64_t>& prs = r.block_rank_pairs;
-    prs.clear();
-    uint64_t next_rank = 0, cur_subrank = 0, subranks = 0;
-    prs.push_back(0);
-    for (uint64_t i = 0; i < bits.size(); ++i) {
-        uint64_t word_pop = (uint64_t)__builtin_popcountll(bits[i]);
-        uint64_t shift = i % 8;
-        if (shift) {
-            subranks <<= 9;
-            subranks |= cur_subrank;
-        }
-        next_rank += word_pop;
-        cur_subrank += word_pop;
-        if (shift == 7) {
-            prs.push_back(subranks);
-            prs.push_back(next_rank);
-            subranks = 0;
-            cur_subrank = 0;
-        }
+// Rank index of an rs_bit_vector, written from the layout the reader expects (the accessor side is
+// include/rs_bit_vector.hpp:27-36,108): one (u64, u64) pair per 512-bit block -- the number of ones before the block, then seven
+// 9-bit in-block prefix counts with the count before word j (j = 1..7) at bit (7 - j) * 9 -- and a closing (total ones, 0) pair.
+// A trailing partial block is treated as zero-padded.  Three passes: per-block popcounts, an exclusive scan over the blocks,
+// field packing; the first and last are independent per block.
+void rs_build(RsBitVector& r) {
+    const std::vector<uint64_t>& words = r.bv.bits;
+    const size_t nblocks = (words.size() + 7) / 8;
+    std::vector<uint64_t>& pairs = r.block_rank_pairs;
+    pairs.assign(2 * (nblocks + 1), 0);
+    for (size_t b = 0; b < nblocks; ++b) {  // pass 1: ones inside block b, parked in the slot of its absolute rank
+        const size_t end = std::min(words.size(), 8 * b + 8);
+        uint64_t ones = 0;
+        for (size_t w = 8 * b; w < end; ++w) ones += (uint64_t)__builtin_popcountll(words[w]);
+        pairs[2 * b] = ones;
     }
-    uint64_t left = 8 - bits.size() % 8;
-    for (uint64_t i = 0; i < left; ++i) {
-        subranks <<= 9;
-        subranks |= cur_subrank;
+    uint64_t before = 0;
+    for (size_t b = 0; b <= nblocks; ++b) {  // pass 2: exclusive scan; entry nblocks becomes the closing total
+        const uint64_t ones = pairs[2 * b];
+        pairs[2 * b] = before;
+        before += ones;
     }
-    prs.push_back(subranks);
-    if (bits.size() % 8) {
-        prs.push_back(next_rank);
-        prs.push_back(0);
+    for (size_t b = 0; b < nblocks; ++b) {  // pass 3: the seven in-block prefix counts
+        uint64_t packed = 0, inside = 0;
+        for (size_t j = 1; j < 8; ++j) {
+            const size_t w = 8 * b + j - 1;
+            if (w < words.size()) inside += (uint64_t)__builtin_popcountll(words[w]);
+            packed |= inside << ((7 - j) * 9);
+        }
+        pairs[2 * b + 1] = packed;
     }
     r.select_hints.clear();
 }

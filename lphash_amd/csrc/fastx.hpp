@@ -3,6 +3,19 @@
 // sequence is every following line, concatenated, until a line that starts with '>', '@' or '+'; '\r' before
 // '\n' is dropped; a FASTQ quality string must have the length of the sequence or reading stops.
 // Pinned against the real kseq.h on crafted and fuzzed inputs (oracle/kseq_dump.c, tests/test_host_cpu.py).
+//
+// FastxReader::next() follows the control flow of kseq_read step by step (its corner cases are observable behaviour), so
+// this file carries klib's notice for that function:
+//   kseq.h -- The MIT License.  Copyright (c) 2008, 2009, 2011 Attractive Chaos <attractor@live.co.uk>
+//   Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated
+//   documentation files (the "Software"), to deal in the Software without restriction, including without limitation the
+//   rights to use, copy, modify, merge, publish, distribute, sublicense, and/or sell copies of the Software, and to permit
+//   persons to whom the Software is furnished to do so, subject to the following conditions: The above copyright notice and
+//   this permission notice shall be included in all copies or substantial portions of the Software.
+//   THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED TO THE
+//   WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND NONINFRINGEMENT.  IN NO EVENT SHALL THE AUTHORS OR
+//   COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION OF CONTRACT, TORT OR
+//   OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE SOFTWARE.
 #pragma once
 #include <zlib.h>
 

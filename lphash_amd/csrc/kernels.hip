@@ -49,7 +49,15 @@ static inline int grid_for(size_t n, int per_block, int max_blocks) {
 
 hipError_t launch_query_packed(const lphq_image_header& H, const uint8_t* d_img, const void* d_kmers, size_t n, uint64_t* d_out, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    static const int max_blocks = getenv("LPHQ_PACKED_GRID") ? atoi(getenv("LPHQ_PACKED_GRID")) : (1 << 30);  // one k-mer per thread measured best (sweep: profiles/r01_packed_grid_sweep.txt); grid-stride beyond 2^30 blocks
+    // one k-mer per thread measured best (sweep: profiles/r01_packed_grid_sweep.txt).  HIP requires gridDim.x * blockDim.x < 2^32,
+    // so at most 2^24 - 1 workgroups of 256; larger batches use the kernel's grid-stride loop.  LPHQ_PACKED_GRID (tuning aid)
+    // can only lower the limit; values < 1 are ignored.
+    constexpr int kMaxBlocks = (1 << 24) - 1;
+    static const int max_blocks = [] {
+        const char* e = getenv("LPHQ_PACKED_GRID");
+        const long v = e ? atol(e) : 0;
+        return (v >= 1 && v < kMaxBlocks) ? (int)v : kMaxBlocks;
+    }();
     const int grid = grid_for(n, kBlock, max_blocks);
     LPHQ_DISPATCH(k_query_packed, <<<grid, kBlock, 0, stream>>>(H, d_img, (const uint64_t*)d_kmers, n, d_out));
     return hipGetLastError();
@@ -80,7 +88,9 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
     const int sblock = (!pipelined && (sblock_env == 128 || sblock_env == 512)) ? sblock_env : 256;
     const uint64_t tw = streaming ? stream_tile_windows(H.W, 4 * sblock) : kTileW;
     const uint64_t tiles = (span + tw - 1) / tw;
-    if (tiles > 0x7FFFFFFFull || n_records > 0xFFFFFFFFull) return hipErrorInvalidValue;  // 32-bit tile and record indices in the kernels
+    // one workgroup per tile: HIP requires gridDim.x * blockDim.x < 2^32 (<= 2^23 - 1 tiles of 512 threads, i.e. ~8 G bases
+    // per call); larger batches must be split by the caller (capi.cpp says so in the error text)
+    if (tiles > (0xFFFFFFFFull / 512u) || n_records > 0xFFFFFFFFull) return hipErrorInvalidValue;
     // the pipelined kernel is compiled without the >= 2^32 divisor path (device_query.cuh: mod_u64<WIDE = false>) and without
     // the empty-function early-out of the minimizer PHF
     auto narrow = [](const lphq_phf_desc& f) { return f.num_keys == 0 || (f.div_dense.d != 0 && f.div_sparse.d != 0 && f.div_table.d != 0); };
@@ -95,8 +105,13 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
         if (early) LPHQ_PIPE_LAUNCH(true);
         else LPHQ_PIPE_LAUNCH(false);
     } else if (streaming) {
-        static const uint32_t stop_after = getenv("LPHQ_PROFILE_STREAM_STOP") ? (uint32_t)atoi(getenv("LPHQ_PROFILE_STREAM_STOP")) : 0u;  // phase timing only
-#define LPHQ_STREAM_LAUNCH(B) LPHQ_DISPATCH_B(k_query_tiles_stream, B, <<<(int)tiles, B, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, stop_after))
+#ifdef LPHQ_PROFILE  // phase timing build only (never liblphq.so): return after phase N
+        static const uint32_t stop_after = getenv("LPHQ_PROFILE_STREAM_STOP") ? (uint32_t)atoi(getenv("LPHQ_PROFILE_STREAM_STOP")) : 0u;
+#define LPHQ_STOP_ARG , stop_after
+#else
+#define LPHQ_STOP_ARG
+#endif
+#define LPHQ_STREAM_LAUNCH(B) LPHQ_DISPATCH_B(k_query_tiles_stream, B, <<<(int)tiles, B, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out LPHQ_STOP_ARG))
         if (sblock == 128) LPHQ_STREAM_LAUNCH(128);
         else if (sblock == 512) LPHQ_STREAM_LAUNCH(512);
         else LPHQ_STREAM_LAUNCH(256);

@@ -10,8 +10,8 @@
 //
 // Wave64, 256-thread workgroups, one k-mer per lane / one tile per workgroup, so grids are >> 256 workgroups and all
 // 256 CUs / 8 XCDs are busy; no inter-workgroup communication, so placement is irrelevant to correctness.
-// Environment variables read once by the launchers are profiling / tuning aids only (LPHQ_PROFILE_STREAM_STOP,
-// LPHQ_STREAM_BLOCK, LPHQ_PACKED_GRID); defaults are the measured best (profiles/).
+// Environment variables read once by the launchers are tuning aids only (LPHQ_STREAM_BLOCK, LPHQ_PACKED_GRID: validated and
+// clamped, none changes a result); defaults are the measured best (profiles/).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -269,6 +269,16 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_random(const uint8_t* __
 //   F  every window: hval = base +- p (or the per-k-mer fallback lookup for colliding minimizers,
 //      partitioned_mphf.hpp:133-135), coalesced stores
 // Windows holding a non-ACGT base get LPHQ_INVALID (the reference emits nothing for them).
+// Phase timing (tools/pmc_stream_phases.sh) needs the kernel to return after a chosen phase.  That changes results, so it exists
+// only in a -DLPHQ_PROFILE build of this file (tools/ builds its own object); liblphq.so is compiled without it and has no
+// such parameter.
+#ifdef LPHQ_PROFILE
+#define LPHQ_STOP_PARAM , uint32_t stop_after
+#define LPHQ_STOP_AFTER(n) do { if (stop_after == (n)) return; } while (0)
+#else
+#define LPHQ_STOP_PARAM
+#define LPHQ_STOP_AFTER(n) do { } while (0)
+#endif
 constexpr int kStreamBlockDefault = 256;  // threads per workgroup of the streaming kernel; 4 m-mer positions per lane
 __host__ __device__ inline uint32_t stream_tile_windows(uint32_t W, int npos) { return (uint32_t)(npos - (int)W + 1) & ~15u; }
 
@@ -360,8 +370,8 @@ __device__ __forceinline__ void window_argmin4(const uint64_t* __restrict__ sm_h
 template <int KIND, bool K128, int P, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
                                                                 uint64_t shift, uint64_t total, const uint64_t* __restrict__ seq_off,
-                                                                const uint64_t* __restrict__ out_off, uint32_t n_records, uint64_t* __restrict__ out,
-                                                                uint32_t stop_after /* profiling aid: 0 = run everything */) {
+                                                                const uint64_t* __restrict__ out_off, uint32_t n_records, uint64_t* __restrict__ out
+                                                                LPHQ_STOP_PARAM) {
     const lphq_image_header& H = *(const lphq_image_header*)img;  // read from the image: 77 SGPRs instead of 112 -> 8 workgroups / CU (+11 %)
     constexpr int kStreamPos = 4 * BLOCK, NW = tile_words(kStreamPos), WPL = 4;
     constexpr int NBADW = (NW + 8) / 2 + 2;       // 32-bit words of the bad-base bitmask (1 bit per base)
@@ -410,7 +420,7 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
         if (b4) atomicOr(&sm_bad[d >> 3], b4 << (4 * (d & 7)));
     }
     __syncthreads();
-    if (stop_after == 1u) return;
+    LPHQ_STOP_AFTER(1);
 
     // ---- B: hashes of the m-mers starting at local positions 4*lane .. 4*lane+3 ----
     {
@@ -433,7 +443,7 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
         hash_pad<BLOCK>(sm_hash, threadIdx.x);
     }
     __syncthreads();
-    if (stop_after == 2u) return;
+    LPHQ_STOP_AFTER(2);
 
     // ---- C: leftmost minimum of 4 consecutive windows per lane ----
     {
@@ -474,7 +484,7 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
         *(uint2*)&sm_q[a] = make_uint2((uint32_t)qv[0] | ((uint32_t)qv[1] << 16), (uint32_t)qv[2] | ((uint32_t)qv[3] << 16));
     }
     __syncthreads();
-    if (stop_after == 3u) return;
+    LPHQ_STOP_AFTER(3);
 
     // ---- D: leaders -> queue (one LDS atomic per wave and round) ----
     const uint32_t lane = threadIdx.x & 63u;
@@ -490,7 +500,7 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
         if (leader) sm_queue[base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = qv;
     }
     __syncthreads();
-    if (stop_after == 4u) return;
+    LPHQ_STOP_AFTER(4);
 
     // ---- E: one lookup per super-k-mer, dense lanes ----
     const uint32_t nlead = sm_count;
@@ -503,7 +513,7 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
         sm_mode[q] = (uint8_t)c.mode;
     }
     __syncthreads();
-    if (stop_after == 5u) return;
+    LPHQ_STOP_AFTER(5);
 
     // ---- F: every window, lane-contiguous stores ----
     const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];

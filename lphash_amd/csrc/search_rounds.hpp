@@ -10,6 +10,7 @@
 //   void launch_advance(const search::SearchArgs&);
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -62,6 +63,15 @@ bool run_rounds(Dev& dev, SearchArgs a, uint64_t n_nonempty, uint32_t look_ahead
     // one wave per bucket of the largest commit window
     const int search_grid = (int)std::min<uint64_t>(look_ahead, n_nonempty);
     const int commit_grid = (int)((std::min<uint64_t>(8192u, n_nonempty) * (uint64_t)kWave + 255) / 256);
+    // Host-side bounds, independent of the control words the device writes: every round either commits >= 1 bucket or
+    // counts towards kMaxIdle, so a correct search needs at most n_nonempty + kMaxIdle rounds (C2: ~9 K for 1.9 M buckets);
+    // and a wall-clock limit (LPHQ_SEARCH_MAX_SECONDS, default 120 s; C4-scale searches take < 20 s).  On either the caller
+    // (builder.cpp) finishes with the sequential CPU search.
+    const uint64_t round_cap = n_nonempty + (uint64_t)c[kMaxIdle] + 64u;
+    double max_seconds = 120.0;
+    if (const char* e = getenv("LPHQ_SEARCH_MAX_SECONDS")) max_seconds = std::min(3600.0, std::max(1.0, atof(e)));
+    const auto t_start = std::chrono::steady_clock::now();
+    uint64_t enqueued = 0;
     for (;;) {
         for (uint32_t r = 0; r < rounds_per_sync; ++r) {
             dev.launch_search(a, search_grid);
@@ -84,6 +94,15 @@ bool run_rounds(Dev& dev, SearchArgs a, uint64_t n_nonempty, uint32_t look_ahead
             return false;
         }
         if (c[kDone]) return true;
+        enqueued += rounds_per_sync;
+        if (enqueued > round_cap) {
+            err = "gpu pilot search: round cap reached without completion";
+            return false;
+        }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > max_seconds) {
+            err = "gpu pilot search: wall-clock limit reached";
+            return false;
+        }
     }
 }
 

@@ -61,6 +61,13 @@ void orc_query_packed(const orc_index* idx, const uint64_t* kmers, size_t n, uin
 int orc_build(const char* const* contigs, const size_t* lengths, size_t n_contigs, int k, int m,
               uint64_t mm_seed, double c, int kind, int kmer_bits, const char* out_path);
 
+/* The reference's query driver, src/query.cpp:24-88 (lph_oracle_driver.c): both passes over a FASTA/FASTQ(.gz) file with inflate
+ * and record parsing inside the timers, one result vector per record.  Returns 0, or 2 if the file cannot be opened. */
+int orc_query_file(const orc_index* idx, const char* query_path, uint64_t* total_kmers_streaming, uint64_t* total_kmers_random,
+                   double* us_streaming, double* us_random);
+/* records / bases / FNV-1a digest of a file as the driver's reader sees it (pinned against the real kseq.h by the tests) */
+int orc_file_digest(const char* path, uint64_t* n_records, uint64_t* n_bases, uint64_t* digest);
+
 /* pieces exported for known-answer / model tests */
 uint64_t orc_murmur64a(const void* key, size_t len, uint64_t seed);
 uint64_t orc_minimizer_order(const orc_index* idx, uint64_t minimizer); /* PTHash over minimizers */

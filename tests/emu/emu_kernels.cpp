@@ -51,8 +51,8 @@ extern "C" int emu_kernel_query_records(const uint8_t* img, size_t nbytes, const
         const unsigned tiles = (unsigned)((span + tw - 1) / tw);
 #define CALL(KIND, K128, P)                                                                                                                             \
     do {                                                                                                                                                \
-        if (block == 128) emu::launch(tiles, 128, [&] { k_query_tiles_stream<KIND, K128, P, 128>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0u); }); \
-        else emu::launch(tiles, 256, [&] { k_query_tiles_stream<KIND, K128, P, 256>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0u); });              \
+        if (block == 128) emu::launch(tiles, 128, [&] { k_query_tiles_stream<KIND, K128, P, 128>(img, seq_al, shift, total, seq_off, out_off, n_records, out); }); \
+        else emu::launch(tiles, 256, [&] { k_query_tiles_stream<KIND, K128, P, 256>(img, seq_al, shift, total, seq_off, out_off, n_records, out); });              \
     } while (0)
         EMU_DISPATCH(CALL);
 #undef CALL

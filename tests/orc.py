@@ -32,6 +32,10 @@ def _lib():
     lib.orc_build.restype = C.c_int
     lib.orc_build.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int,
                               C.c_uint64, C.c_double, C.c_int, C.c_int, C.c_char_p]
+    lib.orc_query_file.restype = C.c_int
+    lib.orc_query_file.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.orc_file_digest.restype = C.c_int
+    lib.orc_file_digest.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.orc_murmur64a.restype = C.c_uint64
     lib.orc_murmur64a.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64]
     lib.orc_minimizer_order.restype = C.c_uint64
@@ -50,6 +54,14 @@ def build(contigs, k, m, out_path, kind=PARTITIONED, kmer_bits=64, mm_seed=42, c
     rc = lib.orc_build(arr, lens, n, k, m, mm_seed, c, kind, kmer_bits, out_path.encode())
     if rc != 0:
         raise RuntimeError(lib.orc_last_error().decode())
+
+
+def file_digest(path):
+    """(records, bases, FNV-1a digest) of a FASTA/FASTQ(.gz) file as the oracle driver's reader parses it."""
+    a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    if lib.orc_file_digest(path.encode(), C.byref(a), C.byref(b), C.byref(c)) != 0:
+        raise RuntimeError("cannot open " + path)
+    return a.value, b.value, c.value
 
 
 class Index:
@@ -80,6 +92,14 @@ class Index:
         out = np.empty(n, dtype=np.uint64)
         lib.orc_query_packed(self.h, kmers.ctypes.data, n, out.ctypes.data)
         return out
+
+    def query_file(self, path):
+        """The reference's driver (src/query.cpp:24-88): returns (k-mers streaming, k-mers random, us streaming, us random)."""
+        ns, nr, us, ur = C.c_uint64(), C.c_uint64(), C.c_double(), C.c_double()
+        rc = lib.orc_query_file(self.h, path.encode(), C.byref(ns), C.byref(nr), C.byref(us), C.byref(ur))
+        if rc != 0:
+            raise RuntimeError(f"Unable to open the input file {path}")
+        return ns.value, nr.value, us.value, ur.value
 
     def minimizer_order(self, mm):
         return lib.orc_minimizer_order(self.h, mm)

@@ -1,5 +1,7 @@
 #!/bin/bash
-# Per-phase instruction counts of k_query_tiles_stream (LPHQ_PROFILE_STREAM_STOP = 1..5, 0 = all)
+# Per-phase instruction counts of k_query_tiles_stream (LPHQ_PROFILE_STREAM_STOP = 1..5, 0 = all).
+# Needs a PROFILING build of the library: make -C lphash_amd/csrc clean && make -C lphash_amd/csrc PROFILE=1 (the shipped
+# liblphq.so has no stop switch); rebuild without PROFILE=1 afterwards.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 for s in 1 2 3 4 5 0; do

@@ -6,8 +6,7 @@
 #   2. bench.py: C2 random (headline line, with cpu_baseline), C3 streaming default, C3 streaming pipelined, C5, the two
 #      secondary workloads of SURVEY 8(d) (50 % non-member probes; shuffled records) and the HBM copy/read/write probe
 #   3. rocprofv3 --kernel-trace --stats of the C2 and C3 commands -> kernel summaries (tools/rocpd_summary.py)
-#   4. tools/stream_pipeline_sweep.sh
-#   5. index build time with the GPU pilot search (1 vs 16 rounds per host read-back) and the byte comparison with the CPU search
+# QUERY PATH ONLY (SURVEY 8 a-e).  Construction code and opt-in kernels run in a separate, later call: tools/round_next.sh.
 # Copy what is to be judged from gpurun_out/<tag>/ into profiles/ afterwards.
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -18,14 +17,13 @@ cd "$R"
 step() { echo "[$(date +%H:%M:%S)] $*" | tee -a "$O/log.txt"; }
 
 step "1. gpu test suite"
-timeout 1500 python -m pytest tests -m gpu -x -q > "$O/pytest_gpu.txt" 2>&1
+timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > "$O/pytest_gpu.txt" 2>&1
 echo "exit code $?" >> "$O/pytest_gpu.txt"
 tail -3 "$O/pytest_gpu.txt" | tee -a "$O/log.txt"
 
 step "2. bench lines"
 timeout 900 python bench.py > "$O/bench_c2_random.json" 2> "$O/bench_c2_random.err" || step "C2 bench failed"
 timeout 600 python bench.py --mode stream --no-cpu-baseline > "$O/bench_c3_stream.json" 2> "$O/bench_c3_stream.err" || step "C3 bench failed"
-timeout 600 python bench.py --mode stream --stream-pipeline --no-cpu-baseline > "$O/bench_c3_stream_pipe.json" 2> "$O/bench_c3_stream_pipe.err" || step "C3 pipelined bench failed"
 timeout 600 python bench.py --kind u --no-cpu-baseline > "$O/bench_c5_unpartitioned.json" 2> "$O/bench_c5_unpartitioned.err" || step "C5 bench failed"
 timeout 600 python bench.py --nonmember-frac 0.5 --no-cpu-baseline > "$O/bench_c2_random_half_nonmembers.json" 2> "$O/bench_c2_random_half_nonmembers.err" || step "C2 non-member bench failed"
 timeout 600 python bench.py --mode stream --shuffle-records --no-cpu-baseline > "$O/bench_c3_stream_shuffled.json" 2> "$O/bench_c3_stream_shuffled.err" || step "C3 shuffled bench failed"
@@ -37,22 +35,11 @@ step "3. kernel traces"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d "$O/prof_c2" -o c2 -- python3 "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$O/prof_c2.json" 2> "$O/prof_c2.err"
 timeout 600 rocprofv3 --kernel-trace --stats -d "$O/prof_c3" -o c3 -- python3 "$R/bench.py" --mode stream --steps 20 --warmup 3 --no-cpu-baseline > "$O/prof_c3.json" 2> "$O/prof_c3.err"
-LPHQ_STREAM_PIPELINE=1 timeout 600 rocprofv3 --kernel-trace --stats -d "$O/prof_c3_pipe" -o c3p -- python3 "$R/bench.py" --mode stream --steps 20 --warmup 3 --no-cpu-baseline > "$O/prof_c3_pipe.json" 2> "$O/prof_c3_pipe.err"
 cd "$R"
-for t in c2 c3 c3_pipe; do
+for t in c2 c3; do
     db=$(find "$O/prof_$t" -name '*_results.db' | head -1)
     [ -n "$db" ] && python3 tools/rocpd_summary.py "$db" "$O/${t}_kernel_stats.txt" > /dev/null && head -4 "$O/${t}_kernel_stats.txt" | cut -c1-150 | tee -a "$O/log.txt"
     rm -rf "$O/prof_$t"   # the rocpd databases are large; the summaries are what is kept
 done
 
-step "4. pipeline sweep"
-timeout 1500 bash tools/stream_pipeline_sweep.sh > "$O/sweep_stdout.txt" 2>&1
-cp gpurun_out/stream_pipe_sweep.txt gpurun_out/stream_pipe_sweep_summary.txt "$O/" 2> /dev/null
-step "5. index build: GPU pilot search, 1 vs 16 rounds per host read-back; CPU search for the byte comparison"
-for rps in 1 16; do
-    LPHQ_BUILD_VERBOSE=1 LPHQ_SEARCH_ROUNDS_PER_SYNC=$rps timeout 600 python tools/gpu_build_time.py 1000 31 > "$O/build_rps$rps.txt" 2>&1 || step "build (rounds per sync $rps) failed"
-    grep -E "gpu-search build|gpu pilot search" "$O/build_rps$rps.txt" | tee -a "$O/log.txt"
-done
-timeout 900 python tools/gpu_build_time.py 1000 31 --cpu > "$O/build_cpu_compare.txt" 2>&1 || step "cpu comparison build failed"
-tail -1 "$O/build_cpu_compare.txt" | tee -a "$O/log.txt"
 step "done"
