@@ -24,12 +24,6 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-import lphash_amd as L  # noqa: E402
-from lphash_amd.synth import synthetic_records  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 
 
@@ -37,19 +31,66 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def algorithmic_bytes_per_lookup(h, mode, k, W):
+def algorithmic_bytes_per_lookup(h, mode, k, W, partitioned):
     """bytes of the reference's structures one lookup must touch, each word once at
-    natural width, + the compulsory input/output stream; recomputed from this index's measured type mix."""
+    natural width, + the compulsory input/output stream; recomputed from this index's measured type mix.
+    Partitioned: PTHash ranks word 8 + free-slot EF 26 * P(free) + wavelet tree 48 + EF by type (LEFT 26, RIGHT 34, NONE 60).
+    Unpartitioned (query-u): PTHash 8 + 26 * P(free) + sizes.pair 34 + positions.diff 34."""
     info = h.info
     nk = info.num_kmers
-    f_l, f_r, f_max, f_n = (info.kmers_by_type[i] / nk for i in range(4))
     p_free = 1.0 - info.distinct_minimizers / info.minimizer_table_size
-    chain = 8 + 26 * p_free + 48 + 26 * f_l + 34 * f_r + 60 * f_n
+    if partitioned:
+        f_l, f_r, f_max, f_n = (info.kmers_by_type[i] / nk for i in range(4))
+        chain = 8 + 26 * p_free + 48 + 26 * f_l + 34 * f_r + 60 * f_n
+        mix = {"maximal": round(f_max, 4), "left": round(f_l, 4), "right": round(f_r, 4), "none": round(f_n, 4)}
+    else:
+        chain = 8 + 26 * p_free + 34 + 34
+        mix = None
     kmer_bytes = 8 if k <= 31 else 16
-    mix = {"maximal": round(f_max, 4), "left": round(f_l, 4), "right": round(f_r, 4), "none": round(f_n, 4)}
     if mode == "random":
         return kmer_bytes + 8 + chain, chain, mix
     return 1 + 8 + chain / ((W + 1) / 2.0), chain, mix
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a CHILD process (this
+    process never touches the GPU), relay rank 0's JSON line and exit with the children's code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    log("[bench] WORLD_SIZE unset and --gpus", n, "-> launching", " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def hbm_ceiling_gbs(torch, dev):
+    """Practical HBM ceiling of this box, measured in-run: read-only pass and device-to-device copy over 2-GiB
+    buffers (far beyond the 256-MiB Infinity Cache).  Returns (read GB/s, copy read+write GB/s)."""
+    n = (2 << 30) // 8
+    x = torch.ones(n, dtype=torch.int64, device=dev)
+    y = torch.empty_like(x)
+
+    def timed(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps / 1e3
+
+    t_read = timed(lambda: x.sum())
+    t_copy = timed(lambda: y.copy_(x))
+    del x, y
+    return n * 8 / t_read / 1e9, 2 * n * 8 / t_copy / 1e9
 
 
 def main():
@@ -75,7 +116,18 @@ def main():
     ap.add_argument("--stream-pipeline", action="store_true",
                     help="stream mode: use the opt-in software-pipelined kernel (sets LPHQ_STREAM_PIPELINE=1; see kernels_stream_pipe.cuh)")
     ap.add_argument("--cache-dir", default=os.environ.get("LPHQ_BENCH_CACHE", "/tmp/lphq_bench_cache"))
+    ap.add_argument("--no-hbm-probe", action="store_true", help="skip the in-run measurement of the HBM copy ceiling (roofline.peak_measured)")
+    ap.add_argument("--b1-records", type=int, default=300,
+                    help="records of the index set the reference-faithful driver baseline (B1: gz + parse inside the timer) reads; 0 = skip")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # before anything initialises the GPU in this process
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    global np, torch, L, synthetic_records
+    import numpy as np
+    import torch
+
+    import lphash_amd as L
+    from lphash_amd.synth import synthetic_records
     if args.stream_pipeline:
         os.environ["LPHQ_STREAM_PIPELINE"] = "1"  # read by the launcher at its first streaming launch
 
@@ -83,7 +135,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+        log(f"[bench] ERROR: WORLD_SIZE={world} but --gpus {args.gpus}")
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the query path has no CPU fallback"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -134,17 +187,13 @@ def main():
         dist.barrier()  # the index file exists and rank 0 is attached
         torch.cuda.synchronize()
         t0 = time.time()
-        try:
-            image_t = broadcast_image(h.image() if rank == 0 else None, dist, dev, src=0)  # RCCL over xGMI: the only collective of the job
-            torch.cuda.synchronize()
-            bcast_s = time.time() - t0
-            if rank != 0:
-                h = cls.from_device_image(image_t.data_ptr(), image_t.numel(), local_rank)
-            log(f"[bench r{rank}] image broadcast {image_t.numel() / 1e6:.1f} MB in {bcast_s * 1e3:.1f} ms")
-        except Exception as e:  # noqa: BLE001  -- distribution fallback only (all ranks share the node-local cache); compute is unchanged
-            log(f"[bench r{rank}] RCCL image broadcast failed ({e!r}); loading the image from {path} instead")
-            if rank != 0:
-                h = cls.load(path, kmer_bits=kmer_bits, device=local_rank)
+        # RCCL over xGMI: the only collective of the job.  No fallback: a failure ends this rank (and, through the launcher, the job)
+        image_t = broadcast_image(h.image() if rank == 0 else None, dist, dev, src=0)
+        torch.cuda.synchronize()
+        bcast_s = time.time() - t0
+        if rank != 0:
+            h = cls.from_device_image(image_t.data_ptr(), image_t.numel(), local_rank)
+        log(f"[bench r{rank}] image broadcast {image_t.numel() / 1e6:.1f} MB in {bcast_s * 1e3:.1f} ms")
 
     stream = torch.cuda.current_stream().cuda_stream
     d_seq = torch.from_numpy(flat).to(dev)
@@ -221,6 +270,8 @@ def main():
     # ---- parity of what was just measured + CPU baseline (oracle = checker, rank 0, N=1 only) ----
     cpu = None
     cpu_all = None
+    cpu_b1 = None
+    cli_b1 = None
     parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -265,12 +316,50 @@ def main():
             parity = parity and bool(full.max() < nk)  # positive probes: every code is a valid slot
         log(f"[bench] cpu oracle: {S / cpu_s / 1e6:.2f} M lookups/s on {S} units; GPU == oracle on the sample: {parity}")
         assert parity, "GPU results differ from the oracle"
+        if args.b1_records > 0:
+            # BASELINE.md B1, "the number the reference tool would print": the oracle's restatement of src/query.cpp:24-88 over a
+            # .fa.gz of the first records of the index set -- one thread, inflate + record parsing inside the timers, one result
+            # vector per record, streaming pass then random pass.  Beside it the product's own `lphash query-*` on the same file
+            # (same CSV, PCIe and parsing included): the drop-in comparison, never the reported `value`.
+            import gzip
+            import subprocess
+
+            nb1 = min(n_records, args.b1_records)
+            fa = os.path.join(args.cache_dir, f"b1_seed1_k{k}_r{nb1}.fa.gz")
+            if not os.path.exists(fa):
+                with gzip.open(fa + ".tmp", "wb", compresslevel=6) as f:
+                    for i in range(nb1):
+                        f.write(b">s%d\n" % i)
+                        f.write(recs[i])
+                        f.write(b"\n")
+                os.replace(fa + ".tmp", fa)
+            n_s, n_r, us_s, us_r = o.query_file(fa)
+            assert n_s == n_r == nb1 * (rec_len - k + 1)
+            cpu_b1 = {"value": n_r / (us_r * 1e-6), "unit": "k-mer lookups/s", "cores": 1, "kind": "port",
+                      "streaming_ns_per_kmer": us_s * 1e3 / n_s, "random_ns_per_kmer": us_r * 1e3 / n_r,
+                      "sample": f"oracle restatement of the reference driver (src/query.cpp:24-88) on a .fa.gz of the first {nb1} index records "
+                                f"({n_s} k-mers per pass); gz inflate + parse inside the timers; value = random pass"}
+            exe = os.path.join(ROOT, "lphash_amd", "lphash")
+            if os.path.exists(exe):
+                r = subprocess.run([exe, "query-p" if kind == L.PARTITIONED else "query-u", "-i", path, "-q", fa, "--kmer-bits", str(kmer_bits)],
+                                   capture_output=True, text=True, timeout=600)
+                f5 = r.stdout.strip().split(",")
+                if r.returncode == 0 and len(f5) == 5 and int(f5[2]) == n_s:
+                    cli_b1 = {"streaming_ns_per_kmer": float(f5[3]), "random_ns_per_kmer": float(f5[4]), "kmers": int(f5[2]),
+                              "note": "lphash query-* (this repo's CLI, GPU path) on the same .fa.gz: host parse + PCIe included"}
+                else:
+                    log(f"[bench] CLI run failed ({r.returncode}): {r.stderr[-500:]}")
+            log(f"[bench] B1 reference-faithful driver: {cpu_b1['streaming_ns_per_kmer']:.1f} / {cpu_b1['random_ns_per_kmer']:.1f} ns per k-mer (streaming / random); CLI: {cli_b1}")
 
     if rank == 0:
-        bpl, chain, mix = algorithmic_bytes_per_lookup(h, args.mode, k, W) if kind == L.PARTITIONED else (None, None, None)
+        bpl, chain, mix = algorithmic_bytes_per_lookup(h, args.mode, k, W, kind == L.PARTITIONED)
+        cfg_name = ("C4" if k > 31 else ("C2" if args.mode == "random" else "C3")) if kind == L.PARTITIONED else "C5"
+        peak_read = peak_copy = None
+        if not args.no_hbm_probe:
+            peak_read, peak_copy = hbm_ceiling_gbs(torch, dev)
         value = world * units * args.steps / elapsed
         out = {
-            "metric": "k-mer lookups/sec (whole node), k=31 partitioned MPHF" if args.mode == "random" else "k-mer lookups/sec (whole node), streaming",
+            "metric": f"k-mer lookups/sec (whole node), k={k} {'partitioned' if kind == L.PARTITIONED else 'unpartitioned'} MPHF" + ("" if args.mode == "random" else ", streaming"),
             "value": value,
             "unit": "k-mer lookups/s",
             "n_gpus": world,
@@ -283,7 +372,7 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": ("C2: partitioned" if kind == L.PARTITIONED else "C5: unpartitioned")
+                "workload": cfg_name + (": partitioned" if kind == L.PARTITIONED else ": unpartitioned")
                 + f" LP-MPHF k={k} m={m}, {nk} k-mers (SplitMix64 seed 1, {n_records} records x {rec_len} bases); "
                 + ((f"2^{args.batch_log2} random positive packed k-mer lookups per GPU per step" if args.nonmember_frac == 0.0 else
                     f"2^{args.batch_log2} random packed k-mer lookups per GPU per step, {args.nonmember_frac:.0%} of them uniformly random non-members")
@@ -294,6 +383,7 @@ def main():
             },
             "kernel_ms": kernel_ms,
             "parity_vs_oracle": parity,
+            "rccl_ranks": int(dist.get_world_size()) if dist is not None else 1,
         }
         traffic = None
         try:  # HBM bytes per launch from the committed PMC passes of this exact workload (never measured inside this run)
@@ -308,11 +398,17 @@ def main():
         if bpl is not None:
             achieved = bpl * units / (kernel_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                               "peak_measured": peak_read, "peak_measured_copy": peak_copy,
+                               "frac_of_measured": (achieved / peak_read) if peak_read else None,
                                "traffic": traffic, "bytes_per_lookup": bpl, "kernel": "k_query_packed" if args.mode == "random" else ("k_query_tiles_stream_pipe" if os.environ.get("LPHQ_STREAM_PIPELINE", "0") not in ("", "0") else "k_query_tiles_stream")}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if cpu_all is not None:
             out["cpu_baseline_all_cores"] = cpu_all
+        if cpu_b1 is not None:
+            out["cpu_baseline_reference_driver"] = cpu_b1
+        if cli_b1 is not None:
+            out["cli_end_to_end"] = cli_b1
         if build_s is not None:
             out["index_build_s"] = build_s
         if bcast_s is not None:

@@ -357,6 +357,7 @@ def test_readers_against_the_real_kseq(tmp_path):
         ser = subprocess.run([exe, "records", "-i", str(p), "--serial"], capture_output=True, text=True).stdout.strip().split(",")[:3]
         par = subprocess.run([exe, "records", "-i", str(p), "-t", "4", "--min-piece", "1", "--batch-bytes", str(1 + 37 * i)], capture_output=True,
                              text=True).stdout.strip().split(",")[:3]
+        assert ",".join(str(v) for v in orc.file_digest(str(p))) == want, (i, "oracle driver reader", want, data[:120])
         assert ",".join(ser) == want, (i, "serial", ser, want, data[:120])
         assert ",".join(par) == want, (i, "parallel", par, want, data[:120])
 

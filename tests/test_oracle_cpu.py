@@ -127,3 +127,32 @@ def test_load_rejects_garbage(tmp_path, golden_dir):
         orc.Index(str(p), 0, 64)
     with pytest.raises(RuntimeError):
         orc.Index(os.path.join(golden_dir, "p_k31_m20_b64.lph"), 1, 64)  # wrong kind
+
+
+def test_reference_driver_restatement(tmp_path):
+    """orc_query_file = the reference's query driver (src/query.cpp:24-88): both passes over a .fa.gz / FASTQ, counts equal the sum of the
+    per-record operator() sizes, timers are positive, a missing file gives the driver's exit code 2."""
+    import gzip
+
+    recs = random_records(77, 12, 20, 3000)
+    path = str(tmp_path / "t.lph")
+    orc.build(recs, 31, 20, path)
+    ix = orc.Index(path, 0, 64)
+    fa = tmp_path / "q.fa.gz"
+    with gzip.open(fa, "wb") as f:
+        for i, r in enumerate(recs):
+            f.write(b">r%d some comment\n" % i)
+            for j in range(0, len(r), 61):
+                f.write(r[j:j + 61] + b"\n")
+    fq = tmp_path / "q.fastq"
+    with open(fq, "wb") as f:
+        for i, r in enumerate(recs[:5]):
+            f.write(b"@q%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)))
+    for p, rr in ((fa, recs), (fq, recs[:5])):
+        n_s, n_r, us_s, us_r = ix.query_file(str(p))
+        want = sum(max(0, len(r) - 30) for r in rr)
+        assert n_s == n_r == want and us_s > 0 and us_r > 0
+        nrec, nbases, _ = orc.file_digest(str(p))
+        assert nrec == len(rr) and nbases == sum(len(r) for r in rr)
+    with pytest.raises(RuntimeError):
+        ix.query_file(str(tmp_path / "missing.fa"))
