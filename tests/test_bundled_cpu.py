@@ -68,3 +68,32 @@ def test_readme_build_examples(tmp_path, name, k, m, bits, tool):
         assert len(q) == 1 and len(q[0]) == 4857450  # 1 record, 4,857,450 bases -> 4,857,420 k-mers per pass
         a, b = o(q[0], True), o(q[0], False)
         assert len(a) == 4857420 and np.array_equal(a, b)
+
+
+def test_c1_query_p_bundled_k31_m20(tmp_path):
+    """BASELINE.json configs[0] ("C1") as configured: build-p on data/unitigs_stitched/se.ust.k31.fa.gz with k=31 m=20, then the reference's
+    query driver (src/query.cpp:24-88, oracle restatement: gz inflate + kseq parsing + both passes) on data/queries/salmonella_enterica.fasta.gz.
+    Census of SURVEY 8(c) (computed there independently with numpy): 4,933,494 k-mers, 758,441 distinct minimizers, 14,084 k-mers in the
+    fallback function; the codes of the index set are a bijection onto [0, n) and both passes agree; the driver reads 1 record ->
+    4,857,420 k-mers per pass."""
+    exe = os.path.join(ROOT, "lphash_amd", "lphash")
+    src = os.path.join(DATA, "unitigs_stitched", "se.ust.k31.fa.gz")
+    qry = os.path.join(DATA, "queries", "salmonella_enterica.fasta.gz")
+    out = tmp_path / "se_k31_m20.lph"
+    r = subprocess.run([exe, "build-p", "-i", src, "-k", "31", "-m", "20", "-o", str(out), "--kmer-bits", "64", "--cpu", "-t", "8"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    o = orc.Index(str(out), orc.PARTITIONED, 64)
+    assert (o.nkmers, o.distinct_minimizers, o.fallback_keys) == (4_933_494, 758_441, 14_084)
+    recs = fasta_records(src)
+    assert len(recs) == 611 and sum(len(x) for x in recs) == 4_951_824  # BASELINE.md section 3, C1
+    seen = np.zeros(o.nkmers, dtype=np.uint8)
+    for x in recs:
+        s = o(x, True)
+        assert np.array_equal(s, o(x, False)) and int(s.max()) < o.nkmers and not seen[s].any()
+        seen[s] = 1
+    assert seen.all()
+    assert orc.file_digest(qry)[:2] == (1, 4_857_450)
+    n_s, n_r, us_s, us_r = o.query_file(qry)
+    assert n_s == n_r == 4_857_420 and us_s > 0 and us_r > 0
+    q = fasta_records(qry)[0]
+    assert np.array_equal(o(q, True), o(q, False))
