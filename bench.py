@@ -113,8 +113,6 @@ def main():
     ap.add_argument("--nonmember-frac", type=float, default=0.0,
                     help="random mode: this fraction of the probes are uniformly random k-mers (non-members; SURVEY 8(d) secondary run)")
     ap.add_argument("--shuffle-records", action="store_true", help="stream mode: the index records in a random order (SURVEY 8(d) variant)")
-    ap.add_argument("--stream-pipeline", action="store_true",
-                    help="stream mode: use the opt-in software-pipelined kernel (sets LPHQ_STREAM_PIPELINE=1; see kernels_stream_pipe.cuh)")
     ap.add_argument("--cache-dir", default=os.environ.get("LPHQ_BENCH_CACHE", "/tmp/lphq_bench_cache"))
     ap.add_argument("--no-hbm-probe", action="store_true", help="skip the in-run measurement of the HBM copy ceiling (roofline.peak_measured)")
     ap.add_argument("--b1-records", type=int, default=300,
@@ -128,8 +126,6 @@ def main():
 
     import lphash_amd as L
     from lphash_amd.synth import synthetic_records
-    if args.stream_pipeline:
-        os.environ["LPHQ_STREAM_PIPELINE"] = "1"  # read by the launcher at its first streaming launch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -389,9 +385,8 @@ def main():
         try:  # HBM bytes per launch from the committed PMC passes of this exact workload (never measured inside this run)
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             key = f"{args.mode}|{args.kind}|k{k}|m{m}|n{nk}|b{args.batch_log2 if args.mode == 'random' else 0}"
-            pipelined = args.mode == "stream" and os.environ.get("LPHQ_STREAM_PIPELINE", "0") not in ("", "0")
             variant = args.nonmember_frac != 0.0 or rec_order is not None
-            if key in tj and not pipelined and not variant:  # (counter passes exist for the default kernels on the primary workloads only)
+            if key in tj and not variant:  # (counter passes exist for the default kernels on the primary workloads only)
                 traffic = tj[key]["bytes_per_unit"] * units
         except (OSError, ValueError, KeyError):
             pass
@@ -400,7 +395,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                "peak_measured": peak_read, "peak_measured_copy": peak_copy,
                                "frac_of_measured": (achieved / peak_read) if peak_read else None,
-                               "traffic": traffic, "bytes_per_lookup": bpl, "kernel": "k_query_packed" if args.mode == "random" else ("k_query_tiles_stream_pipe" if os.environ.get("LPHQ_STREAM_PIPELINE", "0") not in ("", "0") else "k_query_tiles_stream")}
+                               "traffic": traffic, "bytes_per_lookup": bpl, "kernel": "k_query_packed" if args.mode == "random" else "k_query_tiles_stream"}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if cpu_all is not None:

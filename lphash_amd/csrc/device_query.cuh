@@ -38,7 +38,7 @@ __device__ __forceinline__ uint32_t div_step(uint32_t r, uint32_t u, uint32_t dn
 // Exact a % d.  pthash fastmod::fastmod_u64(a, M, d) is the exact remainder for all 64-bit a, d; the
 // 128-bit M of the file is replaced by a 32-bit reciprocal when d < 2^32 (always, for < 4 G keys).
 // WIDE = false drops the >= 2^32 divisor path (a software 64-bit division: ~450 instructions and ~15 VGPRs per inlined
-// copy); only for callers that checked d != 0 on the host (launch_query_records does for the pipelined kernel).
+// copy); only for callers that checked d != 0 on the host.
 template <bool WIDE = true>
 __device__ __forceinline__ uint64_t mod_u64(uint64_t a, uint32_t d, uint32_t dn, uint32_t inv, uint32_t shift, uint64_t d64) {
     if (!WIDE || d) {
@@ -59,7 +59,7 @@ __device__ __forceinline__ uint64_t mod_u64(uint64_t a, const lphq_divisor& dv) 
 //   p < num_keys ? p : free_slots[p - num_keys]
 // Device layout: hp[code] = H(pilot) precomputed; free_slots is a plain u32 table.
 // The chain is three dependent gathers; it is written as issue / consume stages so that a caller can put other work
-// between a stage's load and the next stage's use of it (the pipelined streaming kernel does; phf_position() is the
+// between a stage's load and the next stage's use of it (phf_position() is the
 // stages back to back).
 struct PhfRank {       // where the codeword of a bucket sits
     uint32_t sh;       // bit offset of the codeword within the two dwords loaded by phf_load_code

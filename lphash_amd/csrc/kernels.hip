@@ -6,7 +6,6 @@
 
 #include "kernels.hpp"
 #include "kernels_device.cuh"
-#include "kernels_stream_pipe.cuh"
 
 namespace lphq {
 
@@ -84,27 +83,13 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
     const uint8_t* seq_al = (const uint8_t*)d_seq - shift;
     const uint64_t span = shift + total_bases;
     static const int sblock_env = getenv("LPHQ_STREAM_BLOCK") ? atoi(getenv("LPHQ_STREAM_BLOCK")) : kStreamBlockDefault;  // tuning aid
-    static const bool pipelined = getenv("LPHQ_STREAM_PIPELINE") && atoi(getenv("LPHQ_STREAM_PIPELINE")) > 0;  // opt-in, see kernels_stream_pipe.cuh
-    const int sblock = (!pipelined && (sblock_env == 128 || sblock_env == 512)) ? sblock_env : 256;
+    const int sblock = (sblock_env == 128 || sblock_env == 512) ? sblock_env : 256;
     const uint64_t tw = streaming ? stream_tile_windows(H.W, 4 * sblock) : kTileW;
     const uint64_t tiles = (span + tw - 1) / tw;
     // one workgroup per tile: HIP requires gridDim.x * blockDim.x < 2^32 (<= 2^23 - 1 tiles of 512 threads, i.e. ~8 G bases
     // per call); larger batches must be split by the caller (capi.cpp says so in the error text)
     if (tiles > (0xFFFFFFFFull / 512u) || n_records > 0xFFFFFFFFull) return hipErrorInvalidValue;
-    // the pipelined kernel is compiled without the >= 2^32 divisor path (device_query.cuh: mod_u64<WIDE = false>) and without
-    // the empty-function early-out of the minimizer PHF
-    auto narrow = [](const lphq_phf_desc& f) { return f.num_keys == 0 || (f.div_dense.d != 0 && f.div_sparse.d != 0 && f.div_table.d != 0); };
-    if (streaming && pipelined && H.mm.num_keys > 0 && narrow(H.mm) && narrow(H.fb)) {
-        // persistent workgroups, tile = blockIdx.x + i * gridDim.x; ~18 KB LDS and < 96 VGPRs -> 5 workgroups per CU
-        static const int wgs_per_cu = getenv("LPHQ_STREAM_PIPE_WGS") ? std::max(1, atoi(getenv("LPHQ_STREAM_PIPE_WGS"))) : 5;
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        const int grid = (int)std::min<uint64_t>(tiles, (uint64_t)cus * (uint64_t)wgs_per_cu);
-        static const bool early = !(getenv("LPHQ_STREAM_PIPE_EARLY") && atoi(getenv("LPHQ_STREAM_PIPE_EARLY")) == 0);
-#define LPHQ_PIPE_LAUNCH(E) LPHQ_DISPATCH_B(k_query_tiles_stream_pipe, 256 LPHQ_COMMA E, <<<grid, 256, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, (uint32_t)tiles))
-        if (early) LPHQ_PIPE_LAUNCH(true);
-        else LPHQ_PIPE_LAUNCH(false);
-    } else if (streaming) {
+    if (streaming) {
 #ifdef LPHQ_PROFILE  // phase timing build only (never liblphq.so): return after phase N
         static const uint32_t stop_after = getenv("LPHQ_PROFILE_STREAM_STOP") ? (uint32_t)atoi(getenv("LPHQ_PROFILE_STREAM_STOP")) : 0u;
 #define LPHQ_STOP_ARG , stop_after

@@ -3,7 +3,6 @@
 #include <cstring>
 
 #include "kernels_device.cuh"  // -Itests/emu resolves <hip/hip_runtime.h> to the stub
-#include "kernels_stream_pipe.cuh"
 
 using namespace lphq;
 
@@ -62,28 +61,6 @@ extern "C" int emu_kernel_query_records(const uint8_t* img, size_t nbytes, const
         EMU_DISPATCH(CALL);
 #undef CALL
     }
-    return 0;
-}
-
-// the software-pipelined streaming kernel with `grid` persistent workgroups (grid < tiles exercises the double buffering)
-extern "C" int emu_kernel_query_records_pipe(const uint8_t* img, size_t nbytes, const char* seq, uint64_t total, const uint64_t* seq_off, const uint64_t* out_off,
-                                             uint32_t n_records, uint64_t* out, unsigned grid, int early) {
-    lphq_image_header H;
-    if (!header(img, nbytes, H)) return 1;
-    if (n_records == 0 || total < H.k) return 0;
-    const uint64_t shift = (uint64_t)((uintptr_t)seq & 15u);
-    const uint8_t* seq_al = (const uint8_t*)seq - shift;
-    const uint64_t span = shift + total;
-    const uint64_t tw = stream_tile_windows(H.W, 4 * 256);
-    const unsigned tiles = (unsigned)((span + tw - 1) / tw);
-    if (grid == 0 || grid > tiles) grid = tiles;
-#define CALL(KIND, K128, P)                                                                                                                                       \
-    do {                                                                                                                                                          \
-        if (early) emu::launch(grid, 256, [&] { k_query_tiles_stream_pipe<KIND, K128, P, 256, true>(img, seq_al, shift, total, seq_off, out_off, n_records, out, tiles); });  \
-        else emu::launch(grid, 256, [&] { k_query_tiles_stream_pipe<KIND, K128, P, 256, false>(img, seq_al, shift, total, seq_off, out_off, n_records, out, tiles); });      \
-    } while (0)
-    EMU_DISPATCH(CALL);
-#undef CALL
     return 0;
 }
 

@@ -100,8 +100,6 @@ def emuk(emu):
     emu.emu_kernel_query_packed.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
     emu.emu_kernel_query_records.restype = C.c_int
     emu.emu_kernel_query_records.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_int]
-    emu.emu_kernel_query_records_pipe.restype = C.c_int
-    emu.emu_kernel_query_records_pipe.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint, C.c_int]
     emu.emu_kernel_pack_kmers.restype = C.c_int
     emu.emu_kernel_pack_kmers.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_void_p]
     emu.emu_kernel_count_valid.restype = C.c_int
@@ -109,9 +107,8 @@ def emuk(emu):
     return emu
 
 
-def emu_records(lib, h, recs, k, streaming, misalign=0, block=256, pipe=None):
-    """lphq_query_records as kernels.hip launches it, on the emulator; returns one code array per record.
-    pipe=(grid, early) runs the software-pipelined streaming kernel (kernels_stream_pipe.cuh) with `grid` persistent workgroups."""
+def emu_records(lib, h, recs, k, streaming, misalign=0, block=256):
+    """lphq_query_records as kernels.hip launches it, on the emulator; returns one code array per record."""
     img = h.image()
     lens = np.array([len(r) for r in recs], dtype=np.uint64)
     seq_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
@@ -122,12 +119,8 @@ def emu_records(lib, h, recs, k, streaming, misalign=0, block=256, pipe=None):
     base = (-raw.ctypes.data) % 16 + 64 + misalign
     raw[base:base + len(flat)] = flat
     out = np.full(int(out_off[-1]) + 1, 0xDEAD, dtype=np.uint64)
-    if pipe is not None:
-        rc = lib.emu_kernel_query_records_pipe(img.ctypes.data, img.size, raw.ctypes.data + base, len(flat), seq_off.ctypes.data, out_off.ctypes.data, len(recs),
-                                               out.ctypes.data, pipe[0], 1 if pipe[1] else 0)
-    else:
-        rc = lib.emu_kernel_query_records(img.ctypes.data, img.size, raw.ctypes.data + base, len(flat), seq_off.ctypes.data, out_off.ctypes.data, len(recs),
-                                          out.ctypes.data, 1 if streaming else 0, block)
+    rc = lib.emu_kernel_query_records(img.ctypes.data, img.size, raw.ctypes.data + base, len(flat), seq_off.ctypes.data, out_off.ctypes.data, len(recs),
+                                      out.ctypes.data, 1 if streaming else 0, block)
     assert rc == 0 and out[-1] == 0xDEAD
     return [out[int(out_off[i]):int(out_off[i + 1])] for i in range(len(recs))]
 
@@ -151,11 +144,6 @@ def test_tile_kernels_on_the_emulator(emuk, tmp_path, k, m, bits, kind):
         got = emu_records(emuk, h, batch, k, streaming, mis, block)
         for g, e in zip(got, exp):
             assert np.array_equal(g, e), (streaming, mis, block)
-    # the software-pipelined streaming kernel: one persistent workgroup walking every tile, a few, and one per tile
-    for mis, grid, early in ((0, 1, True), (7, 3, False), (15, 2, True), (0, 0, True)):
-        got = emu_records(emuk, h, batch, k, True, mis, pipe=(grid, early))
-        for g, e in zip(got, exp):
-            assert np.array_equal(g, e), ("pipe", mis, grid, early)
 
 
 def test_tile_kernels_non_acgt_on_the_emulator(emuk, tmp_path):
@@ -175,7 +163,7 @@ def test_tile_kernels_non_acgt_on_the_emulator(emuk, tmp_path):
         batch.append(bytes(q))
     got_s = emu_records(emuk, h, batch, k, True)
     got_r = emu_records(emuk, h, batch, k, False)
-    got_p = emu_records(emuk, h, batch, k, True, 3, pipe=(2, True))
+    got_p = emu_records(emuk, h, batch, k, True, 3)  # same batch at another pointer alignment
     for q, gs, gr, gp in zip(batch, got_s, got_r, got_p):
         exp = o(q, False)  # random mode reads a non-ACGT base as 'A' (mphf_utils.hpp:108)
         assert np.array_equal(gr, exp)
@@ -264,7 +252,7 @@ def test_kernels_under_other_thread_schedules(emuk, tmp_path, mode, seed):
     emuk.emu_set_schedule.argtypes = [C.c_int, C.c_uint64]
     emuk.emu_set_schedule(mode, seed)
     try:
-        test_tile_kernels_on_the_emulator(emuk, tmp_path, 31, 20, 64, 0)   # incl. the pipelined kernel, one workgroup walking all tiles
+        test_tile_kernels_on_the_emulator(emuk, tmp_path, 31, 20, 64, 0)
         test_tile_kernels_on_the_emulator(emuk, tmp_path, 9, 7, 64, 0)     # W = 3 path, > 256 leaders per tile
         test_tile_kernels_on_the_emulator(emuk, tmp_path, 47, 17, 128, 1)  # unpartitioned, 128-bit k-mers
         test_tile_kernels_non_acgt_on_the_emulator(emuk, tmp_path)

@@ -17,7 +17,6 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # kernel -> (max VGPRs, max LDS bytes); no scratch and no VGPR spill anywhere
 BUDGET = {
     "k_query_packed": (64, 0),                # 8 waves / SIMD
-    "k_query_tiles_stream_pipe": (96, 24 * 1024),  # >= 5 workgroups / CU (the kernel's __launch_bounds__(256, 5))
     "k_query_tiles_stream": (64, 40 * 1024),  # 256 threads: 8 workgroups / CU need <= 64 VGPRs and <= 20 KB (512-thread build: 2x LDS)
     "k_query_tiles_random": (64, 4 * 1024),
     "k_pack_kmers": (64, 0),
@@ -29,8 +28,8 @@ BUDGET = {
     "k_advance": (64, 0),
 }
 # SGPR spills go to VGPR lanes, not to memory.  k_query_packed takes the 1.2-KB header by value and has ~36 of them (measured 2 %
-# faster than reading the header from the image); the persistent loop of the pipelined kernel keeps a few.
-SGPR_SPILLS = {"k_query_packed": 40, "k_query_tiles_stream_pipe": 16}
+# faster than reading the header from the image).
+SGPR_SPILLS = {"k_query_packed": 40}
 
 
 def resource_usage(src):

@@ -31,18 +31,3 @@ def test_gpu_pilot_search_build_is_byte_identical(tmp_path, k, m, bits, kind, nr
     sg = L.build(recs, k, m, pg, kind=kind, kmer_bits=bits, threads=8, device=0)
     assert sc == sg
     assert open(pc, "rb").read() == open(pg, "rb").read()
-
-
-def test_pipelined_stream_kernel():
-    """The opt-in software-pipelined streaming kernel (LPHQ_STREAM_PIPELINE=1, kernels_stream_pipe.cuh) gives the oracle's codes.
-    Runs tests/pipe_stream_check.py in a child process because the launcher reads the switch once per process.  (Kept last in this
-    file: the kernel was written while GPU access was closed, so this is its first run on hardware.)"""
-    import subprocess
-    import sys
-    torch_dev()
-    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pipe_stream_check.py")
-    # 1 workgroup per CU: every workgroup walks several tiles of the ~1 M-base batches (the double-buffered loop); 5 = the default
-    for wgs, early in (("1", "1"), ("5", "0")):
-        env = dict(os.environ, LPHQ_STREAM_PIPELINE="1", LPHQ_STREAM_PIPE_WGS=wgs, LPHQ_STREAM_PIPE_EARLY=early)
-        r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0 and "PIPE_OK" in r.stdout, (wgs, early, r.stdout[-2000:] + r.stderr[-4000:])

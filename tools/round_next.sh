@@ -13,10 +13,7 @@ step "1. next-tier gpu tests"
 timeout 900 python -m pytest tests/test_zz_gpu_next.py -m gpu -x -q > "$O/pytest_gpu_next.txt" 2>&1
 echo "exit code $?" >> "$O/pytest_gpu_next.txt"
 tail -3 "$O/pytest_gpu_next.txt" | tee -a "$O/log.txt"
-step "2. pipeline sweep"
-timeout 1500 bash tools/stream_pipeline_sweep.sh > "$O/sweep_stdout.txt" 2>&1
-cp gpurun_out/stream_pipe_sweep.txt gpurun_out/stream_pipe_sweep_summary.txt "$O/" 2> /dev/null
-step "3. index build: GPU pilot search, 1 vs 16 rounds per host read-back; CPU search for the byte comparison"
+step "2. index build: GPU pilot search, 1 vs 16 rounds per host read-back; CPU search for the byte comparison"
 for rps in 1 16; do
     LPHQ_BUILD_VERBOSE=1 LPHQ_SEARCH_ROUNDS_PER_SYNC=$rps timeout 600 python tools/gpu_build_time.py 1000 31 > "$O/build_rps$rps.txt" 2>&1 || step "build (rounds per sync $rps) failed"
     grep -E "gpu-search build|gpu pilot search" "$O/build_rps$rps.txt" | tee -a "$O/log.txt"
