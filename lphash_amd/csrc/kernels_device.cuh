@@ -544,6 +544,231 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
 }
 
 // ------------------------------------------------------------------------------------------
+// streaming kernel, register-resident windows (same phases, same results as k_query_tiles_stream)
+// ------------------------------------------------------------------------------------------
+// What changed against k_query_tiles_stream, from its phase profile (profiles/r02_stream_phases.txt: the kernel moves 4.1 GB
+// per launch at ~5.8 TB/s and is short of gathers in flight, because a workgroup holds its slot ~15 us of which the lookup
+// phase E -- the only one with loads in flight -- is 30 %; the other phases are latency (A) and instruction (C, D, F) time):
+//   A  the lane's sequence dwords are requested before the record search, so the search's dependent loads overlap with them;
+//      one wave searches (the last base of a tile is almost always in the record of the first)
+//   C  window validity from a per-tile [w_lo, w_hi) range when the tile lies in one record, and no bad-base arithmetic when
+//      the tile has no non-ACGT base (the common case): ~2 instructions per window instead of ~25
+//   D  fused into C: a lane keeps its four consecutive windows in registers; leaders are found with one cross-lane move, four
+//      ballots and ONE LDS atomic per wave (was four).  The first window of a wave is always queued as a leader (its left
+//      neighbour lives in another wave): at most three redundant lookups per tile, which write the value the real leader writes
+//   F  codes from registers, two 16-byte stores per lane when its four windows are all valid
+template <int KIND, bool K128, int P, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_query_tiles_stream4(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
+                                                                 uint64_t shift, uint64_t total, const uint64_t* __restrict__ seq_off,
+                                                                 const uint64_t* __restrict__ out_off, uint32_t n_records, uint64_t* __restrict__ out) {
+    const lphq_image_header& H = *(const lphq_image_header*)img;
+    constexpr int kStreamPos = 4 * BLOCK, NW = tile_words(kStreamPos);
+    constexpr int NBADW = (NW + 8) / 2 + 2;  // 32-bit words of the bad-base bitmask (1 bit per base)
+    constexpr int NDW = (NW + 1) * 4;        // dwords of sequence (4 bases each) the tile loads; NDW - BLOCK = 20 lanes load two
+    static_assert(NDW > BLOCK && NDW <= 2 * BLOCK, "two sequence dwords per lane at most");
+    __shared__ uint64_t sm_hash[hash_slots<BLOCK>()];  // phase B-C: minimizer hash per m-mer position (hslot order); phase E-F: the leader's base
+    __shared__ uint32_t sm_words[NW + 8];
+    __shared__ uint32_t sm_bad[NBADW];
+    __shared__ uint16_t sm_queue[kStreamPos];
+    __shared__ uint8_t sm_mode[kStreamPos];
+    __shared__ uint32_t sm_rec[2], sm_count, sm_anybad;
+    __shared__ uint64_t sm_roff[3];                // seq_off[rlo], seq_off[rlo+1], out_off[rlo]
+    __shared__ uint64_t sm_rtab[2 * kRecCap + 1];  // multi-record tiles: the tile's slice of seq_off / out_off
+    const uint32_t tid = threadIdx.x;
+    const uint32_t k = H.k, m = H.m, W = H.W;
+    const uint32_t TW = stream_tile_windows(W, kStreamPos);
+    const uint64_t t0 = (uint64_t)blockIdx.x * TW;  // shifted coordinate of the tile's first window start
+
+    // ---- A: sequence dwords first (no dependence on the record search), then the search, then pack into LDS ----
+    uint32_t xs[2] = {0u, 0u};
+    bool have[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t d = tid + (uint32_t)r * BLOCK;
+        const uint64_t a = t0 + (uint64_t)d * 4u;
+        have[r] = d < (uint32_t)NDW && a < shift + total && a + 4u > shift;
+        if (have[r]) xs[r] = *(const uint32_t*)(seq_al + a);
+    }
+    if (tid < 64) {  // wave 0: record of the first base the tile can touch, and of the last
+        const uint64_t gfirst = t0 > shift ? t0 - shift : 0;
+        uint64_t glast = t0 + TW + 64 > shift ? t0 + TW + 64 - shift : 0;
+        if (glast >= total) glast = total ? total - 1 : 0;
+        const uint32_t r = find_record_wave(seq_off, n_records, gfirst);
+        const uint64_t s0 = seq_off[r], e0 = seq_off[r + 1];
+        const uint32_t r2 = glast < e0 ? r : find_record_wave(seq_off, n_records, glast);  // uniform over the wave
+        if (tid == 0) {
+            sm_rec[0] = r;
+            sm_rec[1] = r2;
+            sm_roff[0] = s0;
+            sm_roff[1] = e0;
+            sm_roff[2] = out_off[r];
+            sm_count = 0;
+            sm_anybad = 0;
+        }
+    }
+    for (int c = tid; c < NBADW; c += BLOCK) sm_bad[c] = (c < NDW / 8) ? 0u : 0xFFFFFFFFu;
+    for (int c = NW + 1 + tid; c < NW + 8; c += BLOCK) sm_words[c] = 0;
+    __syncthreads();
+    if (sm_rec[0] != sm_rec[1]) load_record_table(sm_rtab, seq_off, out_off, sm_rec[0], sm_rec[1], tid);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t d = tid + (uint32_t)r * BLOCK;
+        if (d < (uint32_t)NDW) {
+            const uint64_t a = t0 + (uint64_t)d * 4u;
+            uint32_t p8 = 0, b4 = 0xFu;
+            if (have[r]) {
+                p8 = pack4(xs[r], b4);
+                uint32_t outside = 0;  // bytes of the dword that are not bases of the batch
+                if (a < shift || a + 4u > shift + total)
+                    for (int i = 0; i < 4; ++i)
+                        if (a + i < shift || a + i >= shift + total) outside |= 1u << i;
+                if (b4 & ~outside) sm_anybad = 1u;  // a real non-ACGT base (any lane may write the same value)
+                b4 |= outside;
+            }
+            ((uint8_t*)sm_words)[(d & ~3u) + (3u - (d & 3u))] = (uint8_t)p8;  // first base in the top bits of each 32-bit word
+            if (b4) atomicOr(&sm_bad[d >> 3], b4 << (4 * (d & 7)));
+        }
+    }
+    __syncthreads();
+
+    // ---- B: hashes of the m-mers starting at local positions 4*lane .. 4*lane+3 ----
+    {
+        const uint64_t mm_seedx = murmur_seedx(H.mm_seed);
+        const uint32_t a = 4u * tid;
+        const uint32_t w0 = a >> 4, o = (a & 15u) * 2u;
+        const uint32_t x0 = sm_words[w0], x1 = sm_words[w0 + 1], x2 = sm_words[w0 + 2], x3 = sm_words[w0 + 3];
+        const uint64_t A64 = ((uint64_t)x0 << 32) | x1, C64 = ((uint64_t)x2 << 32) | x3;
+        const uint64_t s0 = o ? ((A64 << o) | ((uint64_t)x2 >> (32 - o))) : A64;  // bits [0, 64) of the stream at base a
+        const uint64_t s1 = o ? (C64 << o) : C64;                                  // bits [64, 128): only the top 6 are needed
+        const uint32_t sh = 64u - 2u * m;
+        const uint64_t mask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint64_t v = r == 0 ? (s0 >> sh) : (((s0 << (2 * r)) | (s1 >> (64 - 2 * r))) >> sh);
+            sm_hash[r * hash_row<BLOCK>() + tid] = murmur8(v & mask, mm_seedx);
+        }
+        hash_pad<BLOCK>(sm_hash, tid);
+    }
+    __syncthreads();
+
+    // ---- C + D: leftmost minimum of the lane's 4 windows, their validity, leaders -> queue ----
+    const uint32_t a = 4u * tid;
+    const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];
+    const bool one_record = rlo == rhi;
+    const bool anybad = sm_anybad != 0u;
+    // one record: window i of the tile is a window of the record iff w_lo <= i < w_hi
+    const uint32_t w_lo = t0 >= shift ? 0u : (uint32_t)(shift - t0);
+    uint32_t w_hi = 0;
+    {
+        const uint64_t limit = sm_roff[1] + shift;  // shifted coordinate of the record's end
+        if (limit >= t0 + k) w_hi = (uint32_t)min((uint64_t)TW, limit - k - t0 + 1u);
+    }
+    uint32_t code[4];  // minimizer position of the window; 0xFFFF: holds a non-ACGT base; 0xFFFE: not a window of any record
+    {
+        uint32_t q[4];
+        window_argmin4<BLOCK>(sm_hash, tid, W, q);
+        if (one_record) {
+#pragma unroll
+            for (uint32_t jw = 0; jw < 4; ++jw) code[jw] = (a + jw >= w_lo && a + jw < w_hi) ? q[jw] : 0xFFFEu;
+        } else {
+#pragma unroll
+            for (uint32_t jw = 0; jw < 4; ++jw) {
+                const uint32_t i = a + jw;
+                const uint64_t ga = t0 + i;
+                uint32_t v = 0xFFFEu;
+                if (i < TW && ga >= shift && ga - shift + k <= total) {
+                    uint64_t rs, re;
+                    tile_record(sm_rtab, seq_off, rlo, rhi, ga - shift, rs, re);
+                    if (ga - shift + k <= re) v = q[jw];
+                }
+                code[jw] = v;
+            }
+        }
+        if (anybad) {  // uniform over the workgroup
+            const uint64_t kmask = (1ull << k) - 1ull;  // k <= 63
+            // bad-base bits [a, a + 96): a % 4 == 0, windows a..a+3 need bits up to a + 3 + 62
+            const uint32_t bw = a >> 5, bo = a & 31u;
+            const uint32_t b0 = sm_bad[bw], b1 = sm_bad[bw + 1], b2 = sm_bad[bw + 2], b3 = sm_bad[bw + 3];
+            const uint64_t blo = bo ? (((((uint64_t)b1 << 32) | b0) >> bo) | ((uint64_t)b2 << (64u - bo))) : ((((uint64_t)b1) << 32) | b0);
+            const uint32_t bhi = bo ? (uint32_t)(((((uint64_t)b3 << 32) | b2) >> bo)) : b2;
+#pragma unroll
+            for (uint32_t jw = 0; jw < 4; ++jw) {
+                const uint64_t x = jw ? ((blo >> jw) | ((uint64_t)bhi << (64 - jw))) : blo;
+                if (code[jw] != 0xFFFEu && (x & kmask)) code[jw] = 0xFFFFu;
+            }
+        }
+    }
+    {
+        const uint32_t lane = tid & 63u;
+        uint32_t prev = __shfl(code[3], (int)((lane + 63u) & 63u), 64);  // last window of the lane to the left
+        if (lane == 0) prev = 0xFFFEu;                                     // it lives in another wave: queue the window regardless
+        const bool l0 = code[0] < 0xFFFEu && code[0] != prev, l1 = code[1] < 0xFFFEu && code[1] != code[0];
+        const bool l2 = code[2] < 0xFFFEu && code[2] != code[1], l3 = code[3] < 0xFFFEu && code[3] != code[2];
+        const uint64_t b0 = __ballot(l0), b1 = __ballot(l1), b2 = __ballot(l2), b3 = __ballot(l3);
+        const uint32_t n0 = (uint32_t)__popcll(b0), n1 = (uint32_t)__popcll(b1), n2 = (uint32_t)__popcll(b2), n3 = (uint32_t)__popcll(b3);
+        uint32_t base = 0;
+        if (lane == 0 && (n0 + n1 + n2 + n3)) base = atomicAdd(&sm_count, n0 + n1 + n2 + n3);
+        base = __shfl(base, 0, 64);
+        const uint64_t lt = (1ull << lane) - 1ull;
+        if (l0) sm_queue[base + (uint32_t)__popcll(b0 & lt)] = (uint16_t)code[0];
+        if (l1) sm_queue[base + n0 + (uint32_t)__popcll(b1 & lt)] = (uint16_t)code[1];
+        if (l2) sm_queue[base + n0 + n1 + (uint32_t)__popcll(b2 & lt)] = (uint16_t)code[2];
+        if (l3) sm_queue[base + n0 + n1 + n2 + (uint32_t)__popcll(b3 & lt)] = (uint16_t)code[3];
+    }
+    __syncthreads();
+
+    // ---- E: one lookup per super-k-mer, dense lanes ----
+    const uint32_t nlead = sm_count;
+    for (uint32_t x = tid; x < nlead; x += BLOCK) {
+        const uint32_t q = sm_queue[x];
+        uint64_t mm, hi;
+        extract_kmer<false>(sm_words, q, m, mm, hi);
+        const LookupCtx c = lookup_ctx<KIND, K128, P>(img, H, mm);
+        sm_hash[hslot<BLOCK>(q)] = c.base;
+        sm_mode[q] = (uint8_t)c.mode;
+    }
+    __syncthreads();
+
+    // ---- F: the lane's four codes ----
+    uint64_t hv[4];
+#pragma unroll
+    for (uint32_t jw = 0; jw < 4; ++jw) {
+        const uint32_t q = code[jw];
+        uint64_t hval = ~0ull;  // LPHQ_INVALID
+        if (q < 0xFFFEu) {
+            LookupCtx c;
+            c.base = sm_hash[hslot<BLOCK>(q)];
+            c.mode = sm_mode[q];
+            uint64_t lo = 0, hi = 0;
+            if (c.mode == 2u) extract_kmer<K128>(sm_words, a + jw, k, lo, hi);
+            hval = finish_hval<K128>(img, H, c, lo, hi, q - (a + jw));
+        }
+        hv[jw] = hval;
+    }
+    if (one_record) {
+        struct __attribute__((packed, aligned(8))) u64x2 { uint64_t x, y; };  // one 16-byte store at 8-byte alignment
+        uint64_t* dst = out + (sm_roff[2] + (t0 + a - shift - sm_roff[0]));  // (wraps harmlessly when the lane has no valid window)
+        if (a >= w_lo && a + 4u <= w_hi) {
+            *(u64x2*)dst = u64x2{hv[0], hv[1]};
+            *(u64x2*)(dst + 2) = u64x2{hv[2], hv[3]};
+        } else {
+#pragma unroll
+            for (uint32_t jw = 0; jw < 4; ++jw)
+                if (code[jw] != 0xFFFEu) dst[jw] = hv[jw];
+        }
+    } else {
+#pragma unroll
+        for (uint32_t jw = 0; jw < 4; ++jw) {
+            if (code[jw] == 0xFFFEu) continue;
+            const uint64_t g = t0 + a + jw - shift;
+            uint64_t rs, re;
+            const uint32_t j = tile_record(sm_rtab, seq_off, rlo, rhi, g, rs, re);
+            out[tile_record_out(sm_rtab, out_off, rlo, rhi, j) + (g - rs)] = hv[jw];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // number of valid codes (size of the reference's result vector for a streaming pass)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_count_valid(const uint64_t* __restrict__ codes, size_t n, unsigned long long* __restrict__ count) {
