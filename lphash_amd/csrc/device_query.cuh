@@ -35,24 +35,20 @@ __device__ __forceinline__ uint32_t div_step(uint32_t r, uint32_t u, uint32_t dn
     if (rem >= dn) rem -= dn;
     return rem;
 }
-// Exact a % d.  pthash fastmod::fastmod_u64(a, M, d) is the exact remainder for all 64-bit a, d; the
-// 128-bit M of the file is replaced by a 32-bit reciprocal when d < 2^32 (always, for < 4 G keys).
-// WIDE = false drops the >= 2^32 divisor path (a software 64-bit division: ~450 instructions and ~15 VGPRs per inlined
-// copy); only for callers that checked d != 0 on the host.
-template <bool WIDE = true>
-__device__ __forceinline__ uint64_t mod_u64(uint64_t a, uint32_t d, uint32_t dn, uint32_t inv, uint32_t shift, uint64_t d64) {
-    if (!WIDE || d) {
-        uint32_t u2 = (uint32_t)((a >> 32) >> (32 - shift));
-        uint32_t u1 = (uint32_t)((a << shift) >> 32);
-        uint32_t u0 = (uint32_t)(a << shift);
-        uint32_t r = div_step(u2, u1, dn, inv);
-        r = div_step(r, u0, dn, inv);
-        return r >> shift;
-    }
-    return d64 ? a % d64 : 0;
+// Exact a % d for 0 < d < 2^32.  pthash fastmod::fastmod_u64(a, M, d) is the exact remainder for all 64-bit a, d; the
+// 128-bit M of the file is replaced by a 32-bit reciprocal.  Every divisor of an attached image is in range: table sizes
+// beyond 2^32 - 1 are rejected when the image is built (image.cpp) and when a device image is adopted (capi.cpp:
+// header_is_consistent, which also requires non-zero bucket counts), and an empty function never divides (phf_position).
+// (A generic 64-bit division path would cost ~450 instructions and ~15 VGPRs per inlined copy for a case that cannot occur.)
+__device__ __forceinline__ uint64_t mod_u64(uint64_t a, uint32_t dn, uint32_t inv, uint32_t shift) {
+    uint32_t u2 = (uint32_t)((a >> 32) >> (32 - shift));
+    uint32_t u1 = (uint32_t)((a << shift) >> 32);
+    uint32_t u0 = (uint32_t)(a << shift);
+    uint32_t r = div_step(u2, u1, dn, inv);
+    r = div_step(r, u0, dn, inv);
+    return r >> shift;
 }
-template <bool WIDE = true>
-__device__ __forceinline__ uint64_t mod_u64(uint64_t a, const lphq_divisor& dv) { return mod_u64<WIDE>(a, dv.d, dv.dn, dv.inv, dv.shift, dv.d64); }
+__device__ __forceinline__ uint64_t mod_u64(uint64_t a, const lphq_divisor& dv) { return mod_u64(a, dv.dn, dv.inv, dv.shift); }
 
 // pthash::single_phf<..., dictionary_dictionary, true>::position(hash)  (SURVEY Appendix A):
 //   bucket = skew_bucketer(hash); pilot = dict[ranks[bucket]]; p = (hash ^ H(pilot)) mod table_size;
@@ -66,7 +62,6 @@ struct PhfRank {       // where the codeword of a bucket sits
     uint32_t width;    // codeword width
     bool front;        // front (dense-bucket) or back dictionary
 };
-template <bool WIDE = true>
 __device__ __forceinline__ uint64_t phf_load_code(const uint8_t* __restrict__ img, const lphq_phf_desc& f, uint64_t x, PhfRank& rk) {
     const uint64_t T = 0x9999999999999800ULL;  // uint64_t(0.6 * UINT64_MAX), skew_bucketer
     const bool dense = x < T;
@@ -74,8 +69,7 @@ __device__ __forceinline__ uint64_t phf_load_code(const uint8_t* __restrict__ im
     // the fields themselves selects the ADDRESS, and with the descriptor in memory (tile kernels) that is a per-lane
     // vector load of a header field at the head of the gather chain.
     const lphq_divisor dd = f.div_dense, ds = f.div_sparse;
-    uint64_t b = mod_u64<WIDE>(x, dense ? dd.d : ds.d, dense ? dd.dn : ds.dn, dense ? dd.inv : ds.inv, dense ? dd.shift : ds.shift,
-                               WIDE ? (dense ? dd.d64 : ds.d64) : 0);
+    uint64_t b = mod_u64(x, dense ? dd.dn : ds.dn, dense ? dd.inv : ds.inv, dense ? dd.shift : ds.shift);
     if (!dense) b += f.num_dense;
     const bool front = b < f.front_size;
     const uint64_t bi = front ? b : b - f.front_size;
@@ -96,18 +90,16 @@ __device__ __forceinline__ uint64_t phf_load_hp(const uint8_t* __restrict__ img,
     const uint64_t fo = f.off_front_hp, bo = f.off_back_hp;
     return ((const uint64_t*)(img + (rk.front ? fo : bo)))[code];
 }
-template <bool WIDE = true>
 __device__ __forceinline__ uint64_t phf_finish(const uint8_t* __restrict__ img, const lphq_phf_desc& f, uint64_t x, uint64_t hp) {
-    uint64_t p = mod_u64<WIDE>(x ^ hp, f.div_table);
+    uint64_t p = mod_u64(x ^ hp, f.div_table);
     if (p >= f.num_keys) p = ((const uint32_t*)(img + f.off_free))[p - f.num_keys];
     return p;
 }
-template <bool WIDE = true>
 __device__ __forceinline__ uint64_t phf_position(const uint8_t* __restrict__ img, const lphq_phf_desc& f, uint64_t x) {
     if (f.num_keys == 0) return 0;  // empty function: unreachable for well-formed files
     PhfRank rk;
-    const uint64_t two = phf_load_code<WIDE>(img, f, x, rk);
-    return phf_finish<WIDE>(img, f, x, phf_load_hp(img, f, two, rk));
+    const uint64_t two = phf_load_code(img, f, x, rk);
+    return phf_finish(img, f, x, phf_load_hp(img, f, two, rk));
 }
 
 // mask of the first nb bits of a 32-bit word, nb in [0, 32]
@@ -291,9 +283,9 @@ __device__ __forceinline__ LookupCtx ctx_unpartitioned(const lphq_image_header& 
     }
     return c;
 }
-template <int KIND, bool K128, int P, bool WIDE = true>
+template <int KIND, bool K128, int P>
 __device__ __forceinline__ LookupCtx lookup_ctx(const uint8_t* __restrict__ img, const lphq_image_header& H, uint64_t mm) {
-    const uint32_t h = (uint32_t)phf_position<WIDE>(img, H.mm, murmur8(mm, murmur_seedx(H.mm.seed)));
+    const uint32_t h = (uint32_t)phf_position(img, H.mm, murmur8(mm, murmur_seedx(H.mm.seed)));
     if (KIND == 0) {
         uint32_t type, size, pos;
         uint64_t base;
@@ -306,9 +298,9 @@ __device__ __forceinline__ LookupCtx lookup_ctx(const uint8_t* __restrict__ img,
         return ctx_unpartitioned(H, prefix, size, pos);
     }
 }
-template <bool K128, bool WIDE = true>
+template <bool K128>
 __device__ __forceinline__ uint64_t finish_hval(const uint8_t* __restrict__ img, const lphq_image_header& H, const LookupCtx& c, uint64_t lo, uint64_t hi, uint32_t p) {
-    if (c.mode == 2u) return c.base + phf_position<WIDE>(img, H.fb, fallback_hash<K128>(lo, hi, H.fb.seed));
+    if (c.mode == 2u) return c.base + phf_position(img, H.fb, fallback_hash<K128>(lo, hi, H.fb.seed));
     return c.mode == 0u ? c.base + p : c.base - p;
 }
 

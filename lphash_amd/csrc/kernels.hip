@@ -90,20 +90,8 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
     // per call); larger batches must be split by the caller (capi.cpp says so in the error text)
     if (tiles > (0xFFFFFFFFull / 512u) || n_records > 0xFFFFFFFFull) return hipErrorInvalidValue;
     if (streaming) {
-#ifdef LPHQ_PROFILE  // phase timing build only (never liblphq.so): return after phase N
-        static const uint32_t stop_after = getenv("LPHQ_PROFILE_STREAM_STOP") ? (uint32_t)atoi(getenv("LPHQ_PROFILE_STREAM_STOP")) : 0u;
-#define LPHQ_STOP_ARG , stop_after
-#else
-#define LPHQ_STOP_ARG
-#endif
-#define LPHQ_STREAM_LAUNCH(B) LPHQ_DISPATCH_B(k_query_tiles_stream, B, <<<(int)tiles, B, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out LPHQ_STOP_ARG))
-#define LPHQ_STREAM4_LAUNCH(B) LPHQ_DISPATCH_B(k_query_tiles_stream4, B, <<<(int)tiles, B, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out))
-        static const bool old_kernel = getenv("LPHQ_STREAM_OLD") && atoi(getenv("LPHQ_STREAM_OLD")) > 0;  // A/B aid: same results
-        if (!old_kernel) {
-            if (sblock == 128) LPHQ_STREAM4_LAUNCH(128);
-            else if (sblock == 512) LPHQ_STREAM4_LAUNCH(512);
-            else LPHQ_STREAM4_LAUNCH(256);
-        } else if (sblock == 128) LPHQ_STREAM_LAUNCH(128);
+#define LPHQ_STREAM_LAUNCH(B) LPHQ_DISPATCH_B(k_query_tiles_stream, B, <<<(int)tiles, B, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out))
+        if (sblock == 128) LPHQ_STREAM_LAUNCH(128);
         else if (sblock == 512) LPHQ_STREAM_LAUNCH(512);
         else LPHQ_STREAM_LAUNCH(256);
     }

@@ -24,6 +24,8 @@ constexpr int kBlock = 256;
 // ------------------------------------------------------------------------------------------
 // random batch over packed k-mers
 // ------------------------------------------------------------------------------------------
+// The k-mer and code streams carry the non-temporal hint: they are read / written once, the index lines are what should stay
+// in L2 (+1.5 %, profiles/r02_nt_ab.txt).
 template <int KIND, bool K128, int P>
 // (header by value here: measured 2 % faster than reading it from the image, the opposite of the tile kernels)
 __global__ __launch_bounds__(kBlock) void k_query_packed(const lphq_image_header H, const uint8_t* __restrict__ img,
@@ -32,13 +34,12 @@ __global__ __launch_bounds__(kBlock) void k_query_packed(const lphq_image_header
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         uint64_t lo, hi = 0;
         if (K128) {
-            const ulonglong2 v = ((const ulonglong2*)kmers)[i];
-            lo = v.x;
-            hi = v.y;
+            lo = __builtin_nontemporal_load(kmers + 2 * i);
+            hi = __builtin_nontemporal_load(kmers + 2 * i + 1);
         } else {
-            lo = kmers[i];
+            lo = __builtin_nontemporal_load(kmers + i);
         }
-        out[i] = query_kmer<KIND, K128, P>(img, H, lo, hi);
+        __builtin_nontemporal_store(query_kmer<KIND, K128, P>(img, H, lo, hi), out + i);
     }
 }
 
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_random(const uint8_t* __
         if (g + H.k > seq_off[r + 1]) continue;  // window would run over the end of its record
         uint64_t lo, hi;
         extract_kmer<K128>(sm_words, (uint32_t)i, H.k, lo, hi);
-        out[out_off[r] + (g - seq_off[r])] = query_kmer<KIND, K128, P>(img, H, lo, hi);
+        __builtin_nontemporal_store(query_kmer<KIND, K128, P>(img, H, lo, hi), out + (out_off[r] + (g - seq_off[r])));
     }
 }
 
@@ -269,16 +270,14 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_random(const uint8_t* __
 //   F  every window: hval = base +- p (or the per-k-mer fallback lookup for colliding minimizers,
 //      partitioned_mphf.hpp:133-135), coalesced stores
 // Windows holding a non-ACGT base get LPHQ_INVALID (the reference emits nothing for them).
-// Phase timing (tools/pmc_stream_phases.sh) needs the kernel to return after a chosen phase.  That changes results, so it exists
-// only in a -DLPHQ_PROFILE build of this file (tools/ builds its own object); liblphq.so is compiled without it and has no
-// such parameter.
-#ifdef LPHQ_PROFILE
-#define LPHQ_STOP_PARAM , uint32_t stop_after
-#define LPHQ_STOP_AFTER(n) do { if (stop_after == (n)) return; } while (0)
-#else
-#define LPHQ_STOP_PARAM
-#define LPHQ_STOP_AFTER(n) do { } while (0)
-#endif
+// two consecutive codes as one 16-byte non-temporal store; dst is only 8-byte aligned (gfx950 global accesses may be unaligned)
+__device__ __forceinline__ void store_codes_nt(uint64_t* dst, uint64_t c0, uint64_t c1) {
+    typedef uint64_t u64x2 __attribute__((vector_size(16), aligned(8)));
+    u64x2 v;
+    v[0] = c0;
+    v[1] = c1;
+    __builtin_nontemporal_store(v, (u64x2*)dst);
+}
 constexpr int kStreamBlockDefault = 256;  // threads per workgroup of the streaming kernel; 4 m-mer positions per lane
 __host__ __device__ inline uint32_t stream_tile_windows(uint32_t W, int npos) { return (uint32_t)(npos - (int)W + 1) & ~15u; }
 
@@ -367,198 +366,20 @@ __device__ __forceinline__ void window_argmin4(const uint64_t* __restrict__ sm_h
     }
 }
 
-template <int KIND, bool K128, int P, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
-                                                                uint64_t shift, uint64_t total, const uint64_t* __restrict__ seq_off,
-                                                                const uint64_t* __restrict__ out_off, uint32_t n_records, uint64_t* __restrict__ out
-                                                                LPHQ_STOP_PARAM) {
-    const lphq_image_header& H = *(const lphq_image_header*)img;  // read from the image: 77 SGPRs instead of 112 -> 8 workgroups / CU (+11 %)
-    constexpr int kStreamPos = 4 * BLOCK, NW = tile_words(kStreamPos), WPL = 4;
-    constexpr int NBADW = (NW + 8) / 2 + 2;       // 32-bit words of the bad-base bitmask (1 bit per base)
-    constexpr int NDW = (NW + 1) * 4;             // dwords of sequence (4 bases each) the tile loads
-    __shared__ uint64_t sm_hash[hash_slots<BLOCK>()];  // phase B-C: minimizer hash per m-mer position (hslot order); phase E-F: the leader's base
-    __shared__ uint32_t sm_words[NW + 8];
-    __shared__ uint32_t sm_bad[NBADW];
-    __shared__ __attribute__((aligned(16))) uint16_t sm_q[kStreamPos + 8];
-    __shared__ uint16_t sm_queue[kStreamPos];
-    __shared__ uint8_t sm_mode[kStreamPos];
-    __shared__ uint32_t sm_rec[2], sm_count;
-    __shared__ uint64_t sm_roff[3];  // seq_off[rlo], seq_off[rlo+1], out_off[rlo]
-    __shared__ uint64_t sm_rtab[2 * kRecCap + 1];  // multi-record tiles: the tile's slice of seq_off / out_off
-    const uint32_t k = H.k, m = H.m, W = H.W;
-    const uint32_t TW = stream_tile_windows(W, kStreamPos);
-    const uint64_t t0 = (uint64_t)blockIdx.x * TW;
-    if (threadIdx.x < 128) {  // wave 0 locates the record of the first base the tile can touch, wave 1 that of the last
-        const uint64_t gfirst = t0 > shift ? t0 - shift : 0;
-        uint64_t glast = t0 + TW + 64 > shift ? t0 + TW + 64 - shift : 0;
-        if (glast >= total) glast = total ? total - 1 : 0;
-        const uint32_t r = find_record_wave(seq_off, n_records, threadIdx.x < 64 ? gfirst : glast);
-        if (threadIdx.x == 0) {
-            sm_rec[0] = r;
-            sm_roff[0] = seq_off[r];
-            sm_roff[1] = seq_off[r + 1];
-            sm_roff[2] = out_off[r];
-            sm_count = 0;
-        }
-        if (threadIdx.x == 64) sm_rec[1] = r;
-    }
-    // ---- A: 4 bases per lane -> one byte of the 2-bit stream + 4 bits of the bad-base mask ----
-    for (int c = threadIdx.x; c < NBADW; c += BLOCK) sm_bad[c] = (c < NDW / 8) ? 0u : 0xFFFFFFFFu;
-    for (int c = NW + 1 + threadIdx.x; c < NW + 8; c += BLOCK) sm_words[c] = 0;
-    __syncthreads();
-    if (sm_rec[0] != sm_rec[1]) load_record_table(sm_rtab, seq_off, out_off, sm_rec[0], sm_rec[1], threadIdx.x);
-    for (int d = threadIdx.x; d < NDW; d += BLOCK) {
-        const uint64_t a = t0 + (uint64_t)d * 4u;  // shifted coordinate of the dword
-        uint32_t p8 = 0, b4 = 0xFu;
-        if (a < shift + total && a + 4u > shift) {
-            p8 = pack4(*(const uint32_t*)(seq_al + a), b4);
-            if (a < shift || a + 4u > shift + total)  // bytes outside [shift, shift+total) are not bases
-                for (int i = 0; i < 4; ++i)
-                    if (a + i < shift || a + i >= shift + total) b4 |= 1u << i;
-        }
-        ((uint8_t*)sm_words)[(d & ~3) + (3 - (d & 3))] = (uint8_t)p8;  // first base in the top bits of each 32-bit word
-        if (b4) atomicOr(&sm_bad[d >> 3], b4 << (4 * (d & 7)));
-    }
-    __syncthreads();
-    LPHQ_STOP_AFTER(1);
-
-    // ---- B: hashes of the m-mers starting at local positions 4*lane .. 4*lane+3 ----
-    {
-        const uint64_t mm_seedx = murmur_seedx(H.mm_seed);
-        const uint32_t a = 4u * threadIdx.x;
-        // 2m + 6 <= 70 bits starting at base a (a % 4 == 0, so the bit offset within the first word is a multiple of 8)
-        const uint32_t w0 = a >> 4, o = (a & 15u) * 2u;
-        const uint32_t x0 = sm_words[w0], x1 = sm_words[w0 + 1], x2 = sm_words[w0 + 2], x3 = sm_words[w0 + 3];
-        const uint64_t A64 = ((uint64_t)x0 << 32) | x1, C64 = ((uint64_t)x2 << 32) | x3;
-        const uint64_t s0 = o ? ((A64 << o) | ((uint64_t)x2 >> (32 - o))) : A64;  // bits [0, 64) of the stream at base a
-        const uint64_t s1 = o ? (C64 << o) : C64;                                  // bits [64, 128): only the top 6 are needed
-        const uint32_t sh = 64u - 2u * m;
-        const uint64_t mask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
-#pragma unroll
-        for (uint32_t r = 0; r < 4; ++r) {
-            // m-mer r = bits [2r, 2r + 2m) of (s0 : s1)
-            const uint64_t v = r == 0 ? (s0 >> sh) : (((s0 << (2 * r)) | (s1 >> (64 - 2 * r))) >> sh);
-            sm_hash[r * hash_row<BLOCK>() + threadIdx.x] = murmur8(v & mask, mm_seedx);
-        }
-        hash_pad<BLOCK>(sm_hash, threadIdx.x);
-    }
-    __syncthreads();
-    LPHQ_STOP_AFTER(2);
-
-    // ---- C: leftmost minimum of 4 consecutive windows per lane ----
-    {
-        const uint32_t a = 4u * threadIdx.x;
-        uint32_t q[4];
-        window_argmin4<BLOCK>(sm_hash, threadIdx.x, W, q);
-        // window validity: inside the batch, inside one record, no non-ACGT base in [i, i+k)
-        const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];
-        const uint64_t kmask = (1ull << k) - 1ull;  // k <= 63
-        // bad-base bits [a, a + 96): a % 4 == 0, windows a..a+3 need bits up to a + 3 + 62
-        const uint32_t bw = a >> 5, bo = a & 31u;
-        const uint32_t b0 = sm_bad[bw], b1 = sm_bad[bw + 1], b2 = sm_bad[bw + 2], b3 = sm_bad[bw + 3];
-        const uint64_t blo = bo ? (((((uint64_t)b1 << 32) | b0) >> bo) | ((uint64_t)b2 << (64u - bo))) : ((((uint64_t)b1) << 32) | b0);
-        const uint32_t bhi = bo ? (uint32_t)(((((uint64_t)b3 << 32) | b2) >> bo)) : b2;
-        const uint64_t end1 = sm_roff[1];
-        uint16_t qv[4];
-#pragma unroll
-        for (int jw = 0; jw < 4; ++jw) {
-            const uint32_t i = a + jw;
-            const uint64_t ga = t0 + i;
-            uint16_t v = 0xFFFEu;  // not a window of any record
-            if (i < TW && ga >= shift && ga - shift + k <= total) {
-                const uint64_t g = ga - shift;
-                bool inside;
-                if (rlo == rhi) inside = g + k <= end1;
-                else {
-                    uint64_t rs, re;
-                    tile_record(sm_rtab, seq_off, rlo, rhi, g, rs, re);
-                    inside = g + k <= re;
-                }
-                if (inside) {
-                    const uint64_t x = jw ? ((blo >> jw) | ((uint64_t)bhi << (64 - jw))) : blo;
-                    v = (x & kmask) ? (uint16_t)0xFFFFu : (uint16_t)q[jw];
-                }
-            }
-            qv[jw] = v;
-        }
-        *(uint2*)&sm_q[a] = make_uint2((uint32_t)qv[0] | ((uint32_t)qv[1] << 16), (uint32_t)qv[2] | ((uint32_t)qv[3] << 16));
-    }
-    __syncthreads();
-    LPHQ_STOP_AFTER(3);
-
-    // ---- D: leaders -> queue (one LDS atomic per wave and round) ----
-    const uint32_t lane = threadIdx.x & 63u;
-#pragma unroll
-    for (int r = 0; r < WPL; ++r) {
-        const uint32_t i = threadIdx.x + r * BLOCK;
-        const uint16_t qv = sm_q[i];
-        const bool leader = qv < 0xFFFEu && (i == 0 || sm_q[i - 1] != qv);
-        const uint64_t bal = __ballot(leader);
-        uint32_t base = 0;
-        if (lane == 0 && bal) base = atomicAdd(&sm_count, (uint32_t)__popcll(bal));
-        base = __shfl(base, 0, 64);
-        if (leader) sm_queue[base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = qv;
-    }
-    __syncthreads();
-    LPHQ_STOP_AFTER(4);
-
-    // ---- E: one lookup per super-k-mer, dense lanes ----
-    const uint32_t nlead = sm_count;
-    for (uint32_t x = threadIdx.x; x < nlead; x += BLOCK) {
-        const uint32_t q = sm_queue[x];
-        uint64_t mm, hi;
-        extract_kmer<false>(sm_words, q, m, mm, hi);
-        const LookupCtx c = lookup_ctx<KIND, K128, P>(img, H, mm);
-        sm_hash[hslot<BLOCK>(q)] = c.base;
-        sm_mode[q] = (uint8_t)c.mode;
-    }
-    __syncthreads();
-    LPHQ_STOP_AFTER(5);
-
-    // ---- F: every window, lane-contiguous stores ----
-    const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];
-#pragma unroll
-    for (int r = 0; r < WPL; ++r) {
-        const uint32_t i = threadIdx.x + r * BLOCK;
-        const uint32_t q = sm_q[i];
-        if (q == 0xFFFEu) continue;
-        const uint64_t g = t0 + i - shift;
-        uint64_t oidx;
-        if (rlo == rhi) oidx = sm_roff[2] + (g - sm_roff[0]);
-        else {
-            uint64_t rs, re;
-            const uint32_t j = tile_record(sm_rtab, seq_off, rlo, rhi, g, rs, re);
-            oidx = tile_record_out(sm_rtab, out_off, rlo, rhi, j) + (g - rs);
-        }
-        uint64_t hval = ~0ull;  // LPHQ_INVALID
-        if (q != 0xFFFFu) {
-            LookupCtx c;
-            c.base = sm_hash[hslot<BLOCK>(q)];
-            c.mode = sm_mode[q];
-            uint64_t lo = 0, hi = 0;
-            if (c.mode == 2u) extract_kmer<K128>(sm_words, i, k, lo, hi);
-            hval = finish_hval<K128>(img, H, c, lo, hi, q - i);
-        }
-        out[oidx] = hval;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// streaming kernel, register-resident windows (same phases, same results as k_query_tiles_stream)
-// ------------------------------------------------------------------------------------------
-// What changed against k_query_tiles_stream, from its phase profile (profiles/r02_stream_phases.txt: the kernel moves 4.1 GB
-// per launch at ~5.8 TB/s and is short of gathers in flight, because a workgroup holds its slot ~15 us of which the lookup
-// phase E -- the only one with loads in flight -- is 30 %; the other phases are latency (A) and instruction (C, D, F) time):
+// Shaped by the phase profile of its predecessor (profiles/r02_stream_phases.txt, r02_stream_v4_ab.txt: that kernel moved 4.1 GB
+// per launch at ~5.8 TB/s and was short of gathers in flight, because a workgroup holds its slot ~15 us of which the lookup
+// phase E -- the only one with loads in flight -- was 30 %; the other phases were latency (A) and instruction (C, D, F) time):
 //   A  the lane's sequence dwords are requested before the record search, so the search's dependent loads overlap with them;
 //      one wave searches (the last base of a tile is almost always in the record of the first)
 //   C  window validity from a per-tile [w_lo, w_hi) range when the tile lies in one record, and no bad-base arithmetic when
 //      the tile has no non-ACGT base (the common case): ~2 instructions per window instead of ~25
 //   D  fused into C: a lane keeps its four consecutive windows in registers; leaders are found with one cross-lane move, four
-//      ballots and ONE LDS atomic per wave (was four).  The first window of a wave is always queued as a leader (its left
-//      neighbour lives in another wave): at most three redundant lookups per tile, which write the value the real leader writes
-//   F  codes from registers, two 16-byte stores per lane when its four windows are all valid
+//      ballots and ONE LDS atomic per wave.  The first window of a wave is always queued as a leader (its left neighbour lives
+//      in another wave): at most three redundant lookups per tile, which write the value the real leader writes
+//   F  codes from registers, two 16-byte non-temporal stores per lane when its four windows are all valid (the codes are
+//      written once and never read here; the hint keeps more of L2 for the index lines: +2.5-5 %, profiles/r02_nt_ab.txt)
 template <int KIND, bool K128, int P, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_query_tiles_stream4(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
+__global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
                                                                  uint64_t shift, uint64_t total, const uint64_t* __restrict__ seq_off,
                                                                  const uint64_t* __restrict__ out_off, uint32_t n_records, uint64_t* __restrict__ out) {
     const lphq_image_header& H = *(const lphq_image_header*)img;
@@ -746,15 +567,14 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream4(const uint8_t* __
         hv[jw] = hval;
     }
     if (one_record) {
-        struct __attribute__((packed, aligned(8))) u64x2 { uint64_t x, y; };  // one 16-byte store at 8-byte alignment
         uint64_t* dst = out + (sm_roff[2] + (t0 + a - shift - sm_roff[0]));  // (wraps harmlessly when the lane has no valid window)
         if (a >= w_lo && a + 4u <= w_hi) {
-            *(u64x2*)dst = u64x2{hv[0], hv[1]};
-            *(u64x2*)(dst + 2) = u64x2{hv[2], hv[3]};
+            store_codes_nt(dst, hv[0], hv[1]);
+            store_codes_nt(dst + 2, hv[2], hv[3]);
         } else {
 #pragma unroll
             for (uint32_t jw = 0; jw < 4; ++jw)
-                if (code[jw] != 0xFFFEu) dst[jw] = hv[jw];
+                if (code[jw] != 0xFFFEu) __builtin_nontemporal_store(hv[jw], dst + jw);
         }
     } else {
 #pragma unroll
@@ -763,7 +583,7 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream4(const uint8_t* __
             const uint64_t g = t0 + a + jw - shift;
             uint64_t rs, re;
             const uint32_t j = tile_record(sm_rtab, seq_off, rlo, rhi, g, rs, re);
-            out[tile_record_out(sm_rtab, out_off, rlo, rhi, j) + (g - rs)] = hv[jw];
+            __builtin_nontemporal_store(hv[jw], out + (tile_record_out(sm_rtab, out_off, rlo, rhi, j) + (g - rs)));
         }
     }
 }

@@ -38,9 +38,7 @@ extern "C" int emu_kernel_query_packed(const uint8_t* img, size_t nbytes, const 
 
 // seq must be 16-byte aligned minus `misalign` (the caller passes base + misalign), padded with >= 64 readable bytes
 extern "C" int emu_kernel_query_records(const uint8_t* img, size_t nbytes, const char* seq, uint64_t total, const uint64_t* seq_off, const uint64_t* out_off,
-                                        uint32_t n_records, uint64_t* out, int streaming, int block_and_version) {
-    const int block = block_and_version & 0xFFFF;
-    const bool v4 = (block_and_version >> 16) != 0;  // k_query_tiles_stream4
+                                        uint32_t n_records, uint64_t* out, int streaming, int block) {
     lphq_image_header H;
     if (!header(img, nbytes, H)) return 1;
     if (n_records == 0 || total < H.k) return 0;
@@ -52,9 +50,7 @@ extern "C" int emu_kernel_query_records(const uint8_t* img, size_t nbytes, const
         const unsigned tiles = (unsigned)((span + tw - 1) / tw);
 #define CALL(KIND, K128, P)                                                                                                                             \
     do {                                                                                                                                                \
-        if (v4 && block == 128) emu::launch(tiles, 128, [&] { k_query_tiles_stream4<KIND, K128, P, 128>(img, seq_al, shift, total, seq_off, out_off, n_records, out); }); \
-        else if (v4) emu::launch(tiles, 256, [&] { k_query_tiles_stream4<KIND, K128, P, 256>(img, seq_al, shift, total, seq_off, out_off, n_records, out); });            \
-        else if (block == 128) emu::launch(tiles, 128, [&] { k_query_tiles_stream<KIND, K128, P, 128>(img, seq_al, shift, total, seq_off, out_off, n_records, out); }); \
+        if (block == 128) emu::launch(tiles, 128, [&] { k_query_tiles_stream<KIND, K128, P, 128>(img, seq_al, shift, total, seq_off, out_off, n_records, out); }); \
         else emu::launch(tiles, 256, [&] { k_query_tiles_stream<KIND, K128, P, 256>(img, seq_al, shift, total, seq_off, out_off, n_records, out); });              \
     } while (0)
         EMU_DISPATCH(CALL);

@@ -15,8 +15,11 @@
 #define __forceinline__ inline
 #define __shared__ static
 #define __launch_bounds__(...)
-// optimisation barrier used by kernels_stream_pipe.cuh (the device version names an AMDGPU register class)
-#define LPHQ_OPAQUE_LANE(x) asm volatile("" : "+r"(x))
+// clang's cache-hint builtins (g++ has none): plain accesses on the host
+template <typename T>
+static inline T __builtin_nontemporal_load(const T* p) { return *p; }
+template <typename T>
+static inline void __builtin_nontemporal_store(T v, T* p) { __builtin_memcpy((void*)p, &v, sizeof(T)); }  // (p may be under-aligned for T)
 
 struct uint4 {
     uint32_t x, y, z, w;

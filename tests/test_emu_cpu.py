@@ -140,9 +140,7 @@ def test_tile_kernels_on_the_emulator(emuk, tmp_path, k, m, bits, kind):
     # > 64 records inside one tile (beyond the LDS record table of the streaming kernels), then ~20 records per tile
     batch += random_records(11, 150, 0, 5) + [recs[0][:k + 2]] + random_records(12, 40, k, k + 20) + [recs[1]]
     exp = [o(r, False) for r in batch]
-    V4 = 1 << 16  # k_query_tiles_stream4
-    for streaming, mis, block in ((True, 0, 256), (True, 5, 256), (True, 15, 128), (False, 0, 256), (False, 9, 256), (True, 0, 256 | V4), (True, 7, 256 | V4),
-                                  (True, 15, 128 | V4), (True, 2, 256 | V4)):
+    for streaming, mis, block in ((True, 0, 256), (True, 5, 256), (True, 15, 128), (False, 0, 256), (False, 9, 256), (True, 7, 256), (True, 2, 128)):
         got = emu_records(emuk, h, batch, k, streaming, mis, block)
         for g, e in zip(got, exp):
             assert np.array_equal(g, e), (streaming, mis, block)
@@ -165,7 +163,7 @@ def test_tile_kernels_non_acgt_on_the_emulator(emuk, tmp_path):
         batch.append(bytes(q))
     got_s = emu_records(emuk, h, batch, k, True)
     got_r = emu_records(emuk, h, batch, k, False)
-    got_p = emu_records(emuk, h, batch, k, True, 3, 256 | (1 << 16))  # k_query_tiles_stream4, another pointer alignment
+    got_p = emu_records(emuk, h, batch, k, True, 3)  # another pointer alignment
     for q, gs, gr, gp in zip(batch, got_s, got_r, got_p):
         exp = o(q, False)  # random mode reads a non-ACGT base as 'A' (mphf_utils.hpp:108)
         assert np.array_equal(gr, exp)
