@@ -87,13 +87,23 @@ int lphq_image_copy(const lphq_index* idx, void* host_dst, size_t cap);
  * ownership of the memory and must keep it alive until lphq_close. */
 int lphq_open_device_image(const void* d_image, size_t nbytes, int device, lphq_index** out);
 
-/* Upload the image to `device` (hipMalloc + hipMemcpy).  One device per handle. */
+/* Put a replica of the image on `device`.  The first attach uploads the host image (hipMalloc + hipMemcpy) and makes that
+ * device the PRIMARY one; attaching further devices copies the primary replica peer to peer (hipMemcpyPeer: xGMI between the
+ * GPUs of one node).  Attaching a device twice is a no-op.  Attach before sharing the handle between threads. */
 int lphq_attach(lphq_index* idx, int device);
-/* Device pointer of the attached image (for broadcast from the root rank). */
+/* lphq_attach for devices[0..n): the single-process form of "index replicated on every GPU, query batches sharded"
+ * (one process per GPU uses lphq_open_device_image after an RCCL broadcast instead).  The reference object a
+ * binding replaces is one immutable `MPHF hf` shared by all callers (include/partitioned_mphf.hpp:21-23). */
+int lphq_attach_devices(lphq_index* idx, const int* devices, int n);
+/* Attached devices in attach order (primary first): writes min(*n, cap) ordinals, *n = number attached. */
+int lphq_attached_devices(const lphq_index* idx, int* devices, int cap, int* n);
+/* Device pointer of the replica the calling thread would use (for broadcast from the root rank). */
 int lphq_device_image(const lphq_index* idx, const void** d_image, size_t* nbytes);
 
 /* ---- queries on device-resident buffers (stream = hipStream_t, NULL = default stream) ----
- * All are asynchronous with respect to the host. */
+ * All are asynchronous with respect to the host.  Device selection: a call runs on the calling thread's CURRENT HIP device if
+ * the index has a replica there, otherwise on the primary device; buffers and stream must belong to that device.  Any number
+ * of host threads may call concurrently on one handle (the index is immutable, as `const` MPHF::operator() is). */
 
 /* Random (non-streaming) lookups of n packed k-mers: the `streaming == false` branch
  * (include/partitioned_mphf.hpp:185-195) applied to kmer_t values as produced by
@@ -118,14 +128,18 @@ int lphq_query_records(const lphq_index* idx, const char* d_seq, size_t total_ba
 int lphq_pack_kmers(const lphq_index* idx, const char* d_seq, const uint64_t* d_pos, size_t n, void* d_kmers, void* stream);
 
 /* Number of codes != LPHQ_INVALID in d_codes[0..n) (what vector.size() of the reference's streaming pass
- * would be).  Synchronous: waits for the default stream. */
-int lphq_count_valid(const lphq_index* idx, const uint64_t* d_codes, size_t n, uint64_t* count);
+ * would be).  Runs on `stream` (so it is ordered after the query that produced d_codes there) and waits for it. */
+int lphq_count_valid(const lphq_index* idx, const uint64_t* d_codes, size_t n, void* stream, uint64_t* count);
+/* The same count left in *d_count (8 bytes of device memory, overwritten) without waiting: for callers that keep several
+ * batches in flight and read the count back with their own copy on `stream`. */
+int lphq_count_valid_async(const lphq_index* idx, const uint64_t* d_codes, size_t n, uint64_t* d_count, void* stream);
 
 /* ---- host-buffer convenience: mirrors MPHF::operator()(contig, length, streaming) ----
  * Copies the record to the device, runs the GPU path, copies the codes back and (streaming
  * only) drops the windows that hold a non-ACGT base -- decided from the input bases, not from the
  * LPHQ_INVALID sentinel -- so *n_out is what the reference's vector.size() would be for
- * ACGT input.  length < k yields 0 codes in both modes. */
+ * ACGT input.  length < k yields 0 codes in both modes.  Each call works on its own stream and device buffers (recycled
+ * between calls), so concurrent callers do not serialise on the library. */
 int lphq_query_contig(const lphq_index* idx, const char* contig, size_t length, int streaming,
                       uint64_t* out, size_t cap, size_t* n_out);
 

@@ -47,12 +47,15 @@ SIGNATURES = {
     "lphq_image_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "lphq_open_device_image": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
     "lphq_attach": (C.c_int, [C.c_void_p, C.c_int]),
+    "lphq_attach_devices": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
+    "lphq_attached_devices": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     "lphq_device_image": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "lphq_query_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "lphq_query_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_void_p]),
     "lphq_pack_kmers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
-    "lphq_count_valid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "lphq_count_valid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint64)]),
+    "lphq_count_valid_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "lphq_query_contig": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
                                     C.POINTER(C.c_size_t)]),
     "lphq_build": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int, C.c_uint64,

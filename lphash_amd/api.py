@@ -84,6 +84,25 @@ class _MphfBase:
         self._refresh()
         return self
 
+    def attach_devices(self, devices):
+        """Replicas on several GPUs of one process (lphq_attach_devices: upload to the first, peer copies to the others)."""
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        check(lib.lphq_attach_devices(self._h, devs, len(devices)))
+        self._refresh()
+        return self
+
+    def attached_devices(self):
+        n = C.c_int()
+        devs = (C.c_int * 64)()
+        check(lib.lphq_attached_devices(self._h, devs, 64, C.byref(n)))
+        return [devs[i] for i in range(min(n.value, 64))]
+
+    def count_valid(self, d_codes, n, stream=0):
+        """Codes != LPHQ_INVALID among d_codes[0..n) (device pointer), counted on `stream`."""
+        c = C.c_uint64()
+        check(lib.lphq_count_valid(self._h, C.c_void_p(d_codes), n, C.c_void_p(stream), C.byref(c)))
+        return c.value
+
     def close(self):
         if self._h:
             lib.lphq_close(self._h)

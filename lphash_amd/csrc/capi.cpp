@@ -16,21 +16,32 @@
 
 using namespace lphq;
 
+// One replica of the flat image per attached device.  Replicas are added by lphq_attach / lphq_attach_devices before the
+// index is shared between threads and never change afterwards, so the query entry points read them without a lock.
+struct Replica {
+    int device = -1;
+    uint8_t* d_image = nullptr;
+    bool owns = false;
+};
+// Per-call scratch of the host-buffer path and of lphq_count_valid: buffers plus a private non-blocking stream, so that
+// concurrent callers neither serialise on a lock nor meet on the null stream.  Slots are recycled through a free list.
+struct Scratch {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    char* d_seq = nullptr;
+    size_t d_seq_cap = 0;
+    uint64_t* d_out = nullptr;
+    size_t d_out_cap = 0;
+    uint64_t* d_offs = nullptr;  // 4 record offsets + 1 counter
+};
 struct lphq_index {
     lphq_image_header hdr;
     std::vector<uint8_t> image;  // host copy of the flat image (empty for lphq_open_device_image handles)
     uint64_t file_bytes = 0;
     size_t image_bytes = 0;
-    int device = -1;
-    uint8_t* d_image = nullptr;
-    bool owns_device_image = false;
-    // grow-only scratch of the host-buffer convenience path
-    std::mutex scratch_mu;
-    char* d_seq = nullptr;
-    size_t d_seq_cap = 0;
-    uint64_t* d_out = nullptr;
-    size_t d_out_cap = 0;
-    uint64_t* d_offs = nullptr;
+    std::vector<Replica> reps;   // reps[0] = primary device
+    std::mutex pool_mu;          // guards pool only (pop / push of a slot), never held across device work
+    std::vector<Scratch*> pool;
 };
 
 static thread_local std::string g_err;
@@ -118,17 +129,80 @@ extern "C" int lphq_open(const char* path, int kind, int kmer_bits, lphq_index**
     return lphq_open_memory(buf.data(), buf.size(), kind, kmer_bits, out);
 }
 
+static void scratch_destroy(Scratch* s) {
+    DeviceGuard g(s->device);
+    if (s->stream) {
+        (void)hipStreamSynchronize(s->stream);
+        (void)hipStreamDestroy(s->stream);
+    }
+    if (s->d_seq) (void)hipFree(s->d_seq);
+    if (s->d_out) (void)hipFree(s->d_out);
+    if (s->d_offs) (void)hipFree(s->d_offs);
+    delete s;
+}
+
 extern "C" void lphq_close(lphq_index* idx) {
     if (!idx) return;
-    if (idx->device >= 0) {
-        DeviceGuard g(idx->device);
-        if (idx->owns_device_image && idx->d_image) (void)hipFree(idx->d_image);
-        if (idx->d_seq) (void)hipFree(idx->d_seq);
-        if (idx->d_out) (void)hipFree(idx->d_out);
-        if (idx->d_offs) (void)hipFree(idx->d_offs);
+    for (Scratch* s : idx->pool) scratch_destroy(s);
+    for (const Replica& r : idx->reps) {
+        if (r.owns && r.d_image) {
+            DeviceGuard g(r.device);
+            (void)hipFree(r.d_image);
+        }
     }
     delete idx;
 }
+
+// the replica queries of the calling thread run on: its current HIP device if the index is attached there, else the primary
+static const Replica* pick_replica(const lphq_index* idx) {
+    if (idx->reps.empty()) return nullptr;
+    if (idx->reps.size() > 1) {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess)
+            for (const Replica& r : idx->reps)
+                if (r.device == cur) return &r;
+    }
+    return &idx->reps[0];
+}
+
+// a scratch slot for `device` (recycled or new); returns nullptr with the error text set on failure
+static Scratch* scratch_acquire(lphq_index* idx, int device) {
+    {
+        std::lock_guard<std::mutex> lk(idx->pool_mu);
+        for (size_t i = 0; i < idx->pool.size(); ++i)
+            if (idx->pool[i]->device == device) {
+                Scratch* s = idx->pool[i];
+                idx->pool[i] = idx->pool.back();
+                idx->pool.pop_back();
+                return s;
+            }
+    }
+    Scratch* s = new (std::nothrow) Scratch();
+    if (!s) {
+        g_err = "out of memory";
+        return nullptr;
+    }
+    s->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_offs, 8 * sizeof(uint64_t));
+    if (e != hipSuccess) {
+        (void)fail_hip(e, "scratch slot");
+        scratch_destroy(s);
+        return nullptr;
+    }
+    return s;
+}
+static void scratch_release(lphq_index* idx, Scratch* s) {
+    std::lock_guard<std::mutex> lk(idx->pool_mu);
+    idx->pool.push_back(s);
+}
+struct ScratchLease {  // returns the slot on every exit path
+    lphq_index* idx;
+    Scratch* s;
+    ~ScratchLease() {
+        if (s) scratch_release(idx, s);
+    }
+};
 
 extern "C" int lphq_get_info(const lphq_index* idx, lphq_info* info) {
     if (!idx || !info) return fail(LPHQ_ERR_ARG, "null argument");
@@ -143,7 +217,7 @@ extern "C" int lphq_get_info(const lphq_index* idx, lphq_info* info) {
     info->fallback_kmers = idx->hdr.fallback_kmers;
     info->file_bytes = idx->file_bytes;
     info->image_bytes = idx->image_bytes;
-    info->device = idx->device;
+    info->device = idx->reps.empty() ? -1 : idx->reps[0].device;
     for (int i = 0; i < 4; ++i) info->kmers_by_type[i] = idx->hdr.kmers_by_type[i];
     info->minimizer_table_size = idx->hdr.mm.table_size;
     return LPHQ_OK;
@@ -205,24 +279,52 @@ static int check_device(int device) {
     return LPHQ_OK;
 }
 
-extern "C" int lphq_attach(lphq_index* idx, int device) {
-    if (!idx) return fail(LPHQ_ERR_ARG, "null argument");
-    if (idx->device >= 0) return idx->device == device ? LPHQ_OK : fail(LPHQ_ERR_STATE, "already attached to another device");
-    if (idx->image.empty()) return fail(LPHQ_ERR_STATE, "no host image to upload");
+// Add a replica on `device`: from the host image when there is one and no replica exists yet, otherwise by a peer copy of
+// the primary replica (xGMI between GPUs of one node; the runtime stages through the host when peer access is unavailable).
+static int add_replica(lphq_index* idx, int device) {
+    for (const Replica& r : idx->reps)
+        if (r.device == device) return LPHQ_OK;
+    if (idx->reps.empty() && idx->image.empty()) return fail(LPHQ_ERR_STATE, "no host image to upload");
     int rc = check_device(device);
     if (rc) return rc;
     DeviceGuard g(device);
     if (!g.ok) return fail(LPHQ_ERR_HIP, "hipSetDevice failed");
     uint8_t* d = nullptr;
-    HIP_TRY(hipMalloc((void**)&d, idx->image.size()));
-    hipError_t e = hipMemcpy(d, idx->image.data(), idx->image.size(), hipMemcpyHostToDevice);
+    HIP_TRY(hipMalloc((void**)&d, idx->image_bytes));
+    hipError_t e;
+    if (idx->reps.empty()) e = hipMemcpy(d, idx->image.data(), idx->image_bytes, hipMemcpyHostToDevice);
+    else e = hipMemcpyPeer(d, device, idx->reps[0].d_image, idx->reps[0].device, idx->image_bytes);
     if (e != hipSuccess) {
         (void)hipFree(d);
-        return fail_hip(e, "hipMemcpy(image)");
+        return fail_hip(e, idx->reps.empty() ? "hipMemcpy(image)" : "hipMemcpyPeer(image)");
     }
-    idx->d_image = d;
-    idx->owns_device_image = true;
-    idx->device = device;
+    Replica r;
+    r.device = device;
+    r.d_image = d;
+    r.owns = true;
+    idx->reps.push_back(r);
+    return LPHQ_OK;
+}
+
+extern "C" int lphq_attach(lphq_index* idx, int device) {
+    if (!idx) return fail(LPHQ_ERR_ARG, "null argument");
+    return add_replica(idx, device);
+}
+
+extern "C" int lphq_attach_devices(lphq_index* idx, const int* devices, int n) {
+    if (!idx || (n > 0 && !devices)) return fail(LPHQ_ERR_ARG, "null argument");
+    if (n <= 0) return fail(LPHQ_ERR_ARG, "no device given");
+    for (int i = 0; i < n; ++i) {
+        int rc = add_replica(idx, devices[i]);
+        if (rc) return rc;
+    }
+    return LPHQ_OK;
+}
+
+extern "C" int lphq_attached_devices(const lphq_index* idx, int* devices, int cap, int* n) {
+    if (!idx || !n) return fail(LPHQ_ERR_ARG, "null argument");
+    *n = (int)idx->reps.size();
+    for (int i = 0; i < *n && i < cap && devices; ++i) devices[i] = idx->reps[i].device;
     return LPHQ_OK;
 }
 
@@ -252,18 +354,21 @@ extern "C" int lphq_open_device_image(const void* d_image, size_t nbytes, int de
             return fail(LPHQ_ERR_FORMAT, "flat LPHQ image rejected: " + why);
         }
     }
-    idx->d_image = (uint8_t*)d_image;
-    idx->owns_device_image = false;
+    Replica r;
+    r.device = device;
+    r.d_image = (uint8_t*)d_image;
+    r.owns = false;
+    idx->reps.push_back(r);
     idx->image_bytes = nbytes;
-    idx->device = device;
     *out = idx;
     return LPHQ_OK;
 }
 
 extern "C" int lphq_device_image(const lphq_index* idx, const void** d_image, size_t* nbytes) {
     if (!idx || !d_image || !nbytes) return fail(LPHQ_ERR_ARG, "null argument");
-    if (idx->device < 0) return fail(LPHQ_ERR_STATE, "index is not attached to a device");
-    *d_image = idx->d_image;
+    const Replica* r = pick_replica(idx);
+    if (!r) return fail(LPHQ_ERR_STATE, "index is not attached to a device");
+    *d_image = r->d_image;
     *nbytes = idx->image_bytes;
     return LPHQ_OK;
 }
@@ -271,14 +376,15 @@ extern "C" int lphq_device_image(const lphq_index* idx, const void** d_image, si
 #define REQUIRE_ATTACHED(idx)                                                                        \
     do {                                                                                             \
         if (!(idx)) return fail(LPHQ_ERR_ARG, "null index");                                         \
-        if ((idx)->device < 0) return fail(LPHQ_ERR_STATE, "index is not attached to a device (no CPU fallback exists)"); \
+        if ((idx)->reps.empty()) return fail(LPHQ_ERR_STATE, "index is not attached to a device (no CPU fallback exists)"); \
     } while (0)
 
 extern "C" int lphq_query_packed(const lphq_index* idx, const void* d_kmers, size_t n, uint64_t* d_out, void* stream) {
     REQUIRE_ATTACHED(idx);
     if (n && (!d_kmers || !d_out)) return fail(LPHQ_ERR_ARG, "null buffer");
-    DeviceGuard g(idx->device);
-    HIP_TRY(launch_query_packed(idx->hdr, idx->d_image, d_kmers, n, d_out, (hipStream_t)stream));
+    const Replica* r = pick_replica(idx);
+    DeviceGuard g(r->device);
+    HIP_TRY(launch_query_packed(idx->hdr, r->d_image, d_kmers, n, d_out, (hipStream_t)stream));
     return LPHQ_OK;
 }
 
@@ -288,31 +394,50 @@ extern "C" int lphq_query_records(const lphq_index* idx, const char* d_seq, size
     if (n_records && (!d_seq_offsets || !d_out_offsets)) return fail(LPHQ_ERR_ARG, "null buffer");
     if (n_records > 0xFFFFFFFFull) return fail(LPHQ_ERR_ARG, "more than 2^32-1 records in one batch");
     if (total_bases && !d_seq) return fail(LPHQ_ERR_ARG, "null buffer");
-    DeviceGuard g(idx->device);
-    HIP_TRY(launch_query_records(idx->hdr, idx->d_image, d_seq, total_bases, d_seq_offsets, d_out_offsets, n_records, d_out, streaming, (hipStream_t)stream));
+    const Replica* r = pick_replica(idx);
+    DeviceGuard g(r->device);
+    hipError_t e = launch_query_records(idx->hdr, r->d_image, d_seq, total_bases, d_seq_offsets, d_out_offsets, n_records, d_out, streaming, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) return fail(LPHQ_ERR_ARG, "batch too large for one launch (more than ~8 G bases): split it");
+    HIP_TRY(e);
     return LPHQ_OK;
 }
 
 extern "C" int lphq_pack_kmers(const lphq_index* idx, const char* d_seq, const uint64_t* d_pos, size_t n, void* d_kmers, void* stream) {
     REQUIRE_ATTACHED(idx);
     if (n && (!d_seq || !d_pos || !d_kmers)) return fail(LPHQ_ERR_ARG, "null buffer");
-    DeviceGuard g(idx->device);
+    const Replica* r = pick_replica(idx);
+    DeviceGuard g(r->device);
     HIP_TRY(launch_pack_kmers(idx->hdr, d_seq, d_pos, n, d_kmers, (hipStream_t)stream));
     return LPHQ_OK;
 }
 
-extern "C" int lphq_count_valid(const lphq_index* cidx, const uint64_t* d_codes, size_t n, uint64_t* count) {
+extern "C" int lphq_count_valid(const lphq_index* cidx, const uint64_t* d_codes, size_t n, void* stream, uint64_t* count) {
     lphq_index* idx = const_cast<lphq_index*>(cidx);
     REQUIRE_ATTACHED(idx);
     if (!count || (n && !d_codes)) return fail(LPHQ_ERR_ARG, "null argument");
     *count = 0;
     if (n == 0) return LPHQ_OK;
-    DeviceGuard g(idx->device);
-    std::lock_guard<std::mutex> lk(idx->scratch_mu);
-    if (!idx->d_offs) HIP_TRY(hipMalloc((void**)&idx->d_offs, 4 * sizeof(uint64_t)));
-    HIP_TRY(hipMemsetAsync(idx->d_offs, 0, 8, nullptr));
-    HIP_TRY(launch_count_valid(d_codes, n, (unsigned long long*)idx->d_offs, nullptr));
-    HIP_TRY(hipMemcpy(count, idx->d_offs, 8, hipMemcpyDeviceToHost));
+    const Replica* r = pick_replica(idx);
+    DeviceGuard g(r->device);
+    ScratchLease sl{idx, scratch_acquire(idx, r->device)};
+    if (!sl.s) return LPHQ_ERR_HIP;
+    // everything on the caller's stream: ordered after whatever produced d_codes there
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* d_count = (unsigned long long*)(sl.s->d_offs + 4);
+    HIP_TRY(hipMemsetAsync(d_count, 0, 8, st));
+    HIP_TRY(launch_count_valid(d_codes, n, d_count, st));
+    HIP_TRY(hipMemcpyAsync(count, d_count, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return LPHQ_OK;
+}
+
+extern "C" int lphq_count_valid_async(const lphq_index* idx, const uint64_t* d_codes, size_t n, uint64_t* d_count, void* stream) {
+    REQUIRE_ATTACHED(idx);
+    if (!d_count || (n && !d_codes)) return fail(LPHQ_ERR_ARG, "null argument");
+    const Replica* r = pick_replica(idx);
+    DeviceGuard g(r->device);
+    HIP_TRY(hipMemsetAsync(d_count, 0, 8, (hipStream_t)stream));
+    HIP_TRY(launch_count_valid(d_codes, n, (unsigned long long*)d_count, (hipStream_t)stream));
     return LPHQ_OK;
 }
 
@@ -325,31 +450,36 @@ extern "C" int lphq_query_contig(const lphq_index* cidx, const char* contig, siz
     if (length < k) return LPHQ_OK;  // partitioned_mphf.hpp:79 (streaming); the random branch is undefined there
     const size_t nwin = length - k + 1;
     if (!out || cap < nwin) return fail(LPHQ_ERR_ARG, "output buffer too small");
-    DeviceGuard g(idx->device);
-    std::lock_guard<std::mutex> lk(idx->scratch_mu);
-    if (idx->d_seq_cap < length + 64) {
-        if (idx->d_seq) (void)hipFree(idx->d_seq);
-        idx->d_seq = nullptr;
-        idx->d_seq_cap = 0;
+    const Replica* r = pick_replica(idx);
+    DeviceGuard g(r->device);
+    ScratchLease sl{idx, scratch_acquire(idx, r->device)};
+    Scratch* sc = sl.s;
+    if (!sc) return LPHQ_ERR_HIP;
+    if (sc->d_seq_cap < length + 64) {
+        if (sc->d_seq) (void)hipFree(sc->d_seq);
+        sc->d_seq = nullptr;
+        sc->d_seq_cap = 0;
         size_t want = (length + 64) * 5 / 4;
-        HIP_TRY(hipMalloc((void**)&idx->d_seq, want));
-        idx->d_seq_cap = want;
+        HIP_TRY(hipMalloc((void**)&sc->d_seq, want));
+        sc->d_seq_cap = want;
     }
-    if (idx->d_out_cap < nwin) {
-        if (idx->d_out) (void)hipFree(idx->d_out);
-        idx->d_out = nullptr;
-        idx->d_out_cap = 0;
+    if (sc->d_out_cap < nwin) {
+        if (sc->d_out) (void)hipFree(sc->d_out);
+        sc->d_out = nullptr;
+        sc->d_out_cap = 0;
         size_t want = nwin * 5 / 4 + 16;
-        HIP_TRY(hipMalloc((void**)&idx->d_out, want * 8));
-        idx->d_out_cap = want;
+        HIP_TRY(hipMalloc((void**)&sc->d_out, want * 8));
+        sc->d_out_cap = want;
     }
-    if (!idx->d_offs) HIP_TRY(hipMalloc((void**)&idx->d_offs, 4 * sizeof(uint64_t)));
+    // the slot's own stream: callers on other threads run concurrently (the copies from / to pageable memory are staged by the
+    // runtime; pinned caller buffers make them truly asynchronous)
     const uint64_t offs[4] = {0, (uint64_t)length, 0, (uint64_t)nwin};
-    HIP_TRY(hipMemcpyAsync(idx->d_seq, contig, length, hipMemcpyHostToDevice, nullptr));
-    HIP_TRY(hipMemcpyAsync(idx->d_offs, offs, sizeof offs, hipMemcpyHostToDevice, nullptr));
-    HIP_TRY(launch_query_records(idx->hdr, idx->d_image, idx->d_seq, length, idx->d_offs, idx->d_offs + 2, 1, idx->d_out, streaming, nullptr));
-    HIP_TRY(hipMemcpyAsync(out, idx->d_out, nwin * 8, hipMemcpyDeviceToHost, nullptr));
-    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipMemcpyAsync(sc->d_seq, contig, length, hipMemcpyHostToDevice, sc->stream));
+    HIP_TRY(hipMemcpyAsync(sc->d_offs, offs, sizeof offs, hipMemcpyHostToDevice, sc->stream));
+    HIP_TRY(hipStreamSynchronize(sc->stream));  // `offs` lives on this stack frame
+    HIP_TRY(launch_query_records(idx->hdr, r->d_image, sc->d_seq, length, sc->d_offs, sc->d_offs + 2, 1, sc->d_out, streaming, sc->stream));
+    HIP_TRY(hipMemcpyAsync(out, sc->d_out, nwin * 8, hipMemcpyDeviceToHost, sc->stream));
+    HIP_TRY(hipStreamSynchronize(sc->stream));
     size_t n = nwin;
     if (streaming) {
         // Drop windows holding a non-ACGT base (the reference emits nothing for them).  Validity is taken from the input, not

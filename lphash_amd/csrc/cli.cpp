@@ -5,12 +5,14 @@
 // Same flags, same CSV on stdout, same exit codes (1 usage/parse error, 2 cannot open the query file).
 // Extra flags (all optional, defaults keep the reference behaviour): --kmer-bits 64|128 (the reference's
 // compile-time kmer_t, default 128 like include/compile_constants.tpd:1; 64 reproduces a `uint64_t` build),
-// --device N, --batch-mb N, --threads N (FASTA parsing threads of the query tools), --pinned (parse into pinned host
-// memory).  The work itself runs on the GPU through the C ABI (include/lphq.h).
+// --device N or --gpus N (replicas on devices 0..N-1, every batch sharded over them), --batch-mb N, --threads N (FASTA parsing
+// threads of the query tools), --pageable (parse into ordinary instead of pinned host memory).  The work itself runs on the GPU through the C ABI (include/lphq.h).
 //   lphash records -i <fasta|fastq[.gz]> [-t N] [--serial] [--batch-bytes N] [--min-piece N]
 // is a diagnostic: it prints the record count, base count and a checksum of what the reader yields (tests compare the
 // multi-threaded reader with the serial one through it).
 #include <hip/hip_runtime.h>
+
+#include <sys/stat.h>
 
 #include <chrono>
 #include <cstring>
@@ -77,26 +79,77 @@ Args parse(int argc, char** argv, const std::vector<std::string>& valued, const 
     return a;
 }
 
-struct DeviceBatch {
-    char* d_seq = nullptr;
-    uint64_t* d_offs = nullptr;  // seq offsets then out offsets
-    uint64_t* d_out = nullptr;
-    size_t seq_cap = 0, rec_cap = 0, out_cap = 0;
-    bool ensure(size_t bases, size_t recs, size_t outs) {
-        if (bases + 64 > seq_cap) {
-            if (d_seq) (void)hipFree(d_seq);
-            seq_cap = (bases + 64) * 5 / 4;
-            if (hipMalloc((void**)&d_seq, seq_cap) != hipSuccess) return false;
+// Device side of one GPU of the query tools: its own stream and two slots of device buffers, used alternately, so that the
+// copy-in of batch i+1 overlaps the kernels of batch i.  One host thread drives every GPU: all copies come from pinned
+// memory and every call here is asynchronous, so the devices run concurrently without a thread each.
+struct GpuWorker {
+    struct Slot {
+        char* d_seq = nullptr;
+        uint64_t* d_offs = nullptr;  // seq offsets then out offsets
+        uint64_t* d_out = nullptr;
+        size_t seq_cap = 0, rec_cap = 0, out_cap = 0;
+        uint64_t* h_offs = nullptr;  // pinned staging of the offsets
+        size_t h_offs_cap = 0;
+        uint64_t* h_codes = nullptr;  // pinned, only with --output
+        size_t h_codes_cap = 0;
+        uint64_t* d_count = nullptr;  // number of valid codes of the batch, counted on the device ...
+        uint64_t* h_count = nullptr;  // ... and copied here (pinned)
+        hipEvent_t copied = nullptr;  // the batch's bases have left the parse arena
+        bool busy = false;
+        size_t n_out = 0;
+    };
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Slot slot[2];
+
+    bool init(int dev) {
+        device = dev;
+        if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
+        for (Slot& s : slot)
+            if (hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess || hipMalloc((void**)&s.d_count, 8) != hipSuccess ||
+                hipHostMalloc((void**)&s.h_count, 8, hipHostMallocDefault) != hipSuccess)
+                return false;
+        return true;
+    }
+    void destroy() {
+        (void)hipSetDevice(device);
+        for (Slot& s : slot) {
+            if (s.d_seq) (void)hipFree(s.d_seq);
+            if (s.d_offs) (void)hipFree(s.d_offs);
+            if (s.d_out) (void)hipFree(s.d_out);
+            if (s.h_offs) (void)hipHostFree(s.h_offs);
+            if (s.h_codes) (void)hipHostFree(s.h_codes);
+            if (s.d_count) (void)hipFree(s.d_count);
+            if (s.h_count) (void)hipHostFree(s.h_count);
+            if (s.copied) (void)hipEventDestroy(s.copied);
         }
-        if (2 * (recs + 1) > rec_cap) {
-            if (d_offs) (void)hipFree(d_offs);
-            rec_cap = 2 * (recs + 1) * 5 / 4;
-            if (hipMalloc((void**)&d_offs, rec_cap * 8) != hipSuccess) return false;
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    static bool ensure(Slot& s, size_t bases, size_t recs, size_t outs, bool want_codes) {
+        if (bases + 64 > s.seq_cap) {
+            if (s.d_seq) (void)hipFree(s.d_seq);
+            s.seq_cap = (bases + 64) * 5 / 4;
+            if (hipMalloc((void**)&s.d_seq, s.seq_cap) != hipSuccess) return false;
         }
-        if (outs + 1 > out_cap) {
-            if (d_out) (void)hipFree(d_out);
-            out_cap = (outs + 1) * 5 / 4;
-            if (hipMalloc((void**)&d_out, out_cap * 8) != hipSuccess) return false;
+        if (2 * (recs + 1) > s.rec_cap) {
+            if (s.d_offs) (void)hipFree(s.d_offs);
+            s.rec_cap = 2 * (recs + 1) * 5 / 4;
+            if (hipMalloc((void**)&s.d_offs, s.rec_cap * 8) != hipSuccess) return false;
+        }
+        if (2 * (recs + 1) > s.h_offs_cap) {
+            if (s.h_offs) (void)hipHostFree(s.h_offs);
+            s.h_offs_cap = 2 * (recs + 1) * 5 / 4;
+            if (hipHostMalloc((void**)&s.h_offs, s.h_offs_cap * 8, hipHostMallocDefault) != hipSuccess) return false;
+        }
+        if (outs + 1 > s.out_cap) {
+            if (s.d_out) (void)hipFree(s.d_out);
+            s.out_cap = (outs + 1) * 5 / 4;
+            if (hipMalloc((void**)&s.d_out, s.out_cap * 8) != hipSuccess) return false;
+        }
+        if (want_codes && outs + 1 > s.h_codes_cap) {
+            if (s.h_codes) (void)hipHostFree(s.h_codes);
+            s.h_codes_cap = (outs + 1) * 5 / 4;
+            if (hipHostMalloc((void**)&s.h_codes, s.h_codes_cap * 8, hipHostMallocDefault) != hipSuccess) return false;
         }
         return true;
     }
@@ -138,65 +191,37 @@ void arena_free(void* p) { g_arenas.put(p); }
 int default_parse_threads() { return (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency())); }
 
 // One pass of src/query.cpp:48-56 / :68-76 over the whole file, batched: returns false if the file cannot be opened.
-bool query_pass(lphq_index* idx, const lphq_info& info, const std::string& path, int streaming, size_t batch_bases, int threads, bool pinned, DeviceBatch& db,
-                uint64_t& total_kmers, uint64_t& elapsed_us, std::string& err, FILE* sink) {
+// Every batch is split into contiguous runs of records of about equal base count, one per GPU (the index is replicated,
+// include/lphq.h: lphq_attach_devices); per GPU: copy in (async, from the pinned parse arena), kernel, count, all on that GPU's
+// stream.  The host only waits when it needs a slot or an arena back, so parsing of batch i+1, the copies of batch i and the
+// kernels of batch i-1 overlap.
+bool query_pass(lphq_index* idx, const lphq_info& info, const std::string& path, int streaming, size_t batch_bases, int threads, bool pinned,
+                std::vector<GpuWorker>& gpus, uint64_t& total_kmers, uint64_t& elapsed_us, std::string& err, FILE* sink) {
     g_arenas.pinned = pinned;
     lphq::FastxBatchReader rd(path.c_str(), threads, &arena_alloc, &arena_free);
     if (!rd.ok()) return false;
     auto t0 = std::chrono::high_resolution_clock::now();
     lphq::FastxBatch bufs[2];
-    std::vector<uint64_t> all;
     total_kmers = 0;
-    auto flush = [&](const lphq::FastxBatch& b) -> bool {
-        const size_t n = b.lens.size();
-        if (n == 0) return true;
-        all.resize(2 * (n + 1));
-        uint64_t so = 0, oo = 0;
-        for (size_t i = 0; i < n; ++i) {
-            all[i] = so;
-            all[n + 1 + i] = oo;
-            so += b.lens[i];
-            oo += b.lens[i] >= info.k ? b.lens[i] - info.k + 1 : 0;
-        }
-        all[n] = so;
-        all[2 * n + 1] = oo;
-        if (oo) {
-            if (!db.ensure(so, n, oo)) {
-                err = "device allocation failed";
+    const size_t ng = gpus.size();
+    // wait for slot `si` of every GPU: its count is in, its buffers are free; with --output its codes go to the sink (in GPU
+    // order = record order)
+    auto retire = [&](int si) -> bool {
+        for (GpuWorker& g : gpus) {
+            GpuWorker::Slot& s = g.slot[si];
+            if (!s.busy) continue;
+            (void)hipSetDevice(g.device);
+            if (hipStreamSynchronize(g.stream) != hipSuccess) {
+                err = "device work failed";
                 return false;
             }
-            size_t at = 0;
-            for (const auto& sg : b.segs) {  // one copy per parsed piece, compacting on the way
-                if (hipMemcpy(db.d_seq + at, sg.p, sg.n, hipMemcpyHostToDevice) != hipSuccess) {
-                    err = "host to device copy failed";
-                    return false;
-                }
-                at += sg.n;
-            }
-            if (hipMemcpy(db.d_offs, all.data(), all.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
-                err = "host to device copy failed";
-                return false;
-            }
-            if (lphq_query_records(idx, db.d_seq, so, db.d_offs, n, db.d_out, db.d_offs + n + 1, streaming, nullptr) != LPHQ_OK) {
-                err = lphq_last_error();
-                return false;
-            }
-            uint64_t valid = 0;
-            if (lphq_count_valid(idx, db.d_out, oo, &valid) != LPHQ_OK) {  // synchronises; hashes.size() of the reference
-                err = lphq_last_error();
-                return false;
-            }
-            total_kmers += valid;
-            if (sink) {  // result sink: the reference discards the codes (src/query.cpp:54); here they can be kept (raw little-endian u64)
-                std::vector<uint64_t> codes(oo);
-                if (hipMemcpy(codes.data(), db.d_out, oo * 8, hipMemcpyDeviceToHost) != hipSuccess) {
-                    err = "device to host copy failed";
-                    return false;
-                }
+            s.busy = false;
+            total_kmers += *s.h_count;
+            if (sink && s.n_out) {  // result sink: the reference discards the codes (src/query.cpp:54); here they can be kept (raw little-endian u64)
                 size_t nv = 0;
-                for (size_t i = 0; i < oo; ++i)
-                    if (codes[i] != LPHQ_INVALID) codes[nv++] = codes[i];
-                if (fwrite(codes.data(), 8, nv, sink) != nv) {
+                for (size_t i = 0; i < s.n_out; ++i)
+                    if (s.h_codes[i] != LPHQ_INVALID) s.h_codes[nv++] = s.h_codes[i];
+                if (fwrite(s.h_codes, 8, nv, sink) != nv) {
                     err = "cannot write the output file";
                     return false;
                 }
@@ -204,19 +229,120 @@ bool query_pass(lphq_index* idx, const lphq_info& info, const std::string& path,
         }
         return true;
     };
-    // batch i+1 is parsed (by `threads` threads) while batch i is copied to the device and looked up; the reader keeps
-    // both batches' bases alive (fastx_batch.hpp)
+    // the bases of slot `si` have left the parse arena on every GPU
+    auto arena_released = [&](int si) {
+        for (GpuWorker& g : gpus)
+            if (g.slot[si].busy) {
+                (void)hipSetDevice(g.device);
+                (void)hipEventSynchronize(g.slot[si].copied);
+            }
+    };
+    auto flush = [&](const lphq::FastxBatch& b, int si) -> bool {
+        const size_t n = b.lens.size();
+        if (n == 0) return true;
+        // record runs of about equal base count, one per GPU
+        std::vector<size_t> cut(ng + 1, n);
+        cut[0] = 0;
+        {
+            size_t r = 0;
+            uint64_t acc = 0;
+            for (size_t g = 1; g < ng; ++g) {
+                const uint64_t want = (uint64_t)b.bases * g / ng;
+                while (r < n && acc + b.lens[r] <= want) acc += b.lens[r++];
+                cut[g] = r;
+            }
+        }
+        size_t seg_i = 0, seg_o = 0;  // walk the segments in step with the records
+        for (size_t gi = 0; gi < ng; ++gi) {
+            GpuWorker& g = gpus[gi];
+            GpuWorker::Slot& s = g.slot[si];
+            const size_t r0 = cut[gi], r1 = cut[gi + 1], nr = r1 - r0;
+            uint64_t so = 0, oo = 0;
+            for (size_t i = r0; i < r1; ++i) {
+                so += b.lens[i];
+                oo += b.lens[i] >= info.k ? b.lens[i] - info.k + 1 : 0;
+            }
+            s.n_out = 0;
+            if (nr == 0 || oo == 0) {  // nothing to look up: only move past this run's bases
+                uint64_t left = so;
+                while (left) {
+                    const size_t take = (size_t)std::min<uint64_t>(left, b.segs[seg_i].n - seg_o);
+                    seg_o += take;
+                    left -= take;
+                    if (seg_o == b.segs[seg_i].n) {
+                        ++seg_i;
+                        seg_o = 0;
+                    }
+                }
+                continue;
+            }
+            if (hipSetDevice(g.device) != hipSuccess || !GpuWorker::ensure(s, so, nr, oo, sink != nullptr)) {
+                err = "device allocation failed";
+                return false;
+            }
+            uint64_t a = 0, o = 0;
+            for (size_t i = 0; i < nr; ++i) {
+                s.h_offs[i] = a;
+                s.h_offs[nr + 1 + i] = o;
+                a += b.lens[r0 + i];
+                o += b.lens[r0 + i] >= info.k ? b.lens[r0 + i] - info.k + 1 : 0;
+            }
+            s.h_offs[nr] = a;
+            s.h_offs[2 * nr + 1] = o;
+            uint64_t left = so;
+            size_t at = 0;
+            while (left) {  // one copy per parsed piece, compacting on the way
+                const size_t take = (size_t)std::min<uint64_t>(left, b.segs[seg_i].n - seg_o);
+                if (take && hipMemcpyAsync(s.d_seq + at, b.segs[seg_i].p + seg_o, take, hipMemcpyHostToDevice, g.stream) != hipSuccess) {
+                    err = "host to device copy failed";
+                    return false;
+                }
+                at += take;
+                seg_o += take;
+                left -= take;
+                if (seg_o == b.segs[seg_i].n) {
+                    ++seg_i;
+                    seg_o = 0;
+                }
+            }
+            if (hipEventRecord(s.copied, g.stream) != hipSuccess ||
+                hipMemcpyAsync(s.d_offs, s.h_offs, 2 * (nr + 1) * 8, hipMemcpyHostToDevice, g.stream) != hipSuccess) {
+                err = "host to device copy failed";
+                return false;
+            }
+            s.busy = true;
+            if (lphq_query_records(idx, s.d_seq, so, s.d_offs, nr, s.d_out, s.d_offs + nr + 1, streaming, g.stream) != LPHQ_OK) {
+                err = lphq_last_error();
+                return false;
+            }
+            // hashes.size() of the reference: counted on the device, read back when the slot is retired
+            s.n_out = oo;
+            if (lphq_count_valid_async(idx, s.d_out, oo, s.d_count, g.stream) != LPHQ_OK) {
+                err = lphq_last_error();
+                return false;
+            }
+            if (hipMemcpyAsync(s.h_count, s.d_count, 8, hipMemcpyDeviceToHost, g.stream) != hipSuccess ||
+                (sink && hipMemcpyAsync(s.h_codes, s.d_out, oo * 8, hipMemcpyDeviceToHost, g.stream) != hipSuccess)) {
+                err = "device to host copy failed";
+                return false;
+            }
+        }
+        return true;
+    };
+    // batch i+1 is parsed (by `threads` threads) while batch i is copied to the devices and looked up; the reader keeps
+    // both batches' bases alive (fastx_batch.hpp), and bufs[i] may be parsed into again once slot i's copies are done
     auto parse = [&](int i) { return std::async(std::launch::async, [&rd, &bufs, i, batch_bases] { return rd.next(bufs[i], batch_bases); }); };
     std::future<bool> pending = parse(0);
-    for (int i = 0;; i ^= 1) {
+    bool ok = true;
+    for (int i = 0; ok; i ^= 1) {
         if (!pending.get()) break;
+        arena_released(i ^ 1);
         pending = parse(i ^ 1);
-        if (!flush(bufs[i])) {
-            pending.wait();
-            return true;
-        }
+        ok = retire(i) && flush(bufs[i], i);
+        if (!ok) pending.wait();
     }
-    if (!rd.ok()) err = "out of host memory while reading the query file";
+    ok = ok && retire(0) && retire(1);
+    if (ok && !rd.ok()) err = "out of host memory while reading the query file";
     auto t1 = std::chrono::high_resolution_clock::now();
     elapsed_us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count();
     return true;
@@ -292,10 +418,10 @@ int records_main(int argc, char** argv) {
 }
 
 int query_main(int kind, int argc, char** argv) {
-    Args a = parse(argc, argv, {"-i", "-q", "--kmer-bits", "--device", "--batch-mb", "--output", "--threads"}, {"--pinned"});
+    Args a = parse(argc, argv, {"-i", "-q", "--kmer-bits", "--device", "--gpus", "--batch-mb", "--output", "--threads"}, {"--pinned", "--pageable"});
     if (a.help || a.bad || !a.get("-i") || !a.get("-q")) {
         std::cerr << "Usage: " << argv[0]
-                  << " [-h,--help] -i mphf -q query_filename [--kmer-bits 64|128] [--device N] [--batch-mb N] [--threads N] [--pinned] [--output codes.u64]\n\n"
+                  << " [-h,--help] -i mphf -q query_filename [--kmer-bits 64|128] [--device N | --gpus N] [--batch-mb N] [--threads N] [--pageable] [--output codes.u64]\n\n"
                   << " -i mphf\n\tREQUIRED: LP-Hash MPHF saved on disk.\n\n"
                   << " -q query_filename\n\tREQUIRED: Must be a FASTA file (.fa/fasta extension) compressed with gzip (.gz) or not.\n\n"
                   << " --kmer-bits\n\tk-mer word width the MPHF was built with (the reference's compile-time kmer_t): 128 (default) or 64.\n";
@@ -307,17 +433,33 @@ int query_main(int kind, int argc, char** argv) {
     // 32 MB batches: the parse arenas stay small and warm, and parsing overlaps the device side (see query_pass)
     const size_t batch_bases = (size_t)(a.get("--batch-mb") ? std::max(1l, std::atol(a.get("--batch-mb")->c_str())) : 32) << 20;
     const int threads = a.get("--threads") ? std::max(1, std::atoi(a.get("--threads")->c_str())) : default_parse_threads();
-    const bool pinned = a.has("--pinned");
+    const bool pinned = !a.has("--pageable");  // parse arenas in pinned host memory (default): copies to the devices are asynchronous
+    // --gpus N: replicas on devices 0..N-1, every batch sharded over them; --device D: that one device
+    const int ngpus = a.get("--gpus") ? std::atoi(a.get("--gpus")->c_str()) : 1;
+    if (ngpus < 1 || (a.get("--gpus") && a.get("--device"))) {
+        std::cerr << "--gpus N needs N >= 1 and excludes --device\n";
+        return 1;
+    }
+    std::vector<int> devices;
+    for (int d = 0; d < ngpus; ++d) devices.push_back(a.get("--gpus") ? d : device);
     lphq_index* idx = nullptr;
-    if (lphq_open(mphf_filename.c_str(), kind, kmer_bits, &idx) != LPHQ_OK || lphq_attach(idx, device) != LPHQ_OK) {
+    if (lphq_open(mphf_filename.c_str(), kind, kmer_bits, &idx) != LPHQ_OK || lphq_attach_devices(idx, devices.data(), (int)devices.size()) != LPHQ_OK) {
         std::cerr << "[Error] " << lphq_last_error() << "\n";  // the reference dies in essentials::load here
         if (idx) lphq_close(idx);
         return 2;
     }
     lphq_info info;
     lphq_get_info(idx, &info);
-    (void)hipSetDevice(device);
-    DeviceBatch db;
+    std::vector<GpuWorker> gpus(devices.size());
+    for (size_t d = 0; d < devices.size(); ++d)
+        if (!gpus[d].init(devices[d])) {
+            std::cerr << "[Error] cannot create a stream on device " << devices[d] << "\n";
+            lphq_close(idx);
+            return 2;
+        }
+    auto release_gpus = [&gpus] {
+        for (GpuWorker& g : gpus) g.destroy();
+    };
     uint64_t total_on = 0, total_off = 0, t_on = 0, t_off = 0;
     std::string err;
     FILE* sink = nullptr;
@@ -327,15 +469,17 @@ int query_main(int kind, int argc, char** argv) {
         return 2;
     }
     for (int pass = 0; pass < 2; ++pass) {
-        bool opened = query_pass(idx, info, query_filename, pass == 0, batch_bases, threads, pinned, db, pass == 0 ? total_on : total_off,
+        bool opened = query_pass(idx, info, query_filename, pass == 0, batch_bases, threads, pinned, gpus, pass == 0 ? total_on : total_off,
                                  pass == 0 ? t_on : t_off, err, pass == 0 ? sink : nullptr);
         if (!opened) {
             std::cerr << "Unable to open the input file " << query_filename << "\n";
+            release_gpus();
             lphq_close(idx);
             return 2;  // src/query.cpp:43-46
         }
         if (!err.empty()) {
             std::cerr << "[Error] " << err << "\n";
+            release_gpus();
             lphq_close(idx);
             return 3;
         }
@@ -344,6 +488,7 @@ int query_main(int kind, int argc, char** argv) {
     // src/query.cpp:83-86
     std::cout << query_filename << "," << mphf_filename << "," << total_on << "," << static_cast<double>(t_on * 1000) / total_on << ","
               << static_cast<double>(t_off * 1000) / total_off << std::endl;
+    release_gpus();
     lphq_close(idx);
     return 0;
 }
@@ -376,6 +521,20 @@ int build_main(int kind, int argc, char** argv) {
     if (m > k) {
         std::cerr << "m cannot be larger than k" << std::endl;
         return 3;
+    }
+    // src/parser_build.cpp:74-86: -d creates the directory, --max-memory is capped at 255 (GB).  Construction here is in-memory
+    // (no external-memory sort, include/external_memory_vector.hpp), so both are accepted, checked and otherwise unused -- said
+    // out loud rather than silently.
+    if (a.get("-d")) {
+        (void)::mkdir(a.get("-d")->c_str(), 0777);  // essentials::create_directory
+        std::cerr << "[note] -d " << *a.get("-d") << ": ignored (in-memory construction, no temporary files)" << std::endl;
+    }
+    if (a.get("--max-memory")) {
+        if (std::strtoull(a.get("--max-memory")->c_str(), nullptr, 10) > 255) {
+            std::cerr << "The maximum allowed amount of ram is 255GB" << std::endl;
+            return 3;
+        }
+        std::cerr << "[note] --max-memory " << *a.get("--max-memory") << ": ignored (in-memory construction)" << std::endl;
     }
     if (c > 10.0 || c < 3.0) {
         std::cerr << "3.0 <= c <= 10.0" << std::endl;

@@ -190,7 +190,52 @@ def test_device_image_handle_and_concurrent_callers(tmp_path):
     assert not errs
 
 
-@pytest.mark.parametrize("kind,k,m,bits,n_rec", [(0, 31, 20, 64, 1000), (1, 31, 20, 64, 100), (0, 63, 20, 128, 100)])
+def test_attach_devices_and_stream_ordered_count(tmp_path):
+    """lphq_attach_devices / lphq_attached_devices (replicas, primary first; attaching twice is a no-op) and lphq_count_valid on the
+    caller's NON-BLOCKING stream: the count must see the codes the query wrote on that stream (it used to run on the null stream)."""
+    torch, dev = torch_dev()
+    k = 31
+    recs = random_records(21, 12, 2000, 9000)
+    path = str(tmp_path / "t.lph")
+    L.build(recs, k, 20, path, kmer_bits=64, threads=4)
+    h = L.Mphf.load(path, kmer_bits=64)
+    with pytest.raises(L.LphqError):
+        h.query_packed(0, 0, 0)  # not attached: no CPU fallback
+    h.attach_devices([0, 0])
+    assert h.attached_devices() == [0] and h.info.device == 0
+    h.attach(0)
+    assert h.attached_devices() == [0]
+    with pytest.raises(L.LphqError):
+        h.attach_devices([torch.cuda.device_count() + 3])
+    q = bytearray(b"".join(recs))
+    for p in range(100, len(q), 997):
+        q[p] = ord("N")
+    flat = np.frombuffer(bytes(q), dtype=np.uint8)
+    lens = np.array([len(r) for r in recs], dtype=np.int64)
+    seq_off = np.concatenate([[0], np.cumsum(lens)])
+    out_off = np.concatenate([[0], np.cumsum(lens - k + 1)])
+    d_seq = torch.from_numpy(flat.copy()).to(dev)
+    d_so, d_oo = torch.from_numpy(seq_off).to(dev), torch.from_numpy(out_off).to(dev)
+    n_out = int(out_off[-1])
+    s = torch.cuda.Stream()  # non-blocking with respect to the null stream
+    d_out = torch.full((n_out,), -1, dtype=torch.int64, device=dev)  # all LPHQ_INVALID before the query
+    torch.cuda.synchronize()
+    for _ in range(5):
+        d_out.fill_(-1)
+        torch.cuda.synchronize()
+        h.query_records(d_seq.data_ptr(), len(flat), d_so.data_ptr(), len(recs), d_out.data_ptr(), d_oo.data_ptr(), True, s.cuda_stream)
+        got = h.count_valid(d_out.data_ptr(), n_out, s.cuda_stream)
+        bad = np.array([c not in b"ACGTUacgtu" for c in bytes(q)])
+        want = 0
+        for i in range(len(recs)):
+            b = bad[seq_off[i]:seq_off[i + 1]]
+            cs = np.concatenate([[0], np.cumsum(b)])
+            want += int(((cs[k:] - cs[:-k]) == 0).sum())
+        assert got == want
+    assert h.count_valid(d_out.data_ptr(), 0) == 0
+
+
+@pytest.mark.parametrize("kind,k,m,bits,n_rec", [(0, 31, 20, 64, 1000), (1, 31, 20, 64, 1000), (0, 63, 20, 128, 100)])
 def test_large_index_properties(tmp_path, kind, k, m, bits, n_rec):
     """10 M k-mers, and BASELINE.json's full C2 size (100 M k-mers, k=31 m=20) for the partitioned function -- too many for
     a full oracle pass in a test: the device codes are a bijection onto [0, n) in streaming AND random mode, both modes
@@ -257,6 +302,11 @@ def test_cli_query_end_to_end(tmp_path):
         f = r.stdout.strip().split(",")
         assert len(f) == 5 and f[0] == str(q) and f[1] == str(lph)
         assert int(f[2]) == sum(max(0, len(x) - 30) for x in nrec) and float(f[3]) > 0 and float(f[4]) > 0
+    for extra in (["--gpus", "1"], ["--pageable"], ["--gpus", "1", "--batch-mb", "1", "--threads", "3"]):  # sharded / unpinned / many small batches
+        r = subprocess.run([exe, "query-p", "-i", str(lph), "-q", str(fa), "--kmer-bits", "64"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0 and int(r.stdout.split(",")[2]) == sum(max(0, len(x) - 30) for x in recs), r.stderr
+    r = subprocess.run([exe, "query-p", "-i", str(lph), "-q", str(fa), "--kmer-bits", "64", "--gpus", "64"], capture_output=True, text=True)
+    assert r.returncode == 2 and "device" in r.stderr  # more GPUs than the node has
     r = subprocess.run([exe, "query-p", "-i", str(lph), "-q", str(tmp_path / "missing.fa"), "--kmer-bits", "64"], capture_output=True, text=True)
     assert r.returncode == 2 and "Unable to open the input file" in r.stderr
     # result sink: --output keeps the codes of the streaming pass (the reference discards them, src/query.cpp:54)
@@ -272,6 +322,32 @@ def test_cli_query_end_to_end(tmp_path):
     assert r.returncode == 2
     r = subprocess.run([exe, "query-u", "-i", str(lpu), "-q", str(fa), "--kmer-bits", "64"], capture_output=True, text=True)
     assert r.returncode == 0 and int(r.stdout.split(",")[2]) == sum(max(0, len(x) - 30) for x in recs)
+
+
+def test_cli_many_batches_keep_record_order(tmp_path):
+    """`lphash query-p --batch-mb 1 --output`: several batches in flight (two device slots, asynchronous copies from the pinned
+    parse arenas); the sink must hold the codes of the streaming pass in record order, the counts of both passes must agree."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "lphash_amd", "lphash")
+    _, recs = synthetic_records(seed=77, n_records=45, length=70_000)
+    fa = tmp_path / "idx.fa"
+    with open(fa, "wb") as f:
+        for i, rec in enumerate(recs):
+            f.write(b">r%d\n" % i)
+            for j in range(0, len(rec), 80):
+                f.write(rec[j:j + 80] + b"\n")
+    lph = tmp_path / "x.lph"
+    L.build(recs, 31, 20, str(lph), kmer_bits=64, threads=8)
+    o = orc.Index(str(lph), 0, 64)
+    want = np.concatenate([o(x, True) for x in recs])
+    for extra in ([], ["--gpus", "1", "--threads", "5"], ["--pageable"]):
+        sink = tmp_path / "codes.u64"
+        r = subprocess.run([exe, "query-p", "-i", str(lph), "-q", str(fa), "--kmer-bits", "64", "--batch-mb", "1", "--output", str(sink)] + extra,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert int(r.stdout.split(",")[2]) == len(want)
+        assert np.array_equal(np.fromfile(sink, dtype=np.uint64), want)
 
 
 def test_empty_and_tiny_indexes(tmp_path):
