@@ -334,14 +334,16 @@ bool query_pass(lphq_index* idx, const lphq_info& info, const std::string& path,
     auto parse = [&](int i) { return std::async(std::launch::async, [&rd, &bufs, i, batch_bases] { return rd.next(bufs[i], batch_bases); }); };
     std::future<bool> pending = parse(0);
     bool ok = true;
+    int last = 1;  // slot of the most recent batch
     for (int i = 0; ok; i ^= 1) {
         if (!pending.get()) break;
         arena_released(i ^ 1);
         pending = parse(i ^ 1);
         ok = retire(i) && flush(bufs[i], i);
+        last = i;
         if (!ok) pending.wait();
     }
-    ok = ok && retire(0) && retire(1);
+    ok = ok && retire(last ^ 1) && retire(last);  // the older batch first: the sink keeps record order
     if (ok && !rd.ok()) err = "out of host memory while reading the query file";
     auto t1 = std::chrono::high_resolution_clock::now();
     elapsed_us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count();
