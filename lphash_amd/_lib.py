@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblphq.so")
+LIB_PATH = os.environ.get("LPHQ_LIB_PATH") or os.path.join(_HERE, "liblphq.so")  # override: A/B of two builds (tools/ab_lib.sh), sanitizer builds
 
 OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(8)
 PARTITIONED, UNPARTITIONED = 0, 1

@@ -82,18 +82,27 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
     const uint64_t shift = (uint64_t)((uintptr_t)d_seq & 15u);
     const uint8_t* seq_al = (const uint8_t*)d_seq - shift;
     const uint64_t span = shift + total_bases;
-    static const int sblock_env = getenv("LPHQ_STREAM_BLOCK") ? atoi(getenv("LPHQ_STREAM_BLOCK")) : kStreamBlockDefault;  // tuning aid
-    const int sblock = (sblock_env == 128 || sblock_env == 512) ? sblock_env : 256;
+    constexpr int sblock = kStreamBlockDefault;  // 256 threads measured best in both rounds (128: -4 %, 512: -6 %, profiles/r02_stream_v4_ab.txt)
     const uint64_t tw = streaming ? stream_tile_windows(H.W, 4 * sblock) : kTileW;
     const uint64_t tiles = (span + tw - 1) / tw;
-    // one workgroup per tile: HIP requires gridDim.x * blockDim.x < 2^32 (<= 2^23 - 1 tiles of 512 threads, i.e. ~8 G bases
+    // one workgroup per tile: HIP requires gridDim.x * blockDim.x < 2^32 (<= 2^24 - 1 tiles of 256 threads, i.e. ~16 G bases
     // per call); larger batches must be split by the caller (capi.cpp says so in the error text)
-    if (tiles > (0xFFFFFFFFull / 512u) || n_records > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    if (tiles > (0xFFFFFFFFull / 256u) || n_records > 0xFFFFFFFFull) return hipErrorInvalidValue;
     if (streaming) {
-#define LPHQ_STREAM_LAUNCH(B) LPHQ_DISPATCH_B(k_query_tiles_stream, B, <<<(int)tiles, B, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out))
-        if (sblock == 128) LPHQ_STREAM_LAUNCH(128);
-        else if (sblock == 512) LPHQ_STREAM_LAUNCH(512);
-        else LPHQ_STREAM_LAUNCH(256);
+        // window minima: direct form, or block decomposition for wide windows (P == 6 <=> W > 15; kernels_device.cuh: kBlockMinW)
+#define LPHQ_STREAM_LAUNCH(KIND, K128) \
+    do { \
+        if (H.P != 6) k_query_tiles_stream<KIND, K128, 4, sblock, false><<<(int)tiles, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out); \
+        else if (H.W >= kBlockMinW) k_query_tiles_stream<KIND, K128, 6, sblock, true><<<(int)tiles, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out); \
+        else k_query_tiles_stream<KIND, K128, 6, sblock, false><<<(int)tiles, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out); \
+    } while (0)
+        if (H.kind == 0) {
+            if (H.kmer_bits == 128) LPHQ_STREAM_LAUNCH(0, true);
+            else LPHQ_STREAM_LAUNCH(0, false);
+        } else {
+            if (H.kmer_bits == 128) LPHQ_STREAM_LAUNCH(1, true);
+            else LPHQ_STREAM_LAUNCH(1, false);
+        }
     }
     else
         LPHQ_DISPATCH(k_query_tiles_random, <<<(int)tiles, kBlock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out));

@@ -10,8 +10,7 @@
 //
 // Wave64, 256-thread workgroups, one k-mer per lane / one tile per workgroup, so grids are >> 256 workgroups and all
 // 256 CUs / 8 XCDs are busy; no inter-workgroup communication, so placement is irrelevant to correctness.
-// Environment variables read once by the launchers are tuning aids only (LPHQ_STREAM_BLOCK, LPHQ_PACKED_GRID: validated and
-// clamped, none changes a result); defaults are the measured best (profiles/).
+// LPHQ_PACKED_GRID, read once by the launcher, is a tuning aid only (validated and clamped; it changes no result).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -308,12 +307,84 @@ __device__ __forceinline__ void hash_pad(uint64_t* __restrict__ sm_hash, uint32_
     if (tid < 4u * 17u) sm_hash[(tid / 17u) * hash_row<BLOCK>() + (uint32_t)BLOCK + tid % 17u] = ~0ull;
 }
 
-// Phase C core: leftmost minimum of the 4 consecutive windows starting at local positions a .. a+3, a = 4 * tid, each W
-// positions wide -> q[0..3] (local positions).  Offsets from a are uniform over the wave, so they live in scalar
-// registers and the W-3 positions common to the four windows are read four per step at immediate LDS offsets.
-// Ties keep the LEFT position, as the strict `>` comparisons of partitioned_mphf.hpp:122,150-163 do.
+// Phases B + C for wide windows (W >= kBlockMinW): leftmost minimum of the 4 consecutive windows starting at local positions
+// a .. a+3, a = 4 * tid, each W positions wide -> q[0..3] (local positions), by BLOCK DECOMPOSITION of the sliding minimum.  A lane hashes the four positions of its
+// own block [a, a+4) and keeps, in registers, the suffix minima S[j] over a+j .. a+3; it publishes in LDS (column c of
+// sm_hash, hslot layout) the prefix minima P[c] over a .. a+c -- P[3] is the minimum M of the whole block -- and, in one byte,
+// which position each of them is.  Window a+j is then S[j] + the blocks it covers completely + a prefix of the block after them:
+//     min( S[j],  M[l+1] .. M[l+nf],  P[l+nf+1][hc-1] ),   nf = (j + W - 4) / 4,  hc = (j + W - 4) % 4
+// i.e. ~W/4 + 3 LDS reads and ~W/4 + 12 compare-selects per lane instead of W + 3 and ~W + 8 (W = 12: 5 reads instead of 15;
+// W = 44: 13 instead of 47); the block range M[l+1 .. l+(W-4)/4] is shared by the lane's four windows.  Candidates are taken
+// left to right with a strict `<`, so ties keep the LEFT position, as the strict `>` comparisons of
+// partitioned_mphf.hpp:122,150-163 do.  Measured against the direct form on one box (profiles/r02_argmin_ab.txt): W = 44 +5 %,
+// W = 31 +1 %, W = 12 -4 % (no fewer LDS instructions there, and every window pays the decode of its winner's position), hence
+// the threshold.
+constexpr uint32_t kBlockMinW = 24;
+struct BlockMin {  // a lane's suffix minima, alive from phase B to phase C
+    uint64_t h1, h2, h3;  // S[1], S[2], S[3] (S[0] = M, re-read from LDS)
+    uint32_t p;           // their positions within the block, 2 bits each: S[1] | S[2] << 2 | S[3] << 4
+};
+// byte published per lane: position (0..3) within the block of P[1] (bit 0), P[2] (bits 1-2), P[3] = M (bits 3-4)
+__device__ __forceinline__ uint32_t prefix_off(uint32_t ob, uint32_t c) { return c == 0u ? 0u : (c == 1u ? (ob & 1u) : (c == 2u ? ((ob >> 1) & 3u) : ((ob >> 3) & 3u))); }
+
 template <int BLOCK>
-__device__ __forceinline__ void window_argmin4(const uint64_t* __restrict__ sm_hash, uint32_t tid, uint32_t W, uint32_t (&q)[4]) {
+__device__ __forceinline__ BlockMin publish_block_minima(uint64_t* __restrict__ sm_hash, uint8_t* __restrict__ sm_off, uint32_t tid, const uint64_t (&h)[4]) {
+    constexpr uint32_t ROW = hash_row<BLOCK>();
+    HashPos p{h[0], 0};
+    sm_hash[tid] = p.h;
+    take_if_less(p, h[1], 1);
+    sm_hash[ROW + tid] = p.h;
+    uint32_t ob = p.p;
+    take_if_less(p, h[2], 2);
+    sm_hash[2 * ROW + tid] = p.h;
+    ob |= p.p << 1;
+    take_if_less(p, h[3], 3);
+    sm_hash[3 * ROW + tid] = p.h;
+    ob |= p.p << 3;
+    sm_off[tid] = (uint8_t)ob;
+    BlockMin s;
+    s.h3 = h[3];
+    uint32_t p3 = 3, p2, p1;
+    s.h2 = (h[2] <= s.h3) ? h[2] : s.h3;  // `<=`: scanning from the right, the left one wins ties
+    p2 = (h[2] <= s.h3) ? 2u : p3;
+    s.h1 = (h[1] <= s.h2) ? h[1] : s.h2;
+    p1 = (h[1] <= s.h2) ? 1u : p2;
+    s.p = p1 | (p2 << 2) | (p3 << 4);
+    return s;
+}
+
+template <int BLOCK>
+__device__ __forceinline__ void window_argmin4(const uint64_t* __restrict__ sm_hash, const uint8_t* __restrict__ sm_off, uint32_t tid, uint32_t W,
+                                               const BlockMin& s, uint32_t (&q)[4]) {
+    constexpr uint32_t ROW = hash_row<BLOCK>();
+    const uint64_t* colM = sm_hash + 3 * ROW + tid;  // M of the block t lanes to the right: colM[t]
+    // id of a candidate: (t << 2) | c for column c of the block t lanes to the right (t >= 1); the position itself for the own block
+    const uint32_t nf0 = (W - 4u) >> 2;  // blocks covered completely by all four windows: l+1 .. l+nf0
+    HashPos r{~0ull, 0};
+    if (nf0) {
+        r = HashPos{colM[1], (1u << 2) | 3u};
+        for (uint32_t t = 2; t <= nf0; ++t) take_if_less(r, colM[t], (t << 2) | 3u);
+    }
+    const uint64_t m0 = colM[0];
+    const uint32_t ob0 = sm_off[tid];
+    HashPos w[4] = {HashPos{m0, (ob0 >> 3) & 3u}, HashPos{s.h1, s.p & 3u}, HashPos{s.h2, (s.p >> 2) & 3u}, HashPos{s.h3, (s.p >> 4) & 3u}};
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint32_t nf = (j + W - 4u) >> 2, hc = (j + W - 4u) & 3u;  // uniform over the wave
+        if (nf0) take_if_less(w[j], r.h, r.p);
+        if (nf > nf0) take_if_less(w[j], colM[nf], (nf << 2) | 3u);
+        if (hc) take_if_less(w[j], sm_hash[(hc - 1u) * ROW + tid + nf + 1u], ((nf + 1u) << 2) | (hc - 1u));
+        const uint32_t t = w[j].p >> 2;
+        q[j] = 4u * tid + (t ? 4u * t + prefix_off(sm_off[tid + t], w[j].p & 3u) : w[j].p);
+    }
+}
+
+// Phase C, direct form (W < kBlockMinW): raw hashes in sm_hash (hslot layout); leftmost minimum of the 4 consecutive windows
+// starting at local positions a .. a+3, a = 4 * tid, each W positions wide -> q[0..3] (local positions).  Offsets from a are
+// uniform over the wave, so they live in scalar registers and the W-3 positions common to the four windows are read four per
+// step at immediate LDS offsets.  Ties keep the LEFT position, as the strict `>` comparisons of partitioned_mphf.hpp:122,150-163 do.
+template <int BLOCK>
+__device__ __forceinline__ void window_argmin4_raw(const uint64_t* __restrict__ sm_hash, uint32_t tid, uint32_t W, uint32_t (&q)[4]) {
     constexpr uint32_t ROW = hash_row<BLOCK>();
     const uint64_t* col = sm_hash + tid;  // position a + c: col[(c & 3) * ROW + (c >> 2)]
     auto H = [&](uint32_t c) { return col[(c & 3u) * ROW + (c >> 2)]; };
@@ -378,7 +449,9 @@ __device__ __forceinline__ void window_argmin4(const uint64_t* __restrict__ sm_h
 //      in another wave): at most three redundant lookups per tile, which write the value the real leader writes
 //   F  codes from registers, two 16-byte non-temporal stores per lane when its four windows are all valid (the codes are
 //      written once and never read here; the hint keeps more of L2 for the index lines: +2.5-5 %, profiles/r02_nt_ab.txt)
-template <int KIND, bool K128, int P, int BLOCK>
+// BLKMIN: window minima by block decomposition (the launcher picks it when W >= kBlockMinW; a template parameter because both
+// forms in one kernel cost 78 VGPRs instead of 57, i.e. 6 instead of 8 waves per SIMD)
+template <int KIND, bool K128, int P, int BLOCK, bool BLKMIN>
 __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
                                                                  uint64_t shift, uint64_t total, const uint64_t* __restrict__ seq_off,
                                                                  const uint64_t* __restrict__ out_off, uint32_t n_records, uint64_t* __restrict__ out) {
@@ -387,11 +460,12 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
     constexpr int NBADW = (NW + 8) / 2 + 2;  // 32-bit words of the bad-base bitmask (1 bit per base)
     constexpr int NDW = (NW + 1) * 4;        // dwords of sequence (4 bases each) the tile loads; NDW - BLOCK = 20 lanes load two
     static_assert(NDW > BLOCK && NDW <= 2 * BLOCK, "two sequence dwords per lane at most");
-    __shared__ uint64_t sm_hash[hash_slots<BLOCK>()];  // phase B-C: minimizer hash per m-mer position (hslot order); phase E-F: the leader's base
+    __shared__ uint64_t sm_hash[hash_slots<BLOCK>()];  // phase B-C: minimizer hash per m-mer position (hslot order), or the blocks' prefix minima when W >= kBlockMinW; phase E-F: the leader's base
     __shared__ uint32_t sm_words[NW + 8];
     __shared__ uint32_t sm_bad[NBADW];
     __shared__ uint16_t sm_queue[kStreamPos];
     __shared__ uint8_t sm_mode[kStreamPos];
+    __shared__ uint8_t sm_off[hash_row<BLOCK>() + 3];  // phase B-C: where in its block each published prefix minimum sits
     __shared__ uint32_t sm_rec[2], sm_count, sm_anybad;
     __shared__ uint64_t sm_roff[3];                // seq_off[rlo], seq_off[rlo+1], out_off[rlo]
     __shared__ uint64_t sm_rtab[2 * kRecCap + 1];  // multi-record tiles: the tile's slice of seq_off / out_off
@@ -452,7 +526,8 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
     }
     __syncthreads();
 
-    // ---- B: hashes of the m-mers starting at local positions 4*lane .. 4*lane+3 ----
+    // ---- B: hashes of the m-mers starting at local positions 4*lane .. 4*lane+3; block minima published for phase C ----
+    BlockMin bmin;
     {
         const uint64_t mm_seedx = murmur_seedx(H.mm_seed);
         const uint32_t a = 4u * tid;
@@ -463,12 +538,21 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
         const uint64_t s1 = o ? (C64 << o) : C64;                                  // bits [64, 128): only the top 6 are needed
         const uint32_t sh = 64u - 2u * m;
         const uint64_t mask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
+        uint64_t h[4];
 #pragma unroll
         for (uint32_t r = 0; r < 4; ++r) {
             const uint64_t v = r == 0 ? (s0 >> sh) : (((s0 << (2 * r)) | (s1 >> (64 - 2 * r))) >> sh);
-            sm_hash[r * hash_row<BLOCK>() + tid] = murmur8(v & mask, mm_seedx);
+            h[r] = murmur8(v & mask, mm_seedx);
+        }
+        if (BLKMIN) {
+            bmin = publish_block_minima<BLOCK>(sm_hash, sm_off, tid, h);
+        } else {
+            bmin = BlockMin{0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t r = 0; r < 4; ++r) sm_hash[r * hash_row<BLOCK>() + tid] = h[r];
         }
         hash_pad<BLOCK>(sm_hash, tid);
+        if (tid < 20u) sm_off[(uint32_t)BLOCK + tid] = 0;
     }
     __syncthreads();
 
@@ -487,7 +571,8 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
     uint32_t code[4];  // minimizer position of the window; 0xFFFF: holds a non-ACGT base; 0xFFFE: not a window of any record
     {
         uint32_t q[4];
-        window_argmin4<BLOCK>(sm_hash, tid, W, q);
+        if (BLKMIN) window_argmin4<BLOCK>(sm_hash, sm_off, tid, W, bmin, q);
+        else window_argmin4_raw<BLOCK>(sm_hash, tid, W, q);
         if (one_record) {
 #pragma unroll
             for (uint32_t jw = 0; jw < 4; ++jw) code[jw] = (a + jw >= w_lo && a + jw < w_hi) ? q[jw] : 0xFFFEu;

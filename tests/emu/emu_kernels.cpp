@@ -46,12 +46,17 @@ extern "C" int emu_kernel_query_records(const uint8_t* img, size_t nbytes, const
     const uint8_t* seq_al = (const uint8_t*)seq - shift;
     const uint64_t span = shift + total;
     if (streaming) {
-        const uint64_t tw = stream_tile_windows(H.W, 4 * block);
+        const uint64_t tw = stream_tile_windows(H.W, 4 * (block & 0xFFFF));
         const unsigned tiles = (unsigned)((span + tw - 1) / tw);
 #define CALL(KIND, K128, P)                                                                                                                             \
     do {                                                                                                                                                \
-        if (block == 128) emu::launch(tiles, 128, [&] { k_query_tiles_stream<KIND, K128, P, 128>(img, seq_al, shift, total, seq_off, out_off, n_records, out); }); \
-        else emu::launch(tiles, 256, [&] { k_query_tiles_stream<KIND, K128, P, 256>(img, seq_al, shift, total, seq_off, out_off, n_records, out); });              \
+        const bool blk = (block & 0x10000) ? true : ((block & 0x20000) ? false : H.W >= kBlockMinW); /* forced either way, or as the launcher chooses */ \
+        const int bs = block & 0xFFFF;                                                                                                                    \
+        if (H.W >= 4 && blk) {                                                                                                                            \
+            if (bs == 128) emu::launch(tiles, 128, [&] { k_query_tiles_stream<KIND, K128, P, 128, true>(img, seq_al, shift, total, seq_off, out_off, n_records, out); }); \
+            else emu::launch(tiles, 256, [&] { k_query_tiles_stream<KIND, K128, P, 256, true>(img, seq_al, shift, total, seq_off, out_off, n_records, out); });            \
+        } else if (bs == 128) emu::launch(tiles, 128, [&] { k_query_tiles_stream<KIND, K128, P, 128, false>(img, seq_al, shift, total, seq_off, out_off, n_records, out); }); \
+        else emu::launch(tiles, 256, [&] { k_query_tiles_stream<KIND, K128, P, 256, false>(img, seq_al, shift, total, seq_off, out_off, n_records, out); });               \
     } while (0)
         EMU_DISPATCH(CALL);
 #undef CALL

@@ -140,7 +140,8 @@ def test_tile_kernels_on_the_emulator(emuk, tmp_path, k, m, bits, kind):
     # > 64 records inside one tile (beyond the LDS record table of the streaming kernels), then ~20 records per tile
     batch += random_records(11, 150, 0, 5) + [recs[0][:k + 2]] + random_records(12, 40, k, k + 20) + [recs[1]]
     exp = [o(r, False) for r in batch]
-    for streaming, mis, block in ((True, 0, 256), (True, 5, 256), (True, 15, 128), (False, 0, 256), (False, 9, 256), (True, 7, 256), (True, 2, 128)):
+    BLK, RAW = 0x10000, 0x20000  # window minima by block decomposition / in the direct form, whatever W (the launcher picks by W)
+    for streaming, mis, block in ((True, 0, 256), (True, 5, 256 | BLK), (True, 15, 128 | RAW), (False, 0, 256), (False, 9, 256), (True, 7, 256 | RAW), (True, 2, 128 | BLK)):
         got = emu_records(emuk, h, batch, k, streaming, mis, block)
         for g, e in zip(got, exp):
             assert np.array_equal(g, e), (streaming, mis, block)
