@@ -111,9 +111,7 @@ __device__ __forceinline__ uint32_t low_mask(int nb) { return nb >= 32 ? ~0u : (
 // terms of src/partitioned_mphf.cpp:297-336, already including (k-m+1)*n_maximal), size and position.
 template <int P>
 struct UniRegs {  // one fused block in registers
-    static constexpr uint32_t T = 2, E = LPHQ_UNI_PER_BLOCK(P), NPLANES = 2 + 2 * P;
-    static constexpr uint32_t NWORDS = P == 4 ? 2 * NPLANES : NPLANES + NPLANES / 2;  // stored words (image_layout.h)
-    static constexpr uint32_t NV = (NWORDS + 3) / 4;
+    static constexpr uint32_t T = LPHQ_UNI_T(P), E = LPHQ_UNI_PER_BLOCK(P), NWORDS = (2 + 2 * P) * T, NV = (NWORDS + 3) / 4;
     uint4 b01, b23;
     uint4 v[NV];
 };
@@ -127,28 +125,16 @@ __device__ __forceinline__ void uni_load(const uint8_t* __restrict__ img, uint64
 }
 template <int P>
 __device__ __forceinline__ void uni_decode(const UniRegs<P>& r, uint32_t W, uint32_t h, uint32_t& type, uint64_t& base, uint32_t& size, uint32_t& pos) {
-    constexpr uint32_t T = UniRegs<P>::T, E = UniRegs<P>::E, NV = UniRegs<P>::NV, NPLANES = UniRegs<P>::NPLANES;
+    constexpr uint32_t T = UniRegs<P>::T, E = UniRegs<P>::E, NV = UniRegs<P>::NV;
     const uint32_t j = h % E;
     const uint4 b01 = r.b01, b23 = r.b23;
-    uint32_t sw[NV * 4];  // stored words
+    uint32_t w[NV * 4];
 #pragma unroll
     for (uint32_t i = 0; i < NV; ++i) {
-        sw[4 * i] = r.v[i].x;
-        sw[4 * i + 1] = r.v[i].y;
-        sw[4 * i + 2] = r.v[i].z;
-        sw[4 * i + 3] = r.v[i].w;
-    }
-    // every plane as two words (entries 0..31, 32..E-1); for P == 6 the second one is a 16-bit half word (image_layout.h)
-    uint32_t w[NPLANES * 2];
-#pragma unroll
-    for (uint32_t p = 0; p < NPLANES; ++p) {
-        if (P == 4) {
-            w[2 * p] = sw[2 * p];
-            w[2 * p + 1] = sw[2 * p + 1];
-        } else {
-            w[2 * p] = sw[p];
-            w[2 * p + 1] = (p & 1u) ? (sw[14 + (p >> 1)] >> 16) : (sw[14 + (p >> 1)] & 0xFFFFu);
-        }
+        w[4 * i] = r.v[i].x;
+        w[4 * i + 1] = r.v[i].y;
+        w[4 * i + 2] = r.v[i].z;
+        w[4 * i + 3] = r.v[i].w;
     }
     const uint32_t wj = j >> 5, bj = j & 31u;
     auto pick = [&](uint32_t first) {  // word wj of the plane starting at w[first]

@@ -156,7 +156,7 @@ bool build_image(const LphFile& x, std::vector<uint8_t>& img, std::string& err) 
         h.collision_base = vals[nps] + base;  // sizes_and_positions.access(none_pos_start) + W*n_maximal, partitioned_mphf.cpp:309-311
 
         // fused blocks, in minimizer order (src/partitioned_mphf.cpp:183-267 builds the four arrays in this order)
-        const uint32_t E = LPHQ_UNI_PER_BLOCK(h.P), P = h.P;
+        const uint32_t T = LPHQ_UNI_T(h.P), E = LPHQ_UNI_PER_BLOCK(h.P), P = h.P;
         const uint64_t nblk = (D + E - 1) / E;
         h.off_uni = w.reserve((nblk + 1) * sizeof(lphq_uni_block));
         uint64_t n_max_seen = 0, i_l = 0, i_r = 0, i_n = 0, i_lr = 0, i_mn = 0;
@@ -189,12 +189,12 @@ bool build_image(const LphFile& x, std::vector<uint8_t>& img, std::string& err) 
                 err = "stored size/position does not fit the plane width (value > k-m+1?)";
                 return false;
             }
-            auto set = [&](uint32_t plane) { blk->w[lphq_uni_word(P, plane, j)] |= 1u << lphq_uni_bit(P, plane, j); };
-            if (msb) set(0);
-            if (lsb) set(1);
+            const uint32_t wi = j >> 5, bit = 1u << (j & 31);
+            if (msb) blk->w[wi] |= bit;
+            if (lsb) blk->w[T + wi] |= bit;
             for (uint32_t q = 0; q < P; ++q) {
-                if ((size >> q) & 1) set(2 + q);
-                if ((pos >> q) & 1) set(2 + P + q);
+                if ((size >> q) & 1) blk->w[2 * T + q * T + wi] |= bit;
+                if ((pos >> q) & 1) blk->w[2 * T + P * T + q * T + wi] |= bit;
             }
         }
         if (i_l != n_left || i_r != n_right || i_n != n_none || n_max_seen != x.n_maximal) {

@@ -12,7 +12,7 @@
  *   quartet_wtree + ef_sequence (partitioned)
  *                   three rank9 bit vectors (2 levels x {bits word, rank pair} = 4 lines) and the
  *                   Elias-Fano prefix sums (select + low bits = 3-4 lines, twice for NONE)
- *                   -> ONE 128-B block per 64 (k-m+1 <= 15) or 48 minimizers, indexed by the minimizer
+ *                   -> ONE 128-B block per 64 (k-m+1 <= 15) or 32 minimizers, indexed by the minimizer
  *                   order: the four per-type global-rank bases at the block start, the msb/lsb type
  *                   planes, and bit planes of the stored size / position values.  type, rank and
  *                   prefix sum of a lookup = one line + masked popcounts.  (Beyond L2 the fetch
@@ -29,12 +29,9 @@
 
 #define LPHQ_IMAGE_MAGIC 0x3130474d4951504cULL /* "LPQIMG01" */
 #define LPHQ_PAIR_PER_BLOCK 32u                /* entries per (size,pos) pair block         */
-/* fused block: 2 type planes + P size planes + P position planes of E bits each in 24 words.
- *   P == 4 (W <= 15): E = 64, plane p = words w[2p], w[2p + 1]                                       (10 planes, 20 words)
- *   P == 6 (W <= 63): E = 48, plane p = word w[p] (entries 0..31) + 16 bits of w[14 + p/2] at bit 16 * (p & 1)
- *                     (entries 32..47)                                                                (14 planes, 21 words)
- * plane numbering: 0 msb, 1 lsb, 2 + q size bit q, 2 + P + q position bit q */
-#define LPHQ_UNI_PER_BLOCK(P) ((P) == 4 ? 64u : 48u)
+/* fused block: T words per plane, 2 type planes + P size planes + P position planes, (2 + 2P) * T <= 24 words */
+#define LPHQ_UNI_T(P) ((P) == 4 ? 2u : 1u)
+#define LPHQ_UNI_PER_BLOCK(P) (32u * LPHQ_UNI_T(P))
 
 /* 2-by-1 division by an invariant 32-bit divisor (Moeller & Granlund 2011, Alg. 4) */
 typedef struct lphq_divisor {
@@ -69,13 +66,14 @@ typedef struct lphq_image_header {
     lphq_phf_desc mm, fb;
 } lphq_image_header;
 
-/* 128-B fused block of minimizers [E*b, E*b+E), E = LPHQ_UNI_PER_BLOCK(P):
+/* 128-B fused block of minimizers [E*b, E*b+E), E = LPHQ_UNI_PER_BLOCK(P), T = LPHQ_UNI_T(P):
  *   base[0] = (k-m+1) * #MAXIMAL before the block                         (MAXIMAL: base + W*rank_in_block + p)
  *   base[1] = W*n_maximal + sum of LEFT values before the block           (EF[r] + W*n_maximal)
  *   base[2] = W*n_maximal + all LEFT + RIGHT sizes before the block       (pair(rcs+r).first + W*n_maximal)
  *   base[3] = W*n_maximal + all LEFT + all RIGHT + NONE sizes before      (EF[nss+r] + W*n_maximal)
- *   planes (layout above): msb, lsb (type = msb<<1|lsb, quartet_wtree.hpp:7), the P bits of the stored size
- *   (LEFT: p1+1, RIGHT: size or 0 = collision, NONE: size), the P bits of the NONE position p1. */
+ *   w[0..T) msb plane, w[T..2T) lsb plane (type = msb<<1|lsb, quartet_wtree.hpp:7),
+ *   w[2T + q*T + t] bit plane q of the stored size (LEFT: p1+1, RIGHT: size or 0 = collision, NONE: size),
+ *   w[2T + P*T + q*T + t] bit plane q of the NONE position p1. */
 typedef struct lphq_uni_block {
     uint64_t base[4];
     uint32_t w[24];
@@ -87,10 +85,5 @@ typedef struct lphq_plane_block {
     uint64_t abs;
     uint32_t w[14];
 } lphq_plane_block;
-
-/* word and bit of entry j (< E) in plane p: the one place that knows the two layouts (host writer; the device decoder builds
- * two-word planes from the same rule, device_query.cuh: uni_decode) */
-static inline uint32_t lphq_uni_word(uint32_t P, uint32_t p, uint32_t j) { return P == 4 ? 2u * p + (j >> 5) : (j < 32u ? p : 14u + (p >> 1)); }
-static inline uint32_t lphq_uni_bit(uint32_t P, uint32_t p, uint32_t j) { return (P == 4 || j < 32u) ? (j & 31u) : 16u * (p & 1u) + (j - 32u); }
 
 #endif

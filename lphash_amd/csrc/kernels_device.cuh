@@ -451,9 +451,8 @@ __device__ __forceinline__ void window_argmin4_raw(const uint64_t* __restrict__ 
 //      written once and never read here; the hint keeps more of L2 for the index lines: +2.5-5 %, profiles/r02_nt_ab.txt)
 // BLKMIN: window minima by block decomposition (the launcher picks it when W >= kBlockMinW; a template parameter because both
 // forms in one kernel cost 78 VGPRs instead of 57, i.e. 6 instead of 8 waves per SIMD)
-// (second launch bound: 8 waves per SIMD, i.e. <= 64 VGPRs and 8 workgroups of 256 threads per CU)
 template <int KIND, bool K128, int P, int BLOCK, bool BLKMIN>
-__global__ __launch_bounds__(BLOCK, 8) void k_query_tiles_stream(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
+__global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
                                                                  uint64_t shift, uint64_t total, const uint64_t* __restrict__ seq_off,
                                                                  const uint64_t* __restrict__ out_off, uint32_t n_records, uint64_t* __restrict__ out) {
     const lphq_image_header& H = *(const lphq_image_header*)img;
