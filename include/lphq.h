@@ -39,7 +39,7 @@ enum {
 
 /* which reference class wrote the file: build-p -> class mphf, build-u -> class mphf_alt
  * (src/lphash.cpp:25-32).  The file carries no magic, so the caller says. */
-enum { LPHQ_PARTITIONED = 0, LPHQ_UNPARTITIONED = 1 };
+enum { LPHQ_PARTITIONED = 0, LPHQ_UNPARTITIONED = 1, LPHQ_PTHASH = 2 /* competitor harness, see lphq_open_pthash */ };
 
 /* Sentinel written by the device streaming entry point for a window that contains a non-ACGT
  * base (the reference's streaming branch emits nothing for those windows,
@@ -165,6 +165,18 @@ int lphq_build(const char* const* records, const size_t* lengths, size_t n_recor
 int lphq_build_device(const char* const* records, const size_t* lengths, size_t n_records, int k, int m,
                       uint64_t mm_seed, double c, int kind, int kmer_bits, int threads, int device, const char* out_path,
                       lphq_build_stats* stats /* may be NULL */);
+
+/* ---- competitor harness: a plain PTHash MPHF over whole k-mers ----
+ * The PTHash half of the reference's `ptbb_build` / `ptbb_query` (src/ptbb/ptbb_build.cpp:83-99, src/ptbb/ptbb_query.cpp:40-55,
+ * src/ptbb/ptbb.hpp:16-34): pthash::single_phf<PTHasher, dictionary_dictionary, true> with
+ * PTHasher::hash(kmer, seed) = {MurmurHash2_64(&kmer, sizeof kmer, seed), MurmurHash2_64(&kmer, sizeof kmer, ~seed)}, built over every window
+ * of k valid bases (forward strand) with seed 1, alpha 0.94, and serialized alone by essentials::save.  The file holds neither k nor
+ * the k-mer width, so the caller says.  The handle works with lphq_attach*, lphq_query_packed, lphq_query_records (any `streaming`
+ * value: one code per window, LPHQ_INVALID for windows holding a non-ACGT base, which ptbb_file_itr skips), lphq_query_contig,
+ * lphq_count_valid, lphq_get_info (kind = LPHQ_PTHASH, m = k, num_kmers = distinct_minimizers = number of keys). */
+int lphq_open_pthash(const char* path, int k, int kmer_bits, lphq_index** out);
+int lphq_build_pthash(const char* const* records, const size_t* lengths, size_t n_records, int k, int kmer_bits, double c, int threads,
+                      int device /* < 0: CPU pilot search */, const char* out_path, lphq_build_stats* stats /* may be NULL */);
 
 #ifdef __cplusplus
 }

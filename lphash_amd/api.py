@@ -15,7 +15,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import PARTITIONED, UNPARTITIONED, LphqError, check, lib
+from ._lib import PARTITIONED, PTHASH, UNPARTITIONED, LphqError, check, lib
 
 
 def build(records, k, m, out_path, kind=PARTITIONED, kmer_bits=None, mm_seed=42, c=3.0, threads=0, device=None):
@@ -31,6 +31,21 @@ def build(records, k, m, out_path, kind=PARTITIONED, kmer_bits=None, mm_seed=42,
     stats = _lib.BuildStats()
     check(lib.lphq_build_device(arr, lens, n, int(k), int(m), int(mm_seed), float(c), int(kind), int(kmer_bits), int(threads),
                                 -1 if device is None else int(device), str(out_path).encode(), C.byref(stats)))
+    return {name: getattr(stats, name) for name, _ in stats._fields_}
+
+
+def build_pthash(records, k, out_path, kmer_bits=None, c=3.0, threads=0, device=None):
+    """`ptbb_build -i ... -k k -p out_path [-c c] [-t threads]` (PTHash half of the reference's competitor harness,
+    src/ptbb/ptbb_build.cpp:83-99) over in-memory records: a bare pthash::single_phf over every window of k valid bases."""
+    records = [bytes(r) for r in records]
+    if kmer_bits is None:
+        kmer_bits = 64 if k <= 31 else 128
+    n = len(records)
+    arr = (C.c_char_p * n)(*records)
+    lens = (C.c_size_t * n)(*[len(r) for r in records])
+    stats = _lib.BuildStats()
+    check(lib.lphq_build_pthash(arr, lens, n, int(k), int(kmer_bits), float(c), int(threads), -1 if device is None else int(device),
+                                str(out_path).encode(), C.byref(stats)))
     return {name: getattr(stats, name) for name, _ in stats._fields_}
 
 
@@ -181,3 +196,18 @@ class Mphf(_MphfBase):
 class MphfAlt(_MphfBase):
     """Unpartitioned LP-MPHF (reference class `mphf_alt`, tool `query-u`)."""
     KIND = UNPARTITIONED
+
+
+class PtHash(_MphfBase):
+    """Plain PTHash MPHF over whole k-mers (`pthash_mphf_t`, src/ptbb/ptbb.hpp:33; tool `ptbb_query`): the competitor the reference
+    measures LPHash against.  hf(contig) yields one code per window of k valid bases (ptbb_file_itr, src/ptbb/ptbb.hpp:108-131)."""
+    KIND = PTHASH
+
+    @classmethod
+    def load(cls, path, k, kmer_bits=128, device=None):
+        self = cls()
+        check(lib.lphq_open_pthash(str(path).encode(), int(k), int(kmer_bits), C.byref(self._h)))
+        self._refresh()
+        if device is not None:
+            self.attach(device)
+        return self

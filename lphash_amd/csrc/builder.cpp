@@ -283,7 +283,10 @@ void dict_encode(Dictionary& d, const uint64_t* v, uint64_t n) {  // pthash::dic
     cv_build(d.dict, dict);
 }
 
-bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed, double c, double alpha, int threads, int device, std::string& err) {
+// hashes[i] = hash.second() of key i (table position, duplicate check); firsts = hash.first() (bucket) for hash128 hashers,
+// nullptr for hash64 hashers, whose first() == second()
+bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed, double c, double alpha, int threads, int device, std::string& err,
+               const std::vector<uint64_t>* firsts = nullptr) {
     f = SinglePhf();
     f.seed = seed;
     const bool verbose = getenv("LPHQ_BUILD_VERBOSE") != nullptr;
@@ -318,7 +321,7 @@ bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed,
     const size_t nchunks = (n + chunk - 1) / chunk;
     parallel_for(nchunks, threads, [&](size_t t) {
         for (size_t i = t * chunk, e = std::min<size_t>(n, i + chunk); i < e; ++i) {
-            uint32_t b = (uint32_t)bucket_of(f, hashes[i]);
+            uint32_t b = (uint32_t)bucket_of(f, firsts ? (*firsts)[i] : hashes[i]);
             bucket_id[i] = b;
             counts[b + 1].fetch_add(1, std::memory_order_relaxed);
         }
@@ -914,6 +917,93 @@ static int build_impl(const char* const* records, const size_t* lengths, size_t 
         stats->distinct_minimizers = D;
         stats->colliding_super_kmers = colliding.size();
         stats->fallback_kmers = x.fallback_kmer_order.num_keys;
+        stats->file_bytes = w.buf.size();
+    }
+    return LPHQ_OK;
+}
+
+// MurmurHash2_64 of the 16 bytes of a __uint128_t (low word first)
+static uint64_t murmur64a_u128(u128 v, uint64_t seed) {
+    const uint64_t M = 0xc6a4a7935bd1e995ULL;
+    uint64_t h = seed ^ (16ull * M);
+    for (int i = 0; i < 2; ++i) {
+        uint64_t k = (uint64_t)(v >> (64 * i)) * M;
+        k ^= k >> 47;
+        k *= M;
+        h ^= k;
+        h *= M;
+    }
+    h ^= h >> 47;
+    h *= M;
+    h ^= h >> 47;
+    return h;
+}
+
+// Competitor harness, PTHash half: ptbb_build -i <fasta> -k k -p <out>  (src/ptbb/ptbb_build.cpp:83-99; keys as ptbb_file_itr yields
+// them, src/ptbb/ptbb.hpp:108-131: every window of k valid bases, forward strand; seed 1, alpha 0.94, minimal output)
+extern "C" int lphq_build_pthash(const char* const* records, const size_t* lengths, size_t n_records, int k_, int kmer_bits, double c, int threads,
+                                 int device, const char* out_path, lphq_build_stats* stats) {
+    auto fail = [&](int code, const std::string& msg) {
+        set_last_error(msg);
+        return code;
+    };
+    if ((n_records && (!records || !lengths)) || !out_path) return fail(LPHQ_ERR_ARG, "null argument");
+    if (kmer_bits != 64 && kmer_bits != 128) return fail(LPHQ_ERR_ARG, "kmer_bits must be 64 or 128");
+    if (k_ < 1 || k_ > kmer_bits / 2 - 1) return fail(LPHQ_ERR_ARG, "k cannot be larger than " + std::to_string(kmer_bits / 2 - 1));
+    if (c < 3.0 || c > 10.0) return fail(LPHQ_ERR_ARG, "3.0 <= c <= 10.0");
+    if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    const uint32_t k = (uint32_t)k_;
+    const uint64_t seed = 1;  // constants::default_pthash_seed
+    const u128 km_mask = (((u128)1) << (2 * k)) - 1;
+    // pass 1: k-mers per record; pass 2: their hash128, in input order
+    std::vector<uint64_t> first_of(n_records + 1, 0);
+    parallel_for(n_records, threads, [&](size_t r) {
+        uint64_t since = 0, n = 0;
+        for (size_t i = 0; i < lengths[r]; ++i) {
+            if (nt4((uint8_t)records[r][i]) < 4) n += ++since >= k;
+            else since = 0;
+        }
+        first_of[r + 1] = n;
+    });
+    for (size_t r = 0; r < n_records; ++r) first_of[r + 1] += first_of[r];
+    const uint64_t n = first_of[n_records];
+    std::vector<uint64_t> firsts(n), seconds(n);
+    parallel_for(n_records, threads, [&](size_t r) {
+        uint64_t since = 0, at = first_of[r];
+        u128 km = 0;
+        for (size_t i = 0; i < lengths[r]; ++i) {
+            const uint8_t cb = nt4((uint8_t)records[r][i]);
+            if (cb < 4) {
+                km = ((km << 2) | (u128)cb) & km_mask;
+                if (++since >= k) {  // ptbb::PTHasher::hash, src/ptbb/ptbb.hpp:16-23
+                    if (kmer_bits == 64) {
+                        firsts[at] = murmur64a_u64((uint64_t)km, seed);
+                        seconds[at] = murmur64a_u64((uint64_t)km, ~seed);
+                    } else {
+                        firsts[at] = murmur64a_u128(km, seed);
+                        seconds[at] = murmur64a_u128(km, ~seed);
+                    }
+                    ++at;
+                }
+            } else {
+                since = 0;
+            }
+        }
+    });
+    SinglePhf f;
+    std::string err;
+    if (!phf_build(f, seconds, seed, c, 0.94, threads, device, err, &firsts)) return fail(LPHQ_ERR_FORMAT, err);
+    Writer w;
+    w.put(f);
+    FILE* fo = fopen(out_path, "wb");
+    if (!fo) return fail(LPHQ_ERR_IO, std::string("cannot write ") + out_path);
+    const size_t put = fwrite(w.buf.data(), 1, w.buf.size(), fo);
+    fclose(fo);
+    if (put != w.buf.size()) return fail(LPHQ_ERR_IO, std::string("short write on ") + out_path);
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->num_kmers = n;
+        stats->num_records = n_records;
         stats->file_bytes = w.buf.size();
     }
     return LPHQ_OK;

@@ -78,16 +78,20 @@ struct DeviceGuard {  // make idx->device current for the duration of a call
     }
 };
 
-extern "C" int lphq_open_memory(const void* buf, size_t len, int kind, int kmer_bits, lphq_index** out) {
+// kind LPHQ_PTHASH: `k` is the caller's (a bare single_phf file does not hold it); otherwise k is read from the file
+static int open_memory(const void* buf, size_t len, int kind, int kmer_bits, int k, lphq_index** out) {
     if (!buf || !out) return fail(LPHQ_ERR_ARG, "null argument");
     *out = nullptr;
-    if (kind != LPHQ_PARTITIONED && kind != LPHQ_UNPARTITIONED) return fail(LPHQ_ERR_ARG, "kind must be LPHQ_PARTITIONED or LPHQ_UNPARTITIONED");
+    if (kind != LPHQ_PARTITIONED && kind != LPHQ_UNPARTITIONED && kind != LPHQ_PTHASH)
+        return fail(LPHQ_ERR_ARG, "kind must be LPHQ_PARTITIONED or LPHQ_UNPARTITIONED");
     if (kmer_bits != 64 && kmer_bits != 128) return fail(LPHQ_ERR_ARG, "kmer_bits must be 64 or 128");
     LphFile file;
     std::string err;
     lphq_index* idx = nullptr;
     try {  // no exception may cross the C ABI (a hostile length field could otherwise surface as std::bad_alloc)
-        if (!parse_lph((const uint8_t*)buf, len, kind, kmer_bits, file, err)) return fail(LPHQ_ERR_FORMAT, err);
+        const bool parsed = kind == LPHQ_PTHASH ? parse_pthash((const uint8_t*)buf, len, k, kmer_bits, file, err)
+                                                : parse_lph((const uint8_t*)buf, len, kind, kmer_bits, file, err);
+        if (!parsed) return fail(LPHQ_ERR_FORMAT, err);
         idx = new (std::nothrow) lphq_index();
         if (!idx) return fail(LPHQ_ERR_ARG, "out of memory");
         if (!build_image(file, idx->image, err)) {
@@ -112,7 +116,12 @@ extern "C" int lphq_open_memory(const void* buf, size_t len, int kind, int kmer_
     return LPHQ_OK;
 }
 
-extern "C" int lphq_open(const char* path, int kind, int kmer_bits, lphq_index** out) {
+extern "C" int lphq_open_memory(const void* buf, size_t len, int kind, int kmer_bits, lphq_index** out) {
+    if (kind == LPHQ_PTHASH) return fail(LPHQ_ERR_ARG, "kind must be LPHQ_PARTITIONED or LPHQ_UNPARTITIONED (bare PTHash files: lphq_open_pthash)");
+    return open_memory(buf, len, kind, kmer_bits, 0, out);
+}
+
+static int open_file(const char* path, int kind, int kmer_bits, int k, lphq_index** out) {
     if (!path || !out) return fail(LPHQ_ERR_ARG, "null argument");
     *out = nullptr;
     FILE* f = fopen(path, "rb");
@@ -126,8 +135,15 @@ extern "C" int lphq_open(const char* path, int kind, int kmer_bits, lphq_index**
     size_t got = buf.empty() ? 0 : fread(buf.data(), 1, buf.size(), f);
     fclose(f);
     if (got != buf.size()) return fail(LPHQ_ERR_IO, std::string("short read on ") + path);
-    return lphq_open_memory(buf.data(), buf.size(), kind, kmer_bits, out);
+    return open_memory(buf.data(), buf.size(), kind, kmer_bits, k, out);
 }
+
+extern "C" int lphq_open(const char* path, int kind, int kmer_bits, lphq_index** out) {
+    if (kind == LPHQ_PTHASH) return fail(LPHQ_ERR_ARG, "kind must be LPHQ_PARTITIONED or LPHQ_UNPARTITIONED (bare PTHash files: lphq_open_pthash)");
+    return open_file(path, kind, kmer_bits, 0, out);
+}
+
+extern "C" int lphq_open_pthash(const char* path, int k, int kmer_bits, lphq_index** out) { return open_file(path, LPHQ_PTHASH, kmer_bits, k, out); }
 
 static void scratch_destroy(Scratch* s) {
     DeviceGuard g(s->device);
@@ -252,12 +268,13 @@ static bool header_is_consistent(const lphq_image_header& h, size_t nbytes, std:
         if (!ok) why = std::string(name) + " descriptor points outside the image";
         return ok;
     };
-    if (h.kind > 1 || (h.kmer_bits != 64 && h.kmer_bits != 128) || h.k < 1 || h.k > h.kmer_bits / 2 - 1 || h.m < 1 || h.m > h.k || h.m > 32 ||
-        h.W != h.k - h.m + 1 || h.P != (h.W <= 15 ? 4u : 6u) || h.distinct_minimizers > 0xFFFFFFFFull || h.mm.num_keys != h.distinct_minimizers) {
+    if (h.kind > 2 || (h.kmer_bits != 64 && h.kmer_bits != 128) || h.k < 1 || h.k > h.kmer_bits / 2 - 1 || h.m < 1 || h.m > h.k ||
+        (h.m > 32 && h.kind != LPHQ_PTHASH) /* no m-mers in a bare PTHash: m = k */ || h.W != h.k - h.m + 1 || h.P != (h.W <= 15 ? 4u : 6u) || h.distinct_minimizers > 0xFFFFFFFFull || h.mm.num_keys != h.distinct_minimizers) {
         why = "inconsistent scalar fields";
         return false;
     }
     if (!phf_ok(h.mm, "minimizer_order") || !phf_ok(h.fb, "fallback_kmer_order")) return false;
+    if (h.kind == LPHQ_PTHASH) return h.m == h.k;
     if (h.kind == LPHQ_PARTITIONED) {
         const uint64_t E = LPHQ_UNI_PER_BLOCK(h.P);
         if (!inside(h.off_uni, ((h.distinct_minimizers + E - 1) / E + 1) * sizeof(lphq_uni_block))) {
@@ -447,6 +464,7 @@ extern "C" int lphq_query_contig(const lphq_index* cidx, const char* contig, siz
     if (!n_out || (length && !contig)) return fail(LPHQ_ERR_ARG, "null argument");
     *n_out = 0;
     const uint32_t k = idx->hdr.k;
+    if (idx->hdr.kind == LPHQ_PTHASH) streaming = 1;  // ptbb_file_itr yields nothing for windows holding a non-ACGT base
     if (length < k) return LPHQ_OK;  // partitioned_mphf.hpp:79 (streaming); the random branch is undefined there
     const size_t nwin = length - k + 1;
     if (!out || cap < nwin) return fail(LPHQ_ERR_ARG, "output buffer too small");

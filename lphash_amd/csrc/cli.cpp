@@ -36,6 +36,8 @@ int help(const char* arg0) {
     std::cerr << "  build-u      build an unpartitioned LP-MPHF\n";
     std::cerr << "  query-p      query a partitioned LP-MPHF\n";
     std::cerr << "  query-u      query an unpartitioned LP-MPHF\n";
+    std::cerr << "  ptbb-build   build a plain PTHash MPHF over the k-mers (the reference's ptbb_build, PTHash half)\n";
+    std::cerr << "  ptbb-query   query it (the reference's ptbb_query, PTHash half)\n";
     return 1;
 }
 
@@ -663,6 +665,196 @@ int build_main(int kind, int argc, char** argv) {
     return rc;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Competitor harness, PTHash half: `ptbb_build` / `ptbb_query` of the reference (src/ptbb/ptbb_build.cpp,
+// src/ptbb/ptbb_query.cpp) as sub-commands.  Same flags and the same CSV, with the BBHash fields left empty (BBHash is not part of
+// this harness: -b is refused).  The PTHash file is the reference's (a bare essentials::save of pthash::single_phf).
+// ---------------------------------------------------------------------------------------------------------------------------
+int ptbb_build_main(int argc, char** argv) {
+    Args a = parse(argc, argv, {"-i", "-k", "-p", "-b", "-a", "-c", "-g", "-d", "-t", "--kmer-bits", "--device"}, {"--verbose", "--check", "--cpu"});
+    if (a.help || a.bad || !a.get("-i") || !a.get("-k")) {
+        std::cerr << "Usage: " << argv[0] << " [-h,--help] -i input_filename -k k [-p pthash_filename] [-c c] [-d tmp_dirname] [-t threads] [--verbose] [--check] "
+                     "[--kmer-bits 64|128] [--device N] [--cpu]\n";
+        return 1;  // !parser.parse() -> 1, ptbb_build.cpp:42
+    }
+    if (a.get("-b")) {
+        std::cerr << "BBHash (-b) is not part of this harness; only the PTHash half (-p) is built\n";
+        return 1;
+    }
+    const std::string input = *a.get("-i");
+    const int k = std::atoi(a.get("-k")->c_str());
+    const int kmer_bits = a.get("--kmer-bits") ? std::atoi(a.get("--kmer-bits")->c_str()) : 128;
+    const double c = a.get("-c") ? std::atof(a.get("-c")->c_str()) : 3.0;  // constants::c
+    const int threads = a.get("-t") ? std::atoi(a.get("-t")->c_str()) : 1;
+    if ((kmer_bits != 64 && kmer_bits != 128) || k < 1 || k > kmer_bits / 2 - 1) {
+        std::cerr << "k cannot be larger than " << kmer_bits / 2 - 1 << std::endl;
+        return 3;
+    }
+    if (a.get("-d")) (void)::mkdir(a.get("-d")->c_str(), 0777);  // essentials::create_directory; construction here is in memory
+    lphq::FastxBatchReader rd(input.c_str(), std::max(1, threads));
+    if (!rd.ok()) {
+        std::cerr << "Unable to open the input file " << input << "\n";
+        return 2;  // ptbb_build.cpp:48-51
+    }
+    lphq::FastxBatch whole;
+    (void)rd.next(whole, ~(size_t)0);
+    if (!rd.ok()) {
+        std::cerr << "[Error] out of host memory while reading " << input << "\n";
+        return 4;
+    }
+    whole.compact();
+    const size_t n_recs = whole.lens.size();
+    std::vector<const char*> ptrs(n_recs);
+    std::vector<size_t> lens(n_recs);
+    {
+        size_t si = 0, so = 0;
+        for (size_t i = 0; i < n_recs; ++i) {
+            while (si < whole.segs.size() && so == whole.segs[si].n) {
+                ++si;
+                so = 0;
+            }
+            lens[i] = (size_t)whole.lens[i];
+            ptrs[i] = si < whole.segs.size() ? whole.segs[si].p + so : "";
+            so += lens[i];
+        }
+    }
+    if (!a.get("-p")) {  // nothing to build: the k-mer count alone (ptbb_build.cpp:52-68), all other fields empty
+        uint64_t total = 0;
+        for (size_t i = 0; i < n_recs; ++i) {
+            uint64_t since = 0;
+            for (size_t j = 0; j < lens[i]; ++j) {
+                switch (ptrs[i][j]) {
+                    case 'A': case 'a': case 'C': case 'c': case 'G': case 'g': case 'T': case 't': case 'U': case 'u': total += ++since >= (uint64_t)k; break;
+                    default: since = 0;
+                }
+            }
+        }
+        std::cout << input << "," << k << "," << total << ",,,," << std::endl;
+        return 0;
+    }
+    const std::string out = *a.get("-p");
+    int build_device = a.has("--cpu") ? -1 : (a.get("--device") ? std::atoi(a.get("--device")->c_str()) : 0);
+    if (build_device >= 0) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || build_device >= ndev) build_device = -1;
+    }
+    lphq_build_stats st;
+    if (lphq_build_pthash(ptrs.data(), lens.data(), n_recs, k, kmer_bits, c, threads, build_device, out.c_str(), &st) != LPHQ_OK) {
+        std::cerr << "[Error] " << lphq_last_error() << "\n";
+        return 4;
+    }
+    // ptbb_build.cpp:69,100-101 (num_bits() of the reference counts the in-memory object; here the serialized size)
+    std::cout << input << "," << k << "," << st.num_kmers << "," << st.file_bytes * 8 << "," << static_cast<double>(st.file_bytes * 8) / st.num_kmers << ",,"
+              << std::endl;
+    if (a.has("--check")) {  // ptbb_build.cpp:103-131 through the GPU path
+        std::cerr << "Checking PTHash...";
+        const int device = a.get("--device") ? std::atoi(a.get("--device")->c_str()) : 0;
+        lphq_index* idx = nullptr;
+        if (lphq_open_pthash(out.c_str(), k, kmer_bits, &idx) != LPHQ_OK || lphq_attach(idx, device) != LPHQ_OK) {
+            std::cerr << "[Error] " << lphq_last_error() << "\n";
+            if (idx) lphq_close(idx);
+            return 4;
+        }
+        std::vector<uint64_t> population((st.num_kmers + 63) / 64, 0), codes;
+        uint64_t seen = 0;
+        for (size_t i = 0; i < n_recs; ++i) {
+            if (lens[i] < (size_t)k) continue;
+            codes.resize(lens[i] - k + 1);
+            size_t n = 0;
+            if (lphq_query_contig(idx, ptrs[i], lens[i], 1, codes.data(), codes.size(), &n) != LPHQ_OK) {
+                std::cerr << "[Error] " << lphq_last_error() << "\n";
+                lphq_close(idx);
+                return 4;
+            }
+            for (size_t j = 0; j < n; ++j) {
+                const uint64_t x = codes[j];
+                if (x >= st.num_kmers) {
+                    std::cerr << "[Error] out of bounds" << std::endl;
+                    lphq_close(idx);
+                    return 2;
+                }
+                if ((population[x >> 6] >> (x & 63)) & 1) {
+                    std::cerr << "[Error] collision" << std::endl;
+                    lphq_close(idx);
+                    return 2;
+                }
+                population[x >> 6] |= 1ULL << (x & 63);
+                ++seen;
+            }
+        }
+        lphq_close(idx);
+        if (seen != st.num_kmers) {
+            std::cerr << "[Error] hash is not perfect" << std::endl;
+            return 2;
+        }
+        std::cerr << "EVERYTHING OK\n";
+    }
+    return 0;
+}
+
+int ptbb_query_main(int argc, char** argv) {
+    Args a = parse(argc, argv, {"-q", "-k", "-p", "-b", "--kmer-bits", "--device", "--gpus", "--batch-mb", "--threads"}, {"--pageable"});
+    if (a.help || a.bad || !a.get("-q") || !a.get("-k")) {
+        std::cerr << "Usage: " << argv[0] << " [-h,--help] -q input_filename -k k [-p pthash_filename] [--kmer-bits 64|128] [--device N | --gpus N] [--batch-mb N] "
+                     "[--threads N] [--pageable]\n";
+        return 1;
+    }
+    if (a.get("-b")) {
+        std::cerr << "BBHash (-b) is not part of this harness; only the PTHash half (-p) is queried\n";
+        return 1;
+    }
+    const std::string input = *a.get("-q");
+    const int k = std::atoi(a.get("-k")->c_str());
+    const int kmer_bits = a.get("--kmer-bits") ? std::atoi(a.get("--kmer-bits")->c_str()) : 128;
+    std::cout << input << "," << k;  // ptbb_query.cpp:23
+    if (!a.get("-p")) {
+        std::cout << ",,,,\n";
+        return 0;
+    }
+    const std::string file = *a.get("-p");
+    const int device = a.get("--device") ? std::atoi(a.get("--device")->c_str()) : 0;
+    const int ngpus = a.get("--gpus") ? std::atoi(a.get("--gpus")->c_str()) : 1;
+    if (ngpus < 1 || (a.get("--gpus") && a.get("--device"))) {
+        std::cerr << "--gpus N needs N >= 1 and excludes --device\n";
+        return 1;
+    }
+    std::vector<int> devices;
+    for (int d = 0; d < ngpus; ++d) devices.push_back(a.get("--gpus") ? d : device);
+    const size_t batch_bases = (size_t)(a.get("--batch-mb") ? std::max(1l, std::atol(a.get("--batch-mb")->c_str())) : 32) << 20;
+    const int threads = a.get("--threads") ? std::max(1, std::atoi(a.get("--threads")->c_str())) : default_parse_threads();
+    lphq_index* idx = nullptr;
+    if (lphq_open_pthash(file.c_str(), k, kmer_bits, &idx) != LPHQ_OK || lphq_attach_devices(idx, devices.data(), (int)devices.size()) != LPHQ_OK) {
+        std::cerr << "[Error] " << lphq_last_error() << "\n";
+        if (idx) lphq_close(idx);
+        return 2;
+    }
+    lphq_info info;
+    lphq_get_info(idx, &info);
+    std::vector<GpuWorker> gpus(devices.size());
+    for (size_t d = 0; d < devices.size(); ++d)
+        if (!gpus[d].init(devices[d])) {
+            std::cerr << "[Error] cannot create a stream on device " << devices[d] << "\n";
+            lphq_close(idx);
+            return 2;
+        }
+    uint64_t total = 0, us = 0;
+    std::string err;
+    const bool opened = query_pass(idx, info, input, 1, batch_bases, threads, !a.has("--pageable"), gpus, total, us, err, nullptr);
+    for (GpuWorker& g : gpus) g.destroy();
+    lphq_close(idx);
+    if (!opened) {
+        std::cerr << "\n[ptbb_file_itr] Unable to open file " << input << "\n";  // ptbb.hpp:84-85 throws here
+        return 2;
+    }
+    if (!err.empty()) {
+        std::cerr << "\n[Error] " << err << "\n";
+        return 3;
+    }
+    // ptbb_query.cpp:74-86: ",<pthash file>,<ns per k-mer>" then the empty BBHash fields
+    std::cout << "," << file << "," << static_cast<double>(us * 1000) / total << ",,\n";
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char* argv[]) {
@@ -673,6 +865,8 @@ int main(int argc, char* argv[]) {
     if (tool == "query-p") return query_main(LPHQ_PARTITIONED, argc - 1, argv + 1);
     if (tool == "query-u") return query_main(LPHQ_UNPARTITIONED, argc - 1, argv + 1);
     if (tool == "records") return records_main(argc - 1, argv + 1);
+    if (tool == "ptbb-build" || tool == "ptbb_build") return ptbb_build_main(argc - 1, argv + 1);
+    if (tool == "ptbb-query" || tool == "ptbb_query") return ptbb_query_main(argc - 1, argv + 1);
     std::cerr << "Unsupported tool '" << tool << "'." << std::endl;
     return help(argv[0]);
 }

@@ -25,6 +25,24 @@ __device__ __forceinline__ uint64_t murmur8(uint64_t v, uint64_t seedx) {
     return h;
 }
 
+// MurmurHash2_64 of the 16 bytes of a 128-bit k-mer (low word first: little-endian __uint128_t), seedx16 = seed ^ (16 * m)
+__device__ __forceinline__ uint64_t murmur_seedx16(uint64_t seed) { return seed ^ (16ull * LPHQ_MURMUR_M); }
+__device__ __forceinline__ uint64_t murmur16(uint64_t lo, uint64_t hi, uint64_t seedx16) {
+    uint64_t h = seedx16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        uint64_t k = (i ? hi : lo) * LPHQ_MURMUR_M;
+        k ^= k >> 47;
+        k *= LPHQ_MURMUR_M;
+        h ^= k;
+        h *= LPHQ_MURMUR_M;
+    }
+    h ^= h >> 47;
+    h *= LPHQ_MURMUR_M;
+    h ^= h >> 47;
+    return h;
+}
+
 // One 2-by-1 division step by a normalised invariant divisor (Moeller & Granlund 2011, Alg. 4):
 // remainder of (r * 2^32 + u) / dn for r < dn.
 __device__ __forceinline__ uint32_t div_step(uint32_t r, uint32_t u, uint32_t dn, uint32_t inv) {
@@ -95,12 +113,15 @@ __device__ __forceinline__ uint64_t phf_finish(const uint8_t* __restrict__ img, 
     if (p >= f.num_keys) p = ((const uint32_t*)(img + f.off_free))[p - f.num_keys];
     return p;
 }
-__device__ __forceinline__ uint64_t phf_position(const uint8_t* __restrict__ img, const lphq_phf_desc& f, uint64_t x) {
+// hash128 hashers: the bucket comes from hash.first(), the table position from hash.second()
+__device__ __forceinline__ uint64_t phf_position2(const uint8_t* __restrict__ img, const lphq_phf_desc& f, uint64_t first, uint64_t second) {
     if (f.num_keys == 0) return 0;  // empty function: unreachable for well-formed files
     PhfRank rk;
-    const uint64_t two = phf_load_code(img, f, x, rk);
-    return phf_finish(img, f, x, phf_load_hp(img, f, two, rk));
+    const uint64_t two = phf_load_code(img, f, first, rk);
+    return phf_finish(img, f, second, phf_load_hp(img, f, two, rk));
 }
+// hash64 hashers (LPHash's own functions): first() == second()
+__device__ __forceinline__ uint64_t phf_position(const uint8_t* __restrict__ img, const lphq_phf_desc& f, uint64_t x) { return phf_position2(img, f, x, x); }
 
 // mask of the first nb bits of a 32-bit word, nb in [0, 32]
 __device__ __forceinline__ uint32_t low_mask(int nb) { return nb >= 32 ? ~0u : (nb <= 0 ? 0u : ((1u << nb) - 1u)); }
@@ -304,8 +325,19 @@ __device__ __forceinline__ uint64_t finish_hval(const uint8_t* __restrict__ img,
     return c.mode == 0u ? c.base + p : c.base - p;
 }
 
+// Competitor harness (KIND 2): pthash_mphf(kmer) of src/ptbb/ptbb_query.cpp:47 with ptbb::PTHasher (src/ptbb/ptbb.hpp:16-23):
+// hash128{Murmur(&kmer, sizeof kmer, seed), Murmur(&kmer, sizeof kmer, ~seed)}
+template <bool K128>
+__device__ __forceinline__ uint64_t pthash_kmer(const uint8_t* __restrict__ img, const lphq_image_header& H, uint64_t lo, uint64_t hi) {
+    const uint64_t seed = H.mm.seed;
+    const uint64_t a = K128 ? murmur16(lo, hi, murmur_seedx16(seed)) : murmur8(lo, murmur_seedx(seed));
+    const uint64_t b = K128 ? murmur16(lo, hi, murmur_seedx16(~seed)) : murmur8(lo, murmur_seedx(~seed));
+    return phf_position2(img, H.mm, a, b);
+}
+
 template <int KIND, bool K128, int P>
 __device__ __forceinline__ uint64_t query_kmer(const uint8_t* __restrict__ img, const lphq_image_header& H, uint64_t lo, uint64_t hi) {
+    if (KIND == 2) return pthash_kmer<K128>(img, H, lo, hi);
     uint64_t mm;
     uint32_t p;
     minimizer_of<K128>(lo, hi, H.k, H.m, H.W, murmur_seedx(H.mm_seed), mm, p);

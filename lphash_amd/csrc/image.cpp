@@ -142,7 +142,9 @@ bool build_image(const LphFile& x, std::vector<uint8_t>& img, std::string& err) 
     if (!build_phf(x.minimizer_order, w, h.mm, "minimizer_order", err)) return false;
     if (!build_phf(x.fallback_kmer_order, w, h.fb, "fallback_kmer_order", err)) return false;
 
-    if (x.kind == LPHQ_PARTITIONED) {
+    if (x.kind == 2) {
+        // bare PTHash over k-mers (competitor harness): the function is all there is
+    } else if (x.kind == LPHQ_PARTITIONED) {
         const uint64_t base = (uint64_t)h.W * x.n_maximal;  // (k - m + 1) * n_maximal, partitioned_mphf.cpp:300
         std::vector<uint64_t> vals;                          // EF[0..n]: prefix sums with the leading 0
         if (!x.sizes_and_positions.decode(vals, err)) return false;

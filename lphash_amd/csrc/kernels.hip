@@ -23,26 +23,14 @@ static inline int grid_for(size_t n, int per_block, int max_blocks) {
     do {                                                                               \
         const bool k128 = H.kmer_bits == 128;                                          \
         const bool p6 = H.P == 6;                                                      \
-        if (H.kind == 0) {                                                             \
+        if (H.kind == 2) { /* competitor harness: plain PTHash over k-mers */          \
+            if (k128) KERNEL<2, true, 4> __VA_ARGS__; else KERNEL<2, false, 4> __VA_ARGS__; \
+        } else if (H.kind == 0) {                                                      \
             if (k128) { if (p6) KERNEL<0, true, 6> __VA_ARGS__; else KERNEL<0, true, 4> __VA_ARGS__; }   \
             else      { if (p6) KERNEL<0, false, 6> __VA_ARGS__; else KERNEL<0, false, 4> __VA_ARGS__; } \
         } else {                                                                       \
             if (k128) { if (p6) KERNEL<1, true, 6> __VA_ARGS__; else KERNEL<1, true, 4> __VA_ARGS__; }   \
             else      { if (p6) KERNEL<1, false, 6> __VA_ARGS__; else KERNEL<1, false, 4> __VA_ARGS__; } \
-        }                                                                              \
-    } while (0)
-
-#define LPHQ_COMMA ,
-#define LPHQ_DISPATCH_B(KERNEL, B, ...)                                                \
-    do {                                                                               \
-        const bool k128 = H.kmer_bits == 128;                                          \
-        const bool p6 = H.P == 6;                                                      \
-        if (H.kind == 0) {                                                             \
-            if (k128) { if (p6) KERNEL<0, true, 6, B> __VA_ARGS__; else KERNEL<0, true, 4, B> __VA_ARGS__; }   \
-            else      { if (p6) KERNEL<0, false, 6, B> __VA_ARGS__; else KERNEL<0, false, 4, B> __VA_ARGS__; } \
-        } else {                                                                       \
-            if (k128) { if (p6) KERNEL<1, true, 6, B> __VA_ARGS__; else KERNEL<1, true, 4, B> __VA_ARGS__; }   \
-            else      { if (p6) KERNEL<1, false, 6, B> __VA_ARGS__; else KERNEL<1, false, 4, B> __VA_ARGS__; } \
         }                                                                              \
     } while (0)
 
@@ -88,7 +76,7 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
     // one workgroup per tile: HIP requires gridDim.x * blockDim.x < 2^32 (<= 2^24 - 1 tiles of 256 threads, i.e. ~16 G bases
     // per call); larger batches must be split by the caller (capi.cpp says so in the error text)
     if (tiles > (0xFFFFFFFFull / 256u) || n_records > 0xFFFFFFFFull) return hipErrorInvalidValue;
-    if (streaming) {
+    if (streaming && H.kind != 2) {
         // window minima: direct form, or block decomposition for wide windows (P == 6 <=> W > 15; kernels_device.cuh: kBlockMinW)
 #define LPHQ_STREAM_LAUNCH(KIND, K128) \
     do { \

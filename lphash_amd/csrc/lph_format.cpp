@@ -271,4 +271,22 @@ bool parse_lph(const uint8_t* buf, size_t len, int kind, int kmer_bits, LphFile&
     return true;
 }
 
+bool parse_pthash(const uint8_t* buf, size_t len, int k, int kmer_bits, LphFile& x, std::string& err) {
+    const char* what = "pthash";
+    CHECK(kmer_bits == 64 || kmer_bits == 128, "kmer_bits must be 64 or 128");
+    CHECK(k >= 1 && k <= kmer_bits / 2 - 1, "k=%d does not fit a %d-bit kmer_t", k, kmer_bits);
+    Reader r{buf, len};
+    x = LphFile();
+    x.kind = 2;
+    x.kmer_bits = kmer_bits;
+    x.k = x.m = (uint8_t)k;
+    r.read(x.minimizer_order);
+    CHECK(!r.bad, "truncated file (needed more than %zu bytes)", len);
+    CHECK(r.off == len, "%zu trailing bytes: not a bare single_phf file", len - r.off);
+    x.bytes_read = r.off;
+    if (!check_phf(x.minimizer_order, what, err)) return false;
+    x.nkmers = x.distinct_minimizers = x.minimizer_order.num_keys;
+    return true;
+}
+
 }  // namespace lphq

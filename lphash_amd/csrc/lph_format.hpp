@@ -60,7 +60,7 @@ struct SinglePhf {  // pthash::single_phf<Hasher, dictionary_dictionary, true>
 };
 
 struct LphFile {
-    int kind = 0;  // LPHQ_PARTITIONED / LPHQ_UNPARTITIONED
+    int kind = 0;  // LPHQ_PARTITIONED / LPHQ_UNPARTITIONED / LPHQ_PTHASH
     int kmer_bits = 64;
     uint8_t k = 0, m = 0;
     uint64_t mm_seed = 0, nkmers = 0, distinct_minimizers = 0;
@@ -74,6 +74,10 @@ struct LphFile {
     SinglePhf minimizer_order, fallback_kmer_order;
     uint64_t bytes_read = 0;
 };
+
+// A bare single_phf file (the reference's ptbb harness, src/ptbb/ptbb_build.cpp:99): kind = 2, k from the caller, m = k; the
+// function goes to minimizer_order, nkmers = distinct_minimizers = its number of keys.
+bool parse_pthash(const uint8_t* buf, size_t len, int k, int kmer_bits, LphFile& out, std::string& err);
 
 // Parse + cross-check redundant fields.  Returns false and fills err on failure.
 bool parse_lph(const uint8_t* buf, size_t len, int kind, int kmer_bits, LphFile& out, std::string& err);

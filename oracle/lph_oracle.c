@@ -338,15 +338,17 @@ static inline uint64_t pilots_access(const phf* f, uint64_t i) {
     i -= f->front.ranks.size;
     return cv_access(&f->back.dict, cv_access(&f->back.ranks, i));
 }
-/* single_phf<...,true>::position(hash)  (hash64: first()==second()) */
-static uint64_t phf_position(const phf* f, uint64_t hash) {
-    uint64_t bucket = bucket_of(&f->bk, hash);
+/* single_phf<...,true>::position(hash): the bucket comes from hash.first(), the table position from hash.second() */
+static uint64_t phf_position2(const phf* f, uint64_t first, uint64_t second) {
+    uint64_t bucket = bucket_of(&f->bk, first);
     uint64_t pilot = pilots_access(f, bucket);
     uint64_t hashed_pilot = hash_u64(pilot, f->seed);
-    uint64_t p = fastmod_u64(hash ^ hashed_pilot, f->M, f->table_size);
+    uint64_t p = fastmod_u64(second ^ hashed_pilot, f->M, f->table_size);
     if (p < f->num_keys) return p;
     return ef_access(&f->free_slots, p - f->num_keys);
 }
+/* hash64 (the hashers of LPHash's own functions): first() == second() */
+static uint64_t phf_position(const phf* f, uint64_t hash) { return phf_position2(f, hash, hash); }
 uint64_t orc_minimizer_order(const orc_index* x, uint64_t mm) {
     return phf_position(&x->minimizer_order, hash_u64(mm, x->minimizer_order.seed));
 }
@@ -784,7 +786,12 @@ static void dict_encode(dictionary* d, const uint64_t* v, uint64_t n) {
     free(s); free(vf); free(dict); free(byval); free(ranks);
 }
 
+static int phf_build2(phf* f, const uint64_t* firsts, const uint64_t* hashes, uint64_t n, uint64_t seed, double c, double alpha);
 static int phf_build(phf* f, const uint64_t* hashes, uint64_t n, uint64_t seed, double c, double alpha) {
+    return phf_build2(f, hashes, hashes, n, seed, c, alpha);
+}
+/* firsts[i] = hash.first() (bucket), hashes[i] = hash.second() (payload: table position, duplicate check) of key i */
+static int phf_build2(phf* f, const uint64_t* firsts, const uint64_t* hashes, uint64_t n, uint64_t seed, double c, double alpha) {
     memset(f, 0, sizeof *f);
     f->seed = seed;
     f->num_keys = n;
@@ -801,7 +808,7 @@ static int phf_build(phf* f, const uint64_t* hashes, uint64_t n, uint64_t seed, 
     f->bk.M_sparse = computeM_u64(f->bk.num_sparse);
 
     bh_t* bh = malloc(n * sizeof *bh);
-    for (uint64_t i = 0; i < n; ++i) { bh[i].hash = hashes[i]; bh[i].bucket = bucket_of(&f->bk, hashes[i]); }
+    for (uint64_t i = 0; i < n; ++i) { bh[i].hash = hashes[i]; bh[i].bucket = bucket_of(&f->bk, firsts[i]); }
     qsort(bh, n, sizeof *bh, cmp_bh);
     uint64_t* bstart = calloc(num_buckets + 1, 8);
     for (uint64_t i = 0; i < n; ++i) bstart[bh[i].bucket + 1]++;
@@ -1276,4 +1283,113 @@ out:
     free(uniq); free(coll_ids);
     orc_free(x);
     return rc;
+}
+
+
+/* ==========================================================================================
+ * Competitor harness: a plain PTHash MPHF over whole k-mers, src/ptbb/ptbb.hpp:16-34,
+ * src/ptbb/ptbb_build.cpp:83-99, src/ptbb/ptbb_query.cpp:40-55.  (The BBHash half of the reference's harness is not restated.)
+ * ======================================================================================== */
+struct orc_ptbb { phf f; uint32_t k; int kmer_bits; };
+
+/* ptbb::PTHasher::hash (ptbb.hpp:16-23): hash128{Murmur(&val, sizeof val, seed), Murmur(&val, sizeof val, ~seed)} */
+static void ptbb_hash(u128 kmer, int kmer_bits, uint64_t seed, uint64_t* first, uint64_t* second) {
+    if (kmer_bits == 64) {
+        uint64_t v = (uint64_t)kmer;
+        *first = orc_murmur64a(&v, 8, seed);
+        *second = orc_murmur64a(&v, 8, ~seed);
+    } else {
+        *first = orc_murmur64a(&kmer, 16, seed);
+        *second = orc_murmur64a(&kmer, 16, ~seed);
+    }
+}
+
+/* the k-mers ptbb_file_itr yields for one record (ptbb.hpp:108-131): every window of k valid bases, forward strand */
+typedef void (*kmer_fn)(u128 kmer, void* ctx);
+static uint64_t ptbb_each_kmer(const char* s, size_t len, uint32_t k, kmer_fn fn, void* ctx) {
+    const u128 km_mask = (((u128)1) << (2 * k)) - 1;
+    u128 km = 0;
+    uint64_t since_break = 0, n = 0;
+    for (size_t i = 0; i < len; ++i) {
+        int c = nt4((uint8_t)s[i]);
+        if (c < 4) {
+            km = ((km << 2) | (u128)c) & km_mask;
+            if (++since_break >= k) { if (fn) fn(km, ctx); ++n; }
+        } else {
+            since_break = 0;
+        }
+    }
+    return n;
+}
+typedef struct { uint64_t* first; uint64_t* second; uint64_t n; int kmer_bits; uint64_t seed; } ptbb_acc;
+static void ptbb_collect(u128 kmer, void* ctx) {
+    ptbb_acc* a = ctx;
+    ptbb_hash(kmer, a->kmer_bits, a->seed, &a->first[a->n], &a->second[a->n]);
+    ++a->n;
+}
+
+/* ptbb_build -i <fasta> -k k -p <out> [-c c]  (ptbb_build.cpp:83-99: seed = default_pthash_seed = 1, alpha = 0.94, minimal) */
+int orc_ptbb_build(const char* const* contigs, const size_t* lengths, size_t n_contigs, int k, int kmer_bits, double c, const char* out_path) {
+    if ((kmer_bits != 64 && kmer_bits != 128) || k < 1 || k > kmer_bits / 2 - 1) { FAIL("ptbb: k out of range for kmer_bits"); return -1; }
+    uint64_t total = 0;
+    for (size_t i = 0; i < n_contigs; ++i) total += ptbb_each_kmer(contigs[i], lengths[i], (uint32_t)k, NULL, NULL);
+    ptbb_acc a = {malloc((total ? total : 1) * 8), malloc((total ? total : 1) * 8), 0, kmer_bits, 1};
+    for (size_t i = 0; i < n_contigs; ++i) ptbb_each_kmer(contigs[i], lengths[i], (uint32_t)k, ptbb_collect, &a);
+    phf f;
+    int rc = phf_build2(&f, a.first, a.second, a.n, 1, c, 0.94);
+    free(a.first); free(a.second);
+    if (rc) return -1;
+    wr_t w = {0, 0, 0};
+    wr_phf(&w, &f);
+    FILE* fp = fopen(out_path, "wb");
+    if (!fp || fwrite(w.p, 1, w.len, fp) != w.len) { if (fp) fclose(fp); free(w.p); phf_free(&f); FAIL("cannot write %s", out_path); return -1; }
+    fclose(fp);
+    free(w.p);
+    phf_free(&f);
+    return 0;
+}
+
+orc_ptbb* orc_ptbb_load(const char* path, int k, int kmer_bits) {
+    FILE* fp = fopen(path, "rb");
+    if (!fp) { FAIL("cannot open %s", path); return NULL; }
+    fseek(fp, 0, SEEK_END);
+    long n = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    uint8_t* buf = malloc(n > 0 ? (size_t)n : 1);
+    if (fread(buf, 1, (size_t)n, fp) != (size_t)n) { fclose(fp); free(buf); FAIL("short read"); return NULL; }
+    fclose(fp);
+    orc_ptbb* h = calloc(1, sizeof *h);
+    h->k = (uint32_t)k; h->kmer_bits = kmer_bits;
+    rd_t r = {buf, (size_t)n, 0, 0};
+    rd_phf(&r, &h->f);
+    const int bad = r.bad || r.off != r.len;
+    free(buf);
+    if (bad) { FAIL("malformed single_phf file"); phf_free(&h->f); free(h); return NULL; }
+    return h;
+}
+void orc_ptbb_free(orc_ptbb* h) { if (h) { phf_free(&h->f); free(h); } }
+uint64_t orc_ptbb_num_keys(const orc_ptbb* h) { return h->f.num_keys; }
+
+/* pthash_mphf(*kmer_itr)  (ptbb_query.cpp:47) on packed k-mers */
+void orc_ptbb_query_packed(const orc_ptbb* h, const uint64_t* kmers, size_t n, uint64_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        u128 kmer = h->kmer_bits == 64 ? (u128)kmers[i] : ((u128)kmers[2 * i] | ((u128)kmers[2 * i + 1] << 64));
+        uint64_t a, b;
+        ptbb_hash(kmer, h->kmer_bits, h->f.seed, &a, &b);
+        out[i] = phf_position2(&h->f, a, b);
+    }
+}
+typedef struct { const orc_ptbb* h; uint64_t* out; size_t cap, n; } ptbb_q;
+static void ptbb_query_one(u128 kmer, void* ctx) {
+    ptbb_q* q = ctx;
+    uint64_t a, b;
+    ptbb_hash(kmer, q->h->kmer_bits, q->h->f.seed, &a, &b);
+    if (q->n < q->cap) q->out[q->n] = phf_position2(&q->h->f, a, b);
+    ++q->n;
+}
+/* the loop of ptbb_query.cpp:46-51 over one record: one code per window of k valid bases; returns how many */
+int64_t orc_ptbb_query_contig(const orc_ptbb* h, const char* contig, size_t length, uint64_t* out, size_t cap) {
+    ptbb_q q = {h, out, cap, 0};
+    ptbb_each_kmer(contig, length, h->k, ptbb_query_one, &q);
+    return (int64_t)q.n;
 }

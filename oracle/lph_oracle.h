@@ -68,6 +68,16 @@ int orc_query_file(const orc_index* idx, const char* query_path, uint64_t* total
 /* records / bases / FNV-1a digest of a file as the driver's reader sees it (pinned against the real kseq.h by the tests) */
 int orc_file_digest(const char* path, uint64_t* n_records, uint64_t* n_bases, uint64_t* digest);
 
+/* Competitor harness, PTHash half (src/ptbb/ptbb.hpp:16-34, ptbb_build.cpp:83-99, ptbb_query.cpp:40-55): a plain
+ * pthash::single_phf<PTHasher, dictionary_dictionary, true> over the k-mers of the records, serialized by essentials::save. */
+typedef struct orc_ptbb orc_ptbb;
+int orc_ptbb_build(const char* const* contigs, const size_t* lengths, size_t n_contigs, int k, int kmer_bits, double c, const char* out_path);
+orc_ptbb* orc_ptbb_load(const char* path, int k, int kmer_bits);
+void orc_ptbb_free(orc_ptbb* h);
+uint64_t orc_ptbb_num_keys(const orc_ptbb* h);
+void orc_ptbb_query_packed(const orc_ptbb* h, const uint64_t* kmers, size_t n, uint64_t* out);
+int64_t orc_ptbb_query_contig(const orc_ptbb* h, const char* contig, size_t length, uint64_t* out, size_t cap);
+
 /* pieces exported for known-answer / model tests */
 uint64_t orc_murmur64a(const void* key, size_t len, uint64_t seed);
 uint64_t orc_minimizer_order(const orc_index* idx, uint64_t minimizer); /* PTHash over minimizers */

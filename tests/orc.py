@@ -36,6 +36,17 @@ def _lib():
     lib.orc_query_file.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.orc_file_digest.restype = C.c_int
     lib.orc_file_digest.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.orc_ptbb_build.restype = C.c_int
+    lib.orc_ptbb_build.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_char_p]
+    lib.orc_ptbb_load.restype = C.c_void_p
+    lib.orc_ptbb_load.argtypes = [C.c_char_p, C.c_int, C.c_int]
+    lib.orc_ptbb_free.argtypes = [C.c_void_p]
+    lib.orc_ptbb_num_keys.restype = C.c_uint64
+    lib.orc_ptbb_num_keys.argtypes = [C.c_void_p]
+    lib.orc_ptbb_query_packed.restype = None
+    lib.orc_ptbb_query_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.orc_ptbb_query_contig.restype = C.c_int64
+    lib.orc_ptbb_query_contig.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
     lib.orc_murmur64a.restype = C.c_uint64
     lib.orc_murmur64a.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64]
     lib.orc_minimizer_order.restype = C.c_uint64
@@ -62,6 +73,47 @@ def file_digest(path):
     if lib.orc_file_digest(path.encode(), C.byref(a), C.byref(b), C.byref(c)) != 0:
         raise RuntimeError("cannot open " + path)
     return a.value, b.value, c.value
+
+
+def ptbb_build(contigs, k, out_path, kmer_bits=64, c=3.0):
+    """ptbb_build -i ... -k k -p out_path (PTHash half of the competitor harness, src/ptbb/ptbb_build.cpp:83-99)."""
+    n = len(contigs)
+    arr = (C.c_char_p * n)(*contigs)
+    lens = (C.c_size_t * n)(*[len(s) for s in contigs])
+    if lib.orc_ptbb_build(arr, lens, n, k, kmer_bits, c, out_path.encode()) != 0:
+        raise RuntimeError(lib.orc_last_error().decode())
+
+
+class PtHash:
+    """pthash_mphf_t of src/ptbb/ptbb.hpp:33 loaded from a file (essentials::load)."""
+
+    def __init__(self, path, k, kmer_bits=64):
+        self.h = lib.orc_ptbb_load(path.encode(), k, kmer_bits)
+        if not self.h:
+            raise RuntimeError(lib.orc_last_error().decode())
+        self.k, self.kmer_bits = k, kmer_bits
+        self.num_keys = lib.orc_ptbb_num_keys(self.h)
+
+    def __call__(self, contig: bytes):
+        cap = max(len(contig), 1)
+        out = np.empty(cap, dtype=np.uint64)
+        n = lib.orc_ptbb_query_contig(self.h, contig, len(contig), out.ctypes.data, cap)
+        return out[:n].copy()
+
+    def query_packed(self, kmers):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        n = kmers.size // (1 if self.kmer_bits == 64 else 2)
+        out = np.empty(n, dtype=np.uint64)
+        lib.orc_ptbb_query_packed(self.h, kmers.ctypes.data, n, out.ctypes.data)
+        return out
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib.orc_ptbb_free(self.h)
+                self.h = None
+        except Exception:
+            pass
 
 
 class Index:

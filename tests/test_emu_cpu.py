@@ -309,3 +309,37 @@ def test_base_encoding_against_the_reference_table(emuk, tmp_path):
             # (the oracle's streaming branch restates the reference literally, including the spurious extra code its stale min_pos can
             # emit after a reset -- SURVEY 8(a) note 4(ii) -- so only its count is bounded here)
             assert int((~bad).sum()) <= len(os_) <= int((~bad).sum()) + 1, c
+
+
+@pytest.mark.parametrize("k,bits", [(31, 64), (31, 128), (63, 128), (21, 64)])
+def test_pthash_competitor_kernels_on_the_emulator(emuk, tmp_path, k, bits):
+    """Competitor harness: a bare PTHash over k-mers (lphq_build_pthash == the oracle's ptbb_build bytes) through the
+    packed kernel and the record-tile kernel (KIND 2): one code per window, LPHQ_INVALID where ptbb_file_itr yields nothing."""
+    recs = dedup_records(random_records(900 + k, 10, k, 2500), k)
+    path, ref = str(tmp_path / "p.pthash"), str(tmp_path / "o.pthash")
+    L.build_pthash(recs, k, path, kmer_bits=bits, threads=4)
+    orc.ptbb_build(recs, k, ref, kmer_bits=bits)
+    assert open(path, "rb").read() == open(ref, "rb").read()
+    o = orc.PtHash(path, k, bits)
+    h = L.PtHash.load(path, k, kmer_bits=bits)
+    assert h.get_kmer_count() == o.num_keys == sum(len(r) - k + 1 for r in recs)
+    img = h.image()
+    # packed: members and non-members
+    seq = b"".join(recs) + random_records(3, 1, 900, 900)[0]
+    pk = pack_kmers(seq, np.arange(0, len(seq) - k + 1), k, bits)
+    out = np.zeros(len(seq) - k + 1, dtype=np.uint64)
+    assert emuk.emu_kernel_query_packed(img.ctypes.data, img.size, pk.ctypes.data, len(out), out.ctypes.data) == 0
+    assert np.array_equal(out, o.query_packed(pk))
+    # records with invalid bases, short and empty records, two alignments
+    q = bytearray(recs[0])
+    q[7] = q[len(q) // 2] = ord("N")
+    batch = [recs[1], bytes(q), b"", recs[2][: k - 1], recs[2][:k]] + recs[3:] + random_records(4, 5, 1, 700)
+    for mis in (0, 11):
+        got = emu_records(emuk, h, batch, k, False, mis)
+        for r, g in zip(batch, got):
+            bad = np.array([c not in b"ACGTUacgtu" for c in r])
+            cs = np.concatenate([[0], np.cumsum(bad)])
+            valid = (cs[k:] - cs[:-k]) == 0 if len(r) >= k else np.zeros(0, dtype=bool)
+            assert np.array_equal(g[valid], o(r)) and (g[~valid] == np.uint64(2**64 - 1)).all()
+    allc = np.concatenate([o(r) for r in recs])
+    assert len(np.unique(allc)) == len(allc) == o.num_keys and int(allc.max()) == len(allc) - 1  # ptbb_build --check

@@ -398,3 +398,33 @@ def test_host_sources_under_sanitizers(tmp_path):
         for cmd in (["load", str(out), str(kind), str(bits)], ["fuzz", str(out), str(kind), str(bits), "150", str(k)]):
             r = subprocess.run([exe] + cmd, capture_output=True, text=True, env=env)
             assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+def test_ptbb_build_cli_and_file(tmp_path):
+    """`lphash ptbb-build` (the reference's ptbb_build, PTHash half, src/ptbb/ptbb_build.cpp): CSV fields, the file equals the oracle's
+    restatement byte for byte, loader round trip; -b (BBHash) is refused; unreadable input -> exit code 2."""
+    import gzip
+
+    exe = os.path.join(ROOT, "lphash_amd", "lphash")
+    recs = random_records(4242, 9, 40, 3000)
+    fa = tmp_path / "in.fa.gz"
+    with gzip.open(fa, "wb") as f:
+        for i, r in enumerate(recs):
+            f.write(b">u%d\n%s\n" % (i, r))
+    n = sum(len(r) - 30 for r in recs)
+    for bits in (64, 128):
+        out, ref = tmp_path / f"cli{bits}.pthash", tmp_path / f"orc{bits}.pthash"
+        r = subprocess.run([exe, "ptbb-build", "-i", str(fa), "-k", "31", "-p", str(out), "--kmer-bits", str(bits), "--cpu", "-t", "4"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        f = r.stdout.strip().split(",")
+        assert len(f) == 7 and f[0] == str(fa) and f[1] == "31" and int(f[2]) == n and int(f[3]) == os.path.getsize(out) * 8 and f[5] == f[6] == ""
+        orc.ptbb_build(recs, 31, str(ref), kmer_bits=bits)
+        assert out.read_bytes() == ref.read_bytes()
+        h = L.PtHash.load(str(out), 31, kmer_bits=bits)
+        assert h.get_kmer_count() == n and h.info.kind == L.PTHASH and h.info.m == 31
+        with pytest.raises(L.LphqError):
+            L.Mphf.load(str(out), kmer_bits=bits)  # a bare PTHash is not an LPHash file
+    r = subprocess.run([exe, "ptbb-build", "-i", str(fa), "-k", "31"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == f"{fa},31,{n},,,,"
+    assert subprocess.run([exe, "ptbb-build", "-i", str(fa), "-k", "31", "-b", "x"], capture_output=True).returncode == 1
+    assert subprocess.run([exe, "ptbb-build", "-i", str(tmp_path / "nope.fa"), "-k", "31", "-p", "x"], capture_output=True).returncode == 2

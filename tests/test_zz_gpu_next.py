@@ -31,3 +31,55 @@ def test_gpu_pilot_search_build_is_byte_identical(tmp_path, k, m, bits, kind, nr
     sg = L.build(recs, k, m, pg, kind=kind, kmer_bits=bits, threads=8, device=0)
     assert sc == sg
     assert open(pc, "rb").read() == open(pg, "rb").read()
+
+
+@pytest.mark.parametrize("k,bits", [(31, 64), (31, 128), (63, 128)])
+def test_pthash_competitor_harness(tmp_path, k, bits):
+    """the PTHash half of the reference's ptbb_build / ptbb_query on the GPU.  Codes == the oracle's restatement of
+    pthash_mphf(kmer) (src/ptbb/ptbb_query.cpp:47) for packed batches (members and non-members) and for records (one code per window of
+    k valid bases, as ptbb_file_itr yields them); bijection onto [0, n); `lphash ptbb-query` prints the reference's CSV."""
+    import subprocess
+
+    import numpy as np
+    import orc
+    from util import pack_kmers, random_records
+
+    torch, dev = torch_dev()
+    _, recs = synthetic_records(seed=5 + k, n_records=12, length=20_000)
+    path = str(tmp_path / "p.pthash")
+    sg = L.build_pthash(recs, k, path, kmer_bits=bits, threads=8, device=0)  # GPU pilot search
+    ref = str(tmp_path / "o.pthash")
+    orc.ptbb_build(recs, k, ref, kmer_bits=bits)
+    assert open(path, "rb").read() == open(ref, "rb").read()
+    o = orc.PtHash(path, k, bits)
+    h = L.PtHash.load(path, k, kmer_bits=bits, device=0)
+    n = sum(len(r) - k + 1 for r in recs)
+    assert sg["num_kmers"] == n == h.get_kmer_count() == o.num_keys
+    allc = []
+    for r in recs[:4]:
+        q = bytearray(r)
+        q[100] = q[5000] = ord("N")
+        for rec in (r, bytes(q)):
+            got = h(rec)
+            assert np.array_equal(got, o(rec))
+        allc.append(h(r))
+    seq = recs[5][:3000] + random_records(3, 1, 2000, 2000)[0]
+    pos = np.arange(0, len(seq) - k + 1, dtype=np.int64)
+    pk = pack_kmers(seq, pos, k, bits)
+    d_k = torch.from_numpy(pk.view(np.int64)).to(dev)
+    d_o = torch.empty(len(pos), dtype=torch.int64, device=dev)
+    h.query_packed(d_k.data_ptr(), len(pos), d_o.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_o.cpu().numpy().view(np.uint64), o.query_packed(pk))
+    every = np.concatenate([h(r) for r in recs])
+    assert len(every) == n and len(np.unique(every)) == n and int(every.max()) == n - 1
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lphash_amd", "lphash")
+    fa = tmp_path / "q.fa"
+    with open(fa, "wb") as f:
+        for i, r in enumerate(recs):
+            f.write(b">r%d\n%s\n" % (i, r))
+    r = subprocess.run([exe, "ptbb-query", "-q", str(fa), "-k", str(k), "-p", path, "--kmer-bits", str(bits)], capture_output=True, text=True)
+    f5 = r.stdout.strip().split(",")
+    assert r.returncode == 0 and len(f5) == 6 and f5[0] == str(fa) and f5[1] == str(k) and f5[2] == path and float(f5[3]) > 0 and f5[4] == f5[5] == "", (r.stdout, r.stderr)
+    r = subprocess.run([exe, "ptbb-build", "-i", str(fa), "-k", str(k), "-p", str(tmp_path / "c.pthash"), "--kmer-bits", str(bits), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0 and "EVERYTHING OK" in r.stderr, r.stderr
