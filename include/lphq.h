@@ -64,6 +64,10 @@ typedef struct lphq_info {
      * NONE (include/quartet_wtree.hpp:7); with fallback_kmers they add up to num_kmers */
     uint64_t kmers_by_type[4];
     uint64_t minimizer_table_size; /* PTHash table_size of minimizer_order (>= distinct_minimizers) */
+    /* serialized bits of the parts print_statistics() reports (src/partitioned_mphf.cpp:341-380, src/unpartitioned_mphf.cpp:208-240):
+     * minimizer MPHF, wavelet tree (0 for query-u), Elias-Fano arrays, fallback MPHF; 0 for handles opened from a device image */
+    uint64_t part_bits[4];
+    uint64_t ef_entries;           /* sizes_and_positions.size() (query-p) / sizes.size() + positions.size() (query-u) */
 } lphq_info;
 
 /* Thread-local text of the last error raised on the calling thread. */
@@ -133,6 +137,15 @@ int lphq_count_valid(const lphq_index* idx, const uint64_t* d_codes, size_t n, v
 /* The same count left in *d_count (8 bytes of device memory, overwritten) without waiting: for callers that keep several
  * batches in flight and read the count back with their own copy on `stream`. */
 int lphq_count_valid_async(const lphq_index* idx, const uint64_t* d_codes, size_t n, uint64_t* d_count, void* stream);
+
+/* ---- result consumer ----
+ * The reference discards the codes (essentials::do_not_optimize_away, src/query.cpp:54); the use of an MPHF is to index per-k-mer data by
+ * them.  d_out[i] = d_table[d_codes[i]] for elements of elem_bytes = 1, 2, 4 or 8 bytes (d_table holds num_kmers of them, in the order of
+ * the hash codes), without leaving the device; codes that are not slots of the function -- LPHQ_INVALID, or what a NON-member k-mer's
+ * wrapped arithmetic produced when it is >= num_kmers -- yield the low elem_bytes bytes of `missing`.  (An MPHF cannot reject non-members
+ * whose code happens to be < num_kmers; that is the nature of the structure, not of this call.) */
+int lphq_gather_payload(const lphq_index* idx, const uint64_t* d_codes, size_t n, const void* d_table, uint32_t elem_bytes, uint64_t missing,
+                        void* d_out, void* stream);
 
 /* ---- host-buffer convenience: mirrors MPHF::operator()(contig, length, streaming) ----
  * Copies the record to the device, runs the GPU path, copies the codes back and (streaming

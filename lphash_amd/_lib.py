@@ -27,7 +27,7 @@ class Info(C.Structure):
         ("mm_seed", C.c_uint64), ("num_kmers", C.c_uint64), ("distinct_minimizers", C.c_uint64),
         ("fallback_kmers", C.c_uint64), ("file_bytes", C.c_uint64), ("image_bytes", C.c_uint64),
         ("device", C.c_int32), ("reserved", C.c_uint32),
-        ("kmers_by_type", C.c_uint64 * 4), ("minimizer_table_size", C.c_uint64),
+        ("kmers_by_type", C.c_uint64 * 4), ("minimizer_table_size", C.c_uint64), ("part_bits", C.c_uint64 * 4), ("ef_entries", C.c_uint64),
     ]
 
 
@@ -55,6 +55,7 @@ SIGNATURES = {
                                      C.c_int, C.c_void_p]),
     "lphq_pack_kmers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "lphq_count_valid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint64)]),
+    "lphq_gather_payload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
     "lphq_count_valid_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "lphq_query_contig": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
                                     C.POINTER(C.c_size_t)]),

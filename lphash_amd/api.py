@@ -118,6 +118,11 @@ class _MphfBase:
         check(lib.lphq_count_valid(self._h, C.c_void_p(d_codes), n, C.c_void_p(stream), C.byref(c)))
         return c.value
 
+    def gather_payload(self, d_codes, n, d_table, elem_bytes, d_out, missing=0, stream=0):
+        """d_out[i] = d_table[d_codes[i]] on the device (codes that are not slots of the function -> `missing`)."""
+        check(lib.lphq_gather_payload(self._h, C.c_void_p(d_codes), n, C.c_void_p(d_table), int(elem_bytes), int(missing) & 0xFFFFFFFFFFFFFFFF,
+                                      C.c_void_p(d_out), C.c_void_p(stream)))
+
     def close(self):
         if self._h:
             lib.lphq_close(self._h)

@@ -38,6 +38,7 @@ struct lphq_index {
     lphq_image_header hdr;
     std::vector<uint8_t> image;  // host copy of the flat image (empty for lphq_open_device_image handles)
     uint64_t file_bytes = 0;
+    uint64_t part_bits[4] = {0, 0, 0, 0}, ef_entries = 0;  // for lphq_get_info (print_statistics of the CLI)
     size_t image_bytes = 0;
     std::vector<Replica> reps;   // reps[0] = primary device
     std::mutex pool_mu;          // guards pool only (pop / push of a slot), never held across device work
@@ -111,6 +112,8 @@ static int open_memory(const void* buf, size_t len, int kind, int kmer_bits, int
         }
     }
     idx->file_bytes = file.bytes_read;
+    for (int i = 0; i < 4; ++i) idx->part_bits[i] = file.part_bytes[i] * 8;
+    idx->ef_entries = file.kind == LPHQ_PARTITIONED ? file.sizes_and_positions.size() : file.sizes.size() + file.positions.size();
     idx->image_bytes = idx->image.size();
     *out = idx;
     return LPHQ_OK;
@@ -236,6 +239,8 @@ extern "C" int lphq_get_info(const lphq_index* idx, lphq_info* info) {
     info->device = idx->reps.empty() ? -1 : idx->reps[0].device;
     for (int i = 0; i < 4; ++i) info->kmers_by_type[i] = idx->hdr.kmers_by_type[i];
     info->minimizer_table_size = idx->hdr.mm.table_size;
+    for (int i = 0; i < 4; ++i) info->part_bits[i] = idx->part_bits[i];
+    info->ef_entries = idx->ef_entries;
     return LPHQ_OK;
 }
 
@@ -445,6 +450,17 @@ extern "C" int lphq_count_valid(const lphq_index* cidx, const uint64_t* d_codes,
     HIP_TRY(launch_count_valid(d_codes, n, d_count, st));
     HIP_TRY(hipMemcpyAsync(count, d_count, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    return LPHQ_OK;
+}
+
+extern "C" int lphq_gather_payload(const lphq_index* idx, const uint64_t* d_codes, size_t n, const void* d_table, uint32_t elem_bytes, uint64_t missing,
+                                   void* d_out, void* stream) {
+    REQUIRE_ATTACHED(idx);
+    if (n && (!d_codes || !d_table || !d_out)) return fail(LPHQ_ERR_ARG, "null buffer");
+    if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8) return fail(LPHQ_ERR_ARG, "elem_bytes must be 1, 2, 4 or 8");
+    const Replica* r = pick_replica(idx);
+    DeviceGuard g(r->device);
+    HIP_TRY(launch_gather_payload(d_codes, n, d_table, idx->hdr.nkmers, elem_bytes, missing, d_out, (hipStream_t)stream));
     return LPHQ_OK;
 }
 

@@ -653,13 +653,35 @@ int build_main(int kind, int argc, char** argv) {
             rc = 5;
         lphq_close(idx);
     }
-    if (verbose) {
+    if (verbose) {  // src/build.cpp:45-48 -> print_statistics(), src/partitioned_mphf.cpp:341-380 / src/unpartitioned_mphf.cpp:208-240
         std::cerr << "Statistics:\n";
-        std::cerr << "Total number of k-mers: " << st.num_kmers << "\n";
-        std::cerr << "Total number of k-mers belonging to ambiguous minimizers: " << st.fallback_kmers << "\n";
-        std::cerr << "xi = " << static_cast<double>(st.fallback_kmers) / st.num_kmers << "\n";
-        std::cerr << "Total size in bits : " << st.file_bytes * 8 << "\n";
-        std::cerr << "\tequivalent to : " << static_cast<double>(st.file_bytes * 8) / st.num_kmers << " bits/k-mer\n";
+        lphq_index* sidx = nullptr;
+        lphq_info si;
+        if (lphq_open(out.c_str(), kind, kmer_bits, &sidx) == LPHQ_OK && lphq_get_info(sidx, &si) == LPHQ_OK) {
+            // Sizes are those of the serialized parts; the reference's num_bits() walks the in-memory objects and adds
+            // sizeof(pthash::build_configuration), so its totals differ by a constant of a few hundred bits.
+            const double total = (double)si.file_bytes * 8;
+            auto pct = [&](uint64_t b) { return (double)b / total * 100; };
+            std::cerr << "Total number of k-mers: " << si.num_kmers << "\n";
+            std::cerr << "Total number of k-mers belonging to ambiguous minimizers: " << si.fallback_kmers << "\n";
+            std::cerr << "xi = " << static_cast<double>(si.fallback_kmers) / si.num_kmers << "\n";
+            std::cerr << "Minimizer MPHF size in bits : " << si.part_bits[0] << " (" << pct(si.part_bits[0]) << "%)\n";
+            std::cerr << "\t = " << static_cast<double>(si.part_bits[0]) / si.distinct_minimizers << " bits/minimizer\n\n";
+            if (kind == LPHQ_PARTITIONED) {
+                std::cerr << "Wavelet tree size in bits : " << si.part_bits[1] << " (" << pct(si.part_bits[1]) << "%)\n";
+                std::cerr << "\t = " << static_cast<double>(si.part_bits[1]) / si.distinct_minimizers << " bits/minimizer\n\n";
+            }
+            std::cerr << "Compressed arrays (EF) : " << si.part_bits[2] << " (" << pct(si.part_bits[2]) << "%)\n";
+            std::cerr << "\t = " << static_cast<double>(si.part_bits[2]) / si.ef_entries << " bits/offset\n\n";
+            std::cerr << "Fallback MPHF : " << si.part_bits[3] << " (" << pct(si.part_bits[3]) << "%)\n";
+            std::cerr << "\t = " << static_cast<double>(si.part_bits[3]) / si.fallback_kmers << " bits/kmer\n\n";
+            std::cerr << "Total size in bits : " << si.file_bytes * 8 << "\n";
+            std::cerr << "\tequivalent to : " << static_cast<double>(si.file_bytes * 8) / si.num_kmers << " bits/k-mer\n";
+            std::cerr << "\n";
+        } else {
+            std::cerr << "[Error] " << lphq_last_error() << "\n";
+        }
+        if (sidx) lphq_close(sidx);
     }
     if (temp_out) std::remove(out.c_str());
     return rc;

@@ -64,6 +64,20 @@ hipError_t launch_count_valid(const uint64_t* d_codes, size_t n, unsigned long l
     return hipGetLastError();
 }
 
+hipError_t launch_gather_payload(const uint64_t* d_codes, size_t n, const void* d_table, uint64_t n_slots, uint32_t elem_bytes, uint64_t missing, void* d_out,
+                                 hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const int grid = grid_for(n, kBlock, (1 << 24) - 1);
+    switch (elem_bytes) {
+        case 1: k_gather_payload<uint8_t><<<grid, kBlock, 0, stream>>>(d_codes, n, (const uint8_t*)d_table, n_slots, (uint8_t)missing, (uint8_t*)d_out); break;
+        case 2: k_gather_payload<uint16_t><<<grid, kBlock, 0, stream>>>(d_codes, n, (const uint16_t*)d_table, n_slots, (uint16_t)missing, (uint16_t*)d_out); break;
+        case 4: k_gather_payload<uint32_t><<<grid, kBlock, 0, stream>>>(d_codes, n, (const uint32_t*)d_table, n_slots, (uint32_t)missing, (uint32_t*)d_out); break;
+        case 8: k_gather_payload<uint64_t><<<grid, kBlock, 0, stream>>>(d_codes, n, (const uint64_t*)d_table, n_slots, missing, (uint64_t*)d_out); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img, const char* d_seq, uint64_t total_bases, const uint64_t* d_seq_off,
                                 const uint64_t* d_out_off, size_t n_records, uint64_t* d_out, int streaming, hipStream_t stream) {
     if (n_records == 0 || total_bases < H.k) return hipSuccess;

@@ -12,5 +12,7 @@ hipError_t launch_query_packed(const lphq_image_header& H, const uint8_t* d_img,
 hipError_t launch_pack_kmers(const lphq_image_header& H, const char* d_seq, const uint64_t* d_pos, size_t n, void* d_kmers, hipStream_t stream);
 hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img, const char* d_seq, uint64_t total_bases, const uint64_t* d_seq_off,
                                 const uint64_t* d_out_off, size_t n_records, uint64_t* d_out, int streaming, hipStream_t stream);
+hipError_t launch_gather_payload(const uint64_t* d_codes, size_t n, const void* d_table, uint64_t n_slots, uint32_t elem_bytes, uint64_t missing, void* d_out,
+                                 hipStream_t stream);
 hipError_t launch_count_valid(const uint64_t* d_codes, size_t n, unsigned long long* d_count, hipStream_t stream);
 }  // namespace lphq

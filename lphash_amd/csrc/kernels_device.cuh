@@ -698,4 +698,20 @@ __global__ __launch_bounds__(kBlock) void k_count_valid(const uint64_t* __restri
 }
 
 
+// ------------------------------------------------------------------------------------------
+// result consumer: payload[code] for every code -- the main downstream use of an MPHF
+// ------------------------------------------------------------------------------------------
+// The reference throws the codes away (src/query.cpp:54); a caller that indexes per-k-mer data by them gathers here without a
+// trip through the host.  Codes that are not slots of the function (>= n_slots: LPHQ_INVALID, or the wrapped arithmetic of a
+// non-member k-mer) yield `missing`.  The code stream is read once (non-temporal), the table is what should stay cached.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_gather_payload(const uint64_t* __restrict__ codes, size_t n, const T* __restrict__ table, uint64_t n_slots, T missing,
+                                                          T* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint64_t c = __builtin_nontemporal_load(codes + i);
+        __builtin_nontemporal_store(c < n_slots ? table[c] : missing, out + i);
+    }
+}
+
 }  // namespace lphq

@@ -217,18 +217,36 @@ bool parse_lph(const uint8_t* buf, size_t len, int kind, int kmer_bits, LphFile&
         x.right_coll_sizes_start = r.u64();
         x.none_sizes_start = r.u64();
         x.none_pos_start = r.u64();
+        size_t at = r.off;
+        auto part = [&](int i) {
+            x.part_bytes[i] += r.off - at;
+            at = r.off;
+        };
         r.read(x.minimizer_order);
+        part(0);
         r.read(x.root);
         r.read(x.left_right);
         r.read(x.max_none);
+        part(1);
         r.read(x.sizes_and_positions);
+        part(2);
+        x.part_bytes[2] += 4 * 8;  // n_maximal and the three region starts are counted with the arrays (partitioned_mphf.cpp:344-347)
         r.read(x.fallback_kmer_order);
+        part(3);
     } else {
         x.num_kmers_in_main_index = r.u64();
+        size_t at = r.off;
+        auto part = [&](int i) {
+            x.part_bytes[i] += r.off - at;
+            at = r.off;
+        };
         r.read(x.minimizer_order);
+        part(0);
         r.read(x.positions);
         r.read(x.sizes);
+        part(2);
         r.read(x.fallback_kmer_order);
+        part(3);
     }
     CHECK(!r.bad, "truncated file (needed more than %zu bytes)", len);
     CHECK(r.off == len, "%zu trailing bytes: wrong kind (query-p vs query-u) or not an LPHash file", len - r.off);

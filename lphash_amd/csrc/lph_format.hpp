@@ -73,6 +73,9 @@ struct LphFile {
     EliasFano positions, sizes;
     SinglePhf minimizer_order, fallback_kmer_order;
     uint64_t bytes_read = 0;
+    // serialized size of the parts print_statistics() reports (src/partitioned_mphf.cpp:341-380): minimizer MPHF, wavelet tree,
+    // Elias-Fano arrays (with their four region scalars; both sequences for the unpartitioned function), fallback MPHF
+    uint64_t part_bytes[4] = {0, 0, 0, 0};
 };
 
 // A bare single_phf file (the reference's ptbb harness, src/ptbb/ptbb_build.cpp:99): kind = 2, k from the caller, m = k; the

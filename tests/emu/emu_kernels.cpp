@@ -83,3 +83,12 @@ extern "C" int emu_kernel_count_valid(const uint64_t* codes, size_t n, unsigned 
     emu::launch((unsigned)((n + kBlock * 8 - 1) / (kBlock * 8)), kBlock, [&] { k_count_valid(codes, n, count); });
     return 0;
 }
+
+extern "C" int emu_kernel_gather_payload(const uint64_t* codes, size_t n, const void* table, uint64_t n_slots, int elem_bytes, uint64_t missing, void* out) {
+    const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+    if (elem_bytes == 4) emu::launch(grid, kBlock, [&] { k_gather_payload<uint32_t>(codes, n, (const uint32_t*)table, n_slots, (uint32_t)missing, (uint32_t*)out); });
+    else if (elem_bytes == 8) emu::launch(grid, kBlock, [&] { k_gather_payload<uint64_t>(codes, n, (const uint64_t*)table, n_slots, missing, (uint64_t*)out); });
+    else if (elem_bytes == 2) emu::launch(grid, kBlock, [&] { k_gather_payload<uint16_t>(codes, n, (const uint16_t*)table, n_slots, (uint16_t)missing, (uint16_t*)out); });
+    else emu::launch(grid, kBlock, [&] { k_gather_payload<uint8_t>(codes, n, (const uint8_t*)table, n_slots, (uint8_t)missing, (uint8_t*)out); });
+    return 0;
+}

@@ -343,3 +343,21 @@ def test_pthash_competitor_kernels_on_the_emulator(emuk, tmp_path, k, bits):
             assert np.array_equal(g[valid], o(r)) and (g[~valid] == np.uint64(2**64 - 1)).all()
     allc = np.concatenate([o(r) for r in recs])
     assert len(np.unique(allc)) == len(allc) == o.num_keys and int(allc.max()) == len(allc) - 1  # ptbb_build --check
+
+
+@pytest.mark.parametrize("eb,dt", [(1, np.uint8), (2, np.uint16), (4, np.uint32), (8, np.uint64)])
+def test_gather_payload_on_the_emulator(emuk, eb, dt):
+    """k_gather_payload (result consumer): payload[code], `missing` for codes that are not slots."""
+    rng = np.random.default_rng(eb)
+    n_slots, n = 1000, 3001
+    table = rng.integers(0, np.iinfo(dt).max, n_slots, dtype=dt)
+    codes = rng.integers(0, n_slots, n).astype(np.uint64)
+    codes[::7] = np.uint64(2**64 - 1)
+    codes[3::11] = np.uint64(n_slots) + codes[3::11]
+    out = np.zeros(n, dtype=dt)
+    emuk.emu_kernel_gather_payload.restype = C.c_int
+    emuk.emu_kernel_gather_payload.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_void_p]
+    assert emuk.emu_kernel_gather_payload(codes.ctypes.data, n, table.ctypes.data, n_slots, eb, 0xABCDEF0123456789, out.ctypes.data) == 0
+    miss = np.array([0xABCDEF0123456789 & (2**(8 * eb) - 1)], dtype=np.uint64).astype(dt)[0]
+    want = np.where(codes < n_slots, table[np.minimum(codes, n_slots - 1).astype(np.int64)], miss)
+    assert np.array_equal(out, want)

@@ -233,6 +233,18 @@ def test_attach_devices_and_stream_ordered_count(tmp_path):
             want += int(((cs[k:] - cs[:-k]) == 0).sum())
         assert got == want
     assert h.count_valid(d_out.data_ptr(), 0) == 0
+    # result consumer: payload[code] without leaving the device; LPHQ_INVALID (windows with an N) -> `missing`
+    for dt, tdt in ((np.uint32, torch.int32), (np.uint64, torch.int64), (np.uint8, torch.uint8)):
+        table = np.random.default_rng(1).integers(0, np.iinfo(dt).max, h.get_kmer_count(), dtype=dt)
+        d_t = torch.from_numpy(table.view(np.int32 if dt == np.uint32 else (np.int64 if dt == np.uint64 else np.uint8))).to(dev)
+        d_p = torch.empty(n_out, dtype=tdt, device=dev)
+        h.gather_payload(d_out.data_ptr(), n_out, d_t.data_ptr(), table.itemsize, d_p.data_ptr(), missing=7, stream=s.cuda_stream)
+        s.synchronize()
+        codes = d_out.cpu().numpy().view(np.uint64)
+        want = np.where(codes < h.get_kmer_count(), table[np.minimum(codes, h.get_kmer_count() - 1).astype(np.int64)], dt(7))
+        assert np.array_equal(d_p.cpu().numpy().view(dt), want)
+    with pytest.raises(L.LphqError):
+        h.gather_payload(d_out.data_ptr(), n_out, d_t.data_ptr(), 3, d_p.data_ptr())
 
 
 @pytest.mark.parametrize("kind,k,m,bits,n_rec", [(0, 31, 20, 64, 1000), (1, 31, 20, 64, 1000), (0, 63, 20, 128, 100)])
