@@ -94,6 +94,15 @@ public:
     FastxBatchReader(const FastxBatchReader&) = delete;
     FastxBatchReader& operator=(const FastxBatchReader&) = delete;
 
+    // Allocate both arenas for batches of about batch_bases bases now (e.g. before a caller starts its timer: pinned host memory
+    // is expensive to allocate); next() grows them if a batch needs more.
+    void prealloc(size_t batch_bases) {
+        const size_t want = map_ ? std::min(size_, batch_bases + (batch_bases >> 3) + (1 << 16)) : batch_bases + (batch_bases >> 3) + (1 << 16);
+        for (int i = 0; i < 2 && ok_; ++i) {
+            which_ ^= 1;
+            (void)reserve(want);
+        }
+    }
     bool ok() const { return ok_; }
     bool parallel() const { return map_ != nullptr && serial_ == nullptr; }  // (tests) which path produced the last batch
 

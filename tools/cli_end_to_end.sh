@@ -1,16 +1,27 @@
 #!/bin/bash
-# End-to-end `lphash` CLI on a synthetic 100 Mbase FASTA (plain and gz): build-p, then query-p (CSV = file,mphf,kmers,ns/kmer streaming,ns/kmer random)
+# End-to-end `lphash query-p` on the C2 set written as plain FASTA and as .fa.gz (the reference's timers include inflate + parse,
+# src/query.cpp:48-56, and so do these): gpurun --timeout 900 -- bash tools/cli_end_to_end.sh
+set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-cd $R
-python3 - <<'PY'
-import sys; sys.path.insert(0, '.')
+cd "$R"
+mkdir -p gpurun_out
+python - <<'PY' 2>&1 | tee gpurun_out/cli_end_to_end.txt
+import gzip, os, subprocess, sys, time
+sys.path.insert(0, ".")
+import lphash_amd as L
 from lphash_amd.synth import synthetic_records
 flat, recs = synthetic_records(1, 1000, 100030)
-with open('/tmp/c2.fa', 'wb') as f:
+with open("/tmp/c2.fa", "wb") as f:
     for i, r in enumerate(recs):
-        f.write(b'>rec%d\n' % i + r + b'\n')
+        f.write(b">s%d\n" % i); f.write(r); f.write(b"\n")
+with gzip.open("/tmp/c2_300.fa.gz", "wb", compresslevel=6) as f:
+    for i, r in enumerate(recs[:300]):
+        f.write(b">s%d\n" % i); f.write(r); f.write(b"\n")
+idx = "/tmp/c2_cli.lph"
+t = time.time(); L.build(recs, 31, 20, idx, kmer_bits=64, threads=64, device=0); print("index built in %.1f s" % (time.time() - t))
+for q in ("/tmp/c2.fa", "/tmp/c2_300.fa.gz"):
+    for extra in ([], ["--threads", "8"], ["--threads", "32"], ["--pageable"], ["--batch-mb", "8"], ["--batch-mb", "128"]):
+        t = time.time()
+        r = subprocess.run(["lphash_amd/lphash", "query-p", "-i", idx, "-q", q, "--kmer-bits", "64"] + extra, capture_output=True, text=True)
+        print(os.path.basename(q), extra, "k-mers, ns/k-mer streaming, random:", r.stdout.strip().split(",")[2:], "wall %.2f s" % (time.time() - t), r.stderr[-200:])
 PY
-gzip -k -1 -f /tmp/c2.fa
-time ./lphash_amd/lphash build-p -i /tmp/c2.fa -k 31 -m 20 -o /tmp/c2_cli.lph --kmer-bits 64 -t 64
-time ./lphash_amd/lphash query-p -i /tmp/c2_cli.lph -q /tmp/c2.fa --kmer-bits 64
-time ./lphash_amd/lphash query-p -i /tmp/c2_cli.lph -q /tmp/c2.fa.gz --kmer-bits 64
