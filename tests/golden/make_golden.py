@@ -3,7 +3,9 @@
 
 The reference holds no golden vectors for the query path and cannot be built in this image (SURVEY.md
 section 8c), so these fixtures pin the ORACLE (against regressions) and give the GPU tests fixed inputs;
-they do not pin the oracle to the reference ("parity unpinned").
+they do not pin the oracle to the reference ("parity unpinned").  tests/golden/pymodel.py -- a second, independently structured
+restatement in pure Python, written from the reference sources -- regenerates every .lph here byte for byte and every query code
+(tests/test_oracle_cpu.py::test_python_model_*): transcription errors are covered; the PTHash recall itself (SURVEY Appendix A) is not.
 
 Each case: <name>.lph (index, reference serialization), <name>.npz with
   records   : the indexed records (uint8, concatenated) + rec_off

@@ -2,6 +2,7 @@
 (bijection, range, streaming == random; build.cpp:53-70, mphf_utils.hpp:51-100) and known-answer checks of the
 pieces that do not depend on PTHash."""
 import glob
+import sys
 import os
 
 import numpy as np
@@ -156,3 +157,33 @@ def test_reference_driver_restatement(tmp_path):
         assert nrec == len(rr) and nbases == sum(len(r) for r in rr)
     with pytest.raises(RuntimeError):
         ix.query_file(str(tmp_path / "missing.fa"))
+
+
+def test_python_model_regenerates_the_golden_files(golden_dir):
+    """tests/golden/pymodel.py -- a second restatement of build + query, pure Python over lists and dictionaries, written from the
+    reference sources independently of oracle/lph_oracle.c -- rebuilds every committed fixture from its records: the serialized bytes equal
+    the committed .lph files (which the C oracle wrote) and its query codes equal the committed ones.  Catches transcription errors on
+    either side; it cannot pin the PTHash recall itself, which both share."""
+    sys.path.insert(0, golden_dir)
+    import pymodel
+
+    assert pymodel.check_against_golden(golden_dir) == 7
+
+
+@pytest.mark.parametrize("k,m,bits,kind,seed", [(33, 5, 128, 0, 1), (21, 8, 64, 1, 2), (15, 9, 64, 0, 3), (31, 31, 64, 0, 4), (63, 32, 128, 1, 5), (9, 7, 64, 0, 6)])
+def test_python_model_equals_the_oracle_on_fresh_inputs(tmp_path, golden_dir, k, m, bits, kind, seed):
+    """The same comparison on inputs that are not fixtures, incl. 128-bit fallback hashing (k=33, m=5: many colliding minimizers), the
+    unpartitioned function, W = 1, and non-member queries with wrapping arithmetic."""
+    sys.path.insert(0, golden_dir)
+    import pymodel
+    from util import dedup_records
+
+    recs = dedup_records(random_records(500 + seed, 5 if k > 12 else 40, k, 1200 if k > 12 else k + 10), k)
+    path = str(tmp_path / "o.lph")
+    orc.build(recs, k, m, path, kind=kind, kmer_bits=bits)
+    mdl = pymodel.Model(recs, k, m, kind, bits)
+    assert mdl.serialize() == open(path, "rb").read()
+    ix = orc.Index(path, kind, bits)
+    assert (mdl.nkmers, mdl.D, len(mdl.fallback_keys)) == (ix.nkmers, ix.distinct_minimizers, ix.fallback_keys)
+    for q in recs[:2] + random_records(seed, 2, k, 300):
+        assert np.array_equal(np.array(mdl.query(q), dtype=np.uint64), ix(q, False))
