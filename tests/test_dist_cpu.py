@@ -73,3 +73,19 @@ def test_image_broadcast_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert res == {0: True, 1: True}
+
+
+def test_bench_launches_its_own_ranks_when_asked_for_several_gpus():
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset): the parent must start the ranks itself through
+    torch.distributed.run -- as a child process, before it touches the GPU -- and exit with the children's code.  Without a GPU (here) the
+    ranks fail on their `torch.cuda.is_available()` check, so the observable behaviour is: the launch line on stderr, a non-zero exit
+    code, no JSON line claiming a 1-GPU result."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--kmers", "100000"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr
+    assert r.returncode != 0
+    assert '"n_gpus"' not in r.stdout
