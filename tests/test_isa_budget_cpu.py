@@ -21,6 +21,7 @@ BUDGET = {
     "k_query_tiles_random": (64, 4 * 1024),
     "k_pack_kmers": (64, 0),
     "k_count_valid": (64, 0),
+    "k_gather_payload": (64, 0),
     "k_search": (64, 1024),
     "k_claim": (64, 0),
     "k_validate": (64, 0),
