@@ -1,6 +1,6 @@
 """One-off robustness run on the GPU (not part of the test suite: minutes of oracle time): random (k, m, width, kind) configurations, random record
 batches with ragged lengths, empty records, non-ACGT bases and every pointer alignment, through lphq_query_records (streaming and random), lphq_query_packed
-and lphq_query_contig -- every code compared with the CPU oracle.   gpurun --timeout 1500 -- python tools/gpu_fuzz.py [seconds]"""
+and lphq_query_contig -- every code compared with the CPU oracle.   gpurun --timeout 1500 -- python tests/gpu_fuzz.py [seconds]"""
 import os
 import sys
 import tempfile
