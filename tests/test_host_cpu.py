@@ -428,3 +428,46 @@ def test_ptbb_build_cli_and_file(tmp_path):
     assert r.returncode == 0 and r.stdout.strip() == f"{fa},31,{n},,,,"
     assert subprocess.run([exe, "ptbb-build", "-i", str(fa), "-k", "31", "-b", "x"], capture_output=True).returncode == 1
     assert subprocess.run([exe, "ptbb-build", "-i", str(tmp_path / "nope.fa"), "-k", "31", "-p", "x"], capture_output=True).returncode == 2
+
+
+def bgzf_compress(data, block=60000, level=6):
+    """BGZF (bgzip / htslib) container: independent gzip members of <= 64 KiB with the 'BC' extra field, plus the empty EOF member."""
+    import struct
+    import zlib
+
+    out = bytearray()
+    for chunk in [data[i:i + block] for i in range(0, len(data), block)] + [b""]:
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        payload = c.compress(chunk) + c.flush()
+        out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(payload) + 25)
+        out += payload + struct.pack("<II", zlib.crc32(chunk), len(chunk))
+    return bytes(out)
+
+
+@pytest.mark.skipif(not os.path.exists(KSEQ_DUMP), reason="oracle/_ref/kseq_dump is built only where /root/reference exists (oracle/Makefile)")
+def test_bgzf_input_is_inflated_block_parallel(tmp_path):
+    """A BGZF-compressed FASTA (what bgzip writes; zlib reads it as ordinary multi-member gzip, so the reference does too) is inflated block by
+    block on several threads and then parsed by the multi-threaded reader: same records as the reference's kseq.h and as the serial reader;
+    a damaged block, FASTQ content and a plain single-member .gz fall back to the serial reader (which reports what zlib reports)."""
+    import gzip
+
+    exe = os.path.join(ROOT, "lphash_amd", "lphash")
+    recs = random_records(77, 40, 1, 30000)
+    text = b"".join(b">r%d some text\n" % i + b"\n".join(r[j:j + 61] for j in range(0, len(r), 61)) + b"\n" for i, r in enumerate(recs))
+    cases = {"multi": bgzf_compress(text), "one_block": bgzf_compress(text[:5000]), "tiny_blocks": bgzf_compress(text[:40000], block=777),
+             "fastq": bgzf_compress(b"@q\nACGT\n+\nIIII\n" * 50), "plain_gz": gzip.compress(text[:100000])}
+    broken = bytearray(cases["multi"])
+    broken[len(broken) // 2] ^= 0x5A
+    for name, blob in cases.items():
+        p = tmp_path / f"{name}.fa.gz"
+        p.write_bytes(blob)
+        want = subprocess.run([KSEQ_DUMP, str(p)], capture_output=True, text=True).stdout.strip()
+        ser = subprocess.run([exe, "records", "-i", str(p), "--serial"], capture_output=True, text=True).stdout.strip().split(",")
+        par = subprocess.run([exe, "records", "-i", str(p), "-t", "6", "--min-piece", "1", "--batch-bytes", "50000"], capture_output=True, text=True).stdout.strip().split(",")
+        assert ",".join(ser[:3]) == want and ",".join(par[:3]) == want, (name, ser, par, want)
+        assert (int(par[4]) > 0) == (name in ("multi", "one_block", "tiny_blocks")), (name, par)  # batches that came from the parallel parser
+    p = tmp_path / "broken.fa.gz"
+    p.write_bytes(bytes(broken))
+    ser = subprocess.run([exe, "records", "-i", str(p), "--serial"], capture_output=True, text=True).stdout.strip().split(",")
+    par = subprocess.run([exe, "records", "-i", str(p), "-t", "6"], capture_output=True, text=True).stdout.strip().split(",")
+    assert par[:3] == ser[:3] and int(par[4]) == 0  # whatever zlib makes of the damaged stream, both readers agree

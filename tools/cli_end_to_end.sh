@@ -17,9 +17,18 @@ with open("/tmp/c2.fa", "wb") as f:
 with gzip.open("/tmp/c2_300.fa.gz", "wb", compresslevel=6) as f:
     for i, r in enumerate(recs[:300]):
         f.write(b">s%d\n" % i); f.write(r); f.write(b"\n")
+import struct, zlib
+def bgzf(data, block=65280):
+    out = bytearray()
+    for chunk in [data[i:i + block] for i in range(0, len(data), block)] + [b""]:
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        payload = c.compress(chunk) + c.flush()
+        out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(payload) + 25) + payload + struct.pack("<II", zlib.crc32(chunk), len(chunk))
+    return bytes(out)
+open("/tmp/c2_300.bgzf.fa.gz", "wb").write(bgzf(b"".join(b">s%d\n" % i + r + b"\n" for i, r in enumerate(recs[:300]))))
 idx = "/tmp/c2_cli.lph"
 t = time.time(); L.build(recs, 31, 20, idx, kmer_bits=64, threads=64, device=0); print("index built in %.1f s" % (time.time() - t))
-for q in ("/tmp/c2.fa", "/tmp/c2_300.fa.gz"):
+for q in ("/tmp/c2.fa", "/tmp/c2_300.fa.gz", "/tmp/c2_300.bgzf.fa.gz"):
     for extra in ([], ["--threads", "8"], ["--threads", "32"], ["--pageable"], ["--batch-mb", "8"], ["--batch-mb", "128"]):
         t = time.time()
         r = subprocess.run(["lphash_amd/lphash", "query-p", "-i", idx, "-q", q, "--kmer-bits", "64"] + extra, capture_output=True, text=True)
