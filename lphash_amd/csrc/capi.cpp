@@ -418,9 +418,7 @@ extern "C" int lphq_query_records(const lphq_index* idx, const char* d_seq, size
     if (total_bases && !d_seq) return fail(LPHQ_ERR_ARG, "null buffer");
     const Replica* r = pick_replica(idx);
     DeviceGuard g(r->device);
-    hipError_t e = launch_query_records(idx->hdr, r->d_image, d_seq, total_bases, d_seq_offsets, d_out_offsets, n_records, d_out, streaming, (hipStream_t)stream);
-    if (e == hipErrorInvalidValue) return fail(LPHQ_ERR_ARG, "batch too large for one launch (more than ~8 G bases): split it");
-    HIP_TRY(e);
+    HIP_TRY(launch_query_records(idx->hdr, r->d_image, d_seq, total_bases, d_seq_offsets, d_out_offsets, n_records, d_out, streaming, (hipStream_t)stream));
     return LPHQ_OK;
 }
 

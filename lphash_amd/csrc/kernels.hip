@@ -85,30 +85,37 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
     const uint8_t* seq_al = (const uint8_t*)d_seq - shift;
     const uint64_t span = shift + total_bases;
     constexpr int sblock = kStreamBlockDefault;  // 256 threads measured best in both rounds (128: -4 %, 512: -6 %, profiles/r02_stream_v4_ab.txt)
-    const uint64_t tw = streaming ? stream_tile_windows(H.W, 4 * sblock) : kTileW;
+    const bool stream_kernel = streaming && H.kind != 2;  // (the competitor harness has one kernel for both values of `streaming`)
+    const uint64_t tw = stream_kernel ? stream_tile_windows(H.W, 4 * sblock) : kTileW;
     const uint64_t tiles = (span + tw - 1) / tw;
-    // one workgroup per tile: HIP requires gridDim.x * blockDim.x < 2^32 (<= 2^24 - 1 tiles of 256 threads, i.e. ~16 G bases
-    // per call); larger batches must be split by the caller (capi.cpp says so in the error text)
-    if (tiles > (0xFFFFFFFFull / 256u) || n_records > 0xFFFFFFFFull) return hipErrorInvalidValue;
-    if (streaming && H.kind != 2) {
-        // window minima: direct form, or block decomposition for wide windows (P == 6 <=> W > 15; kernels_device.cuh: kBlockMinW)
+    if (n_records > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    // one workgroup per tile; HIP requires gridDim.x * blockDim.x < 2^32, so a batch of more than 2^24 - 1 tiles (~16 G bases) goes
+    // out as several launches on the same stream (tiles are independent)
+    const uint64_t kMaxTiles = (1u << 24) - 1;
+    for (uint64_t tile_base = 0; tile_base < tiles; tile_base += kMaxTiles) {
+        const int grid = (int)std::min<uint64_t>(kMaxTiles, tiles - tile_base);
+        if (stream_kernel) {
+            // window minima: direct form, or block decomposition for wide windows (P == 6 <=> W > 15; kernels_device.cuh: kBlockMinW)
 #define LPHQ_STREAM_LAUNCH(KIND, K128) \
     do { \
-        if (H.P != 6) k_query_tiles_stream<KIND, K128, 4, sblock, false><<<(int)tiles, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out); \
-        else if (H.W >= kBlockMinW) k_query_tiles_stream<KIND, K128, 6, sblock, true><<<(int)tiles, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out); \
-        else k_query_tiles_stream<KIND, K128, 6, sblock, false><<<(int)tiles, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out); \
+        if (H.P != 6) k_query_tiles_stream<KIND, K128, 4, sblock, false><<<grid, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
+        else if (H.W >= kBlockMinW) k_query_tiles_stream<KIND, K128, 6, sblock, true><<<grid, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
+        else k_query_tiles_stream<KIND, K128, 6, sblock, false><<<grid, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
     } while (0)
-        if (H.kind == 0) {
-            if (H.kmer_bits == 128) LPHQ_STREAM_LAUNCH(0, true);
-            else LPHQ_STREAM_LAUNCH(0, false);
+            if (H.kind == 0) {
+                if (H.kmer_bits == 128) LPHQ_STREAM_LAUNCH(0, true);
+                else LPHQ_STREAM_LAUNCH(0, false);
+            } else {
+                if (H.kmer_bits == 128) LPHQ_STREAM_LAUNCH(1, true);
+                else LPHQ_STREAM_LAUNCH(1, false);
+            }
         } else {
-            if (H.kmer_bits == 128) LPHQ_STREAM_LAUNCH(1, true);
-            else LPHQ_STREAM_LAUNCH(1, false);
+            LPHQ_DISPATCH(k_query_tiles_random, <<<grid, kBlock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base));
         }
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
     }
-    else
-        LPHQ_DISPATCH(k_query_tiles_random, <<<(int)tiles, kBlock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out));
-    return hipGetLastError();
+    return hipSuccess;
 }
 
 }  // namespace lphq

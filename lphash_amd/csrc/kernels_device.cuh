@@ -220,12 +220,13 @@ __device__ __forceinline__ void load_tile(const uint8_t* __restrict__ seq_al, ui
 template <int KIND, bool K128, int P>
 __global__ __launch_bounds__(kBlock) void k_query_tiles_random(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
                                                                 uint64_t shift, uint64_t total, const uint64_t* __restrict__ seq_off,
-                                                                const uint64_t* __restrict__ out_off, uint32_t n_records, uint64_t* __restrict__ out) {
+                                                                const uint64_t* __restrict__ out_off, uint32_t n_records, uint64_t* __restrict__ out,
+                                                                uint64_t tile_base /* first tile of this launch: batches beyond one grid are launched in pieces */) {
     const lphq_image_header& H = *(const lphq_image_header*)img;
     __shared__ uint32_t sm_words[kTileWords + 8];
     __shared__ uint32_t sm_bad[(kTileWords + 8) / 2 + 2];  // KIND 2 only: 16 bad-base bits per 16-base chunk
     __shared__ uint32_t sm_rec[2];
-    const uint64_t t0 = (uint64_t)blockIdx.x * kTileW;  // shifted coordinate of the tile's first window start
+    const uint64_t t0 = (tile_base + blockIdx.x) * kTileW;  // shifted coordinate of the tile's first window start
     if (threadIdx.x == 0) {
         const uint64_t gfirst = t0 > shift ? t0 - shift : 0;
         uint64_t glast = t0 + kTileW + 64 > shift ? t0 + kTileW + 64 - shift : 0;
@@ -467,7 +468,8 @@ __device__ __forceinline__ void window_argmin4_raw(const uint64_t* __restrict__ 
 template <int KIND, bool K128, int P, int BLOCK, bool BLKMIN>
 __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al,
                                                                  uint64_t shift, uint64_t total, const uint64_t* __restrict__ seq_off,
-                                                                 const uint64_t* __restrict__ out_off, uint32_t n_records, uint64_t* __restrict__ out) {
+                                                                 const uint64_t* __restrict__ out_off, uint32_t n_records, uint64_t* __restrict__ out,
+                                                                 uint64_t tile_base /* first tile of this launch */) {
     const lphq_image_header& H = *(const lphq_image_header*)img;
     constexpr int kStreamPos = 4 * BLOCK, NW = tile_words(kStreamPos);
     constexpr int NBADW = (NW + 8) / 2 + 2;  // 32-bit words of the bad-base bitmask (1 bit per base)
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
     const uint32_t tid = threadIdx.x;
     const uint32_t k = H.k, m = H.m, W = H.W;
     const uint32_t TW = stream_tile_windows(W, kStreamPos);
-    const uint64_t t0 = (uint64_t)blockIdx.x * TW;  // shifted coordinate of the tile's first window start
+    const uint64_t t0 = (tile_base + blockIdx.x) * TW;  // shifted coordinate of the tile's first window start
 
     // ---- A: sequence dwords first (no dependence on the record search), then the search, then pack into LDS ----
     uint32_t xs[2] = {0u, 0u};

@@ -55,16 +55,16 @@ extern "C" int emu_kernel_query_records(const uint8_t* img, size_t nbytes, const
         const bool blk = (block & 0x10000) ? true : ((block & 0x20000) ? false : H.W >= kBlockMinW); /* forced either way, or as the launcher chooses */ \
         const int bs = block & 0xFFFF;                                                                                                                    \
         if (H.W >= 4 && blk) {                                                                                                                            \
-            if (bs == 128) emu::launch(tiles, 128, [&] { k_query_tiles_stream<KIND, K128, P, 128, true>(img, seq_al, shift, total, seq_off, out_off, n_records, out); }); \
-            else emu::launch(tiles, 256, [&] { k_query_tiles_stream<KIND, K128, P, 256, true>(img, seq_al, shift, total, seq_off, out_off, n_records, out); });            \
-        } else if (bs == 128) emu::launch(tiles, 128, [&] { k_query_tiles_stream<KIND, K128, P, 128, false>(img, seq_al, shift, total, seq_off, out_off, n_records, out); }); \
-        else emu::launch(tiles, 256, [&] { k_query_tiles_stream<KIND, K128, P, 256, false>(img, seq_al, shift, total, seq_off, out_off, n_records, out); });               \
+            if (bs == 128) emu::launch(tiles, 128, [&] { k_query_tiles_stream<KIND, K128, P, 128, true>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0); }); \
+            else emu::launch(tiles, 256, [&] { k_query_tiles_stream<KIND, K128, P, 256, true>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0); });            \
+        } else if (bs == 128) emu::launch(tiles, 128, [&] { k_query_tiles_stream<KIND, K128, P, 128, false>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0); }); \
+        else emu::launch(tiles, 256, [&] { k_query_tiles_stream<KIND, K128, P, 256, false>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0); });               \
     } while (0)
         EMU_DISPATCH(CALL);
 #undef CALL
     } else {
         const unsigned tiles = (unsigned)((span + kTileW - 1) / kTileW);
-#define CALL(KIND, K128, P) emu::launch(tiles, kBlock, [&] { k_query_tiles_random<KIND, K128, P>(img, seq_al, shift, total, seq_off, out_off, n_records, out); })
+#define CALL(KIND, K128, P) emu::launch(tiles, kBlock, [&] { k_query_tiles_random<KIND, K128, P>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0); })
         EMU_DISPATCH(CALL);
 #undef CALL
     }
