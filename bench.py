@@ -103,8 +103,8 @@ def main():
     ap.add_argument("--batch-log2", type=int, default=28, help="random mode: 2^x lookups per step per GPU")
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--m", type=int, default=20)
-    ap.add_argument("--kind", choices=["p", "u", "pthash"], default="p",
-                    help="p / u: LPHash partitioned / unpartitioned; pthash: the competitor of SURVEY 8(f)-4, a plain PTHash over the same k-mers (random mode)")
+    ap.add_argument("--kind", choices=["p", "u", "pthash", "bbhash"], default="p",
+                    help="p / u: LPHash partitioned / unpartitioned; pthash / bbhash: the competitors of SURVEY 8(f)-4 over the same k-mers (random mode)")
     ap.add_argument("--build-threads", type=int, default=0)
     ap.add_argument("--gpu-build", action="store_true",
                     help="run the PTHash pilot search of the index build on the GPU (same file bytes; default is the sequential CPU search so that "
@@ -148,11 +148,12 @@ def main():
     k, m = args.k, args.m
     W = k - m + 1
     kmer_bits = 64 if k <= 31 else 128
-    kind = {"p": L.PARTITIONED, "u": L.UNPARTITIONED, "pthash": L.PTHASH}[args.kind]
-    cls = {L.PARTITIONED: L.Mphf, L.UNPARTITIONED: L.MphfAlt, L.PTHASH: L.PtHash}[kind]
-    load = (lambda p_, dev_: cls.load(p_, k, kmer_bits=kmer_bits, device=dev_)) if kind == L.PTHASH else (lambda p_, dev_: cls.load(p_, kmer_bits=kmer_bits, device=dev_))
-    if kind == L.PTHASH and args.mode != "random":
-        sys.exit("--kind pthash is measured in random mode only")
+    kind = {"p": L.PARTITIONED, "u": L.UNPARTITIONED, "pthash": L.PTHASH, "bbhash": L.BBHASH}[args.kind]
+    cls = {L.PARTITIONED: L.Mphf, L.UNPARTITIONED: L.MphfAlt, L.PTHASH: L.PtHash, L.BBHASH: L.BbHash}[kind]
+    competitor = kind in (L.PTHASH, L.BBHASH)
+    load = (lambda p_, dev_: cls.load(p_, k, kmer_bits=kmer_bits, device=dev_)) if competitor else (lambda p_, dev_: cls.load(p_, kmer_bits=kmer_bits, device=dev_))
+    if competitor and args.mode != "random":
+        sys.exit("--kind pthash / bbhash is measured in random mode only")
     rec_len = 100_000 + k - 1
     n_records = max(1, args.kmers // 100_000)
     nk = n_records * 100_000
@@ -170,7 +171,9 @@ def main():
         if not os.path.exists(path):
             t0 = time.time()
             tmp = path + f".tmp{os.getpid()}"
-            if kind == L.PTHASH:
+            if kind == L.BBHASH:
+                L.build_bbhash(recs, k, tmp, kmer_bits=kmer_bits, gamma=1.0, threads=args.build_threads or min(os.cpu_count() or 8, 64))
+            elif kind == L.PTHASH:
                 L.build_pthash(recs, k, tmp, kmer_bits=kmer_bits, threads=args.build_threads or min(os.cpu_count() or 8, 64),
                                device=local_rank if args.gpu_build else None)
             else:
@@ -281,6 +284,9 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import orc
 
+        if kind == L.BBHASH:
+            log("[bench] --kind bbhash has no CPU oracle leg (its checker is the reference's own BooPHF, tests/golden/bbhash); use --no-cpu-baseline")
+            sys.exit(2)
         o = orc.PtHash(path, k, kmer_bits) if kind == L.PTHASH else orc.Index(path, orc.PARTITIONED if kind == L.PARTITIONED else orc.UNPARTITIONED, kmer_bits)
         S = min(1 << args.cpu_sample_log2, units)
         if args.mode == "random":
@@ -320,7 +326,7 @@ def main():
             parity = parity and bool(full.max() < nk)  # positive probes: every code is a valid slot
         log(f"[bench] cpu oracle: {S / cpu_s / 1e6:.2f} M lookups/s on {S} units; GPU == oracle on the sample: {parity}")
         assert parity, "GPU results differ from the oracle"
-        if args.b1_records > 0 and kind != L.PTHASH:
+        if args.b1_records > 0 and not competitor:
             # BASELINE.md B1, "the number the reference tool would print": the oracle's restatement of src/query.cpp:24-88 over a
             # .fa.gz of the first records of the index set -- one thread, inflate + record parsing inside the timers, one result
             # vector per record, streaming pass then random pass.  Beside it the product's own `lphash query-*` on the same file
@@ -356,19 +362,22 @@ def main():
             log(f"[bench] B1 reference-faithful driver: {cpu_b1['streaming_ns_per_kmer']:.1f} / {cpu_b1['random_ns_per_kmer']:.1f} ns per k-mer (streaming / random); CLI: {cli_b1}")
 
     if rank == 0:
-        if kind == L.PTHASH:  # PTHash ranks word 8 + free-slot EF 26 * P(free) + k-mer in + code out
+        if kind == L.BBHASH:  # per probed level a bit-array word (8 B), on the hit a rank sample (8 B) + up to 7 more words; ~1/(1 - 0.63) levels at gamma 1
+            chain, mix = 2.7 * 8 + 8 + 3.5 * 8, None
+            bpl = (8 if k <= 31 else 16) + 8 + chain
+        elif kind == L.PTHASH:  # PTHash ranks word 8 + free-slot EF 26 * P(free) + k-mer in + code out
             p_free = 1.0 - h.info.distinct_minimizers / h.info.minimizer_table_size
             chain, mix = 8 + 26 * p_free, None
             bpl = (8 if k <= 31 else 16) + 8 + chain
         else:
             bpl, chain, mix = algorithmic_bytes_per_lookup(h, args.mode, k, W, kind == L.PARTITIONED)
-        cfg_name = "PTHash competitor (SURVEY 8f-4)" if kind == L.PTHASH else (("C4" if k > 31 else ("C2" if args.mode == "random" else "C3")) if kind == L.PARTITIONED else "C5")
+        cfg_name = "BBHash competitor (SURVEY 8f-4)" if kind == L.BBHASH else "PTHash competitor (SURVEY 8f-4)" if kind == L.PTHASH else (("C4" if k > 31 else ("C2" if args.mode == "random" else "C3")) if kind == L.PARTITIONED else "C5")
         peak_read = peak_copy = None
         if not args.no_hbm_probe:
             peak_read, peak_copy = hbm_ceiling_gbs(torch, dev)
         value = world * units * args.steps / elapsed
         out = {
-            "metric": f"k-mer lookups/sec (whole node), k={k} {'plain PTHash' if kind == L.PTHASH else ('partitioned' if kind == L.PARTITIONED else 'unpartitioned')} MPHF" + ("" if args.mode == "random" else ", streaming"),
+            "metric": f"k-mer lookups/sec (whole node), k={k} {'BBHash' if kind == L.BBHASH else 'plain PTHash' if kind == L.PTHASH else ('partitioned' if kind == L.PARTITIONED else 'unpartitioned')} MPHF" + ("" if args.mode == "random" else ", streaming"),
             "value": value,
             "unit": "k-mer lookups/s",
             "n_gpus": world,
@@ -381,7 +390,7 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": cfg_name + (": pthash::single_phf over the k-mers," if kind == L.PTHASH else (": partitioned LP-MPHF" if kind == L.PARTITIONED else ": unpartitioned LP-MPHF"))
+                "workload": cfg_name + (": boomphf::mphf over the k-mers, gamma 1," if kind == L.BBHASH else ": pthash::single_phf over the k-mers," if kind == L.PTHASH else (": partitioned LP-MPHF" if kind == L.PARTITIONED else ": unpartitioned LP-MPHF"))
                 + f" k={k} m={m}, {nk} k-mers (SplitMix64 seed 1, {n_records} records x {rec_len} bases); "
                 + ((f"2^{args.batch_log2} random positive packed k-mer lookups per GPU per step" if args.nonmember_frac == 0.0 else
                     f"2^{args.batch_log2} random packed k-mer lookups per GPU per step, {args.nonmember_frac:.0%} of them uniformly random non-members")

@@ -39,7 +39,7 @@ enum {
 
 /* which reference class wrote the file: build-p -> class mphf, build-u -> class mphf_alt
  * (src/lphash.cpp:25-32).  The file carries no magic, so the caller says. */
-enum { LPHQ_PARTITIONED = 0, LPHQ_UNPARTITIONED = 1, LPHQ_PTHASH = 2 /* competitor harness, see lphq_open_pthash */ };
+enum { LPHQ_PARTITIONED = 0, LPHQ_UNPARTITIONED = 1, LPHQ_PTHASH = 2, LPHQ_BBHASH = 3 /* competitor harness, see lphq_open_pthash / lphq_open_bbhash */ };
 
 /* Sentinel written by the device streaming entry point for a window that contains a non-ACGT
  * base (the reference's streaming branch emits nothing for those windows,
@@ -190,6 +190,16 @@ int lphq_build_device(const char* const* records, const size_t* lengths, size_t 
 int lphq_open_pthash(const char* path, int k, int kmer_bits, lphq_index** out);
 int lphq_build_pthash(const char* const* records, const size_t* lengths, size_t n_records, int k, int kmer_bits, double c, int threads,
                       int device /* < 0: CPU pilot search */, const char* out_path, lphq_build_stats* stats /* may be NULL */);
+
+/* The BBHash half of the same harness (src/ptbb/ptbb_build.cpp:140-199, src/ptbb/ptbb_query.cpp:56-72): boomphf::mphf<kmer_t, ptbb::BBHasher>
+ * (external/BooPHF.hpp) with BBHasher(kmer, seed) = MurmurHash2_64(&kmer, sizeof kmer, seed) ^ MurmurHash2_64(&kmer, sizeof kmer, ~seed), in the
+ * file format of boomphf::mphf::save.  lphq_open_bbhash reads a file written by the reference (or by lphq_build_bbhash) and cross-checks its
+ * redundant fields; lphq_build_bbhash writes one the reference's load() accepts (gamma >= 1; same 25-level cascade; the exact map of the last level
+ * numbers its keys in input order, where the reference numbers them in arrival order of its threads).  The handle behaves like a PTHash one; a k-mer
+ * that is not a key yields whatever bit it meets -- or LPHQ_INVALID (ULLONG_MAX in the reference) when it reaches the exact map and is not in it. */
+int lphq_open_bbhash(const char* path, int k, int kmer_bits, lphq_index** out);
+int lphq_build_bbhash(const char* const* records, const size_t* lengths, size_t n_records, int k, int kmer_bits, double gamma, int threads,
+                      const char* out_path, lphq_build_stats* stats /* may be NULL */);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LPHQ_LIB_PATH") or os.path.join(_HERE, "liblphq.so")  # override: A/B of two builds (tools/ab_lib.sh), sanitizer builds
 
 OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(8)
-PARTITIONED, UNPARTITIONED, PTHASH = 0, 1, 2
+PARTITIONED, UNPARTITIONED, PTHASH, BBHASH = 0, 1, 2, 3
 INVALID = 0xFFFFFFFFFFFFFFFF
 
 
@@ -63,6 +63,9 @@ SIGNATURES = {
                              C.c_double, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(BuildStats)]),
     "lphq_build_device": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int, C.c_uint64,
                                     C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(BuildStats)]),
+    "lphq_open_bbhash": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "lphq_build_bbhash": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_int, C.c_char_p,
+                                    C.POINTER(BuildStats)]),
     "lphq_open_pthash": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "lphq_build_pthash": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
                                     C.c_char_p, C.POINTER(BuildStats)]),

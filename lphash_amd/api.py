@@ -15,7 +15,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import PARTITIONED, PTHASH, UNPARTITIONED, LphqError, check, lib
+from ._lib import BBHASH, PARTITIONED, PTHASH, UNPARTITIONED, LphqError, check, lib
 
 
 def build(records, k, m, out_path, kind=PARTITIONED, kmer_bits=None, mm_seed=42, c=3.0, threads=0, device=None):
@@ -46,6 +46,20 @@ def build_pthash(records, k, out_path, kmer_bits=None, c=3.0, threads=0, device=
     stats = _lib.BuildStats()
     check(lib.lphq_build_pthash(arr, lens, n, int(k), int(kmer_bits), float(c), int(threads), -1 if device is None else int(device),
                                 str(out_path).encode(), C.byref(stats)))
+    return {name: getattr(stats, name) for name, _ in stats._fields_}
+
+
+def build_bbhash(records, k, out_path, kmer_bits=None, gamma=1.0, threads=0):
+    """`ptbb_build -i ... -k k -b out_path [-g gamma] [-t threads]` (BBHash half of the reference's competitor harness,
+    src/ptbb/ptbb_build.cpp:140-199) over in-memory records: a file boomphf::mphf::load accepts."""
+    records = [bytes(r) for r in records]
+    if kmer_bits is None:
+        kmer_bits = 64 if k <= 31 else 128
+    n = len(records)
+    arr = (C.c_char_p * n)(*records)
+    lens = (C.c_size_t * n)(*[len(r) for r in records])
+    stats = _lib.BuildStats()
+    check(lib.lphq_build_bbhash(arr, lens, n, int(k), int(kmer_bits), float(gamma), int(threads), str(out_path).encode(), C.byref(stats)))
     return {name: getattr(stats, name) for name, _ in stats._fields_}
 
 
@@ -212,6 +226,20 @@ class PtHash(_MphfBase):
     def load(cls, path, k, kmer_bits=128, device=None):
         self = cls()
         check(lib.lphq_open_pthash(str(path).encode(), int(k), int(kmer_bits), C.byref(self._h)))
+        self._refresh()
+        if device is not None:
+            self.attach(device)
+        return self
+
+
+class BbHash(PtHash):
+    """BBHash MPHF over whole k-mers (`bbhash_mphf_t`, src/ptbb/ptbb.hpp:34): the reference's second competitor."""
+    KIND = BBHASH
+
+    @classmethod
+    def load(cls, path, k, kmer_bits=128, device=None):
+        self = cls()
+        check(lib.lphq_open_bbhash(str(path).encode(), int(k), int(kmer_bits), C.byref(self._h)))
         self._refresh()
         if device is not None:
             self.attach(device)

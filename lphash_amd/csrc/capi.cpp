@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/lphq.h"
+#include "bbhash.hpp"
 #include "image.hpp"
 #include "kernels.hpp"
 #include "lph_format.hpp"
@@ -148,6 +149,67 @@ extern "C" int lphq_open(const char* path, int kind, int kmer_bits, lphq_index**
 
 extern "C" int lphq_open_pthash(const char* path, int k, int kmer_bits, lphq_index** out) { return open_file(path, LPHQ_PTHASH, kmer_bits, k, out); }
 
+extern "C" int lphq_open_bbhash(const char* path, int k, int kmer_bits, lphq_index** out) {
+    if (!path || !out) return fail(LPHQ_ERR_ARG, "null argument");
+    *out = nullptr;
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(LPHQ_ERR_IO, std::string("Unable to open the input file ") + path);
+    std::vector<uint8_t> buf;
+    if (fseek(f, 0, SEEK_END) == 0) {
+        long n = ftell(f);
+        if (n > 0) buf.resize((size_t)n);
+        fseek(f, 0, SEEK_SET);
+    }
+    size_t got = buf.empty() ? 0 : fread(buf.data(), 1, buf.size(), f);
+    fclose(f);
+    if (got != buf.size()) return fail(LPHQ_ERR_IO, std::string("short read on ") + path);
+    lphq_index* idx = nullptr;
+    try {
+        BbhFile file;
+        std::string err;
+        if (!parse_bbhash(buf.data(), buf.size(), k, kmer_bits, file, err)) return fail(LPHQ_ERR_FORMAT, err);
+        idx = new (std::nothrow) lphq_index();
+        if (!idx) return fail(LPHQ_ERR_ARG, "out of memory");
+        if (!build_bbhash_image(file, idx->image, err)) {
+            delete idx;
+            return fail(LPHQ_ERR_FORMAT, err);
+        }
+        idx->file_bytes = file.bytes_read;
+    } catch (const std::exception& e) {
+        delete idx;
+        return fail(LPHQ_ERR_FORMAT, std::string("malformed file: ") + e.what());
+    }
+    memcpy(&idx->hdr, idx->image.data(), sizeof idx->hdr);
+    idx->image_bytes = idx->image.size();
+    *out = idx;
+    return LPHQ_OK;
+}
+
+extern "C" int lphq_build_bbhash(const char* const* records, const size_t* lengths, size_t n_records, int k, int kmer_bits, double gamma, int threads,
+                                 const char* out_path, lphq_build_stats* stats) {
+    if ((n_records && (!records || !lengths)) || !out_path) return fail(LPHQ_ERR_ARG, "null argument");
+    std::vector<uint8_t> bytes;
+    uint64_t nkeys = 0;
+    std::string err;
+    try {
+        if (!build_bbhash_file(records, lengths, n_records, k, kmer_bits, gamma, threads, bytes, nkeys, err)) return fail(LPHQ_ERR_ARG, err);
+    } catch (const std::exception& e) {
+        return fail(LPHQ_ERR_ARG, std::string("bbhash build: ") + e.what());
+    }
+    FILE* fo = fopen(out_path, "wb");
+    if (!fo) return fail(LPHQ_ERR_IO, std::string("cannot write ") + out_path);
+    const size_t put = fwrite(bytes.data(), 1, bytes.size(), fo);
+    fclose(fo);
+    if (put != bytes.size()) return fail(LPHQ_ERR_IO, std::string("short write on ") + out_path);
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->num_kmers = nkeys;
+        stats->num_records = n_records;
+        stats->file_bytes = bytes.size();
+    }
+    return LPHQ_OK;
+}
+
 static void scratch_destroy(Scratch* s) {
     DeviceGuard g(s->device);
     if (s->stream) {
@@ -273,13 +335,21 @@ static bool header_is_consistent(const lphq_image_header& h, size_t nbytes, std:
         if (!ok) why = std::string(name) + " descriptor points outside the image";
         return ok;
     };
-    if (h.kind > 2 || (h.kmer_bits != 64 && h.kmer_bits != 128) || h.k < 1 || h.k > h.kmer_bits / 2 - 1 || h.m < 1 || h.m > h.k ||
-        (h.m > 32 && h.kind != LPHQ_PTHASH) /* no m-mers in a bare PTHash: m = k */ || h.W != h.k - h.m + 1 || h.P != (h.W <= 15 ? 4u : 6u) || h.distinct_minimizers > 0xFFFFFFFFull || h.mm.num_keys != h.distinct_minimizers) {
+    if (h.kind > 3 || (h.kmer_bits != 64 && h.kmer_bits != 128) || h.k < 1 || h.k > h.kmer_bits / 2 - 1 || h.m < 1 || h.m > h.k ||
+        (h.m > 32 && h.kind < LPHQ_PTHASH) /* no m-mers in the competitor functions: m = k */ || h.W != h.k - h.m + 1 || h.P != (h.W <= 15 ? 4u : 6u) || h.distinct_minimizers > 0xFFFFFFFFull || h.mm.num_keys != h.distinct_minimizers) {
         why = "inconsistent scalar fields";
         return false;
     }
     if (!phf_ok(h.mm, "minimizer_order") || !phf_ok(h.fb, "fallback_kmer_order")) return false;
     if (h.kind == LPHQ_PTHASH) return h.m == h.k;
+    if (h.kind == LPHQ_BBHASH) {  // every level's arrays and the exact map lie inside the image
+        const uint64_t nl = h.n_maximal;
+        if (h.m != h.k || nl < 2 || nl > 1024 || !inside(h.off_uni, nl * sizeof(lphq_bbh_level))) {
+            why = "bbhash level table lies outside the image";
+            return false;
+        }
+        return true;  // (the level table itself is checked by bbh_levels_inside, on the host copy or after reading it back from the device)
+    }
     if (h.kind == LPHQ_PARTITIONED) {
         const uint64_t E = LPHQ_UNI_PER_BLOCK(h.P);
         if (!inside(h.off_uni, ((h.distinct_minimizers + E - 1) / E + 1) * sizeof(lphq_uni_block))) {
@@ -291,6 +361,16 @@ static bool header_is_consistent(const lphq_image_header& h, size_t nbytes, std:
         return false;
     }
     return true;
+}
+
+// kind 3: every level's bit array and rank samples, and the exact map, lie inside the image
+static bool bbh_levels_inside(const lphq_image_header& h, const lphq_bbh_level* lv, size_t nbytes) {
+    auto inside = [&](uint64_t off, uint64_t bytes) { return off >= sizeof(lphq_image_header) && off <= nbytes && bytes <= nbytes - off; };
+    for (uint64_t i = 0; i < h.n_maximal; ++i)
+        if (lv[i].hash_domain == 0 || lv[i].nwords != 1 + lv[i].hash_domain / 64 || !inside(lv[i].off_bits, lv[i].nwords * 8) ||
+            !inside(lv[i].off_ranks, (lv[i].nwords + 7) / 8 * 8))
+            return false;
+    return inside(h.off_upair, h.fallback_kmers * (h.kmer_bits / 64 + 1) * 8);
 }
 
 static int check_device(int device) {
@@ -374,6 +454,14 @@ extern "C" int lphq_open_device_image(const void* d_image, size_t nbytes, int de
         if (!header_is_consistent(idx->hdr, nbytes, why)) {
             delete idx;
             return fail(LPHQ_ERR_FORMAT, "flat LPHQ image rejected: " + why);
+        }
+    }
+    if (idx->hdr.kind == LPHQ_BBHASH) {  // the level table lives in the image: read it back before trusting its offsets
+        std::vector<lphq_bbh_level> lv(idx->hdr.n_maximal);
+        e = hipMemcpy(lv.data(), (const uint8_t*)d_image + idx->hdr.off_uni, lv.size() * sizeof(lphq_bbh_level), hipMemcpyDeviceToHost);
+        if (e != hipSuccess || !bbh_levels_inside(idx->hdr, lv.data(), nbytes)) {
+            delete idx;
+            return fail(LPHQ_ERR_FORMAT, "flat LPHQ image rejected: bbhash level table points outside the image");
         }
     }
     Replica r;
@@ -478,7 +566,7 @@ extern "C" int lphq_query_contig(const lphq_index* cidx, const char* contig, siz
     if (!n_out || (length && !contig)) return fail(LPHQ_ERR_ARG, "null argument");
     *n_out = 0;
     const uint32_t k = idx->hdr.k;
-    if (idx->hdr.kind == LPHQ_PTHASH) streaming = 1;  // ptbb_file_itr yields nothing for windows holding a non-ACGT base
+    if (idx->hdr.kind >= LPHQ_PTHASH) streaming = 1;  // ptbb_file_itr yields nothing for windows holding a non-ACGT base
     if (length < k) return LPHQ_OK;  // partitioned_mphf.hpp:79 (streaming); the random branch is undefined there
     const size_t nwin = length - k + 1;
     if (!out || cap < nwin) return fail(LPHQ_ERR_ARG, "output buffer too small");

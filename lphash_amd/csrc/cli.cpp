@@ -705,8 +705,8 @@ int build_main(int kind, int argc, char** argv) {
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Competitor harness, PTHash half: `ptbb_build` / `ptbb_query` of the reference (src/ptbb/ptbb_build.cpp,
-// src/ptbb/ptbb_query.cpp) as sub-commands.  Same flags and the same CSV, with the BBHash fields left empty (BBHash is not part of
-// this harness: -b is refused).  The PTHash file is the reference's (a bare essentials::save of pthash::single_phf).
+// src/ptbb/ptbb_query.cpp) as sub-commands: same flags, same CSV.  The PTHash file is the reference's (a bare essentials::save of
+// pthash::single_phf), the BBHash file is boomphf::mphf::save's.
 // ---------------------------------------------------------------------------------------------------------------------------
 int ptbb_build_main(int argc, char** argv) {
     Args a = parse(argc, argv, {"-i", "-k", "-p", "-b", "-a", "-c", "-g", "-d", "-t", "--kmer-bits", "--device"}, {"--verbose", "--check", "--cpu"});
@@ -715,14 +715,15 @@ int ptbb_build_main(int argc, char** argv) {
                      "[--kmer-bits 64|128] [--device N] [--cpu]\n";
         return 1;  // !parser.parse() -> 1, ptbb_build.cpp:42
     }
-    if (a.get("-b")) {
-        std::cerr << "BBHash (-b) is not part of this harness; only the PTHash half (-p) is built\n";
-        return 1;
-    }
     const std::string input = *a.get("-i");
     const int k = std::atoi(a.get("-k")->c_str());
     const int kmer_bits = a.get("--kmer-bits") ? std::atoi(a.get("--kmer-bits")->c_str()) : 128;
     const double c = a.get("-c") ? std::atof(a.get("-c")->c_str()) : 3.0;  // constants::c
+    const double gamma = a.get("-g") ? std::atof(a.get("-g")->c_str()) : 1.0;  // ptbb_build.cpp:143-148
+    if (a.get("-b") && gamma < 1.0) {
+        std::cerr << "BBHash gamma factor < 1\n";  // the reference throws std::runtime_error here (ptbb_build.cpp:149)
+        return 3;
+    }
     const int threads = a.get("-t") ? std::atoi(a.get("-t")->c_str()) : 1;
     if ((kmer_bits != 64 && kmer_bits != 128) || k < 1 || k > kmer_bits / 2 - 1) {
         std::cerr << "k cannot be larger than " << kmer_bits / 2 - 1 << std::endl;
@@ -756,7 +757,7 @@ int ptbb_build_main(int argc, char** argv) {
             so += lens[i];
         }
     }
-    if (!a.get("-p")) {  // nothing to build: the k-mer count alone (ptbb_build.cpp:52-68), all other fields empty
+    if (!a.get("-p") && !a.get("-b")) {  // nothing to build: the k-mer count alone (ptbb_build.cpp:52-68), all other fields empty
         uint64_t total = 0;
         for (size_t i = 0; i < n_recs; ++i) {
             uint64_t since = 0;
@@ -770,30 +771,15 @@ int ptbb_build_main(int argc, char** argv) {
         std::cout << input << "," << k << "," << total << ",,,," << std::endl;
         return 0;
     }
-    const std::string out = *a.get("-p");
-    int build_device = a.has("--cpu") ? -1 : (a.get("--device") ? std::atoi(a.get("--device")->c_str()) : 0);
-    if (build_device >= 0) {
-        int ndev = 0;
-        if (hipGetDeviceCount(&ndev) != hipSuccess || build_device >= ndev) build_device = -1;
-    }
-    lphq_build_stats st;
-    if (lphq_build_pthash(ptrs.data(), lens.data(), n_recs, k, kmer_bits, c, threads, build_device, out.c_str(), &st) != LPHQ_OK) {
-        std::cerr << "[Error] " << lphq_last_error() << "\n";
-        return 4;
-    }
-    // ptbb_build.cpp:69,100-101 (num_bits() of the reference counts the in-memory object; here the serialized size)
-    std::cout << input << "," << k << "," << st.num_kmers << "," << st.file_bytes * 8 << "," << static_cast<double>(st.file_bytes * 8) / st.num_kmers << ",,"
-              << std::endl;
-    if (a.has("--check")) {  // ptbb_build.cpp:103-131 through the GPU path
-        std::cerr << "Checking PTHash...";
+    // bijection check of ptbb_build.cpp:103-131 / :165-193 through the GPU path, for either function
+    auto check_bijection = [&](lphq_index* idx, uint64_t nkeys, const char* what) -> int {
+        std::cerr << "Checking " << what << "...";
         const int device = a.get("--device") ? std::atoi(a.get("--device")->c_str()) : 0;
-        lphq_index* idx = nullptr;
-        if (lphq_open_pthash(out.c_str(), k, kmer_bits, &idx) != LPHQ_OK || lphq_attach(idx, device) != LPHQ_OK) {
+        if (!idx || lphq_attach(idx, device) != LPHQ_OK) {
             std::cerr << "[Error] " << lphq_last_error() << "\n";
-            if (idx) lphq_close(idx);
             return 4;
         }
-        std::vector<uint64_t> population((st.num_kmers + 63) / 64, 0), codes;
+        std::vector<uint64_t> population((nkeys + 63) / 64, 0), codes;
         uint64_t seen = 0;
         for (size_t i = 0; i < n_recs; ++i) {
             if (lens[i] < (size_t)k) continue;
@@ -801,33 +787,73 @@ int ptbb_build_main(int argc, char** argv) {
             size_t n = 0;
             if (lphq_query_contig(idx, ptrs[i], lens[i], 1, codes.data(), codes.size(), &n) != LPHQ_OK) {
                 std::cerr << "[Error] " << lphq_last_error() << "\n";
-                lphq_close(idx);
                 return 4;
             }
             for (size_t j = 0; j < n; ++j) {
                 const uint64_t x = codes[j];
-                if (x >= st.num_kmers) {
+                if (x >= nkeys) {
                     std::cerr << "[Error] out of bounds" << std::endl;
-                    lphq_close(idx);
                     return 2;
                 }
                 if ((population[x >> 6] >> (x & 63)) & 1) {
                     std::cerr << "[Error] collision" << std::endl;
-                    lphq_close(idx);
                     return 2;
                 }
                 population[x >> 6] |= 1ULL << (x & 63);
                 ++seen;
             }
         }
-        lphq_close(idx);
-        if (seen != st.num_kmers) {
+        if (seen != nkeys) {
             std::cerr << "[Error] hash is not perfect" << std::endl;
             return 2;
         }
         std::cerr << "EVERYTHING OK\n";
+        return 0;
+    };
+    uint64_t total_kmers = 0;
+    std::string pt_fields = ",,", bb_fields = ",,";
+    int rc = 0;
+    if (a.get("-p")) {
+        const std::string out = *a.get("-p");
+        int build_device = a.has("--cpu") ? -1 : (a.get("--device") ? std::atoi(a.get("--device")->c_str()) : 0);
+        if (build_device >= 0) {
+            int ndev = 0;
+            if (hipGetDeviceCount(&ndev) != hipSuccess || build_device >= ndev) build_device = -1;
+        }
+        lphq_build_stats st;
+        if (lphq_build_pthash(ptrs.data(), lens.data(), n_recs, k, kmer_bits, c, threads, build_device, out.c_str(), &st) != LPHQ_OK) {
+            std::cerr << "[Error] " << lphq_last_error() << "\n";
+            return 4;
+        }
+        total_kmers = st.num_kmers;
+        // ptbb_build.cpp:100-101 (num_bits() of the reference counts the in-memory object; here the serialized size)
+        pt_fields = "," + std::to_string(st.file_bytes * 8) + "," + std::to_string(static_cast<double>(st.file_bytes * 8) / st.num_kmers);
+        if (a.has("--check")) {
+            lphq_index* idx = nullptr;
+            if (lphq_open_pthash(out.c_str(), k, kmer_bits, &idx) != LPHQ_OK) idx = nullptr;
+            rc = check_bijection(idx, st.num_kmers, "PTHash");
+            if (idx) lphq_close(idx);
+        }
     }
-    return 0;
+    if (a.get("-b") && rc == 0) {
+        const std::string out = *a.get("-b");
+        lphq_build_stats st;
+        if (lphq_build_bbhash(ptrs.data(), lens.data(), n_recs, k, kmer_bits, gamma, threads, out.c_str(), &st) != LPHQ_OK) {
+            std::cerr << "[Error] " << lphq_last_error() << "\n";
+            return 4;
+        }
+        total_kmers = st.num_kmers;
+        // ptbb_build.cpp:161-162 (totalBitSize() of the reference adds 42 bytes per exact-map entry; here the serialized size)
+        bb_fields = "," + std::to_string(st.file_bytes * 8) + "," + std::to_string(static_cast<double>(st.file_bytes * 8) / st.num_kmers);
+        if (a.has("--check")) {
+            lphq_index* idx = nullptr;
+            if (lphq_open_bbhash(out.c_str(), k, kmer_bits, &idx) != LPHQ_OK) idx = nullptr;
+            rc = check_bijection(idx, st.num_kmers, "BBHash");
+            if (idx) lphq_close(idx);
+        }
+    }
+    std::cout << input << "," << k << "," << total_kmers << pt_fields << bb_fields << std::endl;
+    return rc;
 }
 
 int ptbb_query_main(int argc, char** argv) {
@@ -837,19 +863,10 @@ int ptbb_query_main(int argc, char** argv) {
                      "[--threads N] [--pageable]\n";
         return 1;
     }
-    if (a.get("-b")) {
-        std::cerr << "BBHash (-b) is not part of this harness; only the PTHash half (-p) is queried\n";
-        return 1;
-    }
     const std::string input = *a.get("-q");
     const int k = std::atoi(a.get("-k")->c_str());
     const int kmer_bits = a.get("--kmer-bits") ? std::atoi(a.get("--kmer-bits")->c_str()) : 128;
     std::cout << input << "," << k;  // ptbb_query.cpp:23
-    if (!a.get("-p")) {
-        std::cout << ",,,,\n";
-        return 0;
-    }
-    const std::string file = *a.get("-p");
     const int device = a.get("--device") ? std::atoi(a.get("--device")->c_str()) : 0;
     const int ngpus = a.get("--gpus") ? std::atoi(a.get("--gpus")->c_str()) : 1;
     if (ngpus < 1 || (a.get("--gpus") && a.get("--device"))) {
@@ -860,36 +877,54 @@ int ptbb_query_main(int argc, char** argv) {
     for (int d = 0; d < ngpus; ++d) devices.push_back(a.get("--gpus") ? d : device);
     const size_t batch_bases = (size_t)(a.get("--batch-mb") ? std::max(1l, std::atol(a.get("--batch-mb")->c_str())) : 32) << 20;
     const int threads = a.get("--threads") ? std::max(1, std::atoi(a.get("--threads")->c_str())) : default_parse_threads();
-    lphq_index* idx = nullptr;
-    if (lphq_open_pthash(file.c_str(), k, kmer_bits, &idx) != LPHQ_OK || lphq_attach_devices(idx, devices.data(), (int)devices.size()) != LPHQ_OK) {
-        std::cerr << "[Error] " << lphq_last_error() << "\n";
-        if (idx) lphq_close(idx);
-        return 2;
-    }
-    lphq_info info;
-    lphq_get_info(idx, &info);
-    std::vector<GpuWorker> gpus(devices.size());
-    for (size_t d = 0; d < devices.size(); ++d)
-        if (!gpus[d].init(devices[d])) {
-            std::cerr << "[Error] cannot create a stream on device " << devices[d] << "\n";
-            lphq_close(idx);
+    // one timed pass per function given (ptbb_query.cpp:40-72), each ",<file>,<ns per k-mer>", else ",,"
+    for (const char* flag : {"-p", "-b"}) {
+        if (!a.get(flag)) {
+            std::cout << ",,";
+            continue;
+        }
+        const std::string file = *a.get(flag);
+        lphq_index* idx = nullptr;
+        const int orc = flag[1] == 'p' ? lphq_open_pthash(file.c_str(), k, kmer_bits, &idx) : lphq_open_bbhash(file.c_str(), k, kmer_bits, &idx);
+        if (orc != LPHQ_OK || lphq_attach_devices(idx, devices.data(), (int)devices.size()) != LPHQ_OK) {
+            std::cerr << "\n[Error] " << lphq_last_error() << "\n";
+            if (idx) lphq_close(idx);
             return 2;
         }
-    uint64_t total = 0, us = 0;
-    std::string err;
-    const bool opened = query_pass(idx, info, input, 1, batch_bases, threads, !a.has("--pageable"), gpus, total, us, err, nullptr);
-    for (GpuWorker& g : gpus) g.destroy();
-    lphq_close(idx);
-    if (!opened) {
-        std::cerr << "\n[ptbb_file_itr] Unable to open file " << input << "\n";  // ptbb.hpp:84-85 throws here
-        return 2;
+        lphq_info info;
+        lphq_get_info(idx, &info);
+        std::vector<GpuWorker> gpus(devices.size());
+        for (size_t d = 0; d < devices.size(); ++d)
+            if (!gpus[d].init(devices[d])) {
+                std::cerr << "\n[Error] cannot create a stream on device " << devices[d] << "\n";
+                lphq_close(idx);
+                return 2;
+            }
+        {  // set-up outside the timer: first launch of the kernel (code object load)
+            const std::string dummy(info.k, 'A');
+            std::vector<uint64_t> one(1);
+            size_t n1 = 0;
+            for (size_t d = 0; d < devices.size(); ++d) {
+                (void)hipSetDevice(devices[d]);
+                (void)lphq_query_contig(idx, dummy.data(), dummy.size(), 1, one.data(), 1, &n1);
+            }
+        }
+        uint64_t total = 0, us = 0;
+        std::string err;
+        const bool opened = query_pass(idx, info, input, 1, batch_bases, threads, !a.has("--pageable"), gpus, total, us, err, nullptr);
+        for (GpuWorker& g : gpus) g.destroy();
+        lphq_close(idx);
+        if (!opened) {
+            std::cerr << "\n[ptbb_file_itr] Unable to open file " << input << "\n";  // ptbb.hpp:84-85 throws here
+            return 2;
+        }
+        if (!err.empty()) {
+            std::cerr << "\n[Error] " << err << "\n";
+            return 3;
+        }
+        std::cout << "," << file << "," << static_cast<double>(us * 1000) / total;
     }
-    if (!err.empty()) {
-        std::cerr << "\n[Error] " << err << "\n";
-        return 3;
-    }
-    // ptbb_query.cpp:74-86: ",<pthash file>,<ns per k-mer>" then the empty BBHash fields
-    std::cout << "," << file << "," << static_cast<double>(us * 1000) / total << ",,\n";
+    std::cout << "\n";
     return 0;
 }
 

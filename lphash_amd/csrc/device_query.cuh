@@ -335,9 +335,60 @@ __device__ __forceinline__ uint64_t pthash_kmer(const uint8_t* __restrict__ img,
     return phf_position2(img, H.mm, a, b);
 }
 
+// Competitor harness (KIND 3): boomphf::mphf<kmer_t, ptbb::BBHasher>::lookup (external/BooPHF.hpp:791-822) over the flat image of bbhash.hpp.
+// Level i probes bit fastrange64(h_i, domain_i) of its bit array, h_0 / h_1 = BBHasher with the two fixed seeds, h_i (i >= 2) the xorshift
+// sequence seeded by them (getLevel :1059-1088, XorshiftHashFunctors :405-423); the first level whose bit is set answers with the rank of that
+// bit (ranks sampled every 512 bits, bitVector::rank :616-626); a key that no level holds is looked up in the exact map, ULLONG_MAX if absent.
+// BBHasher (src/ptbb/ptbb.hpp:25-32) = Murmur(key, seed) ^ Murmur(key, ~seed).
+template <bool K128>
+__device__ __forceinline__ uint64_t bbhash_kmer(const uint8_t* __restrict__ img, const lphq_image_header& H, uint64_t lo, uint64_t hi) {
+    auto hasher = [&](uint64_t seed) {
+        return K128 ? (murmur16(lo, hi, murmur_seedx16(seed)) ^ murmur16(lo, hi, murmur_seedx16(~seed)))
+                    : (murmur8(lo, murmur_seedx(seed)) ^ murmur8(lo, murmur_seedx(~seed)));
+    };
+    const lphq_bbh_level* lv = (const lphq_bbh_level*)(img + H.off_uni);
+    const uint32_t nl = (uint32_t)H.n_maximal;
+    uint64_t s0 = 0, s1 = 0;
+    for (uint32_t ii = 0; ii + 1 < nl; ++ii) {
+        uint64_t hsh;
+        if (ii == 0) hsh = s0 = hasher(0xAAAAAAAA55555555ULL);
+        else if (ii == 1) hsh = s1 = hasher(0x33333333CCCCCCCCULL);
+        else {
+            uint64_t t1 = s0;
+            const uint64_t t0 = s1;
+            s0 = t0;
+            t1 ^= t1 << 23;
+            s1 = t1 ^ t0 ^ (t1 >> 17) ^ (t0 >> 26);
+            hsh = s1 + t0;
+        }
+        const uint64_t pos = __umul64hi(hsh, lv[ii].hash_domain);  // fastrange64
+        const uint64_t* bits = (const uint64_t*)(img + lv[ii].off_bits);
+        const uint64_t wi = pos >> 6, word = bits[wi];
+        if ((word >> (pos & 63)) & 1ull) {
+            uint64_t r = ((const uint64_t*)(img + lv[ii].off_ranks))[pos >> 9];
+            for (uint64_t w = (pos >> 9) << 3; w < wi; ++w) r += (uint64_t)__popcll(bits[w]);
+            return r + (uint64_t)__popcll(word & ((1ull << (pos & 63)) - 1ull));
+        }
+    }
+    // exact map of the keys that reached the last level: sorted by (high, low)
+    const uint64_t nfin = H.fallback_kmers;
+    const uint64_t* keys = (const uint64_t*)(img + H.off_upair);
+    const uint64_t* vals = keys + nfin * (K128 ? 2 : 1);
+    uint64_t a = 0, b = nfin;
+    while (a < b) {
+        const uint64_t mid = (a + b) >> 1;
+        const uint64_t klo = K128 ? keys[2 * mid] : keys[mid], khi = K128 ? keys[2 * mid + 1] : 0;
+        if (khi < hi || (khi == hi && klo < lo)) a = mid + 1;
+        else b = mid;
+    }
+    if (a < nfin && (K128 ? (keys[2 * a] == lo && keys[2 * a + 1] == hi) : keys[a] == lo)) return vals[a] + H.collision_base;
+    return ~0ull;  // ULLONG_MAX: not a key
+}
+
 template <int KIND, bool K128, int P>
 __device__ __forceinline__ uint64_t query_kmer(const uint8_t* __restrict__ img, const lphq_image_header& H, uint64_t lo, uint64_t hi) {
     if (KIND == 2) return pthash_kmer<K128>(img, H, lo, hi);
+    if (KIND == 3) return bbhash_kmer<K128>(img, H, lo, hi);
     uint64_t mm;
     uint32_t p;
     minimizer_of<K128>(lo, hi, H.k, H.m, H.W, murmur_seedx(H.mm_seed), mm, p);

@@ -86,4 +86,14 @@ typedef struct lphq_plane_block {
     uint32_t w[14];
 } lphq_plane_block;
 
+/* Competitor harness, BBHash half (image kind 3; bbhash.hpp): header fields reused -- n_maximal = number of levels, collision_base = number of keys
+ * the bit arrays hold (the exact map's values are offset by it), fallback_kmers = entries of the exact map, off_uni = lphq_bbh_level[levels],
+ * off_upair = the exact map: its keys (kmer_bits / 64 words each, sorted ascending by (high, low)) followed by its u64 values. */
+typedef struct lphq_bbh_level {
+    uint64_t hash_domain; /* bits of the level (a multiple of 64) */
+    uint64_t off_bits;    /* u64 words, 1 + hash_domain / 64 of them */
+    uint64_t off_ranks;   /* u64 ones before every 512-bit block, counted over all earlier levels too */
+    uint64_t nwords;
+} lphq_bbh_level;
+
 #endif

@@ -23,7 +23,9 @@ static inline int grid_for(size_t n, int per_block, int max_blocks) {
     do {                                                                               \
         const bool k128 = H.kmer_bits == 128;                                          \
         const bool p6 = H.P == 6;                                                      \
-        if (H.kind == 2) { /* competitor harness: plain PTHash over k-mers */          \
+        if (H.kind == 3) { /* competitor harness: BBHash over k-mers */                \
+            if (k128) KERNEL<3, true, 4> __VA_ARGS__; else KERNEL<3, false, 4> __VA_ARGS__; \
+        } else if (H.kind == 2) { /* competitor harness: plain PTHash over k-mers */   \
             if (k128) KERNEL<2, true, 4> __VA_ARGS__; else KERNEL<2, false, 4> __VA_ARGS__; \
         } else if (H.kind == 0) {                                                      \
             if (k128) { if (p6) KERNEL<0, true, 6> __VA_ARGS__; else KERNEL<0, true, 4> __VA_ARGS__; }   \
@@ -85,7 +87,7 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
     const uint8_t* seq_al = (const uint8_t*)d_seq - shift;
     const uint64_t span = shift + total_bases;
     constexpr int sblock = kStreamBlockDefault;  // 256 threads measured best in both rounds (128: -4 %, 512: -6 %, profiles/r02_stream_v4_ab.txt)
-    const bool stream_kernel = streaming && H.kind != 2;  // (the competitor harness has one kernel for both values of `streaming`)
+    const bool stream_kernel = streaming && H.kind < 2;  // (the competitor harness has one kernel for both values of `streaming`)
     const uint64_t tw = stream_kernel ? stream_tile_windows(H.W, 4 * sblock) : kTileW;
     const uint64_t tiles = (span + tw - 1) / tw;
     if (n_records > 0xFFFFFFFFull) return hipErrorInvalidValue;

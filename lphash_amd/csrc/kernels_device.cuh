@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_random(const uint8_t* __
                                                                 uint64_t tile_base /* first tile of this launch: batches beyond one grid are launched in pieces */) {
     const lphq_image_header& H = *(const lphq_image_header*)img;
     __shared__ uint32_t sm_words[kTileWords + 8];
-    __shared__ uint32_t sm_bad[(kTileWords + 8) / 2 + 2];  // KIND 2 only: 16 bad-base bits per 16-base chunk
+    __shared__ uint32_t sm_bad[(kTileWords + 8) / 2 + 2];  // competitor harness (KIND 2, 3) only: 16 bad-base bits per 16-base chunk
     __shared__ uint32_t sm_rec[2];
     const uint64_t t0 = (tile_base + blockIdx.x) * kTileW;  // shifted coordinate of the tile's first window start
     if (threadIdx.x == 0) {
@@ -234,11 +234,11 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_random(const uint8_t* __
         sm_rec[0] = find_record(seq_off, 0, n_records - 1, gfirst);
         sm_rec[1] = find_record(seq_off, 0, n_records - 1, glast);
     }
-    // the competitor harness (KIND 2) iterates like ptbb_file_itr: windows holding a non-ACGT base yield nothing -> LPHQ_INVALID
-    load_tile<KIND == 2, kTileWords>(seq_al, shift, total, t0, sm_words, sm_bad);
+    // the competitor harness (KIND 2: PTHash, 3: BBHash) iterates like ptbb_file_itr: windows holding a non-ACGT base yield nothing -> LPHQ_INVALID
+    load_tile<(KIND >= 2), kTileWords>(seq_al, shift, total, t0, sm_words, sm_bad);
     for (int c = kTileWords + 1 + threadIdx.x; c < kTileWords + 8; c += kBlock) {
         sm_words[c] = 0;
-        if (KIND == 2) ((uint16_t*)sm_bad)[c] = 0xFFFFu;
+        if (KIND >= 2) ((uint16_t*)sm_bad)[c] = 0xFFFFu;
     }
     __syncthreads();
     const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_random(const uint8_t* __
         uint64_t lo, hi;
         extract_kmer<K128>(sm_words, (uint32_t)i, H.k, lo, hi);
         uint64_t code = query_kmer<KIND, K128, P>(img, H, lo, hi);
-        if (KIND == 2) {  // bad-base bits [i, i + k), k <= 63: five 16-bit chunks cover them
+        if (KIND >= 2) {  // bad-base bits [i, i + k), k <= 63: five 16-bit chunks cover them
             const uint16_t* bad16 = (const uint16_t*)sm_bad;
             const uint32_t c0 = (uint32_t)i >> 4, o = (uint32_t)i & 15u;
             const uint64_t lo64 = (uint64_t)bad16[c0] | ((uint64_t)bad16[c0 + 1] << 16) | ((uint64_t)bad16[c0 + 2] << 32) | ((uint64_t)bad16[c0 + 3] << 48);

@@ -9,7 +9,9 @@ using namespace lphq;
 #define EMU_DISPATCH(CALL_B)                                                                    \
     do {                                                                                        \
         const bool k128 = H.kmer_bits == 128, p6 = H.P == 6;                                    \
-        if (H.kind == 2) {                                                                      \
+        if (H.kind == 3) {                                                                      \
+            if (k128) { CALL_B(3, true, 4); } else { CALL_B(3, false, 4); }                     \
+        } else if (H.kind == 2) {                                                               \
             if (k128) { CALL_B(2, true, 4); } else { CALL_B(2, false, 4); }                     \
         } else if (H.kind == 0) {                                                                \
             if (k128) { if (p6) { CALL_B(0, true, 6); } else { CALL_B(0, true, 4); } }          \
@@ -47,7 +49,7 @@ extern "C" int emu_kernel_query_records(const uint8_t* img, size_t nbytes, const
     const uint64_t shift = (uint64_t)((uintptr_t)seq & 15u);
     const uint8_t* seq_al = (const uint8_t*)seq - shift;
     const uint64_t span = shift + total;
-    if (streaming && H.kind != 2) {
+    if (streaming && H.kind < 2) {
         const uint64_t tw = stream_tile_windows(H.W, 4 * (block & 0xFFFF));
         const unsigned tiles = (unsigned)((span + tw - 1) / tw);
 #define CALL(KIND, K128, P)                                                                                                                             \

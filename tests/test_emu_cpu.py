@@ -361,3 +361,57 @@ def test_gather_payload_on_the_emulator(emuk, eb, dt):
     miss = np.array([0xABCDEF0123456789 & (2**(8 * eb) - 1)], dtype=np.uint64).astype(dt)[0]
     want = np.where(codes < n_slots, table[np.minimum(codes, n_slots - 1).astype(np.int64)], miss)
     assert np.array_equal(out, want)
+
+
+def bbhash_golden_cases():
+    d = os.path.join(ROOT, "tests", "golden", "bbhash")
+    return sorted(os.path.splitext(f)[0] for f in os.listdir(d) if f.endswith(".npz"))
+
+
+def valid_windows(r, k):
+    bad = np.array([c not in b"ACGTUacgtu" for c in r])
+    cs = np.concatenate([[0], np.cumsum(bad)])
+    return (cs[k:] - cs[:-k]) == 0 if len(r) >= k else np.zeros(0, dtype=bool)
+
+
+@pytest.mark.parametrize("name", bbhash_golden_cases())
+def test_bbhash_competitor_against_the_real_boophf(emuk, tmp_path, name):
+    """PINNED against the reference's own code: tests/golden/bbhash/*.bbh were written by the REAL BooPHF (external/BooPHF.hpp compiled from
+    /root/reference, tests/golden/make_bbhash_golden.py) and the expected codes are its lookup().  The loader accepts the files (every redundant
+    field cross-checked), the device lookup (KIND 3; packed kernel and record-tile kernel on the emulator) returns the same code for every window of
+    k valid bases -- members, non-members (incl. ULLONG_MAX from the exact map) -- and LPHQ_INVALID where ptbb_file_itr yields nothing.  The
+    product's builder, given the same records, writes a function with the same bit arrays (byte-identical up to the order of the exact map)."""
+    gd = os.path.join(ROOT, "tests", "golden", "bbhash")
+    z = np.load(os.path.join(gd, name + ".npz"))
+    k, bits = int(z["k"]), int(z["kmer_bits"])
+    h = L.BbHash.load(os.path.join(gd, name + ".bbh"), k, kmer_bits=bits)
+    recs = [bytes(z["records"][z["rec_off"][i]:z["rec_off"][i + 1]]) for i in range(len(z["rec_off"]) - 1)]
+    queries = [bytes(z["queries"][z["q_off"][i]:z["q_off"][i + 1]]) for i in range(len(z["q_off"]) - 1)]
+    assert h.info.kind == L.BBHASH and h.get_kmer_count() == sum(len(r) - k + 1 for r in recs)
+    want = z["codes"]
+    for mis in (0, 9):
+        got = emu_records(emuk, h, queries, k, True, mis)
+        at = 0
+        for q, g in zip(queries, got):
+            v = valid_windows(q, k)
+            n = int(v.sum())
+            assert np.array_equal(g[v], want[at:at + n]) and (g[~v] == np.uint64(2**64 - 1)).all()
+            at += n
+        assert at == len(want)
+    # packed kernel on the windows of the member records: a bijection onto [0, n)
+    img = h.image()
+    seq = recs[0]
+    pk = pack_kmers(seq, np.arange(0, len(seq) - k + 1), k, bits)
+    out = np.zeros(len(seq) - k + 1, dtype=np.uint64)
+    assert emuk.emu_kernel_query_packed(img.ctypes.data, img.size, pk.ctypes.data, len(out), out.ctypes.data) == 0
+    assert np.array_equal(out, want[: len(out)])
+    # the product's builder on the same records: same bit arrays as the reference's
+    ours = tmp_path / "ours.bbh"
+    L.build_bbhash(recs, k, str(ours), kmer_bits=bits, gamma=float(z["gamma"]), threads=3)
+    a, b = ours.read_bytes(), open(os.path.join(gd, name + ".bbh"), "rb").read()
+    nfinal = h.info.fallback_kmers
+    tail = 8 + nfinal * (bits // 8 + 8)  # the exact map: count + (key, value) pairs, in an order the reference does not define
+    assert len(a) == len(b) and a[: len(a) - tail] == b[: len(b) - tail]
+    h2 = L.BbHash.load(str(ours), k, kmer_bits=bits)
+    every = np.concatenate(emu_records(emuk, h2, recs, k, True, 0))
+    assert len(np.unique(every)) == len(every) == h2.get_kmer_count() and int(every.max()) == len(every) - 1

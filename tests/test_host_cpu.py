@@ -426,7 +426,13 @@ def test_ptbb_build_cli_and_file(tmp_path):
             L.Mphf.load(str(out), kmer_bits=bits)  # a bare PTHash is not an LPHash file
     r = subprocess.run([exe, "ptbb-build", "-i", str(fa), "-k", "31"], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip() == f"{fa},31,{n},,,,"
-    assert subprocess.run([exe, "ptbb-build", "-i", str(fa), "-k", "31", "-b", "x"], capture_output=True).returncode == 1
+    # BBHash half: the CSV's last two fields, a file the loader accepts; gamma < 1 is refused
+    bb = tmp_path / "cli.bbh"
+    r = subprocess.run([exe, "ptbb-build", "-i", str(fa), "-k", "31", "-b", str(bb), "--kmer-bits", "64", "-g", "2", "-t", "3"], capture_output=True, text=True)
+    f = r.stdout.strip().split(",")
+    assert r.returncode == 0 and len(f) == 7 and int(f[2]) == n and f[3] == f[4] == "" and int(f[5]) == os.path.getsize(bb) * 8, (r.stdout, r.stderr)
+    assert L.BbHash.load(str(bb), 31, kmer_bits=64).get_kmer_count() == n
+    assert subprocess.run([exe, "ptbb-build", "-i", str(fa), "-k", "31", "-b", str(bb), "-g", "0.5"], capture_output=True).returncode == 3
     assert subprocess.run([exe, "ptbb-build", "-i", str(tmp_path / "nope.fa"), "-k", "31", "-p", "x"], capture_output=True).returncode == 2
 
 
@@ -471,3 +477,46 @@ def test_bgzf_input_is_inflated_block_parallel(tmp_path):
     ser = subprocess.run([exe, "records", "-i", str(p), "--serial"], capture_output=True, text=True).stdout.strip().split(",")
     par = subprocess.run([exe, "records", "-i", str(p), "-t", "6"], capture_output=True, text=True).stdout.strip().split(",")
     assert par[:3] == ser[:3] and int(par[4]) == 0  # whatever zlib makes of the damaged stream, both readers agree
+
+
+BBHASH_REF = os.path.join(ROOT, "oracle", "_ref", "bbhash_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(BBHASH_REF), reason="oracle/_ref/bbhash_ref (the real BooPHF) is built only where /root/reference exists")
+def test_bbhash_files_round_trip_through_the_real_boophf(tmp_path):
+    """The reference's own BooPHF (oracle/_ref/bbhash_ref) LOADS the files lphq_build_bbhash writes and answers with a bijection; files it writes
+    load here (fresh inputs, several gammas and widths); corrupted files are rejected by the loader's cross-checks, not mis-hashed."""
+    for k, bits, gamma, seed in ((31, 64, 1.0, 1), (27, 64, 3.0, 2), (47, 128, 1.5, 3)):
+        recs = [r for r in random_records(600 + seed, 12, k, 4000)]
+        fa = tmp_path / "i.fa"
+        with open(fa, "wb") as f:
+            for i, r in enumerate(recs):
+                f.write(b">r%d\n%s\n" % (i, r))
+        n = sum(len(r) - k + 1 for r in recs)
+        ours, theirs, codes = tmp_path / "ours.bbh", tmp_path / "theirs.bbh", tmp_path / "c.u64"
+        st = L.build_bbhash(recs, k, str(ours), kmer_bits=bits, gamma=gamma, threads=4)
+        assert st["num_kmers"] == n
+        r = subprocess.run([BBHASH_REF, "query", str(ours), str(k), str(bits), str(fa), str(codes)], capture_output=True, text=True, cwd=tmp_path)
+        assert r.returncode == 0 and int(r.stdout) == n, r.stderr
+        c = np.fromfile(codes, dtype=np.uint64)
+        assert len(np.unique(c)) == n and int(c.max()) == n - 1  # ptbb_build --check, by the reference's own lookup()
+        subprocess.run([BBHASH_REF, "build", str(fa), str(k), str(bits), str(gamma), str(theirs)], check=True, capture_output=True, cwd=tmp_path)
+        h = L.BbHash.load(str(theirs), k, kmer_bits=bits)
+        assert h.get_kmer_count() == n
+        blob = bytearray(theirs.read_bytes())
+        for pos in (9, 40, len(blob) // 2, len(blob) - 3):
+            bad = bytearray(blob)
+            bad[pos] ^= 0x10
+            p = tmp_path / "bad.bbh"
+            p.write_bytes(bytes(bad))
+            try:
+                hb = L.BbHash.load(str(p), k, kmer_bits=bits)
+                assert hb.get_kmer_count() == n  # a flip inside an exact-map key or value is not detectable; nothing else may pass
+                assert pos == len(blob) - 3
+            except L.LphqError as e:
+                assert e.code == L._lib.ERR_FORMAT
+        for cut in (3, 20, len(blob) - 1):
+            p = tmp_path / "cut.bbh"
+            p.write_bytes(bytes(blob[:cut]))
+            with pytest.raises(L.LphqError):
+                L.BbHash.load(str(p), k, kmer_bits=bits)

@@ -83,3 +83,68 @@ def test_pthash_competitor_harness(tmp_path, k, bits):
     assert r.returncode == 0 and len(f5) == 6 and f5[0] == str(fa) and f5[1] == str(k) and f5[2] == path and float(f5[3]) > 0 and f5[4] == f5[5] == "", (r.stdout, r.stderr)
     r = subprocess.run([exe, "ptbb-build", "-i", str(fa), "-k", str(k), "-p", str(tmp_path / "c.pthash"), "--kmer-bits", str(bits), "--check"], capture_output=True, text=True)
     assert r.returncode == 0 and "EVERYTHING OK" in r.stderr, r.stderr
+
+
+def _bbhash_cases():
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bbhash")
+    return sorted(os.path.splitext(f)[0] for f in os.listdir(d) if f.endswith(".npz"))
+
+
+@pytest.mark.parametrize("name", _bbhash_cases())
+def test_bbhash_competitor_against_the_real_boophf(tmp_path, name):
+    """The BBHash half of the competitor harness on the GPU, PINNED against the reference's own code: tests/golden/bbhash/*.bbh were written by the real
+    BooPHF (tests/golden/make_bbhash_golden.py) and the expected codes are its lookup().  Where the prebuilt oracle/_ref/bbhash_ref travelled to this
+    box, a larger fresh set is compared with it too."""
+    import subprocess
+
+    import numpy as np
+    from util import pack_kmers
+
+    torch, dev = torch_dev()
+    here = os.path.dirname(os.path.abspath(__file__))
+    z = np.load(os.path.join(here, "golden", "bbhash", name + ".npz"))
+    k, bits = int(z["k"]), int(z["kmer_bits"])
+    h = L.BbHash.load(os.path.join(here, "golden", "bbhash", name + ".bbh"), k, kmer_bits=bits, device=0)
+    queries = [bytes(z["queries"][z["q_off"][i]:z["q_off"][i + 1]]) for i in range(len(z["q_off"]) - 1)]
+    want, at = z["codes"], 0
+    for q in queries:
+        got = h(q)  # lphq_query_contig: one code per window of k valid bases
+        assert np.array_equal(got, want[at:at + len(got)])
+        at += len(got)
+    assert at == len(want)
+    seq = queries[0]
+    pos = np.arange(0, len(seq) - k + 1, dtype=np.int64)
+    pk = pack_kmers(seq, pos, k, bits)
+    d_k = torch.from_numpy(pk.view(np.int64)).to(dev)
+    d_o = torch.empty(len(pos), dtype=torch.int64, device=dev)
+    h.query_packed(d_k.data_ptr(), len(pos), d_o.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_o.cpu().numpy().view(np.uint64), want[: len(pos)])
+    # a larger function from the product's builder: bijection on the GPU; and the real BooPHF agrees code for code where its binary is here
+    _, recs = synthetic_records(seed=21 + k, n_records=10, length=30_000)
+    ours = str(tmp_path / "ours.bbh")
+    st = L.build_bbhash(recs, k, ours, kmer_bits=bits, gamma=float(z["gamma"]), threads=8)
+    h2 = L.BbHash.load(ours, k, kmer_bits=bits, device=0)
+    every = np.concatenate([h2(r) for r in recs])
+    n = st["num_kmers"]
+    assert len(every) == n and len(np.unique(every)) == n and int(every.max()) == n - 1
+    ref = os.path.join(os.path.dirname(here), "oracle", "_ref", "bbhash_ref")
+    if os.path.exists(ref):
+        fa, codes = tmp_path / "i.fa", tmp_path / "c.u64"
+        with open(fa, "wb") as f:
+            for i, r in enumerate(recs):
+                f.write(b">r%d\n%s\n" % (i, r))
+        r = subprocess.run([ref, "query", ours, str(k), str(bits), str(fa), str(codes)], capture_output=True, text=True, cwd=tmp_path)
+        assert r.returncode == 0, r.stderr
+        assert np.array_equal(np.fromfile(codes, dtype=np.uint64), every)
+    exe = os.path.join(os.path.dirname(here), "lphash_amd", "lphash")
+    fa2 = tmp_path / "q.fa"
+    with open(fa2, "wb") as f:
+        for i, r in enumerate(recs):
+            f.write(b">r%d\n%s\n" % (i, r))
+    r = subprocess.run([exe, "ptbb-query", "-q", str(fa2), "-k", str(k), "-b", ours, "--kmer-bits", str(bits)], capture_output=True, text=True)
+    f6 = r.stdout.strip().split(",")
+    assert r.returncode == 0 and len(f6) == 6 and f6[2] == f6[3] == "" and f6[4] == ours and float(f6[5]) > 0, (r.stdout, r.stderr)
+    r = subprocess.run([exe, "ptbb-build", "-i", str(fa2), "-k", str(k), "-b", str(tmp_path / "c.bbh"), "--kmer-bits", str(bits), "--check", "-t", "4"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "EVERYTHING OK" in r.stderr, r.stderr
