@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--m", type=int, default=20)
     ap.add_argument("--kind", choices=["p", "u", "pthash", "bbhash"], default="p",
                     help="p / u: LPHash partitioned / unpartitioned; pthash / bbhash: the competitors of SURVEY 8(f)-4 over the same k-mers (random mode)")
+    ap.add_argument("--bbhash-gamma", type=float, default=1.0, help="--kind bbhash: load factor (the reference's ptbb_build default is 1)")
     ap.add_argument("--build-threads", type=int, default=0)
     ap.add_argument("--gpu-build", action="store_true",
                     help="run the PTHash pilot search of the index build on the GPU (same file bytes; default is the sequential CPU search so that "
@@ -165,14 +166,14 @@ def main():
 
     # ---- index: built once (rank 0), cached on local disk, image broadcast over RCCL ----
     os.makedirs(args.cache_dir, exist_ok=True)
-    path = os.path.join(args.cache_dir, f"synth_seed1_{args.kind}_k{k}_m{m}_n{nk}_b{kmer_bits}.lph")
+    path = os.path.join(args.cache_dir, f"synth_seed1_{args.kind}{args.bbhash_gamma if args.kind == 'bbhash' else ''}_k{k}_m{m}_n{nk}_b{kmer_bits}.lph")
     build_s = None
     if rank == 0:
         if not os.path.exists(path):
             t0 = time.time()
             tmp = path + f".tmp{os.getpid()}"
             if kind == L.BBHASH:
-                L.build_bbhash(recs, k, tmp, kmer_bits=kmer_bits, gamma=1.0, threads=args.build_threads or min(os.cpu_count() or 8, 64))
+                L.build_bbhash(recs, k, tmp, kmer_bits=kmer_bits, gamma=args.bbhash_gamma, threads=args.build_threads or min(os.cpu_count() or 8, 64))
             elif kind == L.PTHASH:
                 L.build_pthash(recs, k, tmp, kmer_bits=kmer_bits, threads=args.build_threads or min(os.cpu_count() or 8, 64),
                                device=local_rank if args.gpu_build else None)
@@ -390,7 +391,7 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": cfg_name + (": boomphf::mphf over the k-mers, gamma 1," if kind == L.BBHASH else ": pthash::single_phf over the k-mers," if kind == L.PTHASH else (": partitioned LP-MPHF" if kind == L.PARTITIONED else ": unpartitioned LP-MPHF"))
+                "workload": cfg_name + (f": boomphf::mphf over the k-mers, gamma {args.bbhash_gamma}," if kind == L.BBHASH else ": pthash::single_phf over the k-mers," if kind == L.PTHASH else (": partitioned LP-MPHF" if kind == L.PARTITIONED else ": unpartitioned LP-MPHF"))
                 + f" k={k} m={m}, {nk} k-mers (SplitMix64 seed 1, {n_records} records x {rec_len} bases); "
                 + ((f"2^{args.batch_log2} random positive packed k-mer lookups per GPU per step" if args.nonmember_frac == 0.0 else
                     f"2^{args.batch_log2} random packed k-mer lookups per GPU per step, {args.nonmember_frac:.0%} of them uniformly random non-members")

@@ -205,9 +205,27 @@ bool build_bbhash_image(const BbhFile& f, std::vector<uint8_t>& img, std::string
         d.nwords = lv.words.size();
         memcpy(img.data() + h.off_uni + (size_t)ii * sizeof d, &d, sizeof d);
     }
-    h.off_upair = reserve(f.final_keys.size() * 8 + f.final_vals.size() * 8 + 8);
-    if (!f.final_keys.empty()) memcpy(img.data() + h.off_upair, f.final_keys.data(), f.final_keys.size() * 8);
-    if (!f.final_vals.empty()) memcpy(img.data() + h.off_upair + f.final_keys.size() * 8, f.final_vals.data(), f.final_vals.size() * 8);
+    // exact map of the last level as an open-addressing table (linear probing, load <= 1/2): capacity 2^reserved0 slots, the keys
+    // (kmer_bits / 64 words each) followed by the values, ~0 = empty slot.  (The reference keeps a std::unordered_map.)
+    const size_t nfin = f.final_vals.size(), nw = (size_t)f.kmer_bits / 64;
+    uint32_t lg = 1;
+    while (((size_t)1 << lg) < 2 * nfin) ++lg;
+    const size_t cap = (size_t)1 << lg;
+    h.reserved0 = lg;
+    h.off_upair = reserve(cap * nw * 8 + cap * 8);
+    {
+        uint64_t* keys = (uint64_t*)(img.data() + h.off_upair);
+        uint64_t* vals = keys + cap * nw;
+        for (size_t i = 0; i < cap; ++i) vals[i] = ~0ull;
+        for (size_t i = 0; i < nfin; ++i) {
+            const uint64_t lo = f.final_keys[i * nw], hi = nw == 2 ? f.final_keys[i * 2 + 1] : 0;
+            size_t slot = (size_t)(bbh_slot_hash(lo, hi) >> (64 - lg));
+            while (vals[slot] != ~0ull) slot = (slot + 1) & (cap - 1);
+            keys[slot * nw] = lo;
+            if (nw == 2) keys[slot * 2 + 1] = hi;
+            vals[slot] = f.final_vals[i];
+        }
+    }
     img.resize((img.size() + 255) & ~(size_t)255, 0);
     h.total_bytes = img.size();
     memcpy(img.data(), &h, sizeof h);

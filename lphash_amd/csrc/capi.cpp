@@ -370,7 +370,8 @@ static bool bbh_levels_inside(const lphq_image_header& h, const lphq_bbh_level* 
         if (lv[i].hash_domain == 0 || lv[i].nwords != 1 + lv[i].hash_domain / 64 || !inside(lv[i].off_bits, lv[i].nwords * 8) ||
             !inside(lv[i].off_ranks, (lv[i].nwords + 7) / 8 * 8))
             return false;
-    return inside(h.off_upair, h.fallback_kmers * (h.kmer_bits / 64 + 1) * 8);
+    if (h.reserved0 < 1 || h.reserved0 > 40 || ((uint64_t)1 << h.reserved0) < 2 * h.fallback_kmers) return false;
+    return inside(h.off_upair, ((uint64_t)1 << h.reserved0) * (h.kmer_bits / 64 + 1) * 8);
 }
 
 static int check_device(int device) {

@@ -340,6 +340,11 @@ __device__ __forceinline__ uint64_t pthash_kmer(const uint8_t* __restrict__ img,
 // sequence seeded by them (getLevel :1059-1088, XorshiftHashFunctors :405-423); the first level whose bit is set answers with the rank of that
 // bit (ranks sampled every 512 bits, bitVector::rank :616-626); a key that no level holds is looked up in the exact map, ULLONG_MAX if absent.
 // BBHasher (src/ptbb/ptbb.hpp:25-32) = Murmur(key, seed) ^ Murmur(key, ~seed).
+__device__ __forceinline__ uint64_t bbh_slot_hash_dev(uint64_t lo, uint64_t hi) {  // == bbh_slot_hash of image_layout.h (the host fills the table with it)
+    uint64_t x = (lo ^ (hi * 0x9E3779B97F4A7C15ULL)) * 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 29;
+    return x * 0x94D049BB133111EBULL;
+}
 template <bool K128>
 __device__ __forceinline__ uint64_t bbhash_kmer(const uint8_t* __restrict__ img, const lphq_image_header& H, uint64_t lo, uint64_t hi) {
     auto hasher = [&](uint64_t seed) {
@@ -370,18 +375,16 @@ __device__ __forceinline__ uint64_t bbhash_kmer(const uint8_t* __restrict__ img,
             return r + (uint64_t)__popcll(word & ((1ull << (pos & 63)) - 1ull));
         }
     }
-    // exact map of the keys that reached the last level: sorted by (high, low)
-    const uint64_t nfin = H.fallback_kmers;
+    // exact map of the keys that reached the last level: open addressing, linear probing (image_layout.h)
+    const uint32_t lg = H.reserved0;
+    const uint64_t cap = 1ull << lg;
     const uint64_t* keys = (const uint64_t*)(img + H.off_upair);
-    const uint64_t* vals = keys + nfin * (K128 ? 2 : 1);
-    uint64_t a = 0, b = nfin;
-    while (a < b) {
-        const uint64_t mid = (a + b) >> 1;
-        const uint64_t klo = K128 ? keys[2 * mid] : keys[mid], khi = K128 ? keys[2 * mid + 1] : 0;
-        if (khi < hi || (khi == hi && klo < lo)) a = mid + 1;
-        else b = mid;
+    const uint64_t* vals = keys + cap * (K128 ? 2 : 1);
+    for (uint64_t slot = bbh_slot_hash_dev(lo, hi) >> (64 - lg);; slot = (slot + 1) & (cap - 1)) {
+        const uint64_t v = vals[slot];
+        if (v == ~0ull) break;  // empty slot: not a key
+        if (K128 ? (keys[2 * slot] == lo && keys[2 * slot + 1] == hi) : keys[slot] == lo) return v + H.collision_base;
     }
-    if (a < nfin && (K128 ? (keys[2 * a] == lo && keys[2 * a + 1] == hi) : keys[a] == lo)) return vals[a] + H.collision_base;
     return ~0ull;  // ULLONG_MAX: not a key
 }
 

@@ -88,7 +88,14 @@ typedef struct lphq_plane_block {
 
 /* Competitor harness, BBHash half (image kind 3; bbhash.hpp): header fields reused -- n_maximal = number of levels, collision_base = number of keys
  * the bit arrays hold (the exact map's values are offset by it), fallback_kmers = entries of the exact map, off_uni = lphq_bbh_level[levels],
- * off_upair = the exact map: its keys (kmer_bits / 64 words each, sorted ascending by (high, low)) followed by its u64 values. */
+ * off_upair = the exact map as an open-addressing table of 2^reserved0 slots (linear probing from the top reserved0 bits of bbh_slot_hash): the keys
+ * (kmer_bits / 64 words each) followed by the u64 values, ~0 marking an empty slot. */
+/* (host side; the kernels carry the same four lines as bbh_slot_hash_dev in device_query.cuh) */
+static inline uint64_t bbh_slot_hash(uint64_t lo, uint64_t hi) {
+    uint64_t x = (lo ^ (hi * 0x9E3779B97F4A7C15ULL)) * 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 29;
+    return x * 0x94D049BB133111EBULL;
+}
 typedef struct lphq_bbh_level {
     uint64_t hash_domain; /* bits of the level (a multiple of 64) */
     uint64_t off_bits;    /* u64 words, 1 + hash_domain / 64 of them */
