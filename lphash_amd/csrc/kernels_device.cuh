@@ -451,6 +451,18 @@ __device__ __forceinline__ void window_argmin4_raw(const uint64_t* __restrict__ 
     }
 }
 
+// Multi-record tiles: a lane resolves the record of its FIRST window with one search and walks on from there for the other three (a lane's four
+// windows are consecutive bases, so they leave a record at most through its end).  rec_walk: record of base g, given a record (j, [rs, re)) that
+// starts at or before g; the offsets come from the tile's LDS table, or from global memory for tiles with more than kRecCap records.
+__device__ __forceinline__ void rec_walk(const uint64_t* __restrict__ rtab, const uint64_t* __restrict__ seq_off, uint32_t rlo, bool cached, uint64_t g,
+                                         uint32_t& j, uint64_t& rs, uint64_t& re) {
+    while (g >= re) {  // (skips empty records)
+        ++j;
+        rs = re;
+        re = cached ? rtab[j + 1] : seq_off[rlo + j + 1];
+    }
+}
+
 // Shaped by the phase profile of its predecessor (profiles/r02_stream_phases.txt, r02_stream_v4_ab.txt: that kernel moved 4.1 GB
 // per launch at ~5.8 TB/s and was short of gathers in flight, because a workgroup holds its slot ~15 us of which the lookup
 // phase E -- the only one with loads in flight -- was 30 %; the other phases were latency (A) and instruction (C, D, F) time):
@@ -584,6 +596,7 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
         if (limit >= t0 + k) w_hi = (uint32_t)min((uint64_t)TW, limit - k - t0 + 1u);
     }
     uint32_t code[4];  // minimizer position of the window; 0xFFFF: holds a non-ACGT base; 0xFFFE: not a window of any record
+    uint32_t jrec = 0, jcur = 0;  // multi-record tiles: record (relative to rlo) of the lane's first in-batch window, and a cursor
     {
         uint32_t q[4];
         if (BLKMIN) window_argmin4<BLOCK>(sm_hash, sm_off, tid, W, bmin, q);
@@ -592,15 +605,22 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
 #pragma unroll
             for (uint32_t jw = 0; jw < 4; ++jw) code[jw] = (a + jw >= w_lo && a + jw < w_hi) ? q[jw] : 0xFFFEu;
         } else {
+            bool have = false;
+            uint64_t rs = 0, re = 0;
 #pragma unroll
             for (uint32_t jw = 0; jw < 4; ++jw) {
                 const uint32_t i = a + jw;
                 const uint64_t ga = t0 + i;
                 uint32_t v = 0xFFFEu;
                 if (i < TW && ga >= shift && ga - shift + k <= total) {
-                    uint64_t rs, re;
-                    tile_record(sm_rtab, seq_off, rlo, rhi, ga - shift, rs, re);
-                    if (ga - shift + k <= re) v = q[jw];
+                    const uint64_t g = ga - shift;
+                    if (!have) {  // one search per lane; its record index is kept for phase F
+                        jrec = tile_record(sm_rtab, seq_off, rlo, rhi, g, rs, re);
+                        jcur = jrec;
+                        have = true;
+                    }
+                    rec_walk(sm_rtab, seq_off, rlo, rhi - rlo < (uint32_t)kRecCap, g, jcur, rs, re);
+                    if (g + k <= re) v = q[jw];
                 }
                 code[jw] = v;
             }
@@ -677,13 +697,26 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
                 if (code[jw] != 0xFFFEu) __builtin_nontemporal_store(hv[jw], dst + jw);
         }
     } else {
+        // the walk of phase C again, from the record found there: where each window's code goes
+        const bool cached = rhi - rlo < (uint32_t)kRecCap;
+        uint32_t j = jrec;
+        uint64_t rs = cached ? sm_rtab[j] : seq_off[rlo + j], re = cached ? sm_rtab[j + 1] : seq_off[rlo + j + 1];
+        uint64_t oidx[4];
 #pragma unroll
         for (uint32_t jw = 0; jw < 4; ++jw) {
+            oidx[jw] = 0;
             if (code[jw] == 0xFFFEu) continue;
             const uint64_t g = t0 + a + jw - shift;
-            uint64_t rs, re;
-            const uint32_t j = tile_record(sm_rtab, seq_off, rlo, rhi, g, rs, re);
-            __builtin_nontemporal_store(hv[jw], out + (tile_record_out(sm_rtab, out_off, rlo, rhi, j) + (g - rs)));
+            rec_walk(sm_rtab, seq_off, rlo, cached, g, j, rs, re);
+            oidx[jw] = tile_record_out(sm_rtab, out_off, rlo, rhi, j) + (g - rs);
+        }
+        if (code[0] != 0xFFFEu && code[3] != 0xFFFEu && oidx[3] == oidx[0] + 3u) {  // four windows of one record (the common case for reads)
+            store_codes_nt(out + oidx[0], hv[0], hv[1]);
+            store_codes_nt(out + oidx[0] + 2, hv[2], hv[3]);
+        } else {
+#pragma unroll
+            for (uint32_t jw = 0; jw < 4; ++jw)
+                if (code[jw] != 0xFFFEu) __builtin_nontemporal_store(hv[jw], out + oidx[jw]);
         }
     }
 }
