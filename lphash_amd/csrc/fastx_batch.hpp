@@ -9,7 +9,7 @@
 // all threads).  A piece that meets a line starting with '+' -- or the one case where kseq's '\r' rule would need the
 // length of a record begun elsewhere -- makes the reader fall back, from the start of the current batch, to the serial
 // FastxReader for the rest of the file, so the records are the serial reader's in every case.  gzip input and files
-// that do not start with '>' take the serial reader from the beginning -- except BGZF (bgzip / htslib: gzip members of
+// that do not start with '>' or '@' take the serial reader from the beginning -- except BGZF (bgzip / htslib: gzip members of
 // <= 64 KiB whose compressed size is in the header's 'BC' extra field): its blocks are independent deflate streams, so the first
 // next() inflates all of them concurrently (raw inflate + CRC-32 and length check per block) into one buffer, which then stands in
 // for the mapped file.  A single-member .gz cannot be split and stays on the serial reader (zlib inflate, ~0.5 GB/s).
@@ -17,7 +17,16 @@
 // A batch is a list of segments (bases in file order; a record may run across segments) plus the record lengths; segments
 // point into one of two arenas owned by the reader, used alternately, so a batch stays valid while the NEXT one is
 // being parsed (the CLI parses batch i+1 on a helper thread while batch i is on its way to the GPU) and dies with the
-// call after that.  Arenas are allocated once and reused: first-touch page faults of fresh memory cost more than the
+// call after that.
+//
+// Plain FASTQ (first byte '@') is parsed by several threads too when it is the usual four-line kind: a record starts at a line that begins
+// with '@' and whose next-but-one line begins with '+' (a quality line may begin with '@', but then the line two further down is a sequence
+// line, which never begins with '+'); batches and pieces are cut at such lines.  A piece is accepted only if every record in it is exactly
+// header / one sequence line / '+' line / one quality line of the same length, without '\r' and with the next record (or the end of the
+// file) right behind -- the one shape in which kseq_read (external/kseq.h:192-240) has no choices to make; anything else sends the rest of
+// the file, from the start of the current batch, to the serial FastxReader.
+//
+// Arenas are allocated once and reused: first-touch page faults of fresh memory cost more than the
 // parsing itself (measured: 40 ms per 100 MB in the build container, against 12 ms to parse them with 8 threads).
 // They come from a caller-supplied allocator so that the CLI can use pinned host memory (hipHostMalloc).
 #pragma once
@@ -76,7 +85,8 @@ public:
         if (fd_ < 0) return;
         struct stat st;
         unsigned char head = 0;
-        if (fstat(fd_, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && ::pread(fd_, &head, 1, 0) == 1 && head == '>') {  // (gzip starts with 0x1f)
+        if (fstat(fd_, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && ::pread(fd_, &head, 1, 0) == 1 && (head == '>' || head == '@')) {  // (gzip starts with 0x1f)
+            fastq_ = head == '@';
             void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd_, 0);
             if (m != MAP_FAILED) {
                 map_ = (const char*)m;
@@ -238,13 +248,14 @@ private:
         }
         munmap((void*)bgzf_, bgzf_size_);
         bgzf_ = nullptr;
-        if (!good || total == 0 || buf[0] != '>') {  // damaged, empty, or FASTQ / headerless text: the serial reader decides
+        if (!good || total == 0 || (buf[0] != '>' && buf[0] != '@')) {  // damaged, empty or headerless text: the serial reader decides
             free(buf);
             return false;
         }
         inflated_ = buf;
         map_ = buf;
         size_ = total;
+        fastq_ = buf[0] == '@';
         return true;
     }
 
@@ -279,7 +290,22 @@ private:
     }
 
     // first position p in [from, size_) with map_[p] == '>' and map_[p - 1] == '\n'; size_ if there is none
+    // FASTQ: first line start p >= from with map_[p] == '@' whose next-but-one line begins with '+'; size_ if there is none
+    size_t next_fastq_record(size_t from) const {
+        size_t p = from;
+        if (p > 0 && map_[p - 1] != '\n') p = next_line_start(p, size_);
+        while (p < size_) {
+            if (map_[p] == '@') {
+                const size_t l1 = next_line_start(p, size_), l2 = l1 < size_ ? next_line_start(l1, size_) : size_;
+                if (l2 < size_ && map_[l2] == '+') return p;
+            }
+            p = next_line_start(p, size_);
+        }
+        return size_;
+    }
+
     size_t next_record_start(size_t from) const {
+        if (fastq_) return next_fastq_record(from);
         size_t p = std::max<size_t>(from, 1);
         while (p < size_) {
             const char* q = (const char*)memchr(map_ + p, '>', size_ - p);
@@ -327,8 +353,51 @@ private:
         return true;
     }
 
+    // four-line FASTQ records only (see the file header); anything else marks the piece unsafe
+    void parse_piece_fastq(Piece& pc) const {
+        const char* s = map_;
+        size_t p = pc.begin;
+        const size_t e = pc.end;
+        char* out = pc.out;
+        while (p < e) {
+            if (s[p] != '@') {
+                pc.unsafe = true;
+                return;
+            }
+            const char* h = (const char*)memchr(s + p, '\n', e - p);                              // header line
+            const char* q = h ? (const char*)memchr(h + 1, '\n', (size_t)(s + e - (h + 1))) : nullptr;  // sequence line
+            if (!h || !q || q + 1 >= s + e || q[1] != '+') {
+                pc.unsafe = true;
+                return;
+            }
+            const char* pl = (const char*)memchr(q + 1, '\n', (size_t)(s + e - (q + 1)));  // '+' line
+            if (!pl) {
+                pc.unsafe = true;
+                return;
+            }
+            const size_t n = (size_t)(q - (h + 1));
+            const char* ql = pl + 1;  // quality line: exactly n characters, then a line end (or the end of the file)
+            const size_t left = (size_t)(s + e - ql);
+            const bool at_eof = pc.end == size_ && left == n;
+            if (n == 0 || left < n || (!at_eof && (left == n || ql[n] != '\n')) || memchr(h + 1, '\r', n) || memchr(ql, '\r', n) ||
+                memchr(ql, '\n', n) != nullptr) {
+                pc.unsafe = true;
+                return;
+            }
+            memcpy(out, h + 1, n);
+            out += n;
+            pc.lens.push_back((uint64_t)n);
+            p = (size_t)(ql - s) + n + (at_eof ? 0 : 1);
+        }
+        pc.n = (size_t)(out - pc.out);
+    }
+
     // kseq's record loop over one piece.
     void parse_piece(Piece& pc) const {
+        if (fastq_) {
+            parse_piece_fastq(pc);
+            return;
+        }
         const char* s = map_;
         size_t p = pc.begin;
         const size_t e = pc.end;
@@ -372,7 +441,7 @@ private:
         std::vector<Piece> pieces;
         size_t from = off_;
         for (int t = 1; t <= T && from < end; ++t) {
-            size_t to = t == T ? end : next_line_start(off_ + (end - off_) / T * t, end);
+            size_t to = t == T ? end : (fastq_ ? std::min(end, next_fastq_record(off_ + (end - off_) / T * t)) : next_line_start(off_ + (end - off_) / T * t, end));
             if (to <= from) continue;
             Piece pc;
             pc.begin = from;
@@ -431,6 +500,7 @@ private:
     int fd_ = -1;
     const char* map_ = nullptr;
     size_t size_ = 0, off_ = 0;
+    bool fastq_ = false;                   // the mapped text begins with '@': four-line FASTQ pieces
     const unsigned char* bgzf_ = nullptr;  // mapped BGZF file until the first next()
     size_t bgzf_size_ = 0;
     char* inflated_ = nullptr;             // its text afterwards (map_ points here)

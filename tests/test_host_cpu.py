@@ -362,6 +362,54 @@ def test_readers_against_the_real_kseq(tmp_path):
         assert ",".join(par) == want, (i, "parallel", par, want, data[:120])
 
 
+@pytest.mark.skipif(not os.path.exists(KSEQ_DUMP), reason="oracle/_ref/kseq_dump is built only where /root/reference exists (oracle/Makefile)")
+def test_parallel_fastq_parser_against_the_real_kseq(tmp_path):
+    """Plain FASTQ goes through the multi-threaded parser when it is the four-line kind; the records must be kseq's in every case: quality lines that
+    begin with '@' or '+', a last record without a line end, and -- via the fall-back to the serial reader -- multi-line records, CRLF, truncated or
+    over-long quality strings, empty sequences, junk between records."""
+    exe = os.path.join(ROOT, "lphash_amd", "lphash")
+    rng = np.random.default_rng(99)
+    qual_alphabet = np.frombuffer(b"@+IIIIFFFF#5:<>", dtype=np.uint8)
+
+    def record(i, n, style):
+        seq = random_records(int(rng.integers(1 << 30)), 1, n, n)[0]
+        qual = bytes(rng.choice(qual_alphabet, size=n))
+        if style == "at":
+            qual = b"@" + qual[1:]
+        if style == "plus":
+            qual = b"+" + qual[1:]
+        if style == "short":
+            qual = qual[:-1]
+        if style == "long":
+            qual = qual + b"I"
+        if style == "multiline" and n > 10:
+            return b"@r%d x\n%s\n%s\n+\n%s\n%s\n" % (i, seq[:7], seq[7:], qual[:5], qual[5:])
+        if style == "crlf":
+            return b"@r%d\r\n%s\r\n+\r\n%s\r\n" % (i, seq, qual)
+        if style == "junk":
+            return b"@r%d\n%s\n+r%d again\n%s\nstray line\n" % (i, seq, i, qual)
+        if style == "empty":
+            return b"@r%d\n\n+\n\n" % i
+        return b"@r%d some comment\n%s\n+\n%s\n" % (i, seq, qual)
+
+    n_parallel = 0
+    for trial in range(60):
+        styles = ["ok", "ok", "ok", "at", "plus"] if trial < 30 else ["ok", "at", "plus", "short", "long", "multiline", "crlf", "junk", "empty"]
+        recs = [record(i, int(rng.integers(1, 200)), styles[int(rng.integers(len(styles)))]) for i in range(int(rng.integers(1, 120)))]
+        data = b"".join(recs)
+        if trial % 4 == 0:
+            data = data.rstrip(b"\n")  # last quality line without a line end
+        p = tmp_path / f"t{trial}.fq"
+        p.write_bytes(data)
+        want = subprocess.run([KSEQ_DUMP, str(p)], capture_output=True, text=True).stdout.strip()
+        for threads, piece, batch in ((4, 1, 700), (7, 1, 100000), (3, 64, 5000)):
+            par = subprocess.run([exe, "records", "-i", str(p), "-t", str(threads), "--min-piece", str(piece), "--batch-bytes", str(batch)], capture_output=True,
+                                 text=True).stdout.strip().split(",")
+            assert ",".join(par[:3]) == want, (trial, threads, piece, batch, par, want, data[:300])
+            n_parallel += int(par[4])
+    assert n_parallel > 100  # the multi-threaded path did take part
+
+
 def test_host_sources_under_sanitizers(tmp_path):
     """The GPU-free host sources of the product (loader, image builder, index builder with the CPU pilot search, FASTA readers) compiled
     with -fsanitize=address,undefined (tests/san/san_host.cpp): builds with 1 and 8 threads, loads, and a few hundred corrupted files
@@ -454,7 +502,7 @@ def bgzf_compress(data, block=60000, level=6):
 def test_bgzf_input_is_inflated_block_parallel(tmp_path):
     """A BGZF-compressed FASTA (what bgzip writes; zlib reads it as ordinary multi-member gzip, so the reference does too) is inflated block by
     block on several threads and then parsed by the multi-threaded reader: same records as the reference's kseq.h and as the serial reader;
-    a damaged block, FASTQ content and a plain single-member .gz fall back to the serial reader (which reports what zlib reports)."""
+    a damaged block and a plain single-member .gz fall back to the serial reader (which reports what zlib reports)."""
     import gzip
 
     exe = os.path.join(ROOT, "lphash_amd", "lphash")
@@ -471,7 +519,7 @@ def test_bgzf_input_is_inflated_block_parallel(tmp_path):
         ser = subprocess.run([exe, "records", "-i", str(p), "--serial"], capture_output=True, text=True).stdout.strip().split(",")
         par = subprocess.run([exe, "records", "-i", str(p), "-t", "6", "--min-piece", "1", "--batch-bytes", "50000"], capture_output=True, text=True).stdout.strip().split(",")
         assert ",".join(ser[:3]) == want and ",".join(par[:3]) == want, (name, ser, par, want)
-        assert (int(par[4]) > 0) == (name in ("multi", "one_block", "tiny_blocks")), (name, par)  # batches that came from the parallel parser
+        assert (int(par[4]) > 0) == (name in ("multi", "one_block", "tiny_blocks", "fastq")), (name, par)  # batches that came from the parallel parser
     p = tmp_path / "broken.fa.gz"
     p.write_bytes(bytes(broken))
     ser = subprocess.run([exe, "records", "-i", str(p), "--serial"], capture_output=True, text=True).stdout.strip().split(",")
