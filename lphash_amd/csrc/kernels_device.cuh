@@ -226,13 +226,27 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_random(const uint8_t* __
     __shared__ uint32_t sm_words[kTileWords + 8];
     __shared__ uint32_t sm_bad[(kTileWords + 8) / 2 + 2];  // competitor harness (KIND 2, 3) only: 16 bad-base bits per 16-base chunk
     __shared__ uint32_t sm_rec[2];
+    __shared__ uint64_t sm_roff[3];                // seq_off[rlo], seq_off[rlo+1], out_off[rlo]
+    __shared__ uint64_t sm_rtab[2 * kRecCap + 1];  // multi-record tiles: the tile's slice of seq_off / out_off
+    __shared__ uint32_t sm_queue[kTileW];          // multi-record tiles: window start | record-in-tile << 11 of every k-mer
+    __shared__ uint32_t sm_qn;
+    static_assert(kTileW == 2048 && kTileW % kBlock == 0, "queue entries carry the window start in 11 bits");
     const uint64_t t0 = (tile_base + blockIdx.x) * kTileW;  // shifted coordinate of the tile's first window start
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) sm_qn = 0;
+    if (threadIdx.x < 64) {  // wave 0: record of the first base the tile can touch, and of the last (64 probes per round, as the streaming kernel)
         const uint64_t gfirst = t0 > shift ? t0 - shift : 0;
         uint64_t glast = t0 + kTileW + 64 > shift ? t0 + kTileW + 64 - shift : 0;
         if (glast >= total) glast = total ? total - 1 : 0;
-        sm_rec[0] = find_record(seq_off, 0, n_records - 1, gfirst);
-        sm_rec[1] = find_record(seq_off, 0, n_records - 1, glast);
+        const uint32_t r = find_record_wave(seq_off, n_records, gfirst);
+        const uint64_t s0 = seq_off[r], e0 = seq_off[r + 1];
+        const uint32_t r2 = glast < e0 ? r : find_record_wave(seq_off, n_records, glast);
+        if (threadIdx.x == 0) {
+            sm_rec[0] = r;
+            sm_rec[1] = r2;
+            sm_roff[0] = s0;
+            sm_roff[1] = e0;
+            sm_roff[2] = out_off[r];
+        }
     }
     // the competitor harness (KIND 2: PTHash, 3: BBHash) iterates like ptbb_file_itr: windows holding a non-ACGT base yield nothing -> LPHQ_INVALID
     load_tile<(KIND >= 2), kTileWords>(seq_al, shift, total, t0, sm_words, sm_bad);
@@ -242,24 +256,60 @@ __global__ __launch_bounds__(kBlock) void k_query_tiles_random(const uint8_t* __
     }
     __syncthreads();
     const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];
-    for (int i = threadIdx.x; i < kTileW; i += kBlock) {
-        const uint64_t a = t0 + i;
-        if (a < shift) continue;
-        const uint64_t g = a - shift;
-        if (g + H.k > total) continue;
-        const uint32_t r = find_record(seq_off, rlo, rhi, g);
-        if (g + H.k > seq_off[r + 1]) continue;  // window would run over the end of its record
+    if (rlo != rhi) {  // (uniform) read batches: the tile's record offsets into LDS, searched there
+        load_record_table(sm_rtab, seq_off, out_off, rlo, rhi, threadIdx.x);
+        __syncthreads();
+    }
+    auto window = [&](uint32_t i, uint64_t dst /* out index of window start i */) {
         uint64_t lo, hi;
-        extract_kmer<K128>(sm_words, (uint32_t)i, H.k, lo, hi);
+        extract_kmer<K128>(sm_words, i, H.k, lo, hi);
         uint64_t code = query_kmer<KIND, K128, P>(img, H, lo, hi);
         if (KIND >= 2) {  // bad-base bits [i, i + k), k <= 63: five 16-bit chunks cover them
             const uint16_t* bad16 = (const uint16_t*)sm_bad;
-            const uint32_t c0 = (uint32_t)i >> 4, o = (uint32_t)i & 15u;
+            const uint32_t c0 = i >> 4, o = i & 15u;
             const uint64_t lo64 = (uint64_t)bad16[c0] | ((uint64_t)bad16[c0 + 1] << 16) | ((uint64_t)bad16[c0 + 2] << 32) | ((uint64_t)bad16[c0 + 3] << 48);
             const uint64_t bits = o ? ((lo64 >> o) | ((uint64_t)bad16[c0 + 4] << (64u - o))) : lo64;
             if (bits & ((1ull << H.k) - 1ull)) code = ~0ull;
         }
-        __builtin_nontemporal_store(code, out + (out_off[r] + (g - seq_off[r])));
+        __builtin_nontemporal_store(code, out + dst);
+    };
+    // (uniform) one record under the whole tile, or so few that nearly every window start is a k-mer: windows in place
+    if ((rhi - rlo) * (H.k - 1u) < (uint32_t)kTileW / 16u) {
+        for (int i = threadIdx.x; i < kTileW; i += kBlock) {
+            const uint64_t a = t0 + i;
+            if (a < shift) continue;
+            const uint64_t g = a - shift;
+            if (g + H.k > total) continue;
+            uint64_t rs = sm_roff[0], re = sm_roff[1], ob = sm_roff[2];
+            if (rlo != rhi) ob = tile_record_out(sm_rtab, out_off, rlo, rhi, tile_record(sm_rtab, seq_off, rlo, rhi, g, rs, re));
+            if (g + H.k > re) continue;  // window would run over the end of its record
+            window((uint32_t)i, ob + (g - rs));
+        }
+        return;
+    }
+    // read batches: the window starts that hold a k-mer (read length - k + 1 of every read) are queued first, so that the lookups run
+    // with dense lanes however short the reads are
+    for (int i = threadIdx.x; i < kTileW; i += kBlock) {  // (kTileW is a multiple of kBlock: whole waves iterate together)
+        const uint64_t a = t0 + i;
+        bool ok = a >= shift && a - shift + H.k <= total;
+        uint32_t j = 0;
+        if (ok) {
+            uint64_t rs, re;
+            j = tile_record(sm_rtab, seq_off, rlo, rhi, a - shift, rs, re);
+            ok = a - shift + H.k <= re;
+        }
+        const uint64_t mask = __ballot(ok);
+        uint32_t base = 0;
+        if ((threadIdx.x & 63u) == 0 && mask) base = atomicAdd(&sm_qn, (uint32_t)__popcll(mask));
+        base = __shfl(base, 0);
+        if (ok) sm_queue[base + (uint32_t)__popcll(mask & ((1ull << (threadIdx.x & 63u)) - 1ull))] = (uint32_t)i | (j << 11);
+    }
+    __syncthreads();
+    const uint32_t qn = sm_qn;
+    for (uint32_t q = threadIdx.x; q < qn; q += kBlock) {
+        const uint32_t e = sm_queue[q], i = e & 2047u, j = e >> 11;
+        const uint64_t rs = (rhi - rlo < (uint32_t)kRecCap) ? sm_rtab[j] : seq_off[rlo + j];
+        window(i, tile_record_out(sm_rtab, out_off, rlo, rhi, j) + (t0 + i - shift - rs));
     }
 }
 
