@@ -179,6 +179,22 @@ int lphq_build_device(const char* const* records, const size_t* lengths, size_t 
                       uint64_t mm_seed, double c, int kind, int kmer_bits, int threads, int device, const char* out_path,
                       lphq_build_stats* stats /* may be NULL */);
 
+/* Construction from a stream of record batches with bounded memory: the reference's two passes over the input
+ * (src/partitioned_mphf.cpp:58-81 kseq loop into external_memory_vector<mm_record_t>, :110-130 second pass collecting the k-mers of
+ * repeated minimizers) with its `--max-memory` / `-d tmp_dirname` behaviour (src/parser_build.cpp:74-88, include/external_memory_vector.hpp:
+ * sorted runs spilled to temporary files, merged by a heap).  `next` is called until it returns 0; every call that returns 1 hands over
+ * one batch of WHOLE records (pointers valid until the following call).  The input is read twice: next(ctx, 0, ...) serves the first
+ * pass, next(ctx, 1, ...) the second (the first call with pass = 1 restarts the input from its beginning).  < 0 from `next` aborts with
+ * LPHQ_ERR_IO.  The sequence is never held whole: a batch at a time.  The super-k-mer records (32 B each, ~2 / (k - m + 2) per k-mer) are
+ * sorted in pieces of at most max_memory_bytes / 4 and spilled to `tmp_dir` (created if absent; files lphash.tmp.<pid>.<n>.runs, removed
+ * before returning); max_memory_bytes = 0: no limit, nothing is spilled.  What stays in memory regardless: 24 B per DISTINCT minimizer and the
+ * PTHash construction over them (the reference keeps those in external memory as well; here they are bounded by the number of minimizers, not by
+ * the input).  The bytes written are those of lphq_build on the same records, whatever the batch boundaries and the memory limit. */
+typedef int (*lphq_record_source)(void* ctx, int pass, const char* const** records, const size_t** lengths, size_t* n_records);
+int lphq_build_stream(lphq_record_source next, void* ctx, int k, int m, uint64_t mm_seed, double c, int kind, int kmer_bits, int threads,
+                      int device /* < 0: CPU pilot search */, const char* tmp_dir /* NULL: "." */, uint64_t max_memory_bytes,
+                      const char* out_path, lphq_build_stats* stats /* may be NULL */);
+
 /* ---- competitor harness: a plain PTHash MPHF over whole k-mers ----
  * The PTHash half of the reference's `ptbb_build` / `ptbb_query` (src/ptbb/ptbb_build.cpp:83-99, src/ptbb/ptbb_query.cpp:40-55,
  * src/ptbb/ptbb.hpp:16-34): pthash::single_phf<PTHasher, dictionary_dictionary, true> with

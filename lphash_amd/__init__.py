@@ -4,4 +4,4 @@ C ABI: include/lphq.h (liblphq.so).  This package is the Python host mirror of t
 interface over that ABI.
 """
 from ._lib import BBHASH, INVALID, PARTITIONED, PTHASH, UNPARTITIONED, LphqError  # noqa: F401
-from .api import BbHash, Mphf, MphfAlt, PtHash, build, build_bbhash, build_pthash  # noqa: F401
+from .api import BbHash, Mphf, MphfAlt, PtHash, build, build_bbhash, build_pthash, build_stream  # noqa: F401

@@ -63,6 +63,8 @@ SIGNATURES = {
                              C.c_double, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(BuildStats)]),
     "lphq_build_device": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int, C.c_uint64,
                                     C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(BuildStats)]),
+    "lphq_build_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p,
+                                    C.c_uint64, C.c_char_p, C.POINTER(BuildStats)]),
     "lphq_open_bbhash": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "lphq_build_bbhash": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_int, C.c_char_p,
                                     C.POINTER(BuildStats)]),
@@ -70,6 +72,10 @@ SIGNATURES = {
     "lphq_build_pthash": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
                                     C.c_char_p, C.POINTER(BuildStats)]),
 }
+
+
+# lphq_record_source: int (*)(void* ctx, int pass, const char* const** records, const size_t** lengths, size_t* n_records)
+RECORD_SOURCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_size_t)), C.POINTER(C.c_size_t))
 
 
 def _preload_hip_runtime():

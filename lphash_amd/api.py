@@ -34,6 +34,46 @@ def build(records, k, m, out_path, kind=PARTITIONED, kmer_bits=None, mm_seed=42,
     return {name: getattr(stats, name) for name, _ in stats._fields_}
 
 
+def build_stream(batches, k, m, out_path, kind=PARTITIONED, kmer_bits=None, mm_seed=42, c=3.0, threads=0, device=None, tmp_dir=None,
+                 max_memory_bytes=0):
+    """`lphash build-p|build-u ... -d tmp_dir --max-memory G` (src/partitioned_mphf.cpp:58-130, include/external_memory_vector.hpp):
+    construction from a stream of record batches with bounded memory.  batches: a callable returning a fresh iterator over batches
+    (lists of bytes, whole records) -- it is called twice, once per pass over the input.  Same file as build() on the same records."""
+    if kmer_bits is None:
+        kmer_bits = 64 if k <= 31 else 128
+    state = {"pass": -1, "it": None, "keep": None, "error": None}
+
+    def source(_ctx, pas, p_recs, p_lens, p_n):
+        try:
+            if state["pass"] != pas:
+                state["pass"], state["it"] = pas, iter(batches())
+            batch = next(state["it"], None)
+            if batch is None:
+                return 0
+            recs = [bytes(r) for r in batch]
+            n = len(recs)
+            arr = (C.c_char_p * max(n, 1))(*recs)
+            lens = (C.c_size_t * max(n, 1))(*[len(r) for r in recs])
+            state["keep"] = (recs, arr, lens)  # valid until the next call
+            p_recs[0] = C.cast(arr, C.POINTER(C.c_char_p))
+            p_lens[0] = C.cast(lens, C.POINTER(C.c_size_t))
+            p_n[0] = n
+            return 1
+        except Exception as e:  # never unwind through the C frames
+            state["error"] = e
+            return -1
+
+    cb = _lib.RECORD_SOURCE(source)
+    stats = _lib.BuildStats()
+    rc = lib.lphq_build_stream(C.cast(cb, C.c_void_p), None, int(k), int(m), int(mm_seed), float(c), int(kind), int(kmer_bits), int(threads),
+                               -1 if device is None else int(device), None if tmp_dir is None else str(tmp_dir).encode(), int(max_memory_bytes),
+                               str(out_path).encode(), C.byref(stats))
+    if state["error"] is not None:
+        raise state["error"]
+    check(rc)
+    return {name: getattr(stats, name) for name, _ in stats._fields_}
+
+
 def build_pthash(records, k, out_path, kmer_bits=None, c=3.0, threads=0, device=None):
     """`ptbb_build -i ... -k k -p out_path [-c c] [-t threads]` (PTHash half of the reference's competitor harness,
     src/ptbb/ptbb_build.cpp:83-99) over in-memory records: a bare pthash::single_phf over every window of k valid bases."""

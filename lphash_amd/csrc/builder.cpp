@@ -19,9 +19,13 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <queue>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "../../include/lphq.h"
 #include "lph_format.hpp"
@@ -538,6 +542,7 @@ struct Run {          // one super-k-mer: windows [first, first + size) of the b
     uint64_t first;   // batch coordinate of the first window
     uint64_t q;       // batch coordinate of the minimizer
     uint32_t size;
+    uint32_t pad;     // (spilled to disk as raw structs: no indeterminate bytes)
 };
 
 // Windows [wa, wb) of one record (record base pointer s, window w covers bases [w, w+k)).
@@ -551,7 +556,7 @@ void extract_runs(const char* s, uint64_t rec_off, uint64_t wa, uint64_t wb, uin
     uint64_t valid_run = 0;  // consecutive valid bases ending at the current base
     // m-mer positions needed: wa .. wb-1+W-1 ; bases wa .. wb+k-2
     uint64_t cur_q = ~0ULL, cur_hash = 0;  // current minimum (leftmost) among the window's m-mers
-    Run run{0, 0, ~0ULL, 0};
+    Run run{0, 0, ~0ULL, 0, 0};
     auto flush = [&] {
         if (run.size) out.push_back(run);
         run.size = 0;
@@ -645,6 +650,168 @@ struct Triplet {  // mm_triplet_t, include/constants.hpp:37-43 (itself is replac
     uint8_t p1, size;
 };
 
+// ---------------------------------------------------------------------------------------------
+// the input of a build: batches of whole records, read twice (src/partitioned_mphf.cpp:58-81 and :110-130)
+// ---------------------------------------------------------------------------------------------
+struct RecordSource {
+    virtual ~RecordSource() {}
+    // next batch of pass `pass` (0, then 1; the first call of pass 1 restarts the input): 1 = a batch, 0 = end of input, < 0 = error
+    virtual int next(int pass, const char* const*& recs, const size_t*& lens, size_t& n) = 0;
+};
+struct MemorySource : RecordSource {  // lphq_build: the whole input is one batch
+    const char* const* recs_;
+    const size_t* lens_;
+    size_t n_;
+    int served_ = -1;
+    MemorySource(const char* const* r, const size_t* l, size_t n) : recs_(r), lens_(l), n_(n) {}
+    int next(int pass, const char* const*& recs, const size_t*& lens, size_t& n) override {
+        if (served_ == pass) return 0;
+        served_ = pass;
+        recs = recs_;
+        lens = lens_;
+        n = n_;
+        return 1;
+    }
+};
+struct CallbackSource : RecordSource {  // lphq_build_stream
+    lphq_record_source fn_;
+    void* ctx_;
+    CallbackSource(lphq_record_source fn, void* ctx) : fn_(fn), ctx_(ctx) {}
+    int next(int pass, const char* const*& recs, const size_t*& lens, size_t& n) override {
+        const char* const* r = nullptr;
+        const size_t* l = nullptr;
+        size_t cnt = 0;
+        const int rc = fn_(ctx_, pass, &r, &l, &cnt);
+        if (rc <= 0) return rc;
+        if (cnt && (!r || !l)) return -1;
+        recs = r;
+        lens = l;
+        n = cnt;
+        return 1;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// super-k-mer records beyond the memory limit: sorted pieces on disk, merged by a heap
+// (include/external_memory_vector.hpp:43-109: push_back -> sort_and_flush, const_iterator = heap over the files)
+// ---------------------------------------------------------------------------------------------
+struct RunFileReader {
+    FILE* f = nullptr;
+    std::vector<Run> buf;
+    size_t at = 0, n = 0;
+    bool failed = false;
+    bool open(const std::string& path, size_t buf_records) {
+        f = fopen(path.c_str(), "rb");
+        buf.resize(std::max<size_t>(1, buf_records));
+        return f != nullptr;
+    }
+    bool next(Run& r) {
+        if (at == n) {
+            if (!f) return false;
+            n = fread(buf.data(), sizeof(Run), buf.size(), f);
+            at = 0;
+            if (n == 0) {
+                failed = ferror(f) != 0;
+                fclose(f);
+                f = nullptr;
+                return false;
+            }
+        }
+        r = buf[at++];
+        return true;
+    }
+    ~RunFileReader() {
+        if (f) fclose(f);
+    }
+};
+
+struct RunSpill {
+    std::string dir;
+    std::vector<std::string> files;
+    uint64_t serial = 0;
+    static constexpr size_t kMaxPieces = 64;  // more sorted pieces than this are first merged into one (open files and read buffers stay bounded)
+    ~RunSpill() {
+        for (const std::string& f : files) ::remove(f.c_str());
+    }
+    std::string fresh_name() { return dir + "/lphash.tmp." + std::to_string((long)getpid()) + "." + std::to_string(serial++) + ".runs"; }
+    // every record of `paths`, ascending by minimizer (ties in no particular order), to fn; false on a read error
+    template <typename Fn>
+    static bool merge(const std::vector<std::string>& paths, size_t buf_records, std::string& err, Fn fn) {
+        std::vector<RunFileReader> rd(paths.size());
+        typedef std::pair<uint64_t, uint32_t> Head;  // (minimizer, piece)
+        std::priority_queue<Head, std::vector<Head>, std::greater<Head>> heap;
+        std::vector<Run> cur(paths.size());
+        for (size_t i = 0; i < paths.size(); ++i) {
+            if (!rd[i].open(paths[i], buf_records)) {
+                err = "cannot reopen the temporary file " + paths[i];
+                return false;
+            }
+            if (rd[i].next(cur[i])) heap.emplace(cur[i].mm, (uint32_t)i);
+        }
+        while (!heap.empty()) {
+            const uint32_t i = heap.top().second;
+            heap.pop();
+            if (!fn(cur[i])) return false;
+            if (rd[i].next(cur[i])) heap.emplace(cur[i].mm, i);
+            else if (rd[i].failed) {
+                err = "read error on the temporary file " + paths[i];
+                return false;
+            }
+        }
+        return true;
+    }
+    bool write_piece(const std::vector<Run>& runs, std::string& err) {
+        const std::string name = fresh_name();
+        FILE* f = fopen(name.c_str(), "wb");
+        if (!f) {
+            err = "cannot create the temporary file " + name;
+            return false;
+        }
+        files.push_back(name);
+        const size_t put = fwrite(runs.data(), sizeof(Run), runs.size(), f);
+        if (fclose(f) != 0 || put != runs.size()) {
+            err = "short write on the temporary file " + name;
+            return false;
+        }
+        return true;
+    }
+    // sort the buffered records and write them as one more piece; the buffer comes back empty
+    bool flush(std::vector<Run>& runs, int threads, uint32_t key_bits, size_t buf_records, std::string& err) {
+        if (runs.empty()) return true;
+        parallel_sort_by_key(runs, threads, key_bits, [](const Run& r) { return r.mm; });
+        if (!write_piece(runs, err)) return false;
+        runs.clear();
+        if (files.size() < kMaxPieces) return true;
+        // too many pieces: merge them all into one
+        const std::string name = fresh_name();
+        FILE* f = fopen(name.c_str(), "wb");
+        if (!f) {
+            err = "cannot create the temporary file " + name;
+            return false;
+        }
+        std::vector<Run> out;
+        out.reserve(buf_records);
+        bool wrote = true;
+        const bool ok = merge(files, buf_records, err, [&](const Run& r) {
+            out.push_back(r);
+            if (out.size() == buf_records) {
+                wrote = fwrite(out.data(), sizeof(Run), out.size(), f) == out.size();
+                out.clear();
+            }
+            return wrote;
+        });
+        if (ok && !out.empty()) wrote = fwrite(out.data(), sizeof(Run), out.size(), f) == out.size();
+        const bool closed = fclose(f) == 0;
+        for (const std::string& p : files) ::remove(p.c_str());
+        files.assign(1, name);
+        if (!ok || !wrote || !closed) {
+            if (err.empty()) err = "short write on the temporary file " + name;
+            return false;
+        }
+        return true;
+    }
+};
+
 }  // namespace
 }  // namespace lphq
 
@@ -652,13 +819,13 @@ using namespace lphq;
 
 namespace lphq { void set_last_error(const std::string& s); }  // capi.cpp
 
-static int build_impl(const char* const* records, const size_t* lengths, size_t n_records, int k_, int m_, uint64_t mm_seed, double c, int kind,
-                      int kmer_bits, int threads, int device, const char* out_path, lphq_build_stats* stats) {
+static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, double c, int kind, int kmer_bits, int threads, int device,
+                      const char* tmp_dir, uint64_t max_memory_bytes, const char* out_path, lphq_build_stats* stats) {
     auto fail = [&](int code, const std::string& msg) {
         set_last_error(msg);
         return code;
     };
-    if ((n_records && (!records || !lengths)) || !out_path) return fail(LPHQ_ERR_ARG, "null argument");
+    if (!out_path) return fail(LPHQ_ERR_ARG, "null argument");
     if (kind != LPHQ_PARTITIONED && kind != LPHQ_UNPARTITIONED) return fail(LPHQ_ERR_ARG, "kind must be LPHQ_PARTITIONED or LPHQ_UNPARTITIONED");
     if (kmer_bits != 64 && kmer_bits != 128) return fail(LPHQ_ERR_ARG, "kmer_bits must be 64 or 128");
     // parser_build.cpp:64-68 with constants::max_k of the chosen kmer_t (constants.hpp:16)
@@ -677,67 +844,120 @@ static int build_impl(const char* const* records, const size_t* lengths, size_t 
     const double alpha = 0.94;       // partitioned_mphf.cpp:48
     const uint64_t pthash_seed = 1;  // constants::default_pthash_seed
 
-    // ---- Part 1: super-k-mers, chunked over windows -------------------------------------------------
-    std::vector<uint64_t> rec_off(n_records + 1, 0);
-    for (size_t r = 0; r < n_records; ++r) rec_off[r + 1] = rec_off[r] + lengths[r];
-    struct Chunk { size_t rec; uint64_t wa, wb; };
-    std::vector<Chunk> chunks;
-    const uint64_t CH = 1u << 20;
-    uint64_t nkmers_upper = 0;
-    for (size_t r = 0; r < n_records; ++r) {
-        if (lengths[r] < k) continue;
-        const uint64_t nw = lengths[r] - k + 1;
-        nkmers_upper += nw;
-        for (uint64_t a = 0; a < nw; a += CH) chunks.push_back({r, a, std::min(nw, a + CH)});
-    }
-    std::vector<std::vector<Run>> chunk_runs(chunks.size());
-    parallel_for(chunks.size(), threads, [&](size_t ci) {
-        const Chunk& ch = chunks[ci];
-        chunk_runs[ci].reserve((ch.wb - ch.wa) * 2 / (W + 1) + 16);
-        extract_runs(records[ch.rec], rec_off[ch.rec], ch.wa, ch.wb, k, m, mm_seed, chunk_runs[ci]);
-    });
+    // ---- Part 1: super-k-mers, batch by batch, chunked over windows -------------------------------------
+    // Coordinates are global: base g of the input = base g - (bases of the earlier records) of its record.
+    // With a memory limit the records are sorted and spilled in pieces (external_memory_vector<mm_record_t>, partitioned_mphf.cpp:62-65).
+    const size_t run_cap = max_memory_bytes ? std::max<size_t>(4096, (size_t)(max_memory_bytes / 4 / sizeof(Run))) : ~(size_t)0;
+    const size_t merge_buf = max_memory_bytes ? std::max<size_t>(256, std::min<size_t>(1 << 16, run_cap / (2 * RunSpill::kMaxPieces))) : 0;
+    RunSpill spill;
+    spill.dir = (tmp_dir && *tmp_dir) ? tmp_dir : ".";
+    if (max_memory_bytes) (void)::mkdir(spill.dir.c_str(), 0777);  // essentials::create_directory, parser_build.cpp:76
+    std::string err;
     std::vector<Run> runs;
+    uint64_t nkmers = 0, n_super_kmers = 0, n_records = 0, base = 0;
     {
-        size_t total = 0;
-        for (auto& v : chunk_runs) total += v.size();
-        runs.reserve(total);
-        for (size_t ci = 0; ci < chunks.size(); ++ci) {
-            for (const Run& r : chunk_runs[ci]) {
-                // a super-k-mer cut by a chunk boundary: same minimizer position, contiguous windows
-                if (!runs.empty() && runs.back().q == r.q && runs.back().first + runs.back().size == r.first && ci > 0 &&
-                    chunks[ci].rec == chunks[ci - 1].rec)
-                    runs.back().size += r.size;
-                else
-                    runs.push_back(r);
+        const char* const* records = nullptr;
+        const size_t* lengths = nullptr;
+        size_t nb = 0;
+        int rc;
+        std::vector<uint64_t> rec_off;
+        struct Chunk { size_t rec; uint64_t wa, wb; };
+        std::vector<Chunk> chunks;
+        std::vector<std::vector<Run>> chunk_runs;
+        while ((rc = src.next(0, records, lengths, nb)) > 0) {
+            rec_off.assign(nb + 1, base);
+            for (size_t r = 0; r < nb; ++r) rec_off[r + 1] = rec_off[r] + lengths[r];
+            chunks.clear();
+            const uint64_t CH = 1u << 20;
+            for (size_t r = 0; r < nb; ++r) {
+                if (lengths[r] < k) continue;
+                const uint64_t nw = lengths[r] - k + 1;
+                for (uint64_t a = 0; a < nw; a += CH) chunks.push_back({r, a, std::min(nw, a + CH)});
             }
-            std::vector<Run>().swap(chunk_runs[ci]);
+            chunk_runs.assign(chunks.size(), std::vector<Run>());
+            parallel_for(chunks.size(), threads, [&](size_t ci) {
+                const Chunk& ch = chunks[ci];
+                chunk_runs[ci].reserve((ch.wb - ch.wa) * 2 / (W + 1) + 16);
+                extract_runs(records[ch.rec], rec_off[ch.rec], ch.wa, ch.wb, k, m, mm_seed, chunk_runs[ci]);
+            });
+            size_t total = runs.size();
+            for (auto& v : chunk_runs) total += v.size();
+            if (runs.capacity() < total) runs.reserve(std::min(run_cap, std::max(total, runs.capacity() * 2)));
+            for (size_t ci = 0; ci < chunks.size(); ++ci) {
+                bool first_of_chunk = true;
+                for (const Run& r : chunk_runs[ci]) {
+                    // a super-k-mer cut by a chunk boundary: same minimizer position, contiguous windows (a chunk never begins a
+                    // batch's first record elsewhere than at its first window, so the piece before is still in `runs`)
+                    if (first_of_chunk && !runs.empty() && runs.back().q == r.q && runs.back().first + runs.back().size == r.first && ci > 0 &&
+                        chunks[ci].rec == chunks[ci - 1].rec) {
+                        runs.back().size += r.size;
+                    } else {
+                        if (runs.size() >= run_cap) {  // (never between the two pieces of a cut super-k-mer: that case is the branch above)
+                            const Run keep = runs.back();  // the last one may still grow at the next chunk boundary
+                            runs.pop_back();
+                            for (const Run& x : runs) nkmers += x.size;
+                            n_super_kmers += runs.size();
+                            if (!spill.flush(runs, threads, 2 * m, merge_buf, err)) return fail(LPHQ_ERR_IO, err);
+                            runs.push_back(keep);
+                        }
+                        runs.push_back(r);
+                    }
+                    first_of_chunk = false;
+                }
+                std::vector<Run>().swap(chunk_runs[ci]);
+            }
+            base = rec_off[nb];
+            n_records += nb;
         }
+        if (rc < 0) return fail(LPHQ_ERR_IO, "the record source failed during the first pass");
     }
+    for (const Run& x : runs) nkmers += x.size;
+    n_super_kmers += runs.size();
     lap("part 1: super-k-mer runs");
-    uint64_t nkmers = 0;
-    for (const Run& r : runs) nkmers += r.size;
-    (void)nkmers_upper;
-    const uint64_t n_super_kmers = runs.size();
 
     // ---- Part 2: classify (src/minimizer.cpp:5-50) + PTHash over the distinct minimizers -------------
-    parallel_sort_by_key(runs, threads, 2 * m, [](const Run& r) { return r.mm; });
-    lap("part 2: sort runs by minimizer");
     std::vector<Triplet> uniq;
     std::vector<uint64_t> uniq_mm;
     std::vector<std::pair<uint64_t, uint32_t>> colliding;  // (first window, size) of every super-k-mer of a repeated minimizer
-    uniq.reserve(runs.size());
-    uniq_mm.reserve(runs.size());
-    for (size_t i = 0; i < runs.size();) {
-        size_t j = i + 1;
-        while (j < runs.size() && runs[j].mm == runs[i].mm) ++j;
-        uniq_mm.push_back(runs[i].mm);
-        if (j - i == 1) {
-            uniq.push_back({0, (uint8_t)(runs[i].q - runs[i].first), (uint8_t)runs[i].size});
+    {
+        // records arrive ascending by minimizer; a minimizer seen once keeps (offset, size), one seen more often sends all its super-k-mers
+        // to the fallback
+        Run prev{0, 0, 0, 0, 0};
+        bool have = false, repeated = false;
+        auto close_group = [&] {
+            if (!have) return;
+            uniq_mm.push_back(prev.mm);
+            if (repeated) uniq.push_back({0, 0, 0});
+            else uniq.push_back({0, (uint8_t)(prev.q - prev.first), (uint8_t)prev.size});
+        };
+        auto feed = [&](const Run& r) {
+            if (have && r.mm == prev.mm) {
+                if (!repeated) colliding.emplace_back(prev.first, prev.size);
+                repeated = true;
+                colliding.emplace_back(r.first, r.size);
+            } else {
+                close_group();
+                prev = r;
+                have = true;
+                repeated = false;
+            }
+            return true;
+        };
+        if (spill.files.empty()) {
+            parallel_sort_by_key(runs, threads, 2 * m, [](const Run& r) { return r.mm; });
+            lap("part 2: sort runs by minimizer");
+            uniq.reserve(runs.size());
+            uniq_mm.reserve(runs.size());
+            for (const Run& r : runs) feed(r);
         } else {
-            uniq.push_back({0, 0, 0});
-            for (size_t t = i; t < j; ++t) colliding.emplace_back(runs[t].first, runs[t].size);
+            if (!spill.flush(runs, threads, 2 * m, merge_buf, err)) return fail(LPHQ_ERR_IO, err);
+            std::vector<Run>().swap(runs);
+            if (verbose) fprintf(stderr, "[lphq_build] %zu sorted pieces of super-k-mer records in %s\n", spill.files.size(), spill.dir.c_str());
+            if (!RunSpill::merge(spill.files, merge_buf, err, feed)) return fail(LPHQ_ERR_IO, err);
+            for (const std::string& f : spill.files) ::remove(f.c_str());
+            spill.files.clear();
         }
-        i = j;
+        close_group();
     }
     std::vector<Run>().swap(runs);
     const uint64_t D = uniq.size();
@@ -751,7 +971,6 @@ static int build_impl(const char* const* records, const size_t* lengths, size_t 
     x.mm_seed = mm_seed;
     x.nkmers = nkmers;
     x.distinct_minimizers = D;
-    std::string err;
     {
         std::vector<uint64_t> hashes(D);
         parallel_for((D + 65535) / 65536, threads, [&](size_t t) {
@@ -857,24 +1076,39 @@ static int build_impl(const char* const* records, const size_t* lengths, size_t 
 
     // ---- Part 4: fallback PTHash over the k-mers of repeated minimizers, in input order ----------------
     {
+        // second pass over the input (partitioned_mphf.cpp:110-130)
         std::sort(colliding.begin(), colliding.end());
         std::vector<uint64_t> fh;
-        size_t rec = 0;
-        for (const auto& cw : colliding) {
-            while (rec_off[rec + 1] <= cw.first) ++rec;  // cw.first < total bases, so this stops
-            const char* s = records[rec] + (cw.first - rec_off[rec]);
-            u128 km = 0;
-            const u128 km_mask = (((u128)1) << (2 * k)) - 1;
-            for (uint32_t j = 0; j < k - 1; ++j) km = (km << 2) | (u128)(nt4((uint8_t)s[j]) & 3);
-            for (uint32_t w = 0; w < cw.second; ++w) {
-                km = ((km << 2) | (u128)(nt4((uint8_t)s[w + k - 1]) & 3)) & km_mask;
-                // fallback_hasher, include/constants.hpp:56-70
-                uint64_t h;
-                if (kmer_bits == 64) h = murmur64a_u64((uint64_t)km, pthash_seed);
-                else h = murmur64a_u64((uint64_t)km, pthash_seed) ^ murmur64a_u64((uint64_t)(km >> 64), ~pthash_seed);
-                fh.push_back(h);
+        const u128 km_mask = (((u128)1) << (2 * k)) - 1;
+        size_t ci = 0;
+        uint64_t at = 0;  // global coordinate of the current record's first base
+        const char* const* records = nullptr;
+        const size_t* lengths = nullptr;
+        size_t nb = 0;
+        int rc = 0;
+        while (ci < colliding.size() && (rc = src.next(1, records, lengths, nb)) > 0) {
+            for (size_t r = 0; r < nb && ci < colliding.size(); ++r) {
+                const uint64_t end = at + lengths[r];
+                for (; ci < colliding.size() && colliding[ci].first < end; ++ci) {
+                    const auto& cw = colliding[ci];
+                    if (cw.first < at || cw.first + cw.second + k - 1 > end) return fail(LPHQ_ERR_IO, "the second pass over the input does not match the first");
+                    const char* s = records[r] + (cw.first - at);
+                    u128 km = 0;
+                    for (uint32_t j = 0; j < k - 1; ++j) km = (km << 2) | (u128)(nt4((uint8_t)s[j]) & 3);
+                    for (uint32_t w = 0; w < cw.second; ++w) {
+                        km = ((km << 2) | (u128)(nt4((uint8_t)s[w + k - 1]) & 3)) & km_mask;
+                        // fallback_hasher, include/constants.hpp:56-70
+                        uint64_t h;
+                        if (kmer_bits == 64) h = murmur64a_u64((uint64_t)km, pthash_seed);
+                        else h = murmur64a_u64((uint64_t)km, pthash_seed) ^ murmur64a_u64((uint64_t)(km >> 64), ~pthash_seed);
+                        fh.push_back(h);
+                    }
+                }
+                at = end;
             }
         }
+        if (rc < 0) return fail(LPHQ_ERR_IO, "the record source failed during the second pass");
+        if (ci != colliding.size()) return fail(LPHQ_ERR_IO, "the second pass over the input is shorter than the first");
         if (!phf_build(x.fallback_kmer_order, fh, pthash_seed, c, alpha, threads, device, err)) return fail(LPHQ_ERR_FORMAT, err);
     }
 
@@ -1009,13 +1243,32 @@ extern "C" int lphq_build_pthash(const char* const* records, const size_t* lengt
     return LPHQ_OK;
 }
 
+static int build_memory(const char* const* records, const size_t* lengths, size_t n_records, int k, int m, uint64_t mm_seed, double c, int kind,
+                        int kmer_bits, int threads, int device, const char* out_path, lphq_build_stats* stats) {
+    if (n_records && (!records || !lengths)) {
+        set_last_error("null argument");
+        return LPHQ_ERR_ARG;
+    }
+    MemorySource src(records, lengths, n_records);
+    return build_impl(src, k, m, mm_seed, c, kind, kmer_bits, threads, device, nullptr, 0, out_path, stats);
+}
+
 extern "C" int lphq_build(const char* const* records, const size_t* lengths, size_t n_records, int k, int m, uint64_t mm_seed, double c, int kind,
                           int kmer_bits, int threads, const char* out_path, lphq_build_stats* stats) {
-    return build_impl(records, lengths, n_records, k, m, mm_seed, c, kind, kmer_bits, threads, -1, out_path, stats);
+    return build_memory(records, lengths, n_records, k, m, mm_seed, c, kind, kmer_bits, threads, -1, out_path, stats);
+}
+
+extern "C" int lphq_build_stream(lphq_record_source next, void* ctx, int k, int m, uint64_t mm_seed, double c, int kind, int kmer_bits, int threads, int device,
+                                 const char* tmp_dir, uint64_t max_memory_bytes, const char* out_path, lphq_build_stats* stats) {
+    if (!next) {
+        set_last_error("null argument");
+        return LPHQ_ERR_ARG;
+    }
+    CallbackSource src(next, ctx);
+    return build_impl(src, k, m, mm_seed, c, kind, kmer_bits, threads, device < 0 ? -1 : device, tmp_dir, max_memory_bytes, out_path, stats);
 }
 
 extern "C" int lphq_build_device(const char* const* records, const size_t* lengths, size_t n_records, int k, int m, uint64_t mm_seed, double c, int kind,
                                  int kmer_bits, int threads, int device, const char* out_path, lphq_build_stats* stats) {
-    if (device < 0) return build_impl(records, lengths, n_records, k, m, mm_seed, c, kind, kmer_bits, threads, -1, out_path, stats);
-    return build_impl(records, lengths, n_records, k, m, mm_seed, c, kind, kmer_bits, threads, device, out_path, stats);
+    return build_memory(records, lengths, n_records, k, m, mm_seed, c, kind, kmer_bits, threads, device < 0 ? -1 : device, out_path, stats);
 }

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <future>
 #include <iostream>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -513,12 +514,65 @@ int query_main(int kind, int argc, char** argv) {
     return 0;
 }
 
+// one pointer and length per record of a batch (the batch is slid together first: pieces of the parallel reader may split a record)
+void batch_pointers(lphq::FastxBatch& b, std::vector<const char*>& ptrs, std::vector<size_t>& lens) {
+    b.compact();
+    const size_t n_recs = b.lens.size();
+    ptrs.resize(n_recs);
+    lens.resize(n_recs);
+    size_t si = 0, so = 0;
+    for (size_t i = 0; i < n_recs; ++i) {
+        while (si < b.segs.size() && so == b.segs[si].n) {
+            ++si;
+            so = 0;
+        }
+        lens[i] = (size_t)b.lens[i];
+        ptrs[i] = si < b.segs.size() ? b.segs[si].p + so : "";
+        so += lens[i];
+    }
+}
+
+// lphq_record_source over a FASTA / FASTQ file: batches of about batch_bases bases, the file reopened for every pass (the reference opens it
+// twice as well, src/partitioned_mphf.cpp:66 and :118)
+struct FileRecordSource {
+    std::string path;
+    int threads = 1;
+    size_t batch_bases = ~(size_t)0;
+    int pass = -1;
+    std::unique_ptr<lphq::FastxBatchReader> rd;
+    lphq::FastxBatch batch;
+    std::vector<const char*> ptrs;
+    std::vector<size_t> lens;
+    // the next batch of `pass` into ptrs / lens: 1, 0 at the end of the file, -1 on error
+    int advance(int want_pass) {
+        if (pass != want_pass) {
+            rd.reset(new lphq::FastxBatchReader(path.c_str(), std::max(1, threads)));
+            pass = want_pass;
+        }
+        if (!rd->ok()) return -1;
+        if (!rd->next(batch, batch_bases)) return rd->ok() ? 0 : -1;
+        if (!rd->ok()) return -1;
+        batch_pointers(batch, ptrs, lens);
+        return 1;
+    }
+    static int next(void* ctx, int pass, const char* const** records, const size_t** lengths, size_t* n_records) {
+        FileRecordSource* s = (FileRecordSource*)ctx;
+        const int rc = s->advance(pass);
+        if (rc <= 0) return rc;
+        *records = s->ptrs.data();
+        *lengths = s->lens.data();
+        *n_records = s->ptrs.size();
+        return 1;
+    }
+};
+
 int build_main(int kind, int argc, char** argv) {
-    Args a = parse(argc, argv, {"-i", "-k", "-m", "-s", "-t", "-o", "-d", "-c", "--max-memory", "--kmer-bits", "--device"}, {"--check", "--verbose", "--cpu"});
+    Args a = parse(argc, argv, {"-i", "-k", "-m", "-s", "-t", "-o", "-d", "-c", "--max-memory", "--max-memory-mb", "--kmer-bits", "--device"},
+                   {"--check", "--verbose", "--cpu"});
     if (a.help || a.bad || !a.get("-i") || !a.get("-k") || !a.get("-m")) {
         std::cerr << "Usage: " << argv[0]
                   << " [-h,--help] -i input_filename -k k -m m [-s seed] [-t threads] [-o output_filename] [-d tmp_dirname] [-c c] "
-                     "[--max-memory max-memory] [--check] [--verbose] [--kmer-bits 64|128] [--device N] [--cpu]\n";
+                     "[--max-memory GB | --max-memory-mb MB] [--check] [--verbose] [--kmer-bits 64|128] [--device N] [--cpu]\n";
         if (!a.help) std::cerr << "Unable to parse the arguments\n";
         return 2;  // ParseError -> 2, src/build.cpp:14-16
     }
@@ -542,52 +596,50 @@ int build_main(int kind, int argc, char** argv) {
         std::cerr << "m cannot be larger than k" << std::endl;
         return 3;
     }
-    // src/parser_build.cpp:74-86: -d creates the directory, --max-memory is capped at 255 (GB).  Construction here is in-memory
-    // (no external-memory sort, include/external_memory_vector.hpp), so both are accepted, checked and otherwise unused -- said
-    // out loud rather than silently.
-    if (a.get("-d")) {
-        (void)::mkdir(a.get("-d")->c_str(), 0777);  // essentials::create_directory
-        std::cerr << "[note] -d " << *a.get("-d") << ": ignored (in-memory construction, no temporary files)" << std::endl;
-    }
+    // src/parser_build.cpp:74-86: -d creates the directory, --max-memory is capped at 255 (GB).  With a limit the input is streamed in
+    // batches and the super-k-mer records are sorted in pieces spilled to -d (lphq_build_stream, the reference's external_memory_vector);
+    // without one (the reference would assume 8 GB) the input is read whole and nothing touches the disk.  --max-memory-mb: the same in MB.
+    const std::string tmp_dir = a.get("-d") ? *a.get("-d") : ".";  // constants::default_tmp_dirname
+    if (a.get("-d")) (void)::mkdir(tmp_dir.c_str(), 0777);         // essentials::create_directory
+    uint64_t max_memory = 0;
     if (a.get("--max-memory")) {
-        if (std::strtoull(a.get("--max-memory")->c_str(), nullptr, 10) > 255) {
+        const uint64_t gb = std::strtoull(a.get("--max-memory")->c_str(), nullptr, 10);
+        if (gb > 255) {
             std::cerr << "The maximum allowed amount of ram is 255GB" << std::endl;
             return 3;
         }
-        std::cerr << "[note] --max-memory " << *a.get("--max-memory") << ": ignored (in-memory construction)" << std::endl;
+        max_memory = gb << 30;
     }
+    if (a.get("--max-memory-mb")) max_memory = std::strtoull(a.get("--max-memory-mb")->c_str(), nullptr, 10) << 20;
+    const bool streamed = max_memory != 0;
     if (c > 10.0 || c < 3.0) {
         std::cerr << "3.0 <= c <= 10.0" << std::endl;
         return 3;
     }
     auto t0 = std::chrono::high_resolution_clock::now();
-    lphq::FastxBatchReader rd(input.c_str(), std::max(1, threads));
-    if (!rd.ok()) {
-        std::cerr << "Unable to open the input file " << input << "\n";
-        return 4;  // the reference throws std::runtime_error here (partitioned_mphf.cpp:66-67)
-    }
-    lphq::FastxBatch whole;  // the whole input as one batch: its segments stay valid while `rd` lives
-    (void)rd.next(whole, ~(size_t)0);
-    if (!rd.ok()) {
-        std::cerr << "[Error] out of host memory while reading " << input << "\n";
-        return 4;
-    }
-    whole.compact();  // one pointer per record below: records must be contiguous (pieces of the parallel reader may split them)
-    const size_t n_recs = whole.lens.size();
-    std::vector<const char*> ptrs(n_recs);
-    std::vector<size_t> lens(n_recs);
+    FileRecordSource file;
+    file.path = input;
+    file.threads = threads;
+    // a streamed batch: an eighth of the limit (the reader keeps two arenas), within [1 MiB, 256 MiB]
+    if (streamed) file.batch_bases = (size_t)std::min<uint64_t>(256u << 20, std::max<uint64_t>(1u << 20, max_memory / 8));
+    std::vector<const char*> ptrs;  // in-memory construction: the whole input as one batch, valid while file.rd lives
+    std::vector<size_t> lens;
     {
-        size_t si = 0, so = 0;
-        for (size_t i = 0; i < n_recs; ++i) {
-            while (si < whole.segs.size() && so == whole.segs[si].n) {
-                ++si;
-                so = 0;
-            }
-            lens[i] = (size_t)whole.lens[i];
-            ptrs[i] = si < whole.segs.size() ? whole.segs[si].p + so : "";
-            so += lens[i];
+        lphq::FastxBatchReader probe(input.c_str(), 1);
+        if (!probe.ok()) {
+            std::cerr << "Unable to open the input file " << input << "\n";
+            return 4;  // the reference throws std::runtime_error here (partitioned_mphf.cpp:66-67)
         }
     }
+    if (!streamed) {
+        if (file.advance(0) < 0) {
+            std::cerr << "[Error] out of host memory while reading " << input << "\n";
+            return 4;
+        }
+        ptrs = file.ptrs;
+        lens = file.lens;
+    }
+    const size_t n_recs = ptrs.size();
     std::string out = a.get("-o") ? *a.get("-o") : "";
     const bool temp_out = out.empty();
     if (temp_out) out = "/tmp/lphash_build_" + std::to_string((long)getpid()) + ".lph";
@@ -600,8 +652,13 @@ int build_main(int kind, int argc, char** argv) {
         if (hipGetDeviceCount(&ndev) != hipSuccess || build_device >= ndev) build_device = -1;
     }
     if (verbose) std::cerr << "PTHash pilot search on " << (build_device >= 0 ? "GPU " + std::to_string(build_device) : std::string("the CPU")) << "\n";
-    if (lphq_build_device(ptrs.data(), lens.data(), n_recs, k, m, seed, c, kind, kmer_bits, threads, build_device, out.c_str(), &st) != LPHQ_OK) {
+    if (verbose && streamed) std::cerr << "Memory limit " << (max_memory >> 20) << " MB: input in batches of " << (file.batch_bases >> 20) << " Mbases, temporary files in " << tmp_dir << "\n";
+    const int brc = streamed ? lphq_build_stream(&FileRecordSource::next, &file, k, m, seed, c, kind, kmer_bits, threads, build_device, tmp_dir.c_str(), max_memory,
+                                                 out.c_str(), &st)
+                             : lphq_build_device(ptrs.data(), lens.data(), n_recs, k, m, seed, c, kind, kmer_bits, threads, build_device, out.c_str(), &st);
+    if (brc != LPHQ_OK) {
         std::cerr << "[Error] " << lphq_last_error() << "\n";
+        if (temp_out) std::remove(out.c_str());
         return 4;
     }
     // partitioned_mphf.cpp:138-144 (the last field is the serialized size: the reference's num_bits() adds
@@ -628,31 +685,43 @@ int build_main(int kind, int argc, char** argv) {
         std::vector<uint64_t> population((st.num_kmers + 63) / 64, 0);
         bool good = true;
         std::vector<uint64_t> a_codes, b_codes;
-        for (size_t i = 0; i < n_recs && good; ++i) {
-            if (lens[i] < (size_t)k) continue;
-            const size_t nw = lens[i] - k + 1;
-            a_codes.resize(nw);
-            b_codes.resize(nw);
-            size_t na = 0, nb = 0;
-            if (lphq_query_contig(idx, ptrs[i], lens[i], 0, a_codes.data(), nw, &na) != LPHQ_OK ||
-                lphq_query_contig(idx, ptrs[i], lens[i], 1, b_codes.data(), nw, &nb) != LPHQ_OK) {
-                std::cerr << "[Error] " << lphq_last_error() << "\n";
-                good = false;
-                break;
-            }
-            for (size_t j = 0; j < na && good; ++j) {
-                const uint64_t hsh = a_codes[j];
-                if (hsh >= st.num_kmers) {
-                    std::cerr << "[Error] overflow : " << hsh << " > " << st.num_kmers << std::endl;
+        auto check_records = [&](const std::vector<const char*>& ptrs, const std::vector<size_t>& lens) {
+            for (size_t i = 0; i < ptrs.size() && good; ++i) {
+                if (lens[i] < (size_t)k) continue;
+                const size_t nw = lens[i] - k + 1;
+                a_codes.resize(nw);
+                b_codes.resize(nw);
+                size_t na = 0, nb = 0;
+                if (lphq_query_contig(idx, ptrs[i], lens[i], 0, a_codes.data(), nw, &na) != LPHQ_OK ||
+                    lphq_query_contig(idx, ptrs[i], lens[i], 1, b_codes.data(), nw, &nb) != LPHQ_OK) {
+                    std::cerr << "[Error] " << lphq_last_error() << "\n";
                     good = false;
-                } else if ((population[hsh >> 6] >> (hsh & 63)) & 1) {
-                    std::cerr << "[Error] collision at position (hash) : " << hsh << std::endl;
+                    break;
+                }
+                for (size_t j = 0; j < na && good; ++j) {
+                    const uint64_t hsh = a_codes[j];
+                    if (hsh >= st.num_kmers) {
+                        std::cerr << "[Error] overflow : " << hsh << " > " << st.num_kmers << std::endl;
+                        good = false;
+                    } else if ((population[hsh >> 6] >> (hsh & 63)) & 1) {
+                        std::cerr << "[Error] collision at position (hash) : " << hsh << std::endl;
+                        good = false;
+                    } else
+                        population[hsh >> 6] |= 1ULL << (hsh & 63);
+                }
+                if (good && (na != nb || std::memcmp(a_codes.data(), b_codes.data(), na * 8) != 0)) {
+                    std::cerr << "[Error] different hashes, maybe there were some Ns in the input (not supported as of now)\n";
                     good = false;
-                } else
-                    population[hsh >> 6] |= 1ULL << (hsh & 63);
+                }
             }
-            if (good && (na != nb || std::memcmp(a_codes.data(), b_codes.data(), na * 8) != 0)) {
-                std::cerr << "[Error] different hashes, maybe there were some Ns in the input (not supported as of now)\n";
+        };
+        if (!streamed) {
+            check_records(ptrs, lens);
+        } else {  // one more pass over the file, a batch at a time
+            int src_rc;
+            while (good && (src_rc = file.advance(2)) > 0) check_records(file.ptrs, file.lens);
+            if (good && src_rc < 0) {
+                std::cerr << "[Error] cannot re-read " << input << "\n";
                 good = false;
             }
         }
@@ -741,22 +810,10 @@ int ptbb_build_main(int argc, char** argv) {
         std::cerr << "[Error] out of host memory while reading " << input << "\n";
         return 4;
     }
-    whole.compact();
-    const size_t n_recs = whole.lens.size();
-    std::vector<const char*> ptrs(n_recs);
-    std::vector<size_t> lens(n_recs);
-    {
-        size_t si = 0, so = 0;
-        for (size_t i = 0; i < n_recs; ++i) {
-            while (si < whole.segs.size() && so == whole.segs[si].n) {
-                ++si;
-                so = 0;
-            }
-            lens[i] = (size_t)whole.lens[i];
-            ptrs[i] = si < whole.segs.size() ? whole.segs[si].p + so : "";
-            so += lens[i];
-        }
-    }
+    std::vector<const char*> ptrs;
+    std::vector<size_t> lens;
+    batch_pointers(whole, ptrs, lens);
+    const size_t n_recs = ptrs.size();
     if (!a.get("-p") && !a.get("-b")) {  // nothing to build: the k-mer count alone (ptbb_build.cpp:52-68), all other fields empty
         uint64_t total = 0;
         for (size_t i = 0; i < n_recs; ++i) {

@@ -3,6 +3,7 @@
 // -fsanitize=address,undefined (tests/test_host_cpu.py::test_host_sources_under_sanitizers).  The two symbols that live in the HIP
 // part of the library are stubbed: the GPU pilot search reports "unavailable", errors go to a string.
 //   san_host build <fasta> <k> <m> <kind> <kmer_bits> <threads> <out.lph>     build with the product builder (CPU search)
+//   san_host build_stream <fasta> <k> <m> <kind> <kmer_bits> <threads> <out.lph> <max_memory_bytes> <tmp_dir>   lphq_build_stream, small batches
 //   san_host load  <file.lph> <kind> <kmer_bits>                             parse + cross-check + flat image
 //   san_host fuzz  <file.lph> <kind> <kmer_bits> <n> <seed>                  n corrupted copies through the loader
 #include <cstdio>
@@ -49,9 +50,52 @@ static int load(const std::vector<uint8_t>& buf, int kind, int bits, bool verbos
     return 0;
 }
 
+struct Source {  // lphq_record_source over a file: batches of ~20,000 bases, the file reopened for the second pass
+    const char* path;
+    int threads, pass = -1;
+    lphq::FastxBatchReader* rd = nullptr;
+    lphq::FastxBatch b;
+    std::vector<const char*> ptrs;
+    std::vector<size_t> lens;
+    ~Source() { delete rd; }
+    static int next(void* ctx, int pass, const char* const** records, const size_t** lengths, size_t* n) {
+        Source* s = (Source*)ctx;
+        if (s->pass != pass) {
+            delete s->rd;
+            s->rd = new lphq::FastxBatchReader(s->path, s->threads, nullptr, nullptr, 4096);
+            s->pass = pass;
+        }
+        if (!s->rd->ok()) return -1;
+        if (!s->rd->next(s->b, 20000)) return 0;
+        s->b.compact();
+        s->ptrs.resize(s->b.lens.size());
+        s->lens.resize(s->b.lens.size());
+        size_t so = 0;
+        for (size_t i = 0; i < s->lens.size(); ++i) {
+            s->lens[i] = (size_t)s->b.lens[i];
+            s->ptrs[i] = s->b.segs.empty() ? "" : s->b.segs[0].p + so;
+            so += s->lens[i];
+        }
+        *records = s->ptrs.data();
+        *lengths = s->lens.data();
+        *n = s->lens.size();
+        return 1;
+    }
+};
+
 int main(int argc, char** argv) {
     if (argc < 2) return 64;
     const std::string cmd = argv[1];
+    if (cmd == "build_stream" && argc == 11) {
+        Source src;
+        src.path = argv[2];
+        src.threads = atoi(argv[7]);
+        lphq_build_stats st;
+        const int rc = lphq_build_stream(&Source::next, &src, atoi(argv[3]), atoi(argv[4]), 42, 3.0, atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), -1, argv[10],
+                                         strtoull(argv[9], nullptr, 10), argv[8], &st);
+        if (rc != LPHQ_OK) fprintf(stderr, "build failed (%d): %s\n", rc, lphq::g_err.c_str());
+        return rc == LPHQ_OK ? 0 : 4;
+    }
     if (cmd == "build" && argc == 9) {
         lphq::FastxBatchReader rd(argv[2], atoi(argv[7]), nullptr, nullptr, 4096);
         if (!rd.ok()) return 3;

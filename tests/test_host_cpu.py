@@ -12,7 +12,7 @@ import pytest
 import lphash_amd as L
 import orc
 from lphash_amd import _lib
-from util import random_records
+from util import dedup_records, random_records
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -321,6 +321,84 @@ def test_cli_build_from_long_records_with_threads(tmp_path):
     assert out.read_bytes() == ref.read_bytes()
 
 
+@pytest.mark.parametrize("k,m,bits,kind", [(31, 20, 64, 0), (31, 15, 64, 1), (63, 20, 128, 0)])
+def test_streamed_build_with_a_memory_limit_writes_the_same_file(tmp_path, k, m, bits, kind):
+    """lphq_build_stream (the reference's two passes over the input + external_memory_vector, src/partitioned_mphf.cpp:58-130): whatever the batch
+    boundaries and the memory limit -- no spill, a few sorted pieces, more than 64 pieces (merged on the way) -- the bytes are those of the in-memory
+    build (itself byte-identical to the oracle's builder), the statistics too, and the temporary files are gone."""
+    recs = dedup_records(random_records(99 + k, 60, max(k - 2, 1), 110_000), k)
+    recs = recs[:7] + [b"", b"ACGT"] + recs[7:]  # empty and too-short records inside a batch and at batch boundaries
+    want_path, got_path, spill = str(tmp_path / "mem.lph"), str(tmp_path / "str.lph"), tmp_path / "spill"
+    want_stats = L.build(recs, k, m, want_path, kind=kind, kmer_bits=bits, threads=4)
+    want = open(want_path, "rb").read()
+    for per_batch, limit in ((len(recs), 0), (5, 0), (1, 1 << 20), (9, 1 << 22), (len(recs), 1 << 18)):
+        calls = []
+
+        def batches():
+            calls.append(1)
+            for i in range(0, len(recs), per_batch):
+                yield recs[i:i + per_batch]
+
+        stats = L.build_stream(batches, k, m, got_path, kind=kind, kmer_bits=bits, threads=4, tmp_dir=str(spill), max_memory_bytes=limit)
+        assert open(got_path, "rb").read() == want, (per_batch, limit)
+        assert stats == want_stats
+        assert len(calls) == (2 if stats["colliding_super_kmers"] else 1)  # the second pass collects the k-mers of repeated minimizers, if any
+        assert not spill.exists() or os.listdir(spill) == []
+    # > 64 pieces at the smallest limit: 32-byte records, pieces of max(4096, limit / 4 / 32) records
+    if (k, m) == (31, 20):
+        assert want_stats["num_super_kmers"] > 64 * max(4096, (1 << 18) // 4 // 32)
+
+
+def test_streamed_build_errors(tmp_path):
+    recs = dedup_records(random_records(5, 12, 200, 4000), 31)
+    out = str(tmp_path / "x.lph")
+
+    def failing():
+        yield recs[:3]
+        raise IOError("disk on fire")
+
+    with pytest.raises(IOError):
+        L.build_stream(failing, 31, 20, out, kmer_bits=64)
+    # a source that does not replay the same input: the second pass cannot find the windows of the first
+    repeated = [recs[0], recs[0][:500]] + recs[1:]  # a repeated stretch -> repeated minimizers -> the second pass has work to do
+    state2 = {"n": 0}
+
+    def repeated_then_short():
+        state2["n"] += 1
+        yield repeated if state2["n"] == 1 else [r[:40] for r in repeated]
+
+    with pytest.raises(L.LphqError) as e:
+        L.build_stream(repeated_then_short, 31, 20, out, kmer_bits=64)
+    assert e.value.code == _lib.ERR_IO
+    with pytest.raises(L.LphqError) as e:  # an unwritable temporary directory
+        big = dedup_records(random_records(6, 8, 20_000, 40_000), 31)  # more super-k-mers than the smallest piece (4096 records)
+        L.build_stream(lambda: iter([big]), 31, 20, out, kmer_bits=64, tmp_dir="/proc/no/such/dir", max_memory_bytes=1 << 12)
+    assert e.value.code == _lib.ERR_IO and "temporary file" in str(e.value)
+
+
+def test_cli_build_with_max_memory(tmp_path):
+    """`lphash build-p|build-u -d tmp --max-memory-mb N` (parser_build.cpp:74-88: -d is created, the limit switches to construction in external
+    memory): same file and same CSV line as without a limit; --check (one more pass over the file, batch by batch) passes where a GPU is present."""
+    exe = os.path.join(ROOT, "lphash_amd", "lphash")
+    recs = dedup_records(random_records(4242, 40, 20, 100_000), 31)
+    fa = tmp_path / "in.fa"
+    with open(fa, "wb") as f:
+        for i, r in enumerate(recs):
+            f.write(b">c%d\n" % i)
+            for j in range(0, len(r), 61):
+                f.write(r[j:j + 61] + b"\n")
+    for sub in ("build-p", "build-u"):
+        a, b, d = tmp_path / "a.lph", tmp_path / "b.lph", tmp_path / "ext"
+        base = [exe, sub, "-i", str(fa), "-k", "31", "-m", "20", "--kmer-bits", "64", "--cpu", "-t", "4"]
+        r1 = subprocess.run(base + ["-o", str(a)], capture_output=True, text=True)
+        r2 = subprocess.run(base + ["-o", str(b), "-d", str(d), "--max-memory-mb", "1", "--verbose"], capture_output=True, text=True)
+        assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr, r2.stderr)
+        assert a.read_bytes() == b.read_bytes() and r1.stdout == r2.stdout
+        assert "Memory limit 1 MB" in r2.stderr and d.is_dir() and os.listdir(d) == []
+    r = subprocess.run(base + ["--max-memory", "256"], capture_output=True, text=True)
+    assert r.returncode == 3 and "The maximum allowed amount of ram is 255GB" in r.stderr
+
+
 KSEQ_DUMP = os.path.join(ROOT, "oracle", "_ref", "kseq_dump")
 
 
@@ -442,6 +520,11 @@ def test_host_sources_under_sanitizers(tmp_path):
             assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
         ref = tmp_path / "ref.lph"
         L.build(recs, k, m, str(ref), kind=kind, kmer_bits=bits, threads=2)
+        assert out.read_bytes() == ref.read_bytes()
+        # the streamed builder: small batches, sorted pieces spilled and merged
+        r = subprocess.run([exe, "build_stream", str(fa), str(k), str(m), str(kind), str(bits), "4", str(out), str(1 << 12), str(tmp_path / "spill")],
+                           capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
         assert out.read_bytes() == ref.read_bytes()
         for cmd in (["load", str(out), str(kind), str(bits)], ["fuzz", str(out), str(kind), str(bits), "150", str(k)]):
             r = subprocess.run([exe] + cmd, capture_output=True, text=True, env=env)
