@@ -28,6 +28,7 @@
 #include <unistd.h>
 
 #include "../../include/lphq.h"
+#include "extract.hpp"
 #include "lph_format.hpp"
 #include "search.hpp"
 
@@ -260,28 +261,39 @@ inline uint64_t bucket_of(const SinglePhf& f, uint64_t hash) {  // skew_bucketer
 }
 
 void dict_encode(Dictionary& d, const uint64_t* v, uint64_t n) {  // pthash::dictionary::encode
-    std::vector<uint64_t> s(v, v + n);
-    std::sort(s.begin(), s.end());
-    std::vector<std::pair<uint64_t, uint64_t>> vf;  // (value, freq)
-    for (uint64_t i = 0; i < n;) {
-        uint64_t j = i;
-        while (j < n && s[j] == s[i]) ++j;
-        vf.emplace_back(s[i], j - i);
-        i = j;
+    std::vector<std::pair<uint64_t, uint64_t>> vf;  // (value, freq), ascending by value
+    uint64_t vmax = 0;
+    for (uint64_t i = 0; i < n; ++i) vmax = std::max(vmax, v[i]);
+    const bool dense = vmax < (1ull << 26) && vmax <= 64 * n + 1024;  // pilots are small: count them in place of sorting them
+    std::vector<uint32_t> count_or_rank;
+    if (dense) {
+        count_or_rank.assign(vmax + 1, 0);
+        for (uint64_t i = 0; i < n; ++i) ++count_or_rank[v[i]];
+        for (uint64_t x = 0; x <= vmax; ++x)
+            if (count_or_rank[x]) vf.emplace_back(x, count_or_rank[x]);
+    } else {
+        std::vector<uint64_t> s(v, v + n);
+        std::sort(s.begin(), s.end());
+        for (uint64_t i = 0; i < n;) {
+            uint64_t j = i;
+            while (j < n && s[j] == s[i]) ++j;
+            vf.emplace_back(s[i], j - i);
+            i = j;
+        }
     }
     // codewords by non-increasing frequency; ties (unordered in PTHash) by increasing value
     std::sort(vf.begin(), vf.end(), [](const auto& a, const auto& b) { return a.second != b.second ? a.second > b.second : a.first < b.first; });
     std::vector<uint64_t> dict(vf.size());
-    std::vector<std::pair<uint64_t, uint64_t>> byval(vf.size());
-    for (size_t i = 0; i < vf.size(); ++i) {
-        dict[i] = vf[i].first;
-        byval[i] = {vf[i].first, i};
-    }
-    std::sort(byval.begin(), byval.end());
+    for (size_t i = 0; i < vf.size(); ++i) dict[i] = vf[i].first;
     std::vector<uint64_t> ranks(n);
-    for (uint64_t i = 0; i < n; ++i) {
-        auto it = std::lower_bound(byval.begin(), byval.end(), std::make_pair(v[i], (uint64_t)0));
-        ranks[i] = it->second;
+    if (dense) {
+        for (size_t i = 0; i < vf.size(); ++i) count_or_rank[vf[i].first] = (uint32_t)i;
+        for (uint64_t i = 0; i < n; ++i) ranks[i] = count_or_rank[v[i]];
+    } else {
+        std::vector<std::pair<uint64_t, uint64_t>> byval(vf.size());
+        for (size_t i = 0; i < vf.size(); ++i) byval[i] = {vf[i].first, i};
+        std::sort(byval.begin(), byval.end());
+        for (uint64_t i = 0; i < n; ++i) ranks[i] = std::lower_bound(byval.begin(), byval.end(), std::make_pair(v[i], (uint64_t)0))->second;
     }
     cv_build(d.ranks, ranks);
     cv_build(d.dict, dict);
@@ -537,17 +549,12 @@ uint64_t phf_eval(const SinglePhf& f, uint64_t hash, const std::vector<uint64_t>
 // ---------------------------------------------------------------------------------------------
 // super-k-mers
 // ---------------------------------------------------------------------------------------------
-struct Run {          // one super-k-mer: windows [first, first + size) of the batch share the minimizer at q
-    uint64_t mm;      // minimizer value (2-bit packed m-mer)
-    uint64_t first;   // batch coordinate of the first window
-    uint64_t q;       // batch coordinate of the minimizer
-    uint32_t size;
-    uint32_t pad;     // (spilled to disk as raw structs: no indeterminate bytes)
-};
+typedef SuperKmerRun Run;  // extract.hpp: {mm, first, q, size, pad}, batch coordinates are global
+typedef SuperKmerRuns RunVec;  // (a vector whose resize() does not touch the new elements)
 
 // Windows [wa, wb) of one record (record base pointer s, window w covers bases [w, w+k)).
 // Windows holding a non-ACGT base are skipped and cut runs (the reference resets there, minimizer.hpp:150-164).
-void extract_runs(const char* s, uint64_t rec_off, uint64_t wa, uint64_t wb, uint32_t k, uint32_t m, uint64_t seed, std::vector<Run>& out) {
+void extract_runs(const char* s, uint64_t rec_off, uint64_t wa, uint64_t wb, uint32_t k, uint32_t m, uint64_t seed, RunVec& out) {
     if (wa >= wb) return;
     const uint32_t W = k - m + 1;
     const uint64_t mask = m >= 32 ? ~0ULL : ((1ULL << (2 * m)) - 1);
@@ -608,8 +615,9 @@ void extract_runs(const char* s, uint64_t rec_off, uint64_t wa, uint64_t wb, uin
     flush();
 }
 
-template <typename T, typename KeyFn>
-void parallel_sort_by_key(std::vector<T>& v, int threads, uint32_t key_bits, KeyFn key) {
+template <typename Vec, typename KeyFn>
+void parallel_sort_by_key(Vec& v, int threads, uint32_t key_bits, KeyFn key) {
+    typedef typename Vec::value_type T;
     // partition by the top 10 key bits, then std::sort each partition
     const size_t n = v.size();
     if (n < (1u << 16) || threads <= 1) {
@@ -635,7 +643,7 @@ void parallel_sort_by_key(std::vector<T>& v, int threads, uint32_t key_bits, Key
         }
         pstart[p + 1] = pstart[p] + s;
     }
-    std::vector<T> tmp(n);
+    Vec tmp(n);
     parallel_for(nch, threads, [&](size_t c) {
         for (size_t i = c * chunk, e = std::min(n, i + chunk); i < e; ++i) tmp[hist[c][part(v[i])]++] = v[i];
     });
@@ -697,7 +705,7 @@ struct CallbackSource : RecordSource {  // lphq_build_stream
 // ---------------------------------------------------------------------------------------------
 struct RunFileReader {
     FILE* f = nullptr;
-    std::vector<Run> buf;
+    RunVec buf;
     size_t at = 0, n = 0;
     bool failed = false;
     bool open(const std::string& path, size_t buf_records) {
@@ -740,7 +748,7 @@ struct RunSpill {
         std::vector<RunFileReader> rd(paths.size());
         typedef std::pair<uint64_t, uint32_t> Head;  // (minimizer, piece)
         std::priority_queue<Head, std::vector<Head>, std::greater<Head>> heap;
-        std::vector<Run> cur(paths.size());
+        RunVec cur(paths.size());
         for (size_t i = 0; i < paths.size(); ++i) {
             if (!rd[i].open(paths[i], buf_records)) {
                 err = "cannot reopen the temporary file " + paths[i];
@@ -760,7 +768,7 @@ struct RunSpill {
         }
         return true;
     }
-    bool write_piece(const std::vector<Run>& runs, std::string& err) {
+    bool write_piece(const RunVec& runs, std::string& err) {
         const std::string name = fresh_name();
         FILE* f = fopen(name.c_str(), "wb");
         if (!f) {
@@ -776,7 +784,7 @@ struct RunSpill {
         return true;
     }
     // sort the buffered records and write them as one more piece; the buffer comes back empty
-    bool flush(std::vector<Run>& runs, int threads, uint32_t key_bits, size_t buf_records, std::string& err) {
+    bool flush(RunVec& runs, int threads, uint32_t key_bits, size_t buf_records, std::string& err) {
         if (runs.empty()) return true;
         parallel_sort_by_key(runs, threads, key_bits, [](const Run& r) { return r.mm; });
         if (!write_piece(runs, err)) return false;
@@ -789,7 +797,7 @@ struct RunSpill {
             err = "cannot create the temporary file " + name;
             return false;
         }
-        std::vector<Run> out;
+        RunVec out;
         out.reserve(buf_records);
         bool wrote = true;
         const bool ok = merge(files, buf_records, err, [&](const Run& r) {
@@ -853,8 +861,11 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
     spill.dir = (tmp_dir && *tmp_dir) ? tmp_dir : ".";
     if (max_memory_bytes) (void)::mkdir(spill.dir.c_str(), 0777);  // essentials::create_directory, parser_build.cpp:76
     std::string err;
-    std::vector<Run> runs;
+    RunVec runs;
     uint64_t nkmers = 0, n_super_kmers = 0, n_records = 0, base = 0;
+    int extract_device = getenv("LPHQ_BUILD_HOST_EXTRACT") ? -1 : device;  // (the variable exists for A/B timing; the result is the same)
+    bool runs_sorted = false;  // `runs` ascending by minimizer already (one batch, extracted and sorted on the GPU)
+    uint64_t gpu_batches = 0;
     {
         const char* const* records = nullptr;
         const size_t* lengths = nullptr;
@@ -863,7 +874,7 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
         std::vector<uint64_t> rec_off;
         struct Chunk { size_t rec; uint64_t wa, wb; };
         std::vector<Chunk> chunks;
-        std::vector<std::vector<Run>> chunk_runs;
+        std::vector<RunVec> chunk_runs;
         while ((rc = src.next(0, records, lengths, nb)) > 0) {
             rec_off.assign(nb + 1, base);
             for (size_t r = 0; r < nb; ++r) rec_off[r + 1] = rec_off[r] + lengths[r];
@@ -874,7 +885,27 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
                 const uint64_t nw = lengths[r] - k + 1;
                 for (uint64_t a = 0; a < nw; a += CH) chunks.push_back({r, a, std::min(nw, a + CH)});
             }
-            chunk_runs.assign(chunks.size(), std::vector<Run>());
+            if (extract_device >= 0) {  // super-k-mers of the batch from the GPU, already sorted by minimizer
+                std::string gerr;
+                const bool was_empty = runs.empty() && spill.files.empty();
+                if (gpu_extract_sorted_runs(extract_device, records, lengths, nb, base, k, m, mm_seed, threads, verbose, runs, gerr)) {
+                    runs_sorted = was_empty;  // still sorted as a whole if this is all there is
+                    if (runs.size() >= run_cap) {  // over the memory limit: one more sorted piece
+                        for (const Run& x : runs) nkmers += x.size;
+                        n_super_kmers += runs.size();
+                        if (!spill.flush(runs, threads, 2 * m, merge_buf, err)) return fail(LPHQ_ERR_IO, err);
+                        runs_sorted = false;
+                    }
+                    ++gpu_batches;
+                    base = rec_off[nb];
+                    n_records += nb;
+                    continue;
+                }
+                fprintf(stderr, "[lphq_build] GPU super-k-mer extraction unavailable (%s): the host extracts\n", gerr.c_str());
+                extract_device = -1;
+            }
+            runs_sorted = false;
+            chunk_runs.assign(chunks.size(), RunVec());
             parallel_for(chunks.size(), threads, [&](size_t ci) {
                 const Chunk& ch = chunks[ci];
                 chunk_runs[ci].reserve((ch.wb - ch.wa) * 2 / (W + 1) + 16);
@@ -904,7 +935,7 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
                     }
                     first_of_chunk = false;
                 }
-                std::vector<Run>().swap(chunk_runs[ci]);
+                RunVec().swap(chunk_runs[ci]);
             }
             base = rec_off[nb];
             n_records += nb;
@@ -913,53 +944,98 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
     }
     for (const Run& x : runs) nkmers += x.size;
     n_super_kmers += runs.size();
+    if (verbose && gpu_batches) fprintf(stderr, "[lphq_build] super-k-mers of %llu batch(es) extracted and sorted on GPU %d\n", (unsigned long long)gpu_batches, device);
     lap("part 1: super-k-mer runs");
 
     // ---- Part 2: classify (src/minimizer.cpp:5-50) + PTHash over the distinct minimizers -------------
-    std::vector<Triplet> uniq;
-    std::vector<uint64_t> uniq_mm;
+    typedef std::vector<Triplet, DefaultInitAllocator<Triplet>> TripletVec;  // (resize() leaves the new elements to the parallel copy that follows)
+    typedef std::vector<uint64_t, DefaultInitAllocator<uint64_t>> WordVec;
+    TripletVec uniq;
+    WordVec uniq_mm;
     std::vector<std::pair<uint64_t, uint32_t>> colliding;  // (first window, size) of every super-k-mer of a repeated minimizer
     {
         // records arrive ascending by minimizer; a minimizer seen once keeps (offset, size), one seen more often sends all its super-k-mers
         // to the fallback
-        Run prev{0, 0, 0, 0, 0};
-        bool have = false, repeated = false;
-        auto close_group = [&] {
-            if (!have) return;
-            uniq_mm.push_back(prev.mm);
-            if (repeated) uniq.push_back({0, 0, 0});
-            else uniq.push_back({0, (uint8_t)(prev.q - prev.first), (uint8_t)prev.size});
-        };
-        auto feed = [&](const Run& r) {
-            if (have && r.mm == prev.mm) {
-                if (!repeated) colliding.emplace_back(prev.first, prev.size);
-                repeated = true;
-                colliding.emplace_back(r.first, r.size);
-            } else {
-                close_group();
-                prev = r;
-                have = true;
-                repeated = false;
+        struct Classifier {
+            TripletVec uniq;
+            WordVec uniq_mm;
+            std::vector<std::pair<uint64_t, uint32_t>> colliding;
+            Run prev{0, 0, 0, 0, 0};
+            bool have = false, repeated = false;
+            void close_group() {
+                if (!have) return;
+                uniq_mm.push_back(prev.mm);
+                if (repeated) uniq.push_back({0, 0, 0});
+                else uniq.push_back({0, (uint8_t)(prev.q - prev.first), (uint8_t)prev.size});
+                have = false;
             }
-            return true;
+            void feed(const Run& r) {
+                if (have && r.mm == prev.mm) {
+                    if (!repeated) colliding.emplace_back(prev.first, prev.size);
+                    repeated = true;
+                    colliding.emplace_back(r.first, r.size);
+                } else {
+                    close_group();
+                    prev = r;
+                    have = true;
+                    repeated = false;
+                }
+            }
         };
         if (spill.files.empty()) {
-            parallel_sort_by_key(runs, threads, 2 * m, [](const Run& r) { return r.mm; });
+            if (!runs_sorted) parallel_sort_by_key(runs, threads, 2 * m, [](const Run& r) { return r.mm; });
             lap("part 2: sort runs by minimizer");
-            uniq.reserve(runs.size());
-            uniq_mm.reserve(runs.size());
-            for (const Run& r : runs) feed(r);
+            // pieces that begin at the first record of a minimizer, one classifier each, joined in order
+            const size_t n = runs.size();
+            const size_t pieces = std::max<size_t>(1, std::min<size_t>((size_t)threads, n / (1u << 16)));
+            std::vector<size_t> cut(pieces + 1, n);
+            cut[0] = 0;
+            for (size_t t = 1; t < pieces; ++t) {
+                size_t c = std::max(cut[t - 1], n * t / pieces);
+                while (c < n && c > 0 && runs[c].mm == runs[c - 1].mm) ++c;
+                cut[t] = c;
+            }
+            std::vector<Classifier> part(pieces);
+            parallel_for(pieces, threads, [&](size_t t) {
+                Classifier& c = part[t];
+                c.uniq.reserve(cut[t + 1] - cut[t]);
+                c.uniq_mm.reserve(cut[t + 1] - cut[t]);
+                for (size_t i = cut[t]; i < cut[t + 1]; ++i) c.feed(runs[i]);
+                c.close_group();
+            });
+            std::vector<size_t> uo(pieces + 1, 0), co(pieces + 1, 0);
+            for (size_t t = 0; t < pieces; ++t) {
+                uo[t + 1] = uo[t] + part[t].uniq.size();
+                co[t + 1] = co[t] + part[t].colliding.size();
+            }
+            uniq.resize(uo[pieces]);
+            uniq_mm.resize(uo[pieces]);
+            colliding.resize(co[pieces]);
+            parallel_for(pieces, threads, [&](size_t t) {
+                std::copy(part[t].uniq.begin(), part[t].uniq.end(), uniq.begin() + uo[t]);
+                std::copy(part[t].uniq_mm.begin(), part[t].uniq_mm.end(), uniq_mm.begin() + uo[t]);
+                std::copy(part[t].colliding.begin(), part[t].colliding.end(), colliding.begin() + co[t]);
+                Classifier().uniq.swap(part[t].uniq);
+            });
         } else {
             if (!spill.flush(runs, threads, 2 * m, merge_buf, err)) return fail(LPHQ_ERR_IO, err);
-            std::vector<Run>().swap(runs);
+            RunVec().swap(runs);
             if (verbose) fprintf(stderr, "[lphq_build] %zu sorted pieces of super-k-mer records in %s\n", spill.files.size(), spill.dir.c_str());
-            if (!RunSpill::merge(spill.files, merge_buf, err, feed)) return fail(LPHQ_ERR_IO, err);
+            Classifier c;
+            if (!RunSpill::merge(spill.files, merge_buf, err, [&](const Run& r) {
+                    c.feed(r);
+                    return true;
+                }))
+                return fail(LPHQ_ERR_IO, err);
+            c.close_group();
+            uniq.swap(c.uniq);
+            uniq_mm.swap(c.uniq_mm);
+            colliding.swap(c.colliding);
             for (const std::string& f : spill.files) ::remove(f.c_str());
             spill.files.clear();
         }
-        close_group();
     }
-    std::vector<Run>().swap(runs);
+    RunVec().swap(runs);
     const uint64_t D = uniq.size();
     lap("part 2: classify");
 
@@ -1001,8 +1077,8 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
         for (uint64_t i = 0; i < D; ++i)
             if (by_order[i].itself != 1) return fail(LPHQ_ERR_FORMAT, "internal: minimizer MPHF is not a bijection");
     }
-    std::vector<Triplet>().swap(uniq);
-    std::vector<uint64_t>().swap(uniq_mm);
+    TripletVec().swap(uniq);
+    WordVec().swap(uniq_mm);
     lap("part 3: order by minimizer MPHF");
 
     if (kind == LPHQ_PARTITIONED) {  // build_inverted_index, src/partitioned_mphf.cpp:163-268

@@ -62,7 +62,7 @@ hipError_t launch_pack_kmers(const lphq_image_header& H, const char* d_seq, cons
 
 hipError_t launch_count_valid(const uint64_t* d_codes, size_t n, unsigned long long* d_count, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    k_count_valid<<<grid_for(n, kBlock * 8, 256 * 8), kBlock, 0, stream>>>(d_codes, n, d_count);
+    k_count_valid<><<<grid_for(n, kBlock * 8, 256 * 8), kBlock, 0, stream>>>(d_codes, n, d_count);
     return hipGetLastError();
 }
 

@@ -774,6 +774,7 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
 // ------------------------------------------------------------------------------------------
 // number of valid codes (size of the reference's result vector for a streaming pass)
 // ------------------------------------------------------------------------------------------
+template <int BLOCK = kBlock>  // (a template only so that every translation unit including this header may hold a copy)
 __global__ __launch_bounds__(kBlock) void k_count_valid(const uint64_t* __restrict__ codes, size_t n, unsigned long long* __restrict__ count) {
     const size_t stride = (size_t)gridDim.x * kBlock;
     unsigned long long c = 0;

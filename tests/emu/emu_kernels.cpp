@@ -3,6 +3,7 @@
 #include <cstring>
 
 #include "kernels_device.cuh"  // -Itests/emu resolves <hip/hip_runtime.h> to the stub
+#include "extract_device.cuh"
 
 using namespace lphq;
 
@@ -82,7 +83,7 @@ extern "C" int emu_kernel_pack_kmers(const char* seq, const uint64_t* pos, size_
 
 extern "C" int emu_kernel_count_valid(const uint64_t* codes, size_t n, unsigned long long* count) {
     *count = 0;
-    emu::launch((unsigned)((n + kBlock * 8 - 1) / (kBlock * 8)), kBlock, [&] { k_count_valid(codes, n, count); });
+    emu::launch((unsigned)((n + kBlock * 8 - 1) / (kBlock * 8)), kBlock, [&] { k_count_valid<>(codes, n, count); });
     return 0;
 }
 
@@ -93,4 +94,30 @@ extern "C" int emu_kernel_gather_payload(const uint64_t* codes, size_t n, const 
     else if (elem_bytes == 2) emu::launch(grid, kBlock, [&] { k_gather_payload<uint16_t>(codes, n, (const uint16_t*)table, n_slots, (uint16_t)missing, (uint16_t*)out); });
     else emu::launch(grid, kBlock, [&] { k_gather_payload<uint8_t>(codes, n, (const uint8_t*)table, n_slots, (uint8_t)missing, (uint8_t*)out); });
     return 0;
+}
+
+// k_extract_runs as extract.hip launches it.  seq: 16-byte aligned, >= 64 readable bytes on both sides.  Returns the number of runs the kernel
+// produced (it may exceed cap: then only cap of them were written), or -1.
+extern "C" long long emu_kernel_extract_runs(const char* seq, uint64_t total, const uint64_t* seq_off, uint32_t n_records, uint32_t k, uint32_t m, uint64_t mm_seed,
+                                             uint64_t first_base, uint64_t* out_mm, uint64_t* out_val /* 2 words per run: first, p1 | size << 32 */, uint64_t cap,
+                                             int force_form /* 0: as the launcher picks, 1: block minima, 2: direct */) {
+    if (((uintptr_t)seq & 15u) || total < k || n_records == 0) return -1;
+    static_assert(sizeof(RunVal) == 16, "two words per run");
+    const uint64_t shift = 16;
+    const uint8_t* seq_al = (const uint8_t*)seq - shift;
+    const uint32_t W = k - m + 1u;
+    const uint32_t S = extract_tile_stride(W, 4 * kStreamBlockDefault);
+    const unsigned tiles = (unsigned)((shift + total - k) / S + 1);
+    unsigned long long cursor = 0;
+    const bool blk = force_form ? force_form == 1 : W >= kBlockMinW;
+    if (blk && W < 4) return -1;
+    if (blk)
+        emu::launch(tiles, kStreamBlockDefault, [&] {
+            k_extract_runs<kStreamBlockDefault, true>(seq_al, shift, total, seq_off, n_records, k, m, mm_seed, first_base, out_mm, (RunVal*)out_val, &cursor, cap, 0);
+        });
+    else
+        emu::launch(tiles, kStreamBlockDefault, [&] {
+            k_extract_runs<kStreamBlockDefault, false>(seq_al, shift, total, seq_off, n_records, k, m, mm_seed, first_base, out_mm, (RunVal*)out_val, &cursor, cap, 0);
+        });
+    return (long long)cursor;
 }

@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE ONLY: the product's host-side sources that need no GPU (loader lph_format.cpp, image builder image.cpp,
 // index builder builder.cpp with the CPU pilot search, the FASTA readers) linked into one executable and compiled with
-// -fsanitize=address,undefined (tests/test_host_cpu.py::test_host_sources_under_sanitizers).  The two symbols that live in the HIP
-// part of the library are stubbed: the GPU pilot search reports "unavailable", errors go to a string.
+// -fsanitize=address,undefined (tests/test_host_cpu.py::test_host_sources_under_sanitizers).  The symbols that live in the HIP
+// part of the library are stubbed: the GPU pilot search and the GPU super-k-mer extraction report "unavailable", errors go to a string.
 //   san_host build <fasta> <k> <m> <kind> <kmer_bits> <threads> <out.lph>     build with the product builder (CPU search)
 //   san_host build_stream <fasta> <k> <m> <kind> <kmer_bits> <threads> <out.lph> <max_memory_bytes> <tmp_dir>   lphq_build_stream, small batches
 //   san_host load  <file.lph> <kind> <kmer_bits>                             parse + cross-check + flat image
@@ -17,6 +17,7 @@
 #include "fastx_batch.hpp"
 #include "image.hpp"
 #include "lph_format.hpp"
+#include "extract.hpp"
 #include "search.hpp"
 
 namespace lphq {
@@ -24,6 +25,11 @@ static std::string g_err;
 void set_last_error(const std::string& e) { g_err = e; }
 bool gpu_pilot_search(int, const std::vector<uint64_t>&, const std::vector<uint64_t>&, const std::vector<uint32_t>&, uint64_t, uint64_t, uint64_t,
                       std::vector<uint64_t>&, std::vector<uint64_t>&, std::string& err) {
+    err = "no GPU in the sanitizer harness";
+    return false;
+}
+bool gpu_extract_sorted_runs(int, const char* const*, const size_t*, size_t, uint64_t, uint32_t, uint32_t, uint64_t, int, bool, SuperKmerRuns&,
+                             std::string& err) {
     err = "no GPU in the sanitizer harness";
     return false;
 }

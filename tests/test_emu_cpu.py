@@ -6,6 +6,7 @@ import ctypes as C
 import glob
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -415,3 +416,73 @@ def test_bbhash_competitor_against_the_real_boophf(emuk, tmp_path, name):
     h2 = L.BbHash.load(str(ours), k, kmer_bits=bits)
     every = np.concatenate(emu_records(emuk, h2, recs, k, True, 0))
     assert len(np.unique(every)) == len(every) == h2.get_kmer_count() and int(every.max()) == len(every) - 1
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# index construction, part 1 on the GPU: k_extract_runs (extract_device.cuh)
+# ------------------------------------------------------------------------------------------------------------------
+def expected_runs(recs, k, m, seed, first_base=0):
+    """Super-k-mers by the independent Python model (tests/golden/pymodel.py): maximal runs of consecutive k-mers of a stretch of valid
+    bases whose leftmost-minimum m-mer sits at the same position -> (minimizer, first window (global), offset, size)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import pymodel
+
+    runs, at = [], first_base
+    for rec in recs:
+        pos = 0
+        text = bytes(rec)  # (iterating bytes yields the ints pymodel.NT is keyed by)
+        while pos < len(text):
+            if text[pos] not in pymodel.NT:
+                pos += 1
+                continue
+            end = pos
+            while end < len(text) and text[end] in pymodel.NT:
+                end += 1
+            codes = [pymodel.NT[c] for c in text[pos:end]]
+            if len(codes) >= k:
+                prev = None
+                for w, (_kv, mm, p, best) in enumerate(pymodel.windows_of(codes, k, m, seed)):
+                    if best == prev:
+                        runs[-1][3] += 1
+                    else:
+                        runs.append([mm, at + pos + w, p, 1])
+                    prev = best
+            pos = end
+        at += len(rec)
+    return sorted(tuple(r) for r in runs)
+
+
+@pytest.mark.parametrize("k,m,form", [(31, 20, 0), (31, 20, 1), (63, 20, 0), (63, 20, 2), (21, 8, 0), (15, 15, 0), (33, 5, 0), (9, 7, 0), (63, 1, 1), (47, 32, 0), (2, 1, 0)])
+def test_extract_runs_kernel_on_the_emulator(emu, k, m, form):
+    """k_extract_runs over ragged multi-record batches (records shorter than k, empty, non-ACGT bases, many records per tile, records spanning
+    several tiles): the set of super-k-mer records equals the independent Python model's; a too-small output buffer is reported through the counter."""
+    emu.emu_kernel_extract_runs.restype = C.c_longlong
+    emu.emu_kernel_extract_runs.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,
+                                            C.c_uint64, C.c_int]
+    rng = np.random.default_rng(k * 100 + m)
+    recs = random_records(k + m, 5, 900, 2600) + [b"", b"ACGT"[: min(4, k - 1)]] + random_records(k, 40, 0, 2 * k) + random_records(m, 3, 3000, 5000)
+    noisy = bytearray(recs[1])
+    for p in rng.integers(0, len(noisy), 6):
+        noisy[p] = ord("N")
+    recs[1] = bytes(noisy)
+    recs[2] = recs[2].lower()
+    seed, first_base = 42, 1_000_000_007
+    want = expected_runs(recs, k, m, seed, first_base)
+    flat = np.frombuffer(b"".join(recs), dtype=np.uint8)
+    raw = np.full(len(flat) + 256, ord("#"), dtype=np.uint8)
+    base = (-raw.ctypes.data) % 16 + 64
+    raw[base:base + len(flat)] = flat
+    seq_off = np.concatenate([[0], np.cumsum([len(r) for r in recs])]).astype(np.uint64)
+    cap = len(want) + 7
+    mm = np.zeros(cap, dtype=np.uint64)
+    val = np.zeros(2 * cap, dtype=np.uint64)
+    n = emu.emu_kernel_extract_runs(raw.ctypes.data + base, len(flat), seq_off.ctypes.data, len(recs), k, m, seed, first_base, mm.ctypes.data, val.ctypes.data, cap, form)
+    assert n == len(want)
+    got = sorted((int(mm[i]), int(val[2 * i]), int(val[2 * i + 1]) & 0xFFFFFFFF, int(val[2 * i + 1]) >> 32) for i in range(n))
+    assert got == want
+    # not enough room: the counter still says how many there are, nothing is written beyond the buffer
+    small = max(1, len(want) // 3)
+    mm2 = np.full(small + 1, 0xDEAD, dtype=np.uint64)
+    val2 = np.full(2 * small + 2, 0xDEAD, dtype=np.uint64)
+    n2 = emu.emu_kernel_extract_runs(raw.ctypes.data + base, len(flat), seq_off.ctypes.data, len(recs), k, m, seed, first_base, mm2.ctypes.data, val2.ctypes.data, small, form)
+    assert n2 == len(want) and mm2[small] == 0xDEAD and val2[2 * small] == 0xDEAD

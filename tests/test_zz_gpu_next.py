@@ -33,6 +33,38 @@ def test_gpu_pilot_search_build_is_byte_identical(tmp_path, k, m, bits, kind, nr
     assert open(pc, "rb").read() == open(pg, "rb").read()
 
 
+@pytest.mark.parametrize("k,m,bits,kind", [(31, 20, 64, 0), (63, 20, 128, 0), (31, 15, 64, 1), (15, 9, 64, 0), (47, 32, 128, 0), (33, 5, 128, 0)])
+def test_gpu_super_kmer_extraction_build_is_byte_identical(tmp_path, k, m, bits, kind):
+    """Parts 1-2 of construction on the GPU (k_extract_runs + radix sort by minimizer, extract.hip) must lead to the file the host extraction
+    leads to: ragged batches with empty / short records, non-ACGT bases, many short records per tile and records spanning many tiles; in one
+    batch, in several batches, and with a memory limit that spills sorted pieces."""
+    import numpy as np
+    from util import random_records
+
+    recs = dedup_records(random_records(77 + k, 30, k - 1, 40_000) + random_records(78 + k, 400, 0, 3 * k) + random_records(79 + k, 3, 150_000, 300_000), k)
+    noisy = bytearray(recs[0])
+    for p in np.random.default_rng(k).integers(0, len(noisy), 9):
+        noisy[p] = ord("N")
+    recs[0] = bytes(noisy)
+    recs.insert(3, b"")
+    pc, pg = str(tmp_path / "cpu.lph"), str(tmp_path / "gpu.lph")
+    os.environ["LPHQ_BUILD_HOST_EXTRACT"] = "1"
+    try:
+        sc = L.build(recs, k, m, pc, kind=kind, kmer_bits=bits, threads=8, device=0)  # host extraction, GPU pilot search
+    finally:
+        del os.environ["LPHQ_BUILD_HOST_EXTRACT"]
+    want = open(pc, "rb").read()
+    sg = L.build(recs, k, m, pg, kind=kind, kmer_bits=bits, threads=8, device=0)
+    assert sg == sc and open(pg, "rb").read() == want
+    for per_batch, limit in ((50, 0), (7, 1 << 20), (len(recs), 1 << 19)):
+        def batches():
+            for i in range(0, len(recs), per_batch):
+                yield recs[i:i + per_batch]
+
+        ss = L.build_stream(batches, k, m, pg, kind=kind, kmer_bits=bits, threads=8, device=0, tmp_dir=str(tmp_path / "spill"), max_memory_bytes=limit)
+        assert ss == sc and open(pg, "rb").read() == want, (per_batch, limit)
+
+
 @pytest.mark.parametrize("k,bits", [(31, 64), (31, 128), (63, 128)])
 def test_pthash_competitor_harness(tmp_path, k, bits):
     """the PTHash half of the reference's ptbb_build / ptbb_query on the GPU.  Codes == the oracle's restatement of
