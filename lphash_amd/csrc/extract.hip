@@ -135,6 +135,10 @@ bool gpu_extract_sorted_runs(int device, const char* const* records, const size_
         // expected number of runs on random sequence: 2 / (W + 1) per window; room for 1.5x that (repetitive input has FEWER runs), exact on a second go
         uint64_t cap = (uint64_t)((double)windows * 3.0 / (double)(W + 1)) + (1u << 16);
         cap = std::min(cap, windows);
+        if (const char* e = getenv("LPHQ_EXTRACT_INITIAL_CAP")) {  // (tests: a too-small first buffer exercises the second launch with the exact count)
+            const uint64_t v = strtoull(e, nullptr, 10);
+            if (v >= 1) cap = std::min(cap, v);
+        }
         const uint64_t shift = 16;  // d_seq + kFront is 16-byte aligned (hipMalloc: 256), the kernel reads from d_seq + kFront - 16 on
         const uint8_t* seq_al = d_seq + kFront - shift;
         const uint32_t S = extract_tile_stride(W, 4 * kStreamBlockDefault);

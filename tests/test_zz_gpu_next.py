@@ -56,6 +56,12 @@ def test_gpu_super_kmer_extraction_build_is_byte_identical(tmp_path, k, m, bits,
     want = open(pc, "rb").read()
     sg = L.build(recs, k, m, pg, kind=kind, kmer_bits=bits, threads=8, device=0)
     assert sg == sc and open(pg, "rb").read() == want
+    os.environ["LPHQ_EXTRACT_INITIAL_CAP"] = "1000"  # the first launch runs out of room: the kernel only counts on, the second launch has the exact size
+    try:
+        sg = L.build(recs, k, m, pg, kind=kind, kmer_bits=bits, threads=8, device=0)
+    finally:
+        del os.environ["LPHQ_EXTRACT_INITIAL_CAP"]
+    assert sg == sc and open(pg, "rb").read() == want
     for per_batch, limit in ((50, 0), (7, 1 << 20), (len(recs), 1 << 19)):
         def batches():
             for i in range(0, len(recs), per_batch):
