@@ -139,7 +139,7 @@ void d1_build(DArray1& d, const BitVector& bv) {  // pthash::darray1::build
 // Elias-Fano over a non-decreasing sequence given by get(i), i < n, universe u.
 // leading_zero: lphash ef_sequence::encode (ef_sequence.hpp:37-75) prepends a 0; otherwise pthash::ef_sequence<false>.
 template <typename Get>
-void ef_encode(EliasFano& e, uint64_t n, uint64_t u, bool leading_zero, Get get) {
+void ef_encode(EliasFano& e, uint64_t n, uint64_t u, bool leading_zero, Get get, int threads = 1) {
     e = EliasFano();
     if (n == 0) return;
     const uint64_t nn = n + (leading_zero ? 1 : 0);
@@ -152,10 +152,28 @@ void ef_encode(EliasFano& e, uint64_t n, uint64_t u, bool leading_zero, Get get)
         bv_set(e.high, 0);
         at = 1;
     }
-    for (uint64_t i = 0; i < n; ++i) {
-        const uint64_t v = get(i);
-        if (l) cv_set(e.low, i + at, v & low_mask);
-        bv_set(e.high, (v >> l) + i + at);
+    if (threads <= 1 || n < (1u << 16)) {
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint64_t v = get(i);
+            if (l) cv_set(e.low, i + at, v & low_mask);
+            bv_set(e.high, (v >> l) + i + at);
+        }
+    } else {  // elements are independent; neighbours share words, hence the atomic ORs
+        uint64_t* high = e.high.bits.data();
+        uint64_t* low = e.low.bits.data();
+        const uint64_t chunk = 1u << 16;
+        parallel_for((size_t)((n + chunk - 1) / chunk), threads, [&](size_t c) {
+            for (uint64_t i = c * chunk, end = std::min(n, i + chunk); i < end; ++i) {
+                const uint64_t v = get(i);
+                if (l) {
+                    const uint64_t pos = (i + at) * l, blk = pos >> 6, sh = pos & 63, x = v & low_mask;
+                    __atomic_fetch_or(&low[blk], x << sh, __ATOMIC_RELAXED);
+                    if (sh + l > 64) __atomic_fetch_or(&low[blk + 1], x >> (64 - sh), __ATOMIC_RELAXED);
+                }
+                const uint64_t hp = (v >> l) + i + at;
+                __atomic_fetch_or(&high[hp >> 6], 1ULL << (hp & 63), __ATOMIC_RELAXED);
+            }
+        });
     }
     d1_build(e.d1, e.high);
 }
@@ -165,32 +183,37 @@ void ef_encode(EliasFano& e, uint64_t n, uint64_t u, bool leading_zero, Get get)
 // 9-bit in-block prefix counts with the count before word j (j = 1..7) at bit (7 - j) * 9 -- and a closing (total ones, 0) pair.
 // A trailing partial block is treated as zero-padded.  Three passes: per-block popcounts, an exclusive scan over the blocks,
 // field packing; the first and last are independent per block.
-void rs_build(RsBitVector& r) {
+void rs_build(RsBitVector& r, int threads = 1) {
     const std::vector<uint64_t>& words = r.bv.bits;
     const size_t nblocks = (words.size() + 7) / 8;
     std::vector<uint64_t>& pairs = r.block_rank_pairs;
     pairs.assign(2 * (nblocks + 1), 0);
-    for (size_t b = 0; b < nblocks; ++b) {  // pass 1: ones inside block b, parked in the slot of its absolute rank
-        const size_t end = std::min(words.size(), 8 * b + 8);
-        uint64_t ones = 0;
-        for (size_t w = 8 * b; w < end; ++w) ones += (uint64_t)__builtin_popcountll(words[w]);
-        pairs[2 * b] = ones;
-    }
+    const size_t bchunk = 1 << 12;
+    parallel_for((nblocks + bchunk - 1) / bchunk, threads, [&](size_t c) {
+        for (size_t b = c * bchunk, e = std::min(nblocks, b + bchunk); b < e; ++b) {  // pass 1: ones inside block b, parked in the slot of its absolute rank
+            const size_t end = std::min(words.size(), 8 * b + 8);
+            uint64_t ones = 0;
+            for (size_t w = 8 * b; w < end; ++w) ones += (uint64_t)__builtin_popcountll(words[w]);
+            pairs[2 * b] = ones;
+        }
+    });
     uint64_t before = 0;
     for (size_t b = 0; b <= nblocks; ++b) {  // pass 2: exclusive scan; entry nblocks becomes the closing total
         const uint64_t ones = pairs[2 * b];
         pairs[2 * b] = before;
         before += ones;
     }
-    for (size_t b = 0; b < nblocks; ++b) {  // pass 3: the seven in-block prefix counts
-        uint64_t packed = 0, inside = 0;
-        for (size_t j = 1; j < 8; ++j) {
-            const size_t w = 8 * b + j - 1;
-            if (w < words.size()) inside += (uint64_t)__builtin_popcountll(words[w]);
-            packed |= inside << ((7 - j) * 9);
+    parallel_for((nblocks + bchunk - 1) / bchunk, threads, [&](size_t c) {
+        for (size_t b = c * bchunk, e = std::min(nblocks, b + bchunk); b < e; ++b) {  // pass 3: the seven in-block prefix counts
+            uint64_t packed = 0, inside = 0;
+            for (size_t j = 1; j < 8; ++j) {
+                const size_t w = 8 * b + j - 1;
+                if (w < words.size()) inside += (uint64_t)__builtin_popcountll(words[w]);
+                packed |= inside << ((7 - j) * 9);
+            }
+            pairs[2 * b + 1] = packed;
         }
-        pairs[2 * b + 1] = packed;
-    }
+    });
     r.select_hints.clear();
 }
 
@@ -1084,58 +1107,119 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
     if (kind == LPHQ_PARTITIONED) {  // build_inverted_index, src/partitioned_mphf.cpp:163-268
         bv_init(x.root.bv, D);
         std::vector<uint8_t> lr, mn;
-        lr.reserve(D);
-        mn.reserve(D);
         std::vector<uint8_t> left_positions, right_or_collision_sizes, none_sizes, none_positions;
         uint64_t universe = 0;
-        for (uint64_t i = 0; i < D; ++i) {
-            const Triplet& t = by_order[i];
-            if (t.size == 0) {  // RIGHT_OR_COLLISION, size 0 marks a repeated minimizer
-                lr.push_back(1);
-                right_or_collision_sizes.push_back(0);
-            } else if (t.p1 == k - m) {
-                if (t.size == W) {  // MAXIMAL
-                    bv_set(x.root.bv, i);
-                    mn.push_back(0);
-                    ++x.n_maximal;
-                } else {  // RIGHT
-                    lr.push_back(1);
-                    right_or_collision_sizes.push_back(t.size);
-                    universe += t.size;
+        {
+            // pieces of a multiple of 64 minimizers (a piece owns its words of the root bit vector), one set of output arrays each, joined in order
+            struct Piece {
+                std::vector<uint8_t> lr, mn, left_positions, right_or_collision_sizes, none_sizes, none_positions;
+                uint64_t universe = 0, n_maximal = 0;
+            };
+            const uint64_t per = std::max<uint64_t>(1u << 16, ((D + (uint64_t)threads - 1) / (uint64_t)threads + 63) & ~63ull);
+            const size_t pieces = (size_t)((D + per - 1) / per);
+            std::vector<Piece> part(pieces);
+            parallel_for(pieces, threads, [&](size_t pi) {
+                Piece& o = part[pi];
+                const uint64_t lo = pi * per, hi = std::min<uint64_t>(D, lo + per);
+                o.lr.reserve(hi - lo);
+                o.mn.reserve(hi - lo);
+                for (uint64_t i = lo; i < hi; ++i) {
+                    const Triplet& t = by_order[i];
+                    if (t.size == 0) {  // RIGHT_OR_COLLISION, size 0 marks a repeated minimizer
+                        o.lr.push_back(1);
+                        o.right_or_collision_sizes.push_back(0);
+                    } else if (t.p1 == k - m) {
+                        if (t.size == W) {  // MAXIMAL
+                            bv_set(x.root.bv, i);
+                            o.mn.push_back(0);
+                            ++o.n_maximal;
+                        } else {  // RIGHT
+                            o.lr.push_back(1);
+                            o.right_or_collision_sizes.push_back(t.size);
+                            o.universe += t.size;
+                        }
+                    } else if (t.p1 == t.size - 1) {  // LEFT: stores p1 + 1
+                        o.lr.push_back(0);
+                        o.left_positions.push_back((uint8_t)(t.p1 + 1));
+                        o.universe += (uint64_t)t.p1 + 1;
+                    } else {  // NONE
+                        bv_set(x.root.bv, i);
+                        o.mn.push_back(1);
+                        o.none_positions.push_back(t.p1);
+                        o.none_sizes.push_back(t.size);
+                        o.universe += (uint64_t)t.p1 + t.size;
+                    }
                 }
-            } else if (t.p1 == t.size - 1) {  // LEFT: stores p1 + 1
-                lr.push_back(0);
-                left_positions.push_back((uint8_t)(t.p1 + 1));
-                universe += (uint64_t)t.p1 + 1;
-            } else {  // NONE
-                bv_set(x.root.bv, i);
-                mn.push_back(1);
-                none_positions.push_back(t.p1);
-                none_sizes.push_back(t.size);
-                universe += (uint64_t)t.p1 + t.size;
+            });
+            auto join = [&](std::vector<uint8_t>& out, std::vector<uint8_t> Piece::*field) {
+                std::vector<size_t> at(pieces + 1, 0);
+                for (size_t pi = 0; pi < pieces; ++pi) at[pi + 1] = at[pi] + (part[pi].*field).size();
+                out.resize(at[pieces]);
+                parallel_for(pieces, threads, [&](size_t pi) {
+                    std::copy((part[pi].*field).begin(), (part[pi].*field).end(), out.begin() + at[pi]);
+                    std::vector<uint8_t>().swap(part[pi].*field);
+                });
+            };
+            join(lr, &Piece::lr);
+            join(mn, &Piece::mn);
+            join(left_positions, &Piece::left_positions);
+            join(right_or_collision_sizes, &Piece::right_or_collision_sizes);
+            join(none_sizes, &Piece::none_sizes);
+            join(none_positions, &Piece::none_positions);
+            for (const Piece& o : part) {
+                universe += o.universe;
+                x.n_maximal += o.n_maximal;
             }
         }
-        bv_init(x.left_right.bv, lr.size());
-        for (size_t i = 0; i < lr.size(); ++i)
-            if (lr[i]) bv_set(x.left_right.bv, i);
-        bv_init(x.max_none.bv, mn.size());
-        for (size_t i = 0; i < mn.size(); ++i)
-            if (mn[i]) bv_set(x.max_none.bv, i);
-        rs_build(x.root);
-        rs_build(x.left_right);
-        rs_build(x.max_none);
+        lap("  inverted index: classify by type");
+        auto pack_bits = [&](BitVector& bv, const std::vector<uint8_t>& bytes) {  // one 64-bit word per step: words are independent
+            bv_init(bv, bytes.size());
+            const size_t nw = bv.bits.size(), wchunk = 1 << 12;
+            parallel_for((nw + wchunk - 1) / wchunk, threads, [&](size_t c) {
+                for (size_t w = c * wchunk, e = std::min(nw, w + wchunk); w < e; ++w) {
+                    uint64_t word = 0;
+                    for (size_t i = w * 64, ie = std::min(bytes.size(), i + 64); i < ie; ++i) word |= (uint64_t)(bytes[i] & 1) << (i & 63);
+                    bv.bits[w] = word;
+                }
+            });
+        };
+        pack_bits(x.left_right.bv, lr);
+        pack_bits(x.max_none.bv, mn);
+        rs_build(x.root, threads);
+        rs_build(x.left_right, threads);
+        rs_build(x.max_none, threads);
+        lap("  inverted index: bit vectors + rank");
         x.right_coll_sizes_start = left_positions.size();
         x.none_sizes_start = x.right_coll_sizes_start + right_or_collision_sizes.size();
         x.none_pos_start = x.none_sizes_start + none_sizes.size();
-        // append_iterator + cumulative_iterator over the four arrays
-        std::vector<uint64_t> cum;
-        cum.reserve(x.none_pos_start + none_positions.size());
-        uint64_t s = 0;
-        for (uint8_t v : left_positions) cum.push_back(s += v);
-        for (uint8_t v : right_or_collision_sizes) cum.push_back(s += v);
-        for (uint8_t v : none_sizes) cum.push_back(s += v);
-        for (uint8_t v : none_positions) cum.push_back(s += v);
-        ef_encode(x.sizes_and_positions, cum.size(), universe, true, [&](uint64_t i) { return cum[i]; });
+        // append_iterator + cumulative_iterator over the four arrays: a prefix sum over their concatenation (per-piece sums, a scan over the pieces,
+        // then every piece on its own)
+        const std::vector<uint8_t>* arrays[4] = {&left_positions, &right_or_collision_sizes, &none_sizes, &none_positions};
+        const uint64_t starts[5] = {0, x.right_coll_sizes_start, x.none_sizes_start, x.none_pos_start, x.none_pos_start + none_positions.size()};
+        const uint64_t n_cum = starts[4];
+        auto value_at = [&](uint64_t i) -> uint8_t {
+            const int a = i < starts[2] ? (i < starts[1] ? 0 : 1) : (i < starts[3] ? 2 : 3);
+            return (*arrays[a])[i - starts[a]];
+        };
+        std::vector<uint64_t, DefaultInitAllocator<uint64_t>> cum(n_cum);
+        {
+            const uint64_t chunk = 1u << 16;
+            const size_t nch = (size_t)((n_cum + chunk - 1) / chunk);
+            std::vector<uint64_t> csum(nch + 1, 0);
+            parallel_for(nch, threads, [&](size_t c) {
+                uint64_t t = 0;
+                for (uint64_t i = c * chunk, e = std::min(n_cum, i + chunk); i < e; ++i) t += value_at(i);
+                csum[c + 1] = t;
+            });
+            for (size_t c = 0; c < nch; ++c) csum[c + 1] += csum[c];
+            parallel_for(nch, threads, [&](size_t c) {
+                uint64_t t = csum[c];
+                for (uint64_t i = c * chunk, e = std::min(n_cum, i + chunk); i < e; ++i) cum[i] = t += value_at(i);
+            });
+        }
+        lap("  inverted index: cumulative sums");
+        ef_encode(x.sizes_and_positions, n_cum, universe, true, [&](uint64_t i) { return cum[i]; }, threads);
+        lap("  inverted index: Elias-Fano");
     } else {  // build_pos_index / build_size_index, src/unpartitioned_mphf.cpp:156-176
         uint64_t pos_sum = 0, size_sum = 0;
         std::vector<uint64_t> cp(D), cs(D);
@@ -1143,8 +1227,8 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
             cp[i] = pos_sum += by_order[i].p1;
             cs[i] = size_sum += by_order[i].size;
         }
-        ef_encode(x.positions, D, pos_sum, true, [&](uint64_t i) { return cp[i]; });
-        ef_encode(x.sizes, D, size_sum, true, [&](uint64_t i) { return cs[i]; });
+        ef_encode(x.positions, D, pos_sum, true, [&](uint64_t i) { return cp[i]; }, threads);
+        ef_encode(x.sizes, D, size_sum, true, [&](uint64_t i) { return cs[i]; }, threads);
         x.num_kmers_in_main_index = size_sum;
     }
     std::vector<Triplet>().swap(by_order);

@@ -116,6 +116,19 @@ def test_builder_is_byte_identical_to_the_oracle_build(tmp_path, k, m, bits, kin
         assert open(po, "rb").read() == open(pp, "rb").read()
 
 
+@pytest.mark.parametrize("k,m,bits,kind", [(31, 20, 64, 0), (31, 20, 64, 1), (47, 30, 128, 0)])
+def test_builder_parallel_pieces_are_byte_identical_to_the_oracle_build(tmp_path, k, m, bits, kind):
+    """Enough minimizers (> 3 x 65,536) that the stages which work on pieces -- classification cut at minimizer boundaries, the type pass of the
+    inverted index in 64-aligned pieces -- really run on several, against the oracle's sequential restatement."""
+    recs = dedup_records(random_records(4321 + k, 20, 90_000, 140_000), k)
+    po, pp = str(tmp_path / "o.lph"), str(tmp_path / "p.lph")
+    orc.build(recs, k, m, po, kind=kind, kmer_bits=bits)
+    for threads in (8, 3):
+        st = L.build(recs, k, m, pp, kind=kind, kmer_bits=bits, threads=threads)
+        assert st["distinct_minimizers"] > 3 * 65536
+        assert open(po, "rb").read() == open(pp, "rb").read()
+
+
 def test_builder_argument_errors(tmp_path):
     recs = random_records(1, 2, 100, 200)
     out = str(tmp_path / "x.lph")
