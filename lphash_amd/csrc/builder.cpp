@@ -1080,7 +1080,8 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
     lap("part 2: PTHash over minimizers");
 
     // ---- Part 3: order by the minimizer MPHF (a bijection onto [0, D): direct placement) ---------------
-    std::vector<Triplet> by_order(D);
+    TripletVec by_order(D);  // zeroed below by all threads (itself == 0: not filled yet)
+    parallel_for((D + 65535) / 65536, threads, [&](size_t t) { memset((void*)(by_order.data() + t * 65536), 0, (std::min<size_t>(D, (t + 1) * 65536) - t * 65536) * sizeof(Triplet)); });
     {
         std::vector<uint64_t> free_table;
         if (!x.minimizer_order.free_slots.decode(free_table, err)) return fail(LPHQ_ERR_FORMAT, err);
@@ -1097,8 +1098,12 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
             }
         });
         if (bad.load()) return fail(LPHQ_ERR_FORMAT, "internal: minimizer MPHF out of range");
-        for (uint64_t i = 0; i < D; ++i)
-            if (by_order[i].itself != 1) return fail(LPHQ_ERR_FORMAT, "internal: minimizer MPHF is not a bijection");
+        std::atomic<bool> hole{false};
+        parallel_for((D + 65535) / 65536, threads, [&](size_t t) {
+            for (size_t i = t * 65536, e = std::min<size_t>(D, i + 65536); i < e; ++i)
+                if (by_order[i].itself != 1) hole.store(true);
+        });
+        if (hole.load()) return fail(LPHQ_ERR_FORMAT, "internal: minimizer MPHF is not a bijection");
     }
     TripletVec().swap(uniq);
     WordVec().swap(uniq_mm);
@@ -1231,7 +1236,7 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
         ef_encode(x.sizes, D, size_sum, true, [&](uint64_t i) { return cs[i]; }, threads);
         x.num_kmers_in_main_index = size_sum;
     }
-    std::vector<Triplet>().swap(by_order);
+    TripletVec().swap(by_order);
     lap("part 3: inverted index (wavelet tree, EF)");
 
     // ---- Part 4: fallback PTHash over the k-mers of repeated minimizers, in input order ----------------
