@@ -69,6 +69,25 @@ def self_launch(n, argv):
     return subprocess.call(cmd, env=env)
 
 
+def cpu_quota_cores():
+    """CPU time the container may use, in cores (cgroup v2 cpu.max / v1 cfs quota); None = unlimited or unknown.  The visible CPU count
+    (sched_getaffinity) says how many threads may run, the quota how much CPU time they share."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = float(f.read())
+        return None if quota <= 0 else quota / period
+    except Exception:
+        return None
+
+
 def hbm_ceiling_gbs(torch, dev):
     """Practical HBM ceiling of this box, measured in-run: read-only pass and device-to-device copy over 2-GiB
     buffers (far beyond the 256-MiB Infinity Cache).  Returns (read GB/s, copy read+write GB/s)."""
@@ -173,12 +192,12 @@ def main():
             t0 = time.time()
             tmp = path + f".tmp{os.getpid()}"
             if kind == L.BBHASH:
-                L.build_bbhash(recs, k, tmp, kmer_bits=kmer_bits, gamma=args.bbhash_gamma, threads=args.build_threads or min(os.cpu_count() or 8, 64))
+                L.build_bbhash(recs, k, tmp, kmer_bits=kmer_bits, gamma=args.bbhash_gamma, threads=args.build_threads or 0)
             elif kind == L.PTHASH:
-                L.build_pthash(recs, k, tmp, kmer_bits=kmer_bits, threads=args.build_threads or min(os.cpu_count() or 8, 64),
+                L.build_pthash(recs, k, tmp, kmer_bits=kmer_bits, threads=args.build_threads or 0,
                                device=local_rank if args.gpu_build else None)
             else:
-                L.build(recs, k, m, tmp, kind=kind, kmer_bits=kmer_bits, threads=args.build_threads or min(os.cpu_count() or 8, 64),
+                L.build(recs, k, m, tmp, kind=kind, kmer_bits=kmer_bits, threads=args.build_threads or 0,
                         device=local_rank if args.gpu_build else None)
             os.replace(tmp, path)
             build_s = time.time() - t0
@@ -307,21 +326,22 @@ def main():
             what = f"first {nrec_s} records of the batch, oracle streaming branch, single thread"
         parity = bool(np.array_equal(got, exp))
         cpu = {"value": S / cpu_s, "unit": "k-mer lookups/s", "cores": 1, "kind": "port", "sample": what}
-        if args.mode == "random":  # the same oracle on all host cores (threads over chunks; ctypes releases the GIL)
-            from concurrent.futures import ThreadPoolExecutor
-
-            nthreads = len(os.sched_getaffinity(0))
+        if args.mode == "random" and not competitor:  # the same oracle on all host cores (POSIX threads over contiguous slices, inside the oracle library)
+            quota = cpu_quota_cores()  # threads beyond the container's CPU-time quota only buy throttling (tools/host_probe.py)
+            nthreads = len(os.sched_getaffinity(0)) if quota is None else max(1, min(len(os.sched_getaffinity(0)), 2 * int(np.ceil(quota))))  # 2x: fastest in the probe
             wpk = kmer_bits // 64
             S3 = min(units, S * 8)
             big = d_kmers[: S3 * wpk].cpu().numpy().view(np.uint64)
-            chunks = np.array_split(np.arange(S3), nthreads * 4)
+            res = np.zeros(S3, dtype=np.uint64)  # pages exist before the timer starts
+            o.query_packed_threads(big[: wpk * min(S3, 1 << 16)], nthreads, res)
             t0 = time.perf_counter()
-            with ThreadPoolExecutor(nthreads) as ex:
-                parts = list(ex.map(lambda ix: o.query_packed(big[ix[0] * wpk:(ix[-1] + 1) * wpk]), [c for c in chunks if len(c)]))
+            parts = [o.query_packed_threads(big, nthreads, res)]
             cpu3_s = time.perf_counter() - t0
             parity = parity and bool(np.array_equal(np.concatenate(parts), d_out[:S3].cpu().numpy().view(np.uint64)))
-            cpu_all = {"value": S3 / cpu3_s, "unit": "k-mer lookups/s", "cores": nthreads, "kind": "port",
-                       "sample": f"first {S3} probes of the timed batch, {nthreads} threads"}
+            cpu_all = {"value": S3 / cpu3_s, "unit": "k-mer lookups/s", "cores": nthreads, "kind": "port", "cpus_visible": len(os.sched_getaffinity(0)),
+                       "cpu_quota_cores": quota,
+                       "sample": f"first {S3} probes of the timed batch, {nthreads} POSIX threads over contiguous slices (= the CPUs visible, capped at twice the "
+                                 f"container's CPU-time quota: the fastest setting on the box, tools/host_probe.py)"}
         if args.mode == "random" and world == 1 and args.nonmember_frac == 0.0:
             full = d_out.cpu().numpy().view(np.uint64)
             parity = parity and bool(full.max() < nk)  # positive probes: every code is a valid slot

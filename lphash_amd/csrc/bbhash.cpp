@@ -1,5 +1,6 @@
 // bbhash.cpp -- see bbhash.hpp.  Host side only (no HIP): parsing, image building and construction of BBHash functions.
 #include "bbhash.hpp"
+#include "host_cpus.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -246,7 +247,7 @@ bool build_bbhash_file(const char* const* records, const size_t* lengths, size_t
         err = "BBHash gamma factor < 1";  // ptbb_build.cpp:149
         return false;
     }
-    if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (threads <= 0) threads = usable_cpus();
     const uint32_t k = (uint32_t)k_;
     const int nw = kmer_bits / 64;
     const u128 mask = (((u128)1) << (2 * k)) - 1;

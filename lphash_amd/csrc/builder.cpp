@@ -29,6 +29,7 @@
 
 #include "../../include/lphq.h"
 #include "extract.hpp"
+#include "host_cpus.hpp"
 #include "lph_format.hpp"
 #include "search.hpp"
 
@@ -863,7 +864,7 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
     if (k_ < 1 || k_ > kmer_bits / 2 - 1) return fail(LPHQ_ERR_ARG, "k cannot be larger than " + std::to_string(kmer_bits / 2 - 1));
     if (m_ < 1 || m_ > k_ || m_ > 32) return fail(LPHQ_ERR_ARG, "m cannot be larger than k (and must be <= 32)");
     if (c < 3.0 || c > 10.0) return fail(LPHQ_ERR_ARG, "3.0 <= c <= 10.0");  // parser_build.cpp:78-81
-    if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (threads <= 0) threads = usable_cpus();
     const uint32_t k = (uint32_t)k_, m = (uint32_t)m_, W = k - m + 1;
     const bool verbose = getenv("LPHQ_BUILD_VERBOSE") != nullptr;
     auto tprev = std::chrono::steady_clock::now();
@@ -1350,7 +1351,7 @@ extern "C" int lphq_build_pthash(const char* const* records, const size_t* lengt
     if (kmer_bits != 64 && kmer_bits != 128) return fail(LPHQ_ERR_ARG, "kmer_bits must be 64 or 128");
     if (k_ < 1 || k_ > kmer_bits / 2 - 1) return fail(LPHQ_ERR_ARG, "k cannot be larger than " + std::to_string(kmer_bits / 2 - 1));
     if (c < 3.0 || c > 10.0) return fail(LPHQ_ERR_ARG, "3.0 <= c <= 10.0");
-    if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (threads <= 0) threads = usable_cpus();
     const uint32_t k = (uint32_t)k_;
     const uint64_t seed = 1;  // constants::default_pthash_seed
     const u128 km_mask = (((u128)1) << (2 * k)) - 1;

@@ -26,6 +26,7 @@
 #include "../../include/lphq.h"
 #include "fastx.hpp"
 #include "fastx_batch.hpp"
+#include "host_cpus.hpp"
 
 namespace {
 
@@ -191,7 +192,7 @@ struct ArenaCache {
 } g_arenas;
 void* arena_alloc(size_t n) { return g_arenas.get(n); }
 void arena_free(void* p) { g_arenas.put(p); }
-int default_parse_threads() { return (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency())); }
+int default_parse_threads() { return std::min(16, lphq::usable_cpus()); }
 
 // One pass of src/query.cpp:48-56 / :68-76 over the whole file, batched: returns false if the file cannot be opened.
 // Every batch is split into contiguous runs of records of about equal base count, one per GPU (the index is replicated,

@@ -10,7 +10,7 @@
  *
  * PARITY UNPINNED: PTHash (external/pthash, empty submodule) is restated from its published
  * v1 algorithm (Pibiri & Trani, SIGIR'21; jermp/pthash v1 include/{single_phf,utils/bucketers,
- * encoders/*,fastmod/fastmod}.hpp as recalled in SURVEY.md Appendix A); there are no golden
+ * encoders/...,fastmod/fastmod}.hpp as recalled in SURVEY.md Appendix A); there are no golden
  * vectors in the reference to pin absolute hash codes.
  */
 #include "lph_oracle.h"
@@ -256,6 +256,7 @@ orc_index* orc_load(const char* path, int kind, int kmer_bits) {
 }
 
 uint64_t orc_k(const orc_index* x) { return x->k; }
+size_t orc_kmer_words(const orc_index* x) { return x->kmer_bits == 64 ? 1 : 2; }
 uint64_t orc_m(const orc_index* x) { return x->m; }
 uint64_t orc_mm_seed(const orc_index* x) { return x->mm_seed; }
 uint64_t orc_kmer_count(const orc_index* x) { return x->nkmers; }

@@ -36,6 +36,7 @@ void orc_free(orc_index* idx);
 const char* orc_last_error(void);
 
 uint64_t orc_k(const orc_index* idx);
+size_t orc_kmer_words(const orc_index* idx); /* 64-bit words per packed k-mer */
 uint64_t orc_m(const orc_index* idx);
 uint64_t orc_mm_seed(const orc_index* idx);
 uint64_t orc_kmer_count(const orc_index* idx);   /* get_kmer_count()   */
@@ -67,6 +68,8 @@ int orc_query_file(const orc_index* idx, const char* query_path, uint64_t* total
                    double* us_streaming, double* us_random);
 /* records / bases / FNV-1a digest of a file as the driver's reader sees it (pinned against the real kseq.h by the tests) */
 int orc_file_digest(const char* path, uint64_t* n_records, uint64_t* n_bases, uint64_t* digest);
+/* orc_query_packed on `threads` POSIX threads over contiguous slices (the all-cores CPU figure) */
+int orc_query_packed_threads(const orc_index* idx, const uint64_t* kmers, size_t n, uint64_t* out, int threads);
 
 /* Competitor harness, PTHash half (src/ptbb/ptbb.hpp:16-34, ptbb_build.cpp:83-99, ptbb_query.cpp:40-55): a plain
  * pthash::single_phf<PTHasher, dictionary_dictionary, true> over the k-mers of the records, serialized by essentials::save. */

@@ -13,6 +13,7 @@
 #include <string.h>
 #include <time.h>
 #include <zlib.h>
+#include <pthread.h>
 
 #include "lph_oracle.h"
 
@@ -202,4 +203,38 @@ int orc_query_file(const orc_index* idx, const char* query_path, uint64_t* total
     rc = one_pass(idx, query_path, 0, total_kmers_random, us_random, &sink);
     if (rc) return rc;
     return sink == 0x5eed5eed5eed5eedull ? 0 : 0; /* keeps `sink` live */
+}
+
+
+/* orc_query_packed over contiguous slices of the batch, one POSIX thread per slice (the lookups are independent; the index is
+ * read-only).  Test infrastructure like the rest of this file: the all-cores CPU figure bench.py reports next to the GPU's. */
+typedef struct { const orc_index* x; const uint64_t* kmers; size_t n; uint64_t* out; } slice_t;
+static void* slice_main(void* p) {
+    slice_t* s = (slice_t*)p;
+    orc_query_packed(s->x, s->kmers, s->n, s->out);
+    return NULL;
+}
+int orc_query_packed_threads(const orc_index* x, const uint64_t* kmers, size_t n, uint64_t* out, int threads) {
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > n) threads = n ? (int)n : 1;
+    const size_t wpk = orc_kmer_words(x);
+    pthread_t* th = calloc((size_t)threads, sizeof *th);
+    slice_t* sl = calloc((size_t)threads, sizeof *sl);
+    if (!th || !sl) { free(th); free(sl); return -1; }
+    int started = 0, rc = 0;
+    for (int t = 0; t < threads; ++t) {
+        const size_t a = n * (size_t)t / (size_t)threads, b = n * (size_t)(t + 1) / (size_t)threads;
+        sl[t] = (slice_t){x, kmers + a * wpk, b - a, out + a};
+        if (pthread_create(&th[t], NULL, slice_main, &sl[t]) != 0) { rc = -1; break; }
+        ++started;
+    }
+    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    if (rc != 0)  /* could not start them all: finish the rest here */
+        for (int t = started; t < threads; ++t) {
+            const size_t a = n * (size_t)t / (size_t)threads, b = n * (size_t)(t + 1) / (size_t)threads;
+            orc_query_packed(x, kmers + a * wpk, b - a, out + a);
+        }
+    free(th);
+    free(sl);
+    return 0;
 }

@@ -145,6 +145,20 @@ class Index:
         lib.orc_query_packed(self.h, kmers.ctypes.data, n, out.ctypes.data)
         return out
 
+    def query_packed_threads(self, kmers: np.ndarray, threads: int, out=None):
+        """query_packed over contiguous slices on POSIX threads (no interpreter in the loop); out: a uint64 array to fill (a timed caller passes
+        one whose pages exist already: first-touch faults of a fresh GB-sized array from hundreds of threads would be what is measured)"""
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        n = kmers.size // (1 if self.kmer_bits == 64 else 2)
+        if out is None:
+            out = np.empty(n, dtype=np.uint64)
+        assert out.dtype == np.uint64 and out.size >= n and out.flags["C_CONTIGUOUS"]
+        lib.orc_query_packed_threads.restype = C.c_int
+        lib.orc_query_packed_threads.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        if lib.orc_query_packed_threads(self.h, kmers.ctypes.data, n, out.ctypes.data, int(threads)) != 0:
+            raise RuntimeError("orc_query_packed_threads failed")
+        return out[:n]
+
     def query_file(self, path):
         """The reference's driver (src/query.cpp:24-88): returns (k-mers streaming, k-mers random, us streaming, us random)."""
         ns, nr, us, ur = C.c_uint64(), C.c_uint64(), C.c_double(), C.c_double()

@@ -187,3 +187,20 @@ def test_python_model_equals_the_oracle_on_fresh_inputs(tmp_path, golden_dir, k,
     assert (mdl.nkmers, mdl.D, len(mdl.fallback_keys)) == (ix.nkmers, ix.distinct_minimizers, ix.fallback_keys)
     for q in recs[:2] + random_records(seed, 2, k, 300):
         assert np.array_equal(np.array(mdl.query(q), dtype=np.uint64), ix(q, False))
+
+
+def test_all_cores_entry_equals_the_single_thread_one(tmp_path):
+    """orc_query_packed_threads (the all-cores CPU figure of bench.py): same codes as orc_query_packed, for any thread count, both k-mer widths."""
+    from util import pack_kmers, random_records
+
+    for k, bits in ((31, 64), (41, 128)):
+        recs = random_records(5 + k, 6, 300, 2000)
+        path = str(tmp_path / f"t{k}.lph")
+        orc.build(recs, k, 13, path, kind=0, kmer_bits=bits)
+        o = orc.Index(path, 0, bits)
+        flat = b"".join(recs)
+        rng = np.random.default_rng(k)
+        pk = pack_kmers(flat, rng.integers(0, len(flat) - k, 5000), k, bits)
+        want = o.query_packed(pk)
+        for threads in (1, 3, 8, 10_000):
+            assert np.array_equal(o.query_packed_threads(pk, threads), want)
