@@ -689,8 +689,10 @@ struct RecordSource {
     virtual ~RecordSource() {}
     // next batch of pass `pass` (0, then 1; the first call of pass 1 restarts the input): 1 = a batch, 0 = end of input, < 0 = error
     virtual int next(int pass, const char* const*& recs, const size_t*& lens, size_t& n) = 0;
+    virtual bool one_batch() const { return false; }  // the first batch is the whole input
 };
 struct MemorySource : RecordSource {  // lphq_build: the whole input is one batch
+    bool one_batch() const override { return true; }
     const char* const* recs_;
     const size_t* lens_;
     size_t n_;
@@ -888,6 +890,8 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
     RunVec runs;
     uint64_t nkmers = 0, n_super_kmers = 0, n_records = 0, base = 0;
     int extract_device = getenv("LPHQ_BUILD_HOST_EXTRACT") ? -1 : device;  // (the variable exists for A/B timing; the result is the same)
+    ClassifiedMinimizers on_device;  // the whole input in one batch and a device: extraction, sort AND classification there (extract.hip)
+    bool classified_on_device = false;
     bool runs_sorted = false;  // `runs` ascending by minimizer already (one batch, extracted and sorted on the GPU)
     uint64_t gpu_batches = 0;
     {
@@ -908,6 +912,20 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
                 if (lengths[r] < k) continue;
                 const uint64_t nw = lengths[r] - k + 1;
                 for (uint64_t a = 0; a < nw; a += CH) chunks.push_back({r, a, std::min(nw, a + CH)});
+            }
+            if (extract_device >= 0 && src.one_batch() && !max_memory_bytes && !getenv("LPHQ_BUILD_HOST_CLASSIFY")) {
+                std::string gerr;
+                if (gpu_extract_classified(extract_device, records, lengths, nb, k, m, mm_seed, threads, verbose, on_device, gerr)) {
+                    classified_on_device = true;
+                    nkmers = on_device.num_kmers;
+                    n_super_kmers = on_device.num_super_kmers;
+                    ++gpu_batches;
+                    base = rec_off[nb];
+                    n_records += nb;
+                    continue;
+                }
+                fprintf(stderr, "[lphq_build] GPU super-k-mer extraction unavailable (%s): the host extracts\n", gerr.c_str());
+                extract_device = -1;
             }
             if (extract_device >= 0) {  // super-k-mers of the batch from the GPU, already sorted by minimizer
                 std::string gerr;
@@ -1006,7 +1024,22 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
                 }
             }
         };
-        if (spill.files.empty()) {
+        if (classified_on_device) {  // only the unpacking is left
+            const size_t nu = on_device.minimizer.size(), nc = on_device.colliding_first.size();
+            uniq_mm.swap(on_device.minimizer);
+            uniq.resize(nu);
+            colliding.resize(nc);
+            parallel_for((nu + 65535) / 65536, threads, [&](size_t t) {
+                for (size_t i = t * 65536, e = std::min(nu, i + 65536); i < e; ++i) {
+                    const uint16_t ps = on_device.offset_size[i];
+                    uniq[i] = Triplet{0, (uint8_t)(ps & 0xFF), (uint8_t)(ps >> 8)};
+                }
+            });
+            parallel_for((nc + 65535) / 65536, threads, [&](size_t t) {
+                for (size_t i = t * 65536, e = std::min(nc, i + 65536); i < e; ++i) colliding[i] = {on_device.colliding_first[i], on_device.colliding_size[i]};
+            });
+            on_device = ClassifiedMinimizers();
+        } else if (spill.files.empty()) {
             if (!runs_sorted) parallel_sort_by_key(runs, threads, 2 * m, [](const Run& r) { return r.mm; });
             lap("part 2: sort runs by minimizer");
             // pieces that begin at the first record of a minimizer, one classifier each, joined in order

@@ -1,6 +1,8 @@
 // extract.hip -- index construction, parts 1-2 on the GPU ("minimizer extraction + radix sort of
 // mm_record_t on GPU"): the super-k-mer records of a batch of records (k_extract_runs, extract_device.cuh), sorted by minimizer
-// (rocPRIM radix sort: a plain library sort of (key, value) pairs; the key is the 2m-bit minimizer).
+// (rocPRIM radix sort: a plain library sort of (key, value) pairs; the key is the 2m-bit minimizer) and, when the whole input is one batch, classified
+// there as well (src/minimizer.cpp:5-50: a minimizer seen once keeps its offset and size, one seen more often sends its super-k-mers to the fallback),
+// so that only the distinct minimizers travel back.
 // Reference: minimizer::from_string (include/minimizer.hpp:11-170) and the sorted external_memory_vector<mm_record_t> it fills
 // (src/partitioned_mphf.cpp:62-65).
 #include <hip/hip_runtime.h>
@@ -15,21 +17,13 @@
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "extract.hpp"
 #include "extract_device.cuh"
 
 namespace lphq {
 namespace {
-
-#define HIP_OK(call)                                                 \
-    do {                                                             \
-        hipError_t e_ = (call);                                      \
-        if (e_ != hipSuccess) {                                      \
-            err = std::string(#call) + ": " + hipGetErrorString(e_); \
-            goto done;                                               \
-        }                                                            \
-    } while (0)
 
 constexpr size_t kStage = 64u << 20;  // bytes per pinned staging buffer (two of them)
 constexpr int kFront = 64;            // spare bytes before the first base and after the last one
@@ -70,19 +64,12 @@ void scatter_bytes(const char* src, char* dst, size_t n, int threads) {
     for (auto& x : th) x.join();
 }
 
-}  // namespace
-
-bool gpu_extract_sorted_runs(int device, const char* const* records, const size_t* lengths, size_t n_records, uint64_t first_base, uint32_t k, uint32_t m,
-                             uint64_t mm_seed, int threads, bool verbose, SuperKmerRuns& out, std::string& err) {
-    bool ok = false;
-    const size_t out_before = out.size();
-    SuperKmerRun* d_runs = nullptr;
-    auto tprev = std::chrono::steady_clock::now();
-    auto lap = [&](const char* what) {
-        auto now = std::chrono::steady_clock::now();
-        if (verbose) fprintf(stderr, "[lphq_build]   gpu extraction: %-30s %8.3f s\n", what, std::chrono::duration<double>(now - tprev).count());
-        tprev = now;
-    };
+// Everything the device path owns, released in one place.  step() = a HIP call checked; after a failure ok is false and err says what.
+struct Extractor {
+    std::string& err;
+    bool verbose;
+    int threads;
+    bool ok = true;
     int prev = -1;
     uint8_t* d_seq = nullptr;
     uint64_t *d_off = nullptr, *d_mm[2] = {nullptr, nullptr};
@@ -92,43 +79,85 @@ bool gpu_extract_sorted_runs(int device, const char* const* records, const size_
     char* h_stage[2] = {nullptr, nullptr};
     hipStream_t stream = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
-    std::vector<uint64_t> off(n_records + 1, 0);
-    for (size_t r = 0; r < n_records; ++r) off[r + 1] = off[r] + lengths[r];
-    const uint64_t total = off[n_records];
-    const uint32_t W = k - m + 1u;
-    if (n_records == 0 || total < k) return true;  // no window at all
-    if (n_records > 0xFFFFFFFFull) {
-        err = "gpu extraction: more than 2^32 - 1 records in one batch";
-        return false;
+    unsigned long long produced = 0;  // super-k-mers of the batch; sorted by minimizer in d_mm[1] / d_val[1] after extract_and_sort()
+    std::chrono::steady_clock::time_point tprev = std::chrono::steady_clock::now();
+
+    Extractor(std::string& e, bool v, int t) : err(e), verbose(v), threads(t) { (void)hipGetDevice(&prev); }
+    ~Extractor() {
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (int i = 0; i < 2; ++i) {
+            if (d_mm[i]) (void)hipFree(d_mm[i]);
+            if (d_val[i]) (void)hipFree(d_val[i]);
+            if (h_stage[i]) (void)hipHostFree(h_stage[i]);
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+        }
+        if (d_tmp) (void)hipFree(d_tmp);
+        if (d_seq) (void)hipFree(d_seq);
+        if (d_off) (void)hipFree(d_off);
+        if (d_cursor) (void)hipFree(d_cursor);
+        if (stream) (void)hipStreamDestroy(stream);
+        if (prev >= 0) (void)hipSetDevice(prev);
     }
-    uint64_t windows = 0;
-    for (size_t r = 0; r < n_records; ++r)
-        if (lengths[r] >= k) windows += lengths[r] - k + 1;
-    if (windows == 0) return true;
-    (void)hipGetDevice(&prev);
-    {
-        HIP_OK(hipSetDevice(device));
-        HIP_OK(hipStreamCreate(&stream));
-        HIP_OK(hipMalloc((void**)&d_seq, (size_t)total + 2 * kFront + 16));
-        HIP_OK(hipMalloc((void**)&d_off, (n_records + 1) * sizeof(uint64_t)));
-        HIP_OK(hipMalloc((void**)&d_cursor, sizeof(unsigned long long)));
-        HIP_OK(hipMemsetAsync(d_seq, 0, kFront, stream));
-        HIP_OK(hipMemsetAsync(d_seq + kFront + total, 0, kFront + 16, stream));
-        HIP_OK(hipMemcpyAsync(d_off, off.data(), (n_records + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    void lap(const char* what) {
+        auto now = std::chrono::steady_clock::now();
+        if (verbose) fprintf(stderr, "[lphq_build]   gpu extraction: %-30s %8.3f s\n", what, std::chrono::duration<double>(now - tprev).count());
+        tprev = now;
+    }
+    bool step(hipError_t e, const char* what) {
+        if (ok && e != hipSuccess) {
+            err = std::string(what) + ": " + hipGetErrorString(e);
+            ok = false;
+        }
+        return ok;
+    }
+#define STEP(call)                \
+    do {                          \
+        if (!step((call), #call)) return false; \
+    } while (0)
+
+    void release(void*& p) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+
+    // bases up, k_extract_runs (a second launch with the exact room if the first buffer was too small), radix sort by minimizer.
+    // true with produced == 0: the batch has no window.
+    bool extract_and_sort(int device, const char* const* records, const size_t* lengths, size_t n_records, uint64_t first_base, uint32_t k, uint32_t m, uint64_t mm_seed) {
+        std::vector<uint64_t> off(n_records + 1, 0);
+        for (size_t r = 0; r < n_records; ++r) off[r + 1] = off[r] + lengths[r];
+        const uint64_t total = off[n_records];
+        const uint32_t W = k - m + 1u;
+        if (n_records == 0 || total < k) return true;
+        if (n_records > 0xFFFFFFFFull) {
+            err = "gpu extraction: more than 2^32 - 1 records in one batch";
+            return ok = false;
+        }
+        uint64_t windows = 0;
+        for (size_t r = 0; r < n_records; ++r)
+            if (lengths[r] >= k) windows += lengths[r] - k + 1;
+        if (windows == 0) return true;
+        STEP(hipSetDevice(device));
+        STEP(hipStreamCreate(&stream));
+        STEP(hipMalloc((void**)&d_seq, (size_t)total + 2 * kFront + 16));
+        STEP(hipMalloc((void**)&d_off, (n_records + 1) * sizeof(uint64_t)));
+        STEP(hipMalloc((void**)&d_cursor, 2 * sizeof(unsigned long long)));
+        STEP(hipMemsetAsync(d_seq, 0, kFront, stream));
+        STEP(hipMemsetAsync(d_seq + kFront + total, 0, kFront + 16, stream));
+        STEP(hipMemcpyAsync(d_off, off.data(), (n_records + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
         // the bases: the concatenated records through two pinned staging buffers (records may be many and small, or few and huge)
         for (int i = 0; i < 2; ++i) {
-            HIP_OK(hipHostMalloc((void**)&h_stage[i], kStage, hipHostMallocDefault));
-            HIP_OK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+            STEP(hipHostMalloc((void**)&h_stage[i], kStage, hipHostMallocDefault));
+            STEP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
         }
         lap("device and pinned buffers");
         {
             int which = 0;
             for (uint64_t at = 0; at < total; at += kStage, which ^= 1) {
                 const size_t n = (size_t)std::min<uint64_t>(kStage, total - at);
-                HIP_OK(hipEventSynchronize(ev[which]));  // the copy that last used this buffer (a fresh event is complete)
+                STEP(hipEventSynchronize(ev[which]));  // the copy that last used this buffer (a fresh event is complete)
                 gather_bytes(records, lengths, off, at, n, h_stage[which], threads);
-                HIP_OK(hipMemcpyAsync(d_seq + kFront + at, h_stage[which], n, hipMemcpyHostToDevice, stream));
-                HIP_OK(hipEventRecord(ev[which], stream));
+                STEP(hipMemcpyAsync(d_seq + kFront + at, h_stage[which], n, hipMemcpyHostToDevice, stream));
+                STEP(hipEventRecord(ev[which], stream));
             }
         }
         lap("bases to the device");
@@ -143,19 +172,16 @@ bool gpu_extract_sorted_runs(int device, const char* const* records, const size_
         const uint8_t* seq_al = d_seq + kFront - shift;
         const uint32_t S = extract_tile_stride(W, 4 * kStreamBlockDefault);
         const uint64_t tiles = (shift + total - k) / S + 1;  // the last window start has shifted coordinate shift + total - k >= 1
-        unsigned long long produced = 0;
         for (int attempt = 0; attempt < 2; ++attempt) {
             for (int i = 0; i < 2; ++i) {
-                if (d_mm[i]) (void)hipFree(d_mm[i]);
-                if (d_val[i]) (void)hipFree(d_val[i]);
-                d_mm[i] = nullptr;
-                d_val[i] = nullptr;
+                release((void*&)d_mm[i]);
+                release((void*&)d_val[i]);
             }
             for (int i = 0; i < 2; ++i) {
-                HIP_OK(hipMalloc((void**)&d_mm[i], (size_t)cap * sizeof(uint64_t)));
-                HIP_OK(hipMalloc((void**)&d_val[i], (size_t)cap * sizeof(RunVal)));
+                STEP(hipMalloc((void**)&d_mm[i], (size_t)cap * sizeof(uint64_t)));
+                STEP(hipMalloc((void**)&d_val[i], (size_t)cap * sizeof(RunVal)));
             }
-            HIP_OK(hipMemsetAsync(d_cursor, 0, sizeof(unsigned long long), stream));
+            STEP(hipMemsetAsync(d_cursor, 0, 2 * sizeof(unsigned long long), stream));
             const uint64_t kMaxTiles = (1u << 24) - 1;
             for (uint64_t tb = 0; tb < tiles; tb += kMaxTiles) {
                 const unsigned grid = (unsigned)std::min<uint64_t>(kMaxTiles, tiles - tb);
@@ -165,80 +191,141 @@ bool gpu_extract_sorted_runs(int device, const char* const* records, const size_
                 else
                     k_extract_runs<kStreamBlockDefault, false><<<grid, kStreamBlockDefault, 0, stream>>>(seq_al, shift, total, d_off, (uint32_t)n_records, k, m, mm_seed,
                                                                                                           first_base, d_mm[0], d_val[0], d_cursor, cap, tb);
-                HIP_OK(hipGetLastError());
+                STEP(hipGetLastError());
             }
-            HIP_OK(hipMemcpyAsync(&produced, d_cursor, sizeof produced, hipMemcpyDeviceToHost, stream));
-            HIP_OK(hipStreamSynchronize(stream));
+            STEP(hipMemcpyAsync(&produced, d_cursor, sizeof produced, hipMemcpyDeviceToHost, stream));
+            STEP(hipStreamSynchronize(stream));
             if (produced <= cap) break;
             if (attempt == 1) {
                 err = "gpu extraction: the run count changed between two launches";
-                goto done;
+                return ok = false;
             }
             cap = produced;
         }
         lap("k_extract_runs");
+        release((void*&)d_seq);
         if (produced) {
             size_t tmp_bytes = 0;
-            HIP_OK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_mm[0], d_mm[1], d_val[0], d_val[1], (size_t)produced, 0u, 2u * m, stream));
-            HIP_OK(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
-            HIP_OK(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_mm[0], d_mm[1], d_val[0], d_val[1], (size_t)produced, 0u, 2u * m, stream));
-            // the unsorted buffers have done their job: the builder's records go where they were (32 B each = the 8 + 16 of a pair and room to spare
-            // only if both are reused; a fresh buffer keeps this simple)
-            (void)hipStreamSynchronize(stream);
-            (void)hipFree(d_mm[0]);
-            (void)hipFree(d_val[0]);
-            d_mm[0] = nullptr;
-            d_val[0] = nullptr;
-            HIP_OK(hipMalloc((void**)&d_runs, (size_t)produced * sizeof(SuperKmerRun)));
-            k_assemble_runs<<<(unsigned)((produced + 255) / 256), 256, 0, stream>>>(d_mm[1], d_val[1], (size_t)produced, d_runs);
-            HIP_OK(hipGetLastError());
-            HIP_OK(hipStreamSynchronize(stream));
+            STEP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_mm[0], d_mm[1], d_val[0], d_val[1], (size_t)produced, 0u, 2u * m, stream));
+            STEP(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
+            STEP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_mm[0], d_mm[1], d_val[0], d_val[1], (size_t)produced, 0u, 2u * m, stream));
+            STEP(hipStreamSynchronize(stream));
+            release((void*&)d_mm[0]);  // the unsorted buffers and the sort's scratch have done their job
+            release((void*&)d_val[0]);
+            release(d_tmp);
             lap("radix sort by minimizer");
-            // out through the two pinned buffers: the copy of one piece overlaps with the host-side move of the piece before
-            out.resize(out_before + (size_t)produced);
-            const size_t per = kStage / sizeof(SuperKmerRun);
-            size_t pending_at = 0, pending_n = 0;
-            int which = 0, pending_which = -1;
-            for (size_t at = 0; at < (size_t)produced || pending_which >= 0;) {
-                size_t n = 0;
-                if (at < (size_t)produced) {
-                    n = std::min(per, (size_t)produced - at);
-                    HIP_OK(hipMemcpyAsync(h_stage[which], d_runs + at, n * sizeof(SuperKmerRun), hipMemcpyDeviceToHost, stream));
-                    HIP_OK(hipEventRecord(ev[which], stream));
-                }
-                if (pending_which >= 0) {
-                    HIP_OK(hipEventSynchronize(ev[pending_which]));
-                    scatter_bytes(h_stage[pending_which], (char*)(out.data() + out_before + pending_at), pending_n * sizeof(SuperKmerRun), threads);
-                    pending_which = -1;
-                }
-                if (n) {
-                    pending_which = which;
-                    pending_at = at;
-                    pending_n = n;
-                    at += n;
-                    which ^= 1;
-                }
-            }
-            lap("records to the host");
         }
-        ok = true;
+        return true;
     }
-done:
-    if (stream) (void)hipStreamSynchronize(stream);
-    for (int i = 0; i < 2; ++i) {
-        if (d_mm[i]) (void)hipFree(d_mm[i]);
-        if (d_val[i]) (void)hipFree(d_val[i]);
-        if (h_stage[i]) (void)hipHostFree(h_stage[i]);
-        if (ev[i]) (void)hipEventDestroy(ev[i]);
+
+    // bytes from device memory into pageable host memory through the two pinned buffers: the copy of one piece overlaps with the host-side move
+    // (all threads: also the first touch of the destination's pages) of the piece before
+    bool download(void* dst, const void* d_src, size_t bytes) {
+        size_t pending_at = 0, pending_n = 0;
+        int which = 0, pending_which = -1;
+        for (size_t at = 0; at < bytes || pending_which >= 0;) {
+            size_t n = 0;
+            if (at < bytes) {
+                n = std::min(kStage, bytes - at);
+                STEP(hipMemcpyAsync(h_stage[which], (const char*)d_src + at, n, hipMemcpyDeviceToHost, stream));
+                STEP(hipEventRecord(ev[which], stream));
+            }
+            if (pending_which >= 0) {
+                STEP(hipEventSynchronize(ev[pending_which]));
+                scatter_bytes(h_stage[pending_which], (char*)dst + pending_at, pending_n, threads);
+                pending_which = -1;
+            }
+            if (n) {
+                pending_which = which;
+                pending_at = at;
+                pending_n = n;
+                at += n;
+                which ^= 1;
+            }
+        }
+        return true;
     }
-    if (d_tmp) (void)hipFree(d_tmp);
-    if (d_runs) (void)hipFree(d_runs);
-    if (d_seq) (void)hipFree(d_seq);
-    if (d_off) (void)hipFree(d_off);
-    if (d_cursor) (void)hipFree(d_cursor);
-    if (stream) (void)hipStreamDestroy(stream);
-    if (prev >= 0) (void)hipSetDevice(prev);
+};
+
+}  // namespace
+
+bool gpu_extract_sorted_runs(int device, const char* const* records, const size_t* lengths, size_t n_records, uint64_t first_base, uint32_t k, uint32_t m,
+                             uint64_t mm_seed, int threads, bool verbose, SuperKmerRuns& out, std::string& err) {
+    const size_t out_before = out.size();
+    Extractor x(err, verbose, threads);
+    auto body = [&]() -> bool {
+        if (!x.extract_and_sort(device, records, lengths, n_records, first_base, k, m, mm_seed)) return false;
+        if (!x.produced) return true;
+        SuperKmerRun* d_runs = nullptr;
+        if (!x.step(hipMalloc((void**)&d_runs, (size_t)x.produced * sizeof(SuperKmerRun)), "hipMalloc(records)")) return false;
+        x.d_tmp = d_runs;  // (released with the rest)
+        k_assemble_runs<<<(unsigned)((x.produced + 255) / 256), 256, 0, x.stream>>>(x.d_mm[1], x.d_val[1], (size_t)x.produced, d_runs);
+        if (!x.step(hipGetLastError(), "k_assemble_runs") || !x.step(hipStreamSynchronize(x.stream), "hipStreamSynchronize")) return false;
+        out.resize(out_before + (size_t)x.produced);
+        if (!x.download(out.data() + out_before, d_runs, (size_t)x.produced * sizeof(SuperKmerRun))) return false;
+        x.lap("records to the host");
+        return true;
+    };
+    const bool ok = body() && x.ok;
     if (!ok) out.resize(out_before);
+    return ok;
+}
+
+bool gpu_extract_classified(int device, const char* const* records, const size_t* lengths, size_t n_records, uint32_t k, uint32_t m, uint64_t mm_seed, int threads,
+                            bool verbose, ClassifiedMinimizers& out, std::string& err) {
+    out = ClassifiedMinimizers();
+    Extractor x(err, verbose, threads);
+    auto body = [&]() -> bool {
+        if (!x.extract_and_sort(device, records, lengths, n_records, 0, k, m, mm_seed)) return false;
+        const size_t n = (size_t)x.produced;
+        out.num_super_kmers = n;
+        if (!n) return true;
+        // flags: low word 1 = first record of its minimizer, high word 1 = record of a minimizer that has several; an exclusive scan of the
+        // packed pair gives every record its slot among the distinct minimizers and among the colliding records
+        uint64_t *d_flags = nullptr, *d_slots = nullptr, *d_umm = nullptr, *d_cfirst = nullptr;
+        uint16_t* d_ups = nullptr;
+        uint32_t* d_csize = nullptr;
+        void* d_scan_tmp = nullptr;
+        bool good = true;
+        auto S = [&](hipError_t e, const char* what) { return good = good && x.step(e, what); };
+        unsigned long long totals[2] = {0, 0};
+        uint64_t last_flag = 0, last_slot = 0;
+        size_t tmp_bytes = 0;
+        const unsigned grid = (unsigned)((n + 255) / 256);
+        do {
+            if (!S(hipMalloc((void**)&d_flags, n * 8), "hipMalloc(flags)") || !S(hipMalloc((void**)&d_slots, n * 8), "hipMalloc(slots)")) break;
+            k_group_flags<<<grid, 256, 0, x.stream>>>(x.d_mm[1], x.d_val[1], n, d_flags, x.d_cursor + 1);  // (d_cursor[1]: zeroed before the extraction)
+            if (!S(hipGetLastError(), "k_group_flags")) break;
+            if (!S(rocprim::exclusive_scan(nullptr, tmp_bytes, d_flags, d_slots, (uint64_t)0, n, rocprim::plus<uint64_t>(), x.stream), "exclusive_scan (size)")) break;
+            if (!S(hipMalloc(&d_scan_tmp, std::max<size_t>(tmp_bytes, 16)), "hipMalloc(scan)")) break;
+            if (!S(rocprim::exclusive_scan(d_scan_tmp, tmp_bytes, d_flags, d_slots, (uint64_t)0, n, rocprim::plus<uint64_t>(), x.stream), "exclusive_scan")) break;
+            if (!S(hipMemcpyAsync(&last_flag, d_flags + (n - 1), 8, hipMemcpyDeviceToHost, x.stream), "copy") ||
+                !S(hipMemcpyAsync(&last_slot, d_slots + (n - 1), 8, hipMemcpyDeviceToHost, x.stream), "copy") ||
+                !S(hipMemcpyAsync(totals, x.d_cursor, sizeof totals, hipMemcpyDeviceToHost, x.stream), "copy") || !S(hipStreamSynchronize(x.stream), "sync"))
+                break;
+            const uint64_t sum = last_flag + last_slot;
+            const size_t n_uniq = (size_t)(sum & 0xFFFFFFFFull), n_coll = (size_t)(sum >> 32);
+            out.num_kmers = totals[1];
+            if (!S(hipMalloc((void**)&d_umm, std::max<size_t>(n_uniq, 1) * 8), "hipMalloc") || !S(hipMalloc((void**)&d_ups, std::max<size_t>(n_uniq, 1) * 2), "hipMalloc") ||
+                !S(hipMalloc((void**)&d_cfirst, std::max<size_t>(n_coll, 1) * 8), "hipMalloc") || !S(hipMalloc((void**)&d_csize, std::max<size_t>(n_coll, 1) * 4), "hipMalloc"))
+                break;
+            k_group_scatter<<<grid, 256, 0, x.stream>>>(x.d_mm[1], x.d_val[1], d_slots, n, d_umm, d_ups, d_cfirst, d_csize);
+            if (!S(hipGetLastError(), "k_group_scatter") || !S(hipStreamSynchronize(x.stream), "sync")) break;
+            x.lap("classification");
+            out.minimizer.resize(n_uniq);
+            out.offset_size.resize(n_uniq);
+            out.colliding_first.resize(n_coll);
+            out.colliding_size.resize(n_coll);
+            good = good && x.download(out.minimizer.data(), d_umm, n_uniq * 8) && x.download(out.offset_size.data(), d_ups, n_uniq * 2) &&
+                   x.download(out.colliding_first.data(), d_cfirst, n_coll * 8) && x.download(out.colliding_size.data(), d_csize, n_coll * 4);
+            x.lap("minimizers to the host");
+        } while (false);
+        for (void* p : {(void*)d_flags, (void*)d_slots, (void*)d_umm, (void*)d_cfirst, (void*)d_ups, (void*)d_csize, d_scan_tmp})
+            if (p) (void)hipFree(p);
+        return good;
+    };
+    const bool ok = body() && x.ok;
+    if (!ok) out = ClassifiedMinimizers();
     return ok;
 }
 

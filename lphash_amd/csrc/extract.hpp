@@ -42,6 +42,20 @@ struct DefaultInitAllocator : std::allocator<T> {
 };
 typedef std::vector<SuperKmerRun, DefaultInitAllocator<SuperKmerRun>> SuperKmerRuns;
 
+// minimizer::classify (src/minimizer.cpp:5-50) done on the device: the distinct minimizers ascending, each with (offset | size << 8) of its one
+// super-k-mer or 0 when it has several; the (first window, size) of every super-k-mer of those, in no particular order; totals.
+struct ClassifiedMinimizers {
+    std::vector<uint64_t, DefaultInitAllocator<uint64_t>> minimizer;
+    std::vector<uint16_t, DefaultInitAllocator<uint16_t>> offset_size;
+    std::vector<uint64_t, DefaultInitAllocator<uint64_t>> colliding_first;
+    std::vector<uint32_t, DefaultInitAllocator<uint32_t>> colliding_size;
+    uint64_t num_super_kmers = 0, num_kmers = 0;
+};
+// The whole input as ONE batch (global coordinates from 0): extraction, sort and classification on the device.  false + err when the device path is
+// unavailable or fails.
+bool gpu_extract_classified(int device, const char* const* records, const size_t* lengths, size_t n_records, uint32_t k, uint32_t m, uint64_t mm_seed, int threads,
+                            bool verbose, ClassifiedMinimizers& out, std::string& err);
+
 // Every super-k-mer of the batch (whole records; first_base = global coordinate of the batch's first base) APPENDED to `out`, ascending by
 // minimizer (ties in no particular order).  false + err when the device path is unavailable or fails (out is then as it was) -- the caller
 // runs the host extraction instead, loudly.

@@ -246,4 +246,47 @@ __global__ __launch_bounds__(256) void k_assemble_runs(const uint64_t* __restric
     out[i] = SuperKmerRun{mm[i], v.first, v.first + v.p1, v.size, 0u};
 }
 
+// ---- classification of the sorted records (src/minimizer.cpp:5-50) ----
+// record i is the first of its minimizer / belongs to a minimizer that has several records
+__device__ __forceinline__ void group_flags(const uint64_t* __restrict__ mm, size_t i, size_t n, bool& head, bool& multi) {
+    const uint64_t x = mm[i];
+    head = i == 0 || mm[i - 1] != x;
+    multi = !head || (i + 1 < n && mm[i + 1] == x);
+}
+// flags[i] = head | multi << 32 (packed so that one scan counts both); *kmers += the sizes (one atomic per wave)
+__global__ __launch_bounds__(256) void k_group_flags(const uint64_t* __restrict__ mm, const RunVal* __restrict__ val, size_t n, uint64_t* __restrict__ flags,
+                                                       unsigned long long* __restrict__ kmers) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    unsigned long long sz = 0;
+    if (i < n) {
+        bool head, multi;
+        group_flags(mm, i, n, head, multi);
+        flags[i] = (uint64_t)head | ((uint64_t)multi << 32);
+        sz = val[i].size;
+    }
+    for (unsigned d = 32; d; d >>= 1) sz += __shfl_down(sz, d, 64);
+    if ((threadIdx.x & 63u) == 0 && sz) atomicAdd(kmers, sz);
+}
+// slots = exclusive scan of flags: low word = index among the distinct minimizers, high word = index among the colliding records
+__global__ __launch_bounds__(256) void k_group_scatter(const uint64_t* __restrict__ mm, const RunVal* __restrict__ val, const uint64_t* __restrict__ slots, size_t n,
+                                                         uint64_t* __restrict__ uniq_mm, uint16_t* __restrict__ uniq_offset_size, uint64_t* __restrict__ coll_first,
+                                                         uint32_t* __restrict__ coll_size) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    bool head, multi;
+    group_flags(mm, i, n, head, multi);
+    const uint64_t slot = slots[i];
+    const RunVal v = val[i];
+    if (head) {
+        const size_t u = (size_t)(slot & 0xFFFFFFFFull);
+        uniq_mm[u] = mm[i];
+        uniq_offset_size[u] = multi ? (uint16_t)0 : (uint16_t)(v.p1 | (v.size << 8));
+    }
+    if (multi) {
+        const size_t c = (size_t)(slot >> 32);
+        coll_first[c] = v.first;
+        coll_size[c] = v.size;
+    }
+}
+
 }  // namespace lphq

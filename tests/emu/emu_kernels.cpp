@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE ONLY.  The product's kernels (lphash_amd/csrc/kernels_device.cuh) compiled for the host and run by the
 // fiber emulator, with the launch geometry of lphash_amd/csrc/kernels.hip restated here.
 #include <cstring>
+#include <vector>
 
 #include "kernels_device.cuh"  // -Itests/emu resolves <hip/hip_runtime.h> to the stub
 #include "extract_device.cuh"
@@ -120,4 +121,22 @@ extern "C" long long emu_kernel_extract_runs(const char* seq, uint64_t total, co
             k_extract_runs<kStreamBlockDefault, false>(seq_al, shift, total, seq_off, n_records, k, m, mm_seed, first_base, out_mm, (RunVal*)out_val, &cursor, cap, 0);
         });
     return (long long)cursor;
+}
+
+// k_group_flags / k_group_scatter as extract.hip runs them (the exclusive scan between them is the library's on the GPU, a loop here).
+// val: 2 words per record (first, p1 | size << 32).  Returns the number of distinct minimizers; *n_coll, *kmers as the device path reports them.
+extern "C" long long emu_kernel_classify(const uint64_t* mm_sorted, const uint64_t* val, size_t n, uint64_t* uniq_mm, uint16_t* uniq_offset_size, uint64_t* coll_first,
+                                         uint32_t* coll_size, uint64_t* n_coll, unsigned long long* kmers) {
+    std::vector<uint64_t> flags(n + 1, 0), slots(n + 1, 0);
+    *kmers = 0;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    emu::launch(grid, 256, [&] { k_group_flags(mm_sorted, (const RunVal*)val, n, flags.data(), kmers); });
+    uint64_t acc = 0;
+    for (size_t i = 0; i < n; ++i) {
+        slots[i] = acc;
+        acc += flags[i];
+    }
+    emu::launch(grid, 256, [&] { k_group_scatter(mm_sorted, (const RunVal*)val, slots.data(), n, uniq_mm, uniq_offset_size, coll_first, coll_size); });
+    *n_coll = acc >> 32;
+    return (long long)(acc & 0xFFFFFFFFull);
 }

@@ -1,6 +1,6 @@
 """One-off robustness run of index construction on the GPU (not part of the test suite): random (k, m, width, kind), random ragged record sets with
-empty / short records and non-ACGT bases, random batch splits and memory limits -- the file written with the super-k-mer extraction + sort and the pilot
-search on the GPU (lphq_build_stream, device 0) must equal, byte for byte, the one the host-only builder writes (itself byte-identical to the oracle's
+empty / short records and non-ACGT bases, random batch splits and memory limits -- the files written with the super-k-mer extraction + sort (+ classification, for the
+in-memory call) and the pilot search on the GPU (lphq_build_stream and lphq_build_device, device 0) must equal, byte for byte, the one the host-only builder writes (itself byte-identical to the oracle's
 builder, tests/test_host_cpu.py).   gpurun --timeout 1200 -- python tests/gpu_build_fuzz.py [seconds]"""
 import os
 import sys
@@ -63,6 +63,8 @@ while time.time() < t_end:
     sg = L.build_stream(batches, k, m, gpu, kind=kind, kmer_bits=bits, threads=8, device=0, tmp_dir=os.path.join(tmp, "spill"), max_memory_bytes=limit)
     assert sg == sh, (k, m, bits, kind, seed, shape, per_batch, limit, sg, sh)
     assert open(gpu, "rb").read() == open(host, "rb").read(), (k, m, bits, kind, seed, shape, per_batch, limit)
+    sm = L.build(recs, k, m, gpu, kind=kind, kmer_bits=bits, threads=8, device=0)  # one batch: classified on the device as well
+    assert sm == sh and open(gpu, "rb").read() == open(host, "rb").read(), ("in-memory", k, m, bits, kind, seed, shape)
     n_cfg += 1
     n_kmers += sh["num_kmers"]
 print(f"gpu build fuzz ok: {n_cfg} random configurations ({n_skipped} skipped: unbuildable key sets), {n_kmers} k-mers, files identical to the host builder's, in {budget:.0f} s")

@@ -33,6 +33,10 @@ bool gpu_extract_sorted_runs(int, const char* const*, const size_t*, size_t, uin
     err = "no GPU in the sanitizer harness";
     return false;
 }
+bool gpu_extract_classified(int, const char* const*, const size_t*, size_t, uint32_t, uint32_t, uint64_t, int, bool, ClassifiedMinimizers&, std::string& err) {
+    err = "no GPU in the sanitizer harness";
+    return false;
+}
 }  // namespace lphq
 
 static std::vector<uint8_t> slurp(const char* p) {

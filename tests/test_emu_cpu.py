@@ -486,3 +486,36 @@ def test_extract_runs_kernel_on_the_emulator(emu, k, m, form):
     val2 = np.full(2 * small + 2, 0xDEAD, dtype=np.uint64)
     n2 = emu.emu_kernel_extract_runs(raw.ctypes.data + base, len(flat), seq_off.ctypes.data, len(recs), k, m, seed, first_base, mm2.ctypes.data, val2.ctypes.data, small, form)
     assert n2 == len(want) and mm2[small] == 0xDEAD and val2[2 * small] == 0xDEAD
+
+
+def test_classify_kernels_on_the_emulator(emu):
+    """k_group_flags / k_group_scatter (minimizer::classify on the device, src/minimizer.cpp:5-50) over sorted records with repeated minimizers at the
+    ends, across workgroup borders and in long stretches: distinct minimizers ascending with the (offset, size) of singletons and 0 for the others, the
+    colliding records as a set, the k-mer total."""
+    emu.emu_kernel_classify.restype = C.c_longlong
+    emu.emu_kernel_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_ulonglong)]
+    rng = np.random.default_rng(5)
+    for n, distinct in ((1, 1), (2, 1), (700, 650), (5000, 1200), (1024, 1024), (513, 3)):
+        keys = np.sort(rng.choice(np.arange(1, 10 * distinct + 2, dtype=np.uint64), size=distinct, replace=False))
+        mm = np.sort(np.concatenate([keys, rng.choice(keys, size=n - distinct)])) if n > distinct else keys.copy()
+        first = rng.permutation(n).astype(np.uint64) * np.uint64(100)
+        p1 = rng.integers(0, 62, n).astype(np.uint64)
+        size = rng.integers(1, 64, n).astype(np.uint64)
+        val = np.empty(2 * n, dtype=np.uint64)
+        val[0::2] = first
+        val[1::2] = p1 | (size << np.uint64(32))
+        umm = np.zeros(n, dtype=np.uint64)
+        ups = np.zeros(n, dtype=np.uint16)
+        cf = np.zeros(n, dtype=np.uint64)
+        cs = np.zeros(n, dtype=np.uint32)
+        nc, km = C.c_uint64(), C.c_ulonglong()
+        nu = emu.emu_kernel_classify(mm.ctypes.data, val.ctypes.data, n, umm.ctypes.data, ups.ctypes.data, cf.ctypes.data, cs.ctypes.data, C.byref(nc), C.byref(km))
+        vals, counts = np.unique(mm, return_counts=True)
+        assert nu == len(vals) and np.array_equal(umm[:nu], vals) and km.value == int(size.sum())
+        single = counts == 1
+        idx_of_single = np.searchsorted(mm, vals[single])
+        assert np.array_equal(ups[:nu][single], (p1[idx_of_single] | (size[idx_of_single] << np.uint64(8))).astype(np.uint16))
+        assert np.all(ups[:nu][~single] == 0)
+        in_multi = np.isin(mm, vals[~single])
+        assert nc.value == int(in_multi.sum())
+        assert sorted(zip(cf[:nc.value].tolist(), cs[:nc.value].tolist())) == sorted(zip(first[in_multi].tolist(), size[in_multi].tolist()))

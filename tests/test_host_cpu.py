@@ -383,6 +383,12 @@ def test_streamed_build_errors(tmp_path):
     with pytest.raises(L.LphqError) as e:
         L.build_stream(repeated_then_short, 31, 20, out, kmer_bits=64)
     assert e.value.code == _lib.ERR_IO
+    stats = _lib.BuildStats()
+    rc = _lib.lib.lphq_build_stream(None, None, 31, 20, 42, 3.0, 0, 64, 1, -1, None, 0, out.encode(), C.byref(stats))  # no source
+    assert rc == _lib.ERR_ARG
+    with pytest.raises(L.LphqError) as e:  # argument checks come before the first batch is asked for
+        L.build_stream(lambda: iter([recs]), 33, 20, out, kmer_bits=64)
+    assert e.value.code == _lib.ERR_ARG
     with pytest.raises(L.LphqError) as e:  # an unwritable temporary directory
         big = dedup_records(random_records(6, 8, 20_000, 40_000), 31)  # more super-k-mers than the smallest piece (4096 records)
         L.build_stream(lambda: iter([big]), 31, 20, out, kmer_bits=64, tmp_dir="/proc/no/such/dir", max_memory_bytes=1 << 12)

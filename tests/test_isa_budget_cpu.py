@@ -24,6 +24,8 @@ BUDGET = {
     "k_gather_payload": (64, 0),
     "k_extract_runs": (64, 40 * 1024),  # the streaming kernel's phases A-C + run starts (index construction, extract.hip)
     "k_assemble_runs": (64, 0),
+    "k_group_flags": (64, 0),
+    "k_group_scatter": (64, 0),
     "k_search": (64, 1024),
     "k_claim": (64, 0),
     "k_validate": (64, 0),
@@ -71,6 +73,6 @@ def test_kernels_fit_their_register_and_lds_budget(src):
         assert u["VGPRs"] + u.get("AGPRs", 0) <= vg, (name, u)
         assert u.get("LDS Size", 0) <= lds, (name, u)
     where = {"k_search": "search.hip", "k_claim": "search.hip", "k_validate": "search.hip", "k_commit": "search.hip", "k_advance": "search.hip",
-             "k_extract_runs": "extract.hip", "k_assemble_runs": "extract.hip"}
+             "k_extract_runs": "extract.hip", "k_assemble_runs": "extract.hip", "k_group_flags": "extract.hip", "k_group_scatter": "extract.hip"}
     expected = {k for k in BUDGET if where.get(k, "kernels.hip") == src}
     assert seen == expected, (seen, expected)
