@@ -989,6 +989,12 @@ int ptbb_query_main(int argc, char** argv) {
 }  // namespace
 
 int main(int argc, char* argv[]) {
+    {  // the reference ships ptbb_build / ptbb_query as executables of their own (CMakeLists.txt:59-63): a link to this binary under those names behaves so
+        const char* slash = std::strrchr(argv[0], '/');
+        const std::string self = slash ? slash + 1 : argv[0];
+        if (self == "ptbb_build") return ptbb_build_main(argc, argv);
+        if (self == "ptbb_query") return ptbb_query_main(argc, argv);
+    }
     if (argc < 2) return help(argv[0]);
     const std::string tool = argv[1];
     if (tool == "build-p") return build_main(LPHQ_PARTITIONED, argc - 1, argv + 1);

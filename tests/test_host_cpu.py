@@ -584,6 +584,12 @@ def test_ptbb_build_cli_and_file(tmp_path):
     assert L.BbHash.load(str(bb), 31, kmer_bits=64).get_kmer_count() == n
     assert subprocess.run([exe, "ptbb-build", "-i", str(fa), "-k", "31", "-b", str(bb), "-g", "0.5"], capture_output=True).returncode == 3
     assert subprocess.run([exe, "ptbb-build", "-i", str(tmp_path / "nope.fa"), "-k", "31", "-p", "x"], capture_output=True).returncode == 2
+    # the reference ships ptbb_build as an executable of its own (CMakeLists.txt:59): a link to the CLI under that name takes the same arguments
+    link = os.path.join(ROOT, "lphash_amd", "ptbb_build")
+    if os.path.exists(link):
+        viaLink = tmp_path / "link.pthash"
+        r = subprocess.run([link, "-i", str(fa), "-k", "31", "-p", str(viaLink), "--kmer-bits", "64", "--cpu"], capture_output=True, text=True)
+        assert r.returncode == 0 and viaLink.read_bytes() == (tmp_path / "cli64.pthash").read_bytes()
 
 
 def bgzf_compress(data, block=60000, level=6):
