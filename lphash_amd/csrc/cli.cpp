@@ -359,6 +359,50 @@ bool query_pass(lphq_index* idx, const lphq_info& info, const std::string& path,
     return true;
 }
 
+// diagnostic: the decompressed bytes of a .gz as the serial reader gets them (gz_source.hpp; --zlib: through gzread instead), to a file or nowhere
+int inflate_main(int argc, char** argv) {
+    Args a = parse(argc, argv, {"-i", "-o"}, {"--zlib"});
+    if (a.help || a.bad || !a.get("-i")) {
+        std::cerr << "Usage: " << argv[0] << " -i file.gz [-o output] [--zlib]\n";
+        return 1;
+    }
+    FILE* out = a.get("-o") ? fopen(a.get("-o")->c_str(), "wb") : nullptr;
+    if (a.get("-o") && !out) return 2;
+    std::vector<char> buf(4u << 20);
+    uint64_t total = 0;
+    bool error = false;
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    if (a.has("--zlib")) {
+        gzFile fp = gzopen(a.get("-i")->c_str(), "r");
+        if (!fp) return 2;
+        gzbuffer(fp, 1 << 20);
+        int n;
+        while ((n = gzread(fp, buf.data(), (unsigned)buf.size())) > 0) {
+            total += (uint64_t)n;
+            if (out) fwrite(buf.data(), 1, (size_t)n, out);
+        }
+        error = n < 0;
+        gzclose(fp);
+    } else {
+        lphq::GzFastSource* src = lphq::GzFastSource::open(a.get("-i")->c_str());
+        if (!src) {
+            std::cerr << "not a regular gzip file\n";
+            return 2;
+        }
+        size_t n;
+        while ((n = src->read(buf.data(), buf.size())) > 0) {
+            total += n;
+            if (out) fwrite(buf.data(), 1, n, out);
+        }
+        error = src->error();
+        delete src;
+    }
+    const double sec = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+    if (out) fclose(out);
+    std::cout << total << "," << (error ? "error" : "ok") << "," << sec << "\n";
+    return error ? 3 : 0;
+}
+
 // diagnostic: what the reader yields (see the file header)
 int records_main(int argc, char** argv) {
     Args a = parse(argc, argv, {"-i", "-t", "--batch-bytes", "--min-piece", "--passes"}, {"--serial", "--no-hash"});
@@ -1002,6 +1046,7 @@ int main(int argc, char* argv[]) {
     if (tool == "query-p") return query_main(LPHQ_PARTITIONED, argc - 1, argv + 1);
     if (tool == "query-u") return query_main(LPHQ_UNPARTITIONED, argc - 1, argv + 1);
     if (tool == "records") return records_main(argc - 1, argv + 1);
+    if (tool == "inflate") return inflate_main(argc - 1, argv + 1);
     if (tool == "ptbb-build" || tool == "ptbb_build") return ptbb_build_main(argc - 1, argv + 1);
     if (tool == "ptbb-query" || tool == "ptbb_query") return ptbb_query_main(argc - 1, argv + 1);
     std::cerr << "Unsupported tool '" << tool << "'." << std::endl;

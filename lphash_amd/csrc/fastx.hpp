@@ -19,23 +19,34 @@
 #pragma once
 #include <zlib.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
+
+#include "gz_source.hpp"
 
 namespace lphq {
 
 class FastxReader {
 public:
+    // A regular .gz file is inflated ahead of the parser by its own threads (gz_source.hpp); anything else -- and everything when
+    // LPHQ_GZ_ZLIB is set (A/B timing, tests) -- goes through zlib's gzread, which also passes plain text through.
     explicit FastxReader(const char* path) : fp_(gzopen(path, "r")), buf_(1 << 22) {
         if (fp_) gzbuffer(fp_, 1 << 20);
+        if (fp_ && !getenv("LPHQ_GZ_ZLIB")) fast_ = GzFastSource::open(path);
     }
     ~FastxReader() {
+        delete fast_;
         if (fp_) gzclose(fp_);
     }
+    FastxReader(const FastxReader&) = delete;
+    FastxReader& operator=(const FastxReader&) = delete;
     bool ok() const { return fp_ != nullptr; }
     // Restart between records at an (uncompressed) byte offset; the next record is the first one that begins at or after it.
     bool seek(size_t offset) {
+        delete fast_;  // (seeking is for plain files handed over by the parallel reader; zlib does it from here on)
+        fast_ = nullptr;
         if (!fp_ || gzseek(fp_, (z_off_t)offset, SEEK_SET) < 0) return false;
         pos_ = end_ = 0;
         eof_ = false;
@@ -80,10 +91,20 @@ public:
 
 private:
     enum Delim { kSpace, kLine };
+    // the next stretch of text: data_[0, n); the fast source lends its own chunk memory (no copy), zlib fills buf_
+    int fill() {
+        if (fast_) {
+            size_t n = 0;
+            data_ = fast_->next_span(n, (size_t)1 << 30);
+            return (int)n;
+        }
+        data_ = buf_.data();
+        return gzread(fp_, buf_.data(), (unsigned)buf_.size());
+    }
     int getc() {
         if (pos_ >= end_) {
             if (eof_) return -1;
-            int n = gzread(fp_, buf_.data(), (unsigned)buf_.size());
+            int n = fill();
             pos_ = 0;
             end_ = n > 0 ? (size_t)n : 0;
             if (n <= 0) {
@@ -91,7 +112,7 @@ private:
                 return -1;
             }
         }
-        return (unsigned char)buf_[pos_++];
+        return (unsigned char)data_[pos_++];
     }
     // ks_getuntil2 (external/kseq.h:99-158): append (or assign) the bytes up to the next delimiter -- any isspace()
     // character for kSpace, '\n' for kLine -- consume the delimiter and report it in *dret (0 if the input ended first).
@@ -104,7 +125,7 @@ private:
         for (;;) {
             if (pos_ >= end_) {
                 if (eof_) break;
-                int n = gzread(fp_, buf_.data(), (unsigned)buf_.size());
+                int n = fill();
                 pos_ = 0;
                 end_ = n > 0 ? (size_t)n : 0;
                 if (n <= 0) {
@@ -112,7 +133,7 @@ private:
                     break;
                 }
             }
-            const char* p = buf_.data() + pos_;
+            const char* p = data_ + pos_;
             size_t i;
             if (d == kLine) {
                 const char* nl = (const char*)memchr(p, '\n', end_ - pos_);
@@ -136,7 +157,9 @@ private:
     }
     std::string scratch_, qual_;
     gzFile fp_;
+    GzFastSource* fast_ = nullptr;
     std::vector<char> buf_;
+    const char* data_ = nullptr;
     size_t pos_ = 0, end_ = 0;
     bool eof_ = false;
     int last_char_ = 0;

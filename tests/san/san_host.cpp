@@ -4,17 +4,21 @@
 // part of the library are stubbed: the GPU pilot search and the GPU super-k-mer extraction report "unavailable", errors go to a string.
 //   san_host build <fasta> <k> <m> <kind> <kmer_bits> <threads> <out.lph>     build with the product builder (CPU search)
 //   san_host build_stream <fasta> <k> <m> <kind> <kmer_bits> <threads> <out.lph> <max_memory_bytes> <tmp_dir>   lphq_build_stream, small batches
+//   san_host inflate <file.gz>                                                 the .gz through GzFastSource (decoder + ring + CRC thread)
+//   san_host inflate_fuzz <file.gz> <n> <seed>                                  n corrupted / truncated copies through DeflateDecoder
 //   san_host load  <file.lph> <kind> <kmer_bits>                             parse + cross-check + flat image
 //   san_host fuzz  <file.lph> <kind> <kmer_bits> <n> <seed>                  n corrupted copies through the loader
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <fstream>
 #include <string>
 #include <vector>
 
 #include "../../include/lphq.h"
 #include "fastx_batch.hpp"
+#include "gz_source.hpp"
 #include "image.hpp"
 #include "lph_format.hpp"
 #include "extract.hpp"
@@ -124,6 +128,53 @@ int main(int argc, char** argv) {
         const int rc = lphq_build(ptrs.data(), lens.data(), lens.size(), atoi(argv[3]), atoi(argv[4]), 42, 3.0, atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), argv[8], &st);
         if (rc != LPHQ_OK) fprintf(stderr, "build failed (%d): %s\n", rc, lphq::g_err.c_str());
         return rc == LPHQ_OK ? 0 : 4;
+    }
+    if (cmd == "inflate" && argc == 3) {
+        lphq::GzFastSource* src = lphq::GzFastSource::open(argv[2]);
+        if (!src) return 3;
+        std::vector<char> buf(1 << 20);
+        uint64_t total = 0, h = 1469598103934665603ull;
+        size_t n;
+        while ((n = src->read(buf.data(), 1 + (total * 7919) % buf.size())) > 0) {  // odd read sizes: chunk borders inside and between reads
+            for (size_t i = 0; i < n; ++i) h = (h ^ (unsigned char)buf[i]) * 1099511628211ull;
+            total += n;
+        }
+        printf("%llu,%016llx,%s\n", (unsigned long long)total, (unsigned long long)h, src->error() ? "error" : "ok");
+        delete src;
+        return 0;
+    }
+    if (cmd == "inflate_fuzz" && argc == 5) {
+        const std::vector<uint8_t> good = slurp(argv[2]);
+        uint64_t s = strtoull(argv[4], nullptr, 10) | 1;
+        auto rnd = [&] {
+            s ^= s << 13;
+            s ^= s >> 7;
+            s ^= s << 17;
+            return s;
+        };
+        static lphq::DeflateDecoder dec;
+        int ended = 0, errors = 0, full = 0;
+        for (int t = 0; t < atoi(argv[3]); ++t) {
+            std::vector<uint8_t> bad = good;
+            switch (rnd() % 3) {
+                case 0: bad.resize(18 + rnd() % (bad.size() - 17)); break;
+                case 1: for (int j = 0; j < 1 + (int)(rnd() % 6); ++j) bad[10 + rnd() % (bad.size() - 10)] ^= (uint8_t)(1u << (rnd() % 8)); break;
+                default: for (size_t j = 10 + rnd() % (bad.size() - 10), e = std::min(bad.size(), j + 1 + rnd() % 64); j < e; ++j) bad[j] = (uint8_t)rnd(); break;
+            }
+            const size_t hdr = lphq::gzip_header_bytes(bad.data(), bad.size());
+            if (!hdr) continue;
+            // exact-size heap blocks: ASan sees any read past the input and any write past limit + kSlack
+            std::vector<uint8_t> in(bad.begin() + (long)hdr, bad.end());
+            const size_t limit = 64 + rnd() % (6 * good.size());
+            std::vector<uint8_t> out(limit + 1 + lphq::DeflateDecoder::kSlack);
+            dec.reset(in.data(), in.data() + in.size());
+            size_t pos = 0;
+            const int r = dec.decode(out.data(), pos, limit);
+            if (pos > out.size()) return 9;
+            (r == 1 ? ended : r == 0 ? full : errors)++;
+        }
+        printf("inflate fuzz: %d ended, %d out of room, %d errors\n", ended, full, errors);
+        return 0;
     }
     if (cmd == "load" && argc == 5) return load(slurp(argv[2]), atoi(argv[3]), atoi(argv[4]), true);
     if (cmd == "fuzz" && argc == 7) {

@@ -549,6 +549,21 @@ def test_host_sources_under_sanitizers(tmp_path):
             r = subprocess.run([exe] + cmd, capture_output=True, text=True, env=env)
             assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
 
+    # the .gz decoder of the serial input path: a file through the threaded source (odd read sizes), then corrupted copies through the decoder
+    import gzip
+
+    gz = tmp_path / "in.fa.gz"
+    with gzip.open(gz, "wb", compresslevel=6) as f:
+        f.write(fa.read_bytes() * 12)  # several 4-MiB chunks
+    r = subprocess.run([exe, "inflate", str(gz)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stdout.split(",")[0] == str(12 * fa.stat().st_size) and r.stdout.strip().endswith(",ok"), (r.stdout, r.stderr[-2000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
+    small = tmp_path / "small.fa.gz"
+    with gzip.open(small, "wb", compresslevel=9) as f:
+        f.write(fa.read_bytes()[:300_000])
+    r = subprocess.run([exe, "inflate_fuzz", str(small), "400", "7"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+
 
 def test_ptbb_build_cli_and_file(tmp_path):
     """`lphash ptbb-build` (the reference's ptbb_build, PTHash half, src/ptbb/ptbb_build.cpp): CSV fields, the file equals the oracle's
@@ -676,3 +691,89 @@ def test_bbhash_files_round_trip_through_the_real_boophf(tmp_path):
             p.write_bytes(bytes(blob[:cut]))
             with pytest.raises(L.LphqError):
                 L.BbHash.load(str(p), k, kmer_bits=bits)
+
+
+def _gzip_member(data, level=6, strategy=0, name=None, comment=None, extra=None, hcrc=False):
+    """One gzip member (RFC 1952) with the header fields asked for; strategy: zlib.Z_DEFAULT_STRATEGY / Z_FIXED / Z_HUFFMAN_ONLY / Z_RLE."""
+    import struct
+    import zlib
+
+    flg = (4 if extra is not None else 0) | (8 if name is not None else 0) | (16 if comment is not None else 0) | (2 if hcrc else 0)
+    head = b"\x1f\x8b\x08" + bytes([flg]) + b"\x00\x00\x00\x00\x00\xff"
+    if extra is not None:
+        head += struct.pack("<H", len(extra)) + extra
+    if name is not None:
+        head += name + b"\x00"
+    if comment is not None:
+        head += comment + b"\x00"
+    if hcrc:
+        head += struct.pack("<H", zlib.crc32(head) & 0xFFFF)
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    return head + c.compress(data) + c.flush() + struct.pack("<II", zlib.crc32(data), len(data) & 0xFFFFFFFF)
+
+
+def test_fast_inflate_equals_zlib(tmp_path):
+    """The .gz decoder of the serial input path (fast_inflate.hpp / gz_source.hpp, `lphash inflate`) against zlib: stored, fixed and dynamic blocks,
+    Huffman-only and run-length streams (long codes, distance-1 matches), every header flag, several members (tiny ones, ones spanning several 4-MiB
+    chunks of the decoder's ring), trailing garbage; truncated and corrupted files end the data early with an error and never crash."""
+    import zlib
+
+    exe = os.path.join(ROOT, "lphash_amd", "lphash")
+    rng = np.random.default_rng(77)
+    dna = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=9_000_000))
+    fasta = b">r\n" + b"\n".join(dna[i:i + 70] for i in range(0, 3_000_000, 70)) + b"\n"
+    repetitive = (b"ACGTTGCA" * 5000 + b"A" * 70000 + dna[:1000]) * 40
+    noise = rng.integers(0, 256, 700_000, dtype=np.uint8).tobytes()
+    text = b"".join(b"@read%d some text\n%s\n+\n%s\n" % (i, dna[i * 50:i * 50 + 150], b"I" * 150) for i in range(20000))
+    cases = {
+        "empty": _gzip_member(b""),
+        "one_byte": _gzip_member(b"A"),
+        "stored": _gzip_member(noise, level=0),
+        "incompressible": _gzip_member(noise, level=6),
+        "fixed": _gzip_member(fasta[:200_000], strategy=zlib.Z_FIXED),
+        "huffman_only": _gzip_member(text, strategy=zlib.Z_HUFFMAN_ONLY),
+        "rle": _gzip_member(repetitive, strategy=zlib.Z_RLE),
+        "level1": _gzip_member(fasta, level=1),
+        "level9_big": _gzip_member(dna + repetitive, level=9),  # > 2 chunks, matches across the chunk borders
+        "fastq": _gzip_member(text, level=6),
+        "flags": _gzip_member(fasta[:50_000], name=b"x.fa", comment=b"made by a test", extra=b"AB\x02\x00xy", hcrc=True),
+        "members": b"".join(_gzip_member(fasta[i:i + 77_777], level=int(rng.integers(0, 10))) for i in range(0, 1_500_000, 77_777)),
+        "members_then_garbage": _gzip_member(text[:100_000]) + _gzip_member(b"") + _gzip_member(text[100_000:300_000]) + b"\x00garbage after the last member",
+    }
+    plain = {"members_then_garbage": text[:300_000], "members": fasta[:1_500_000 // 77_777 * 77_777 + 77_777][:len(b"".join(fasta[i:i + 77_777] for i in range(0, 1_500_000, 77_777)))]}
+    for name, blob in cases.items():
+        f, o = tmp_path / f"{name}.gz", tmp_path / f"{name}.out"
+        f.write_bytes(blob)
+        want = plain.get(name)
+        if want is None:
+            d = zlib.decompressobj(31)
+            want = d.decompress(blob)
+        r = subprocess.run([exe, "inflate", "-i", str(f), "-o", str(o)], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.split(",")[:2] == [str(len(want)), "ok"], (name, r.stdout, r.stderr)
+        assert o.read_bytes() == want, name
+    # the reader on top of it yields the records kseq / zlib yield (`lphash records --serial` with and without LPHQ_GZ_ZLIB)
+    for name in ("level1", "fastq", "members"):
+        a = subprocess.run([exe, "records", "-i", str(tmp_path / f"{name}.gz"), "--serial"], capture_output=True, text=True)
+        b = subprocess.run([exe, "records", "-i", str(tmp_path / f"{name}.gz"), "--serial"], capture_output=True, text=True, env=dict(os.environ, LPHQ_GZ_ZLIB="1"))
+        assert a.returncode == 0 and a.stdout.split(",")[:3] == b.stdout.split(",")[:3] and int(a.stdout.split(",")[0]) > 0, (name, a.stdout, b.stdout)
+    # damage: a prefix of the data comes out, the call says "error", nothing crashes
+    good = cases["level1"]
+    want = fasta
+    for trial in range(40):
+        bad = bytearray(good)
+        if trial % 2 == 0:
+            bad = bad[: int(rng.integers(1, len(bad)))]
+        else:
+            for _ in range(int(rng.integers(1, 4))):
+                bad[int(rng.integers(10, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        f, o = tmp_path / "bad.gz", tmp_path / "bad.out"
+        f.write_bytes(bytes(bad))
+        r = subprocess.run([exe, "inflate", "-i", str(f), "-o", str(o)], capture_output=True, text=True)
+        if r.returncode == 2:  # not even a header left
+            continue
+        assert r.returncode in (0, 3), (trial, r.returncode, r.stderr)
+        got = o.read_bytes()
+        if r.returncode == 0:  # the damage was harmless (e.g. inside the trailing bytes that nothing reads): then the data must be right
+            assert got == want, trial
+        elif trial % 2 == 0:  # truncated: everything decoded is a prefix of the truth
+            assert want.startswith(got), trial
