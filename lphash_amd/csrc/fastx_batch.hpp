@@ -216,27 +216,26 @@ private:
         if (good && buf) {
             std::vector<int> bad((size_t)threads_, 0);
             auto work = [&](int t) {
-                z_stream zs;
+                // every block through the own decoder (fast_inflate.hpp) into a private buffer -- the decoder writes a few bytes past what it has
+                // decoded, which must not land in a neighbour's part of the text -- then into place; CRC-32 and length as the member's trailer says
+                DeflateDecoder* dec = new DeflateDecoder();
+                std::vector<uint8_t> tmp((size_t)65536 + DeflateDecoder::kSlack + 64);
                 for (size_t i = (size_t)t; i < blocks.size(); i += (size_t)threads_) {
                     const BgzfBlock& bl = blocks[i];
-                    memset(&zs, 0, sizeof zs);
-                    if (inflateInit2(&zs, -15) != Z_OK) {
-                        bad[(size_t)t] = 1;
-                        return;
+                    bool okb = bl.out_len <= 65536;
+                    if (okb) {
+                        dec->reset(f + bl.in, f + bl.in + bl.in_len);
+                        size_t pos = 0;
+                        okb = dec->decode(tmp.data(), pos, 65536) == 1 && pos == bl.out_len && dec->stream_end() <= f + bl.in + bl.in_len &&
+                              crc32_slice16(0, tmp.data(), pos) == bl.crc;
+                        if (okb) memcpy(buf + bl.out, tmp.data(), pos);
                     }
-                    zs.next_in = (Bytef*)(f + bl.in);
-                    zs.avail_in = (uInt)bl.in_len;
-                    zs.next_out = (Bytef*)(buf + bl.out);
-                    zs.avail_out = (uInt)bl.out_len;
-                    const int rc = bl.out_len || bl.in_len ? inflate(&zs, Z_FINISH) : Z_STREAM_END;
-                    const bool okb = (rc == Z_STREAM_END) && zs.total_out == bl.out_len &&
-                                     (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef*)(buf + bl.out), (uInt)bl.out_len) == bl.crc;
-                    inflateEnd(&zs);
                     if (!okb) {
                         bad[(size_t)t] = 1;
-                        return;
+                        break;
                     }
                 }
+                delete dec;
             };
             std::vector<std::thread> th;
             for (int t = 1; t < threads_; ++t) th.emplace_back(work, t);
