@@ -740,7 +740,7 @@ def test_fast_inflate_equals_zlib(tmp_path):
         "members": b"".join(_gzip_member(fasta[i:i + 77_777], level=int(rng.integers(0, 10))) for i in range(0, 1_500_000, 77_777)),
         "members_then_garbage": _gzip_member(text[:100_000]) + _gzip_member(b"") + _gzip_member(text[100_000:300_000]) + b"\x00garbage after the last member",
     }
-    plain = {"members_then_garbage": text[:300_000], "members": fasta[:1_500_000 // 77_777 * 77_777 + 77_777][:len(b"".join(fasta[i:i + 77_777] for i in range(0, 1_500_000, 77_777)))]}
+    plain = {"members_then_garbage": text[:300_000], "members": b"".join(fasta[i:i + 77_777] for i in range(0, 1_500_000, 77_777))}
     for name, blob in cases.items():
         f, o = tmp_path / f"{name}.gz", tmp_path / f"{name}.out"
         f.write_bytes(blob)
