@@ -19,6 +19,7 @@
 #pragma once
 #include <zlib.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -96,6 +97,10 @@ private:
         if (fast_) {
             size_t n = 0;
             data_ = fast_->next_span(n, (size_t)1 << 30);
+            if (!n && fast_->error() && !warned_) {  // (gzread would return -1 here; the records read so far stand, as with kseq)
+                warned_ = true;
+                fprintf(stderr, "[warning] the gzip stream is damaged or truncated: input ends early\n");
+            }
             return (int)n;
         }
         data_ = buf_.data();
@@ -160,6 +165,7 @@ private:
     GzFastSource* fast_ = nullptr;
     std::vector<char> buf_;
     const char* data_ = nullptr;
+    bool warned_ = false;
     size_t pos_ = 0, end_ = 0;
     bool eof_ = false;
     int last_char_ = 0;
