@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--shuffle-records", action="store_true", help="stream mode: the index records in a random order (SURVEY 8(d) variant)")
     ap.add_argument("--cache-dir", default=os.environ.get("LPHQ_BENCH_CACHE", "/tmp/lphq_bench_cache"))
     ap.add_argument("--no-hbm-probe", action="store_true", help="skip the in-run measurement of the HBM copy ceiling (roofline.peak_measured)")
+    ap.add_argument("--dist-single", action="store_true",
+                    help="with one rank, still initialise torch.distributed (RCCL) and run the image broadcast and the replica check: exercises the N > 1 code on a 1-GPU box")
     ap.add_argument("--b1-records", type=int, default=300,
                     help="records of the index set the reference-faithful driver baseline (B1: gz + parse inside the timer) reads; 0 = skip")
     args = ap.parse_args()
@@ -158,11 +160,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.dist_single:
         import torch.distributed as dist_mod
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     k, m = args.k, args.m
@@ -208,7 +212,7 @@ def main():
             f"{h.info.fallback_kmers} fallback k-mers, image {h.info.image_bytes / 1e6:.1f} MB")
         assert h.get_kmer_count() == nk, "synthetic set has duplicate k-mers?"
     bcast_s = None
-    if world > 1:
+    if dist is not None:
         from lphash_amd.dist import broadcast_image
 
         dist.barrier()  # the index file exists and rank 0 is attached
@@ -382,6 +386,41 @@ def main():
                     log(f"[bench] CLI run failed ({r.returncode}): {r.stderr[-500:]}")
             log(f"[bench] B1 reference-faithful driver: {cpu_b1['streaming_ns_per_kmer']:.1f} / {cpu_b1['random_ns_per_kmer']:.1f} ns per k-mer (streaming / random); CLI: {cli_b1}")
 
+    # ---- N > 1: every replica (rank 0 parsed the file, the others received the image over RCCL) must answer alike ----
+    replicas_agree = None
+    if dist is not None:
+        if args.mode == "random":  # a probe set common to all ranks (the timed batches differ per rank)
+            gc = torch.Generator(device=dev)
+            gc.manual_seed(777)
+            Qc = 1 << 20
+            win = torch.randint(0, nk, (Qc,), generator=gc, device=dev, dtype=torch.int64)
+            posc = (win // 100_000) * rec_len + win % 100_000
+            d_kc = torch.empty(Qc * (kmer_bits // 64), dtype=torch.int64, device=dev)
+            h.pack_kmers(d_seq.data_ptr(), posc.data_ptr(), Qc, d_kc.data_ptr(), stream)
+            d_chk = torch.empty(Qc, dtype=torch.int64, device=dev)
+            h.query_packed(d_kc.data_ptr(), Qc, d_chk.data_ptr(), stream)
+            torch.cuda.synchronize()
+        else:  # every rank streamed the same records
+            d_chk = d_out
+        weights = torch.arange(d_chk.numel(), dtype=torch.int64, device=dev) * 2 + 1  # order-dependent checksum, wrapping int64 arithmetic
+        t = torch.stack([d_chk.sum(), (d_chk * weights).sum(), d_chk.max()])
+        del weights
+        tmin, tmax = t.clone(), t.clone()
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        replicas_agree = bool(torch.equal(tmin, tmax)) and (competitor or int(t[2].item()) < nk)
+        if rank == 0 and args.mode == "random" and not args.no_cpu_baseline and kind != L.BBHASH:  # the common probes against the oracle (checker only)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import orc
+
+            o = orc.PtHash(path, k, kmer_bits) if kind == L.PTHASH else orc.Index(path, orc.PARTITIONED if kind == L.PARTITIONED else orc.UNPARTITIONED, kmer_bits)
+            parity = bool(np.array_equal(o.query_packed(d_kc.cpu().numpy().view(np.uint64)), d_chk.cpu().numpy().view(np.uint64)))
+            log(f"[bench] {Qc} probes common to all ranks: GPU == oracle: {parity}")
+        log(f"[bench r{rank}] replicas agree on the common probes: {replicas_agree}")
+        if not replicas_agree or parity is False:  # (the same verdict on every rank for replicas_agree; rank 0 alone can fail on parity)
+            log(f"[bench r{rank}] ERROR: replicas disagree or differ from the oracle")
+            sys.exit(3)
+
     if rank == 0:
         if kind == L.BBHASH:  # per probed level a bit-array word (8 B), on the hit a rank sample (8 B) + up to 7 more words; ~1/(1 - 0.63) levels at gamma 1
             chain, mix = 2.7 * 8 + 8 + 3.5 * 8, None
@@ -423,6 +462,7 @@ def main():
             "kernel_ms": kernel_ms,
             "parity_vs_oracle": parity,
             "rccl_ranks": int(dist.get_world_size()) if dist is not None else 1,
+            "replicas_agree": replicas_agree,
         }
         traffic = None
         try:  # HBM bytes per launch from the committed PMC passes of this exact workload (never measured inside this run)

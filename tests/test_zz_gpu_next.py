@@ -189,3 +189,22 @@ def test_bbhash_competitor_against_the_real_boophf(tmp_path, name):
     r = subprocess.run([exe, "ptbb-build", "-i", str(fa2), "-k", str(k), "-b", str(tmp_path / "c.bbh"), "--kmer-bits", str(bits), "--check", "-t", "4"],
                        capture_output=True, text=True)
     assert r.returncode == 0 and "EVERYTHING OK" in r.stderr, r.stderr
+
+
+@pytest.mark.parametrize("mode", ["random", "stream"])
+def test_bench_collective_path_with_one_rank(tmp_path, mode):
+    """bench.py's N > 1 code (RCCL process group, image broadcast, handle over the received image, replica check, max-over-ranks timing) with the
+    one rank a 1-GPU box has: the JSON line says what the collective saw and that the replica answers like the oracle."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--dist-single", "--mode", mode, "--kmers", "2000000", "--batch-log2", "20", "--steps", "2", "--warmup", "1",
+           "--no-hbm-probe", "--b1-records", "0", "--cache-dir", str(tmp_path)]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["rccl_ranks"] == 1 and line["replicas_agree"] is True and line["parity_vs_oracle"] is True
+    assert line["image_broadcast_ms"] > 0 and line["n_gpus"] == 1 and line["roofline"]["frac"] > 0
