@@ -143,6 +143,11 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # before anything initialises the GPU in this process
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    # Everything but the result line goes to stderr, also what native libraries print (RCCL writes a version banner to stdout with C stdio, flushed
+    # when the process ends, i.e. AFTER the JSON line): file descriptor 1 is pointed at stderr and the line is written to a copy of the original.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     global np, torch, L, synthetic_records
     import numpy as np
     import torch
@@ -491,7 +496,8 @@ def main():
             out["index_build_s"] = build_s
         if bcast_s is not None:
             out["image_broadcast_ms"] = bcast_s * 1e3
-        print(json.dumps(out), flush=True)
+        result_out.write(json.dumps(out) + "\n")
+        result_out.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
