@@ -472,11 +472,43 @@ int records_main(int argc, char** argv) {
     return 0;
 }
 
+// --device D: that one device (default 0); --gpus N: devices 0..N-1; --devices a,b,..: the listed devices, one worker (stream, arenas, buffer
+// slots) per entry -- an entry may repeat, which puts several workers on one GPU (the replica is shared): that is how the N-worker sharding
+// is tested on a machine with one GPU.  Every parsed batch is sharded over the workers.
+bool device_list(const Args& a, int device, std::vector<int>& devices) {
+    const int given = (a.get("--gpus") ? 1 : 0) + (a.get("--device") ? 1 : 0) + (a.get("--devices") ? 1 : 0);
+    if (given > 1) {
+        std::cerr << "--device, --gpus and --devices exclude one another\n";
+        return false;
+    }
+    if (a.get("--devices")) {
+        const std::string& l = *a.get("--devices");
+        size_t i = 0;
+        while (i <= l.size()) {
+            const size_t j = std::min(l.find(',', i), l.size());
+            if (j == i || l.find_first_not_of("0123456789", i) < j) {
+                std::cerr << "--devices wants a comma-separated list of device numbers\n";
+                return false;
+            }
+            devices.push_back(std::atoi(l.substr(i, j - i).c_str()));
+            i = j + 1;
+        }
+        return true;
+    }
+    const int ngpus = a.get("--gpus") ? std::atoi(a.get("--gpus")->c_str()) : 1;
+    if (ngpus < 1) {
+        std::cerr << "--gpus N needs N >= 1\n";
+        return false;
+    }
+    for (int d = 0; d < ngpus; ++d) devices.push_back(a.get("--gpus") ? d : device);
+    return true;
+}
+
 int query_main(int kind, int argc, char** argv) {
-    Args a = parse(argc, argv, {"-i", "-q", "--kmer-bits", "--device", "--gpus", "--batch-mb", "--output", "--threads"}, {"--pinned", "--pageable"});
+    Args a = parse(argc, argv, {"-i", "-q", "--kmer-bits", "--device", "--gpus", "--devices", "--batch-mb", "--output", "--threads"}, {"--pinned", "--pageable"});
     if (a.help || a.bad || !a.get("-i") || !a.get("-q")) {
         std::cerr << "Usage: " << argv[0]
-                  << " [-h,--help] -i mphf -q query_filename [--kmer-bits 64|128] [--device N | --gpus N] [--batch-mb N] [--threads N] [--pageable] [--output codes.u64]\n\n"
+                  << " [-h,--help] -i mphf -q query_filename [--kmer-bits 64|128] [--device N | --gpus N | --devices a,b,..] [--batch-mb N] [--threads N] [--pageable] [--output codes.u64]\n\n"
                   << " -i mphf\n\tREQUIRED: LP-Hash MPHF saved on disk.\n\n"
                   << " -q query_filename\n\tREQUIRED: Must be a FASTA file (.fa/fasta extension) compressed with gzip (.gz) or not.\n\n"
                   << " --kmer-bits\n\tk-mer word width the MPHF was built with (the reference's compile-time kmer_t): 128 (default) or 64.\n";
@@ -490,13 +522,8 @@ int query_main(int kind, int argc, char** argv) {
     const int threads = a.get("--threads") ? std::max(1, std::atoi(a.get("--threads")->c_str())) : default_parse_threads();
     const bool pinned = !a.has("--pageable");  // parse arenas in pinned host memory (default): copies to the devices are asynchronous
     // --gpus N: replicas on devices 0..N-1, every batch sharded over them; --device D: that one device
-    const int ngpus = a.get("--gpus") ? std::atoi(a.get("--gpus")->c_str()) : 1;
-    if (ngpus < 1 || (a.get("--gpus") && a.get("--device"))) {
-        std::cerr << "--gpus N needs N >= 1 and excludes --device\n";
-        return 1;
-    }
     std::vector<int> devices;
-    for (int d = 0; d < ngpus; ++d) devices.push_back(a.get("--gpus") ? d : device);
+    if (!device_list(a, device, devices)) return 1;
     lphq_index* idx = nullptr;
     if (lphq_open(mphf_filename.c_str(), kind, kmer_bits, &idx) != LPHQ_OK || lphq_attach_devices(idx, devices.data(), (int)devices.size()) != LPHQ_OK) {
         std::cerr << "[Error] " << lphq_last_error() << "\n";  // the reference dies in essentials::load here
@@ -959,9 +986,9 @@ int ptbb_build_main(int argc, char** argv) {
 }
 
 int ptbb_query_main(int argc, char** argv) {
-    Args a = parse(argc, argv, {"-q", "-k", "-p", "-b", "--kmer-bits", "--device", "--gpus", "--batch-mb", "--threads"}, {"--pageable"});
+    Args a = parse(argc, argv, {"-q", "-k", "-p", "-b", "--kmer-bits", "--device", "--gpus", "--devices", "--batch-mb", "--threads"}, {"--pageable"});
     if (a.help || a.bad || !a.get("-q") || !a.get("-k")) {
-        std::cerr << "Usage: " << argv[0] << " [-h,--help] -q input_filename -k k [-p pthash_filename] [--kmer-bits 64|128] [--device N | --gpus N] [--batch-mb N] "
+        std::cerr << "Usage: " << argv[0] << " [-h,--help] -q input_filename -k k [-p pthash_filename] [--kmer-bits 64|128] [--device N | --gpus N | --devices a,b,..] [--batch-mb N] "
                      "[--threads N] [--pageable]\n";
         return 1;
     }
@@ -970,13 +997,8 @@ int ptbb_query_main(int argc, char** argv) {
     const int kmer_bits = a.get("--kmer-bits") ? std::atoi(a.get("--kmer-bits")->c_str()) : 128;
     std::cout << input << "," << k;  // ptbb_query.cpp:23
     const int device = a.get("--device") ? std::atoi(a.get("--device")->c_str()) : 0;
-    const int ngpus = a.get("--gpus") ? std::atoi(a.get("--gpus")->c_str()) : 1;
-    if (ngpus < 1 || (a.get("--gpus") && a.get("--device"))) {
-        std::cerr << "--gpus N needs N >= 1 and excludes --device\n";
-        return 1;
-    }
     std::vector<int> devices;
-    for (int d = 0; d < ngpus; ++d) devices.push_back(a.get("--gpus") ? d : device);
+    if (!device_list(a, device, devices)) return 1;
     const size_t batch_bases = (size_t)(a.get("--batch-mb") ? std::max(1l, std::atol(a.get("--batch-mb")->c_str())) : 32) << 20;
     const int threads = a.get("--threads") ? std::max(1, std::atoi(a.get("--threads")->c_str())) : default_parse_threads();
     // one timed pass per function given (ptbb_query.cpp:40-72), each ",<file>,<ns per k-mer>", else ",,"

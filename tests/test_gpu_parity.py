@@ -353,13 +353,49 @@ def test_cli_many_batches_keep_record_order(tmp_path):
     L.build(recs, 31, 20, str(lph), kmer_bits=64, threads=8)
     o = orc.Index(str(lph), 0, 64)
     want = np.concatenate([o(x, True) for x in recs])
-    for extra in ([], ["--gpus", "1", "--threads", "5"], ["--pageable"]):
+    # --devices 0,0,0: three workers (streams, arenas, buffer slots) on the one GPU of the box -- the N-worker sharding of every batch
+    for extra in ([], ["--gpus", "1", "--threads", "5"], ["--pageable"], ["--devices", "0,0,0"], ["--devices", "0,0", "--pageable", "--threads", "3"]):
         sink = tmp_path / "codes.u64"
         r = subprocess.run([exe, "query-p", "-i", str(lph), "-q", str(fa), "--kmer-bits", "64", "--batch-mb", "1", "--output", str(sink)] + extra,
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         assert int(r.stdout.split(",")[2]) == len(want)
         assert np.array_equal(np.fromfile(sink, dtype=np.uint64), want)
+
+
+def test_cli_eight_workers_ragged_and_idle_shards(tmp_path):
+    """`--devices 0,0,0,0,0,0,0,0`: the sharding `lphash query-* --gpus 8` does on an 8-GPU node, with eight workers on the one GPU here.  Ragged
+    records (many shorter than k, so some shards hold bases but no k-mer) and files with fewer records than workers (idle shards): codes and
+    counts must equal the single-worker run and the oracle, in record order."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "lphash_amd", "lphash")
+    _, recs = synthetic_records(seed=78, n_records=12, length=50_000)
+    lph = tmp_path / "x.lph"
+    L.build(recs, 31, 20, str(lph), kmer_bits=64, threads=8)
+    o = orc.Index(str(lph), 0, 64)
+    rng = np.random.default_rng(9)
+    big = b"".join(recs)
+    ragged = []
+    for _ in range(400):
+        n = int(rng.choice([3, 17, 30, 31, 32, 64, 500, 4000]))
+        at = int(rng.integers(0, len(big) - n))
+        ragged.append(big[at:at + n])
+    files = {"ragged": ragged, "two": [recs[0][:9000], recs[1][:40]], "short_only": [recs[2][:30], recs[3][:12], recs[4][:1]]}
+    for name, rs in files.items():
+        fa = tmp_path / (name + ".fa")
+        with open(fa, "wb") as f:
+            for i, rec in enumerate(rs):
+                f.write(b">r%d\n%s\n" % (i, rec))
+        parts = [o(x, True) for x in rs if len(x) >= 31]
+        want = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint64)
+        for extra in (["--device", "0"], ["--devices", "0,0,0,0,0,0,0,0"], ["--devices", "0,0,0", "--batch-mb", "1", "--threads", "2"]):
+            sink = tmp_path / (name + ".u64")
+            r = subprocess.run([exe, "query-p", "-i", str(lph), "-q", str(fa), "--kmer-bits", "64", "--output", str(sink)] + extra, capture_output=True, text=True)
+            assert r.returncode == 0, (name, extra, r.stderr)
+            f5 = r.stdout.strip().split(",")
+            assert int(f5[2]) == len(want), (name, extra, r.stdout)
+            assert np.array_equal(np.fromfile(sink, dtype=np.uint64), want), (name, extra)
 
 
 def test_empty_and_tiny_indexes(tmp_path):
