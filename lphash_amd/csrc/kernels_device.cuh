@@ -52,17 +52,18 @@ __device__ __forceinline__ bool base_valid(uint32_t c) {
     const uint32_t B = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20) | (1u << 21);      // A C G T U relative to 0x40
     return ((u & 0xE0u) == 0x40u) && ((B >> (u & 31u)) & 1u);
 }
-// four characters (first at the lowest byte) -> 8 bits, first base in the highest 2 bits; bad = 4-bit mask
+// four characters (first at the lowest byte) -> 8 bits, first base in the highest 2 bits; bad = 4-bit mask (bit i: character i is not a base).
+// All four at once: the 2-bit code of every byte, the letter that code stands for (one v_perm_b32 into "ACGT"), and a byte is a base iff it is that
+// letter after case folding -- or one above it where the code is 3 (U/u share T's code) -- which is the set base_valid() accepts.  ~20 instructions
+// instead of ~50 for four base_valid() calls; the streaming kernel spends them on every base of the batch.
 __device__ __forceinline__ uint32_t pack4(uint32_t x, uint32_t& bad) {
-    bad = 0;
-    uint32_t keep = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const bool ok = base_valid((x >> (8 * i)) & 0xFFu);
-        bad |= (ok ? 0u : 1u) << i;
-        keep |= (ok ? 0xFFu : 0u) << (8 * i);
-    }
-    const uint32_t t = ((x >> 1) ^ (x >> 2)) & 0x03030303u & keep;  // invalid -> 0 ('A'), mphf_utils.hpp:108
+    const uint32_t t_raw = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+    const uint32_t want = __builtin_amdgcn_perm(0u, 0x54474341u, t_raw);  // byte i = "ACGT"[code i]
+    uint32_t d = (x & 0xDFDFDFDFu) ^ want;                                 // 0: A C G T (either case), 1: U/u under code 3, anything else: not a base
+    d &= ~(t_raw & (t_raw >> 1) & 0x01010101u);
+    const uint32_t nz = ((((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) >> 7) & 0x01010101u;  // 1 in every byte that is not a base
+    bad = (nz * 0x01020408u) >> 24;                                                    // bits 0, 8, 16, 24 -> bits 0..3
+    const uint32_t t = t_raw & ~(nz * 3u);  // invalid -> 0 ('A'), mphf_utils.hpp:108
     return (t * 0x40100401u) >> 24;
 }
 
@@ -535,8 +536,8 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
     const lphq_image_header& H = *(const lphq_image_header*)img;
     constexpr int kStreamPos = 4 * BLOCK, NW = tile_words(kStreamPos);
     constexpr int NBADW = (NW + 8) / 2 + 2;  // 32-bit words of the bad-base bitmask (1 bit per base)
-    constexpr int NDW = (NW + 1) * 4;        // dwords of sequence (4 bases each) the tile loads; NDW - BLOCK = 20 lanes load two
-    static_assert(NDW > BLOCK && NDW <= 2 * BLOCK, "two sequence dwords per lane at most");
+    constexpr int NDW = (NW + 1) * 4;        // dwords of sequence (4 bases each) the tile loads; NDW - BLOCK = 20 lanes of the last wave load two
+    static_assert(NDW > BLOCK && NDW <= BLOCK + 64, "the dwords beyond the first BLOCK are loaded by the lanes of the last wave");
     __shared__ uint64_t sm_hash[hash_slots<BLOCK>()];  // phase B-C: minimizer hash per m-mer position (hslot order), or the blocks' prefix minima when W >= kBlockMinW; phase E-F: the leader's base
     __shared__ uint32_t sm_words[NW + 8];
     __shared__ uint32_t sm_bad[NBADW];
@@ -552,13 +553,16 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
     const uint64_t t0 = (tile_base + blockIdx.x) * TW;  // shifted coordinate of the tile's first window start
 
     // ---- A: sequence dwords first (no dependence on the record search), then the search, then pack into LDS ----
+    // (uniform) every dword the tile loads lies inside the batch: true for all tiles but the first and the last, whose lanes check their bytes one by one
+    const bool interior = t0 >= shift && t0 + 4ull * (uint64_t)NDW <= shift + total;
     uint32_t xs[2] = {0u, 0u};
     bool have[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const uint32_t d = tid + (uint32_t)r * BLOCK;
+        const uint32_t d = r == 0 ? tid : tid + 64u;  // second dword: the last wave's lanes (wave 0 has the record search on its hands)
         const uint64_t a = t0 + (uint64_t)d * 4u;
-        have[r] = d < (uint32_t)NDW && a < shift + total && a + 4u > shift;
+        if (interior) have[r] = d >= (uint32_t)r * BLOCK && d < (uint32_t)NDW;
+        else have[r] = d >= (uint32_t)r * BLOCK && d < (uint32_t)NDW && a < shift + total && a + 4u > shift;
         if (have[r]) xs[r] = *(const uint32_t*)(seq_al + a);
     }
     if (tid < 64) {  // wave 0: record of the first base the tile can touch, and of the last
@@ -584,14 +588,14 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
     if (sm_rec[0] != sm_rec[1]) load_record_table(sm_rtab, seq_off, out_off, sm_rec[0], sm_rec[1], tid);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const uint32_t d = tid + (uint32_t)r * BLOCK;
-        if (d < (uint32_t)NDW) {
+        const uint32_t d = r == 0 ? tid : tid + 64u;
+        if (d >= (uint32_t)r * BLOCK && d < (uint32_t)NDW) {
             const uint64_t a = t0 + (uint64_t)d * 4u;
             uint32_t p8 = 0, b4 = 0xFu;
             if (have[r]) {
                 p8 = pack4(xs[r], b4);
                 uint32_t outside = 0;  // bytes of the dword that are not bases of the batch
-                if (a < shift || a + 4u > shift + total)
+                if (!interior && (a < shift || a + 4u > shift + total))
                     for (int i = 0; i < 4; ++i)
                         if (a + i < shift || a + i >= shift + total) outside |= 1u << i;
                 if (b4 & ~outside) sm_anybad = 1u;  // a real non-ACGT base (any lane may write the same value)

@@ -34,6 +34,17 @@ static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 static inline ulonglong2 make_ulonglong2(unsigned long long x, unsigned long long y) { return ulonglong2{x, y}; }
 
 static inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * b) >> 64); }
+// v_perm_b32: result byte i = byte sel_i of the 8 bytes {b (0..3), a (4..7)}; selector 0x0C yields 0x00 (the other special selectors are not used)
+static inline uint32_t __builtin_amdgcn_perm(uint32_t a, uint32_t b, uint32_t sel) {
+    const uint64_t src = ((uint64_t)a << 32) | b;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t s = (sel >> (8 * i)) & 0xFFu;
+        const uint32_t byte = s < 8u ? (uint32_t)(src >> (8 * s)) & 0xFFu : 0u;
+        r |= byte << (8 * i);
+    }
+    return r;
+}
 static inline int __popc(uint32_t v) { return __builtin_popcount(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
