@@ -326,7 +326,7 @@ static bool header_is_consistent(const lphq_image_header& h, size_t nbytes, std:
     auto phf_ok = [&](const lphq_phf_desc& f, const char* name) {
         if (f.num_keys == 0) return true;
         const uint64_t nb = f.num_dense + f.num_sparse;
-        bool ok = f.table_size >= f.num_keys && f.table_size <= 0xFFFFFFFFull && f.front_size <= nb && f.front_width >= 1 && f.front_width <= 32 &&
+        bool ok = f.table_size >= f.num_keys && f.table_size <= 0xFFFFFFFFull && nb <= 0xFFFFFFFFull && f.num_dense <= nb && f.front_size <= nb && f.front_width >= 1 && f.front_width <= 32 &&
                   f.back_width >= 1 && f.back_width <= 32 && f.div_table.d64 == f.table_size && f.div_dense.d64 == f.num_dense &&
                   f.div_sparse.d64 == f.num_sparse && f.num_dense > 0 && f.num_sparse > 0 &&
                   inside(f.off_front_ranks, (f.front_size * f.front_width + 7) / 8 + 8) &&

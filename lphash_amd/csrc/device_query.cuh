@@ -87,15 +87,17 @@ __device__ __forceinline__ uint64_t phf_load_code(const uint8_t* __restrict__ im
     // the fields themselves selects the ADDRESS, and with the descriptor in memory (tile kernels) that is a per-lane
     // vector load of a header field at the head of the gather chain.
     const lphq_divisor dd = f.div_dense, ds = f.div_sparse;
-    uint64_t b = mod_u64(x, dense ? dd.dn : ds.dn, dense ? dd.inv : ds.inv, dense ? dd.shift : ds.shift);
-    if (!dense) b += f.num_dense;
-    const bool front = b < f.front_size;
-    const uint64_t bi = front ? b : b - f.front_size;
+    // bucket numbers fit 32 bits (num_dense + num_sparse <= 2^32 - 1: image.cpp / header_is_consistent), so the arithmetic up to the bit offset does too
+    uint32_t b = (uint32_t)mod_u64(x, dense ? dd.dn : ds.dn, dense ? dd.inv : ds.inv, dense ? dd.shift : ds.shift);
+    if (!dense) b += (uint32_t)f.num_dense;
+    const uint32_t fsz = (uint32_t)f.front_size;
+    const bool front = b < fsz;
+    const uint32_t bi = front ? b : b - fsz;
     const uint32_t fw = f.front_width, bw = f.back_width;
     const uint64_t fo = f.off_front_ranks, bo = f.off_back_ranks;
     const uint32_t width = front ? fw : bw;
     const uint32_t* ranks = (const uint32_t*)(img + (front ? fo : bo));
-    const uint64_t bit = bi * width;
+    const uint64_t bit = (uint64_t)bi * width;
     const uint64_t dw = bit >> 5;
     rk.sh = (uint32_t)bit & 31u;
     rk.width = width;
@@ -109,8 +111,9 @@ __device__ __forceinline__ uint64_t phf_load_hp(const uint8_t* __restrict__ img,
     return ((const uint64_t*)(img + (rk.front ? fo : bo)))[code];
 }
 __device__ __forceinline__ uint64_t phf_finish(const uint8_t* __restrict__ img, const lphq_phf_desc& f, uint64_t x, uint64_t hp) {
-    uint64_t p = mod_u64(x ^ hp, f.div_table);
-    if (p >= f.num_keys) p = ((const uint32_t*)(img + f.off_free))[p - f.num_keys];
+    uint32_t p = (uint32_t)mod_u64(x ^ hp, f.div_table);  // table_size <= 2^32 - 1
+    const uint32_t nk = (uint32_t)f.num_keys;
+    if (p >= nk) p = ((const uint32_t*)(img + f.off_free))[p - nk];
     return p;
 }
 // hash128 hashers: the bucket comes from hash.first(), the table position from hash.second()

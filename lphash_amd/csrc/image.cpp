@@ -52,6 +52,10 @@ bool build_phf(const SinglePhf& f, ImageWriter& w, lphq_phf_desc& d, const char*
         err = std::string(what) + ": more than 2^32-1 keys is beyond the device layout's u32 free-slot table";
         return false;
     }
+    if (f.num_dense > 0xFFFFFFFFull || f.num_sparse > 0xFFFFFFFFull || f.num_dense + f.num_sparse > 0xFFFFFFFFull) {
+        err = std::string(what) + ": more than 2^32-1 buckets is beyond the device layout's 32-bit bucket arithmetic";
+        return false;
+    }
     if (f.front.ranks.width > 32 || f.back.ranks.width > 32) {
         err = std::string(what) + ": pilot codewords wider than 32 bits";
         return false;

@@ -620,10 +620,15 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
         const uint32_t sh = 64u - 2u * m;
         const uint64_t mask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
         uint64_t h[4];
+        if (m <= 29u) {  // (uniform) the four m-mers end inside the first 64 bits: one shift each
 #pragma unroll
-        for (uint32_t r = 0; r < 4; ++r) {
-            const uint64_t v = r == 0 ? (s0 >> sh) : (((s0 << (2 * r)) | (s1 >> (64 - 2 * r))) >> sh);
-            h[r] = murmur8(v & mask, mm_seedx);
+            for (uint32_t r = 0; r < 4; ++r) h[r] = murmur8((s0 >> (sh - 2 * r)) & mask, mm_seedx);
+        } else {
+#pragma unroll
+            for (uint32_t r = 0; r < 4; ++r) {
+                const uint64_t v = r == 0 ? (s0 >> sh) : (((s0 << (2 * r)) | (s1 >> (64 - 2 * r))) >> sh);
+                h[r] = murmur8(v & mask, mm_seedx);
+            }
         }
         if (BLKMIN) {
             bmin = publish_block_minima<BLOCK>(sm_hash, sm_off, tid, h);
@@ -725,20 +730,34 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
     __syncthreads();
 
     // ---- F: the lane's four codes ----
+    // straight-line for the common case (base +- offset); windows under a colliding minimizer (fallback function of the k-mer,
+    // partitioned_mphf.cpp:312-316) are redone afterwards, in the rare waves that hold one
     uint64_t hv[4];
+    uint32_t coll = 0;
 #pragma unroll
     for (uint32_t jw = 0; jw < 4; ++jw) {
         const uint32_t q = code[jw];
-        uint64_t hval = ~0ull;  // LPHQ_INVALID
-        if (q < 0xFFFEu) {
-            LookupCtx c;
-            c.base = sm_hash[hslot<BLOCK>(q)];
-            c.mode = sm_mode[q];
-            uint64_t lo = 0, hi = 0;
-            if (c.mode == 2u) extract_kmer<K128>(sm_words, a + jw, k, lo, hi);
-            hval = finish_hval<K128>(img, H, c, lo, hi, q - (a + jw));
-        }
-        hv[jw] = hval;
+        const bool valid = q < 0xFFFEu;
+        const uint32_t qq = valid ? q : a + jw;  // (any slot of the tile: the value read is discarded)
+        const uint64_t base = sm_hash[hslot<BLOCK>(qq)];
+        const uint32_t mode = sm_mode[qq];
+        const uint32_t p = qq - (a + jw);
+        const int32_t delta = mode == 0u ? (int32_t)p : -(int32_t)p;  // |p| < 2^16; (mode 2 is redone below)
+        const uint64_t hval = base + (uint64_t)(int64_t)delta;
+        hv[jw] = valid ? hval : ~0ull;  // LPHQ_INVALID
+        coll |= (valid && mode == 2u) ? 1u << jw : 0u;
+    }
+    if (__any(coll != 0u)) {
+#pragma unroll
+        for (uint32_t jw = 0; jw < 4; ++jw)
+            if ((coll >> jw) & 1u) {
+                LookupCtx c;
+                c.base = sm_hash[hslot<BLOCK>(code[jw])];
+                c.mode = 2u;
+                uint64_t lo = 0, hi = 0;
+                extract_kmer<K128>(sm_words, a + jw, k, lo, hi);
+                hv[jw] = finish_hval<K128>(img, H, c, lo, hi, 0u);
+            }
     }
     if (one_record) {
         uint64_t* dst = out + (sm_roff[2] + (t0 + a - shift - sm_roff[0]));  // (wraps harmlessly when the lane has no valid window)
