@@ -350,6 +350,10 @@ static bool header_is_consistent(const lphq_image_header& h, size_t nbytes, std:
         }
         return true;  // (the level table itself is checked by bbh_levels_inside, on the host copy or after reading it back from the device)
     }
+    if (h.mm.num_keys != 0 && !inside(h.off_tail, (h.mm.table_size - h.mm.num_keys) * 8)) {
+        why = "tail table lies outside the image";
+        return false;
+    }
     if (h.kind == LPHQ_PARTITIONED) {
         const uint64_t E = LPHQ_UNI_PER_BLOCK(h.P);
         if (!inside(h.off_uni, ((h.distinct_minimizers + E - 1) / E + 1) * sizeof(lphq_uni_block))) {

@@ -309,18 +309,39 @@ __device__ __forceinline__ LookupCtx ctx_unpartitioned(const lphq_image_header& 
 }
 template <int KIND, bool K128, int P>
 __device__ __forceinline__ LookupCtx lookup_ctx(const uint8_t* __restrict__ img, const lphq_image_header& H, uint64_t mm) {
-    const uint32_t h = (uint32_t)phf_position(img, H.mm, murmur8(mm, murmur_seedx(H.mm.seed)));
+    // single_phf::position up to the table position p; positions beyond num_keys (1 - alpha of them) are answered by the tail table
+    // (image_layout.h) instead of free_slots -> block: its load is issued next to the block load of the other lanes, so no wave
+    // waits for a third dependent gather.  (Tail lanes read block 0, a line every wave touches, and discard it.)
+    const lphq_phf_desc& f = H.mm;
+    const uint64_t x = murmur8(mm, murmur_seedx(f.seed));
+    uint32_t p = 0;
+    if (f.num_keys != 0) {  // (uniform; an empty function answers 0, as phf_position2)
+        PhfRank rk;
+        const uint64_t two = phf_load_code(img, f, x, rk);
+        p = (uint32_t)mod_u64(x ^ phf_load_hp(img, f, two, rk), f.div_table);
+    }
+    const uint32_t nk = (uint32_t)f.num_keys;
+    const bool tail = p >= nk && nk != 0u;
+    uint64_t tv = 0;
+    if (tail) tv = ((const uint64_t*)(img + H.off_tail))[p - nk];
+    const uint32_t h = tail ? 0u : p;
+    LookupCtx c;
     if (KIND == 0) {
         uint32_t type, size, pos;
         uint64_t base;
         uni_lookup<P>(img, H.off_uni, H.W, h, type, base, size, pos);
-        return ctx_partitioned(H, type, base, size, pos);
+        c = ctx_partitioned(H, type, base, size, pos);
     } else {
         uint64_t prefix;
         uint32_t size, pos;
         pair_lookup<P>(img, H.off_upair, h, prefix, size, pos);
-        return ctx_unpartitioned(H, prefix, size, pos);
+        c = ctx_unpartitioned(H, prefix, size, pos);
     }
+    if (tail) {
+        c.base = tv & LPHQ_TAIL_BASE_MASK;
+        c.mode = (uint32_t)(tv >> LPHQ_TAIL_MODE_SHIFT);
+    }
+    return c;
 }
 template <bool K128>
 __device__ __forceinline__ uint64_t finish_hval(const uint8_t* __restrict__ img, const lphq_image_header& H, const LookupCtx& c, uint64_t lo, uint64_t hi, uint32_t p) {

@@ -36,7 +36,7 @@ lphq_divisor make_divisor(uint64_t d) {
     return r;
 }
 
-bool build_phf(const SinglePhf& f, ImageWriter& w, lphq_phf_desc& d, const char* what, std::string& err) {
+bool build_phf(const SinglePhf& f, ImageWriter& w, lphq_phf_desc& d, const char* what, std::string& err, std::vector<uint64_t>* free_slots_out = nullptr) {
     memset(&d, 0, sizeof d);
     d.seed = f.seed;
     d.num_keys = f.num_keys;
@@ -91,8 +91,32 @@ bool build_phf(const SinglePhf& f, ImageWriter& w, lphq_phf_desc& d, const char*
         }
         ft[i] = (uint32_t)fs[i];
     }
+    if (free_slots_out) free_slots_out->swap(fs);
     return true;
 }
+
+// (base, mode) of a lookup as the kernels' LookupCtx holds it, packed for the tail table (image_layout.h)
+bool pack_ctx(uint64_t base, uint32_t mode, uint64_t& out, std::string& err) {
+    if (base > LPHQ_TAIL_BASE_MASK) {
+        err = "hash codes beyond 2^62 are beyond the device layout's tail entries";
+        return false;
+    }
+    out = ((uint64_t)mode << LPHQ_TAIL_MODE_SHIFT) | base;
+    return true;
+}
+// tail[t] = ctx of minimizer order fs[t]: orders are visited in increasing order by the callers, fs is non-decreasing (prefix sums of an Elias-Fano code)
+struct TailFiller {
+    const std::vector<uint64_t>& fs;
+    uint64_t* tail;
+    size_t t = 0;
+    bool put(uint64_t order, uint64_t base, uint32_t mode, std::string& err) {
+        while (t < fs.size() && fs[t] == order) {
+            if (!pack_ctx(base, mode, tail[t], err)) return false;
+            ++t;
+        }
+        return true;
+    }
+};
 
 // pair blocks: size planes w[0..P), position planes w[P..2P), 32 entries
 bool fill_pair_blocks(ImageWriter& w, uint64_t off, const uint64_t* size_prefix, const uint64_t* pos_prefix, uint64_t n, uint64_t base, uint32_t P,
@@ -143,7 +167,13 @@ bool build_image(const LphFile& x, std::vector<uint8_t>& img, std::string& err) 
         err = "more than 2^32-1 distinct minimizers is beyond the device layout's u32 rank counters";
         return false;
     }
-    if (!build_phf(x.minimizer_order, w, h.mm, "minimizer_order", err)) return false;
+    std::vector<uint64_t> mm_free;  // free_slots of the minimizer function, decoded
+    if (!build_phf(x.minimizer_order, w, h.mm, "minimizer_order", err, &mm_free)) return false;
+    for (size_t i = 1; i < mm_free.size(); ++i)
+        if (mm_free[i] < mm_free[i - 1]) {
+            err = "minimizer_order free slots are not monotone";
+            return false;
+        }
     if (!build_phf(x.fallback_kmer_order, w, h.fb, "fallback_kmer_order", err)) return false;
 
     if (x.kind == 2) {
@@ -165,6 +195,8 @@ bool build_image(const LphFile& x, std::vector<uint8_t>& img, std::string& err) 
         const uint32_t T = LPHQ_UNI_T(h.P), E = LPHQ_UNI_PER_BLOCK(h.P), P = h.P;
         const uint64_t nblk = (D + E - 1) / E;
         h.off_uni = w.reserve((nblk + 1) * sizeof(lphq_uni_block));
+        h.off_tail = w.reserve((mm_free.size() ? mm_free.size() : 1) * 8);
+        TailFiller tailf{mm_free, w.at<uint64_t>(h.off_tail)};
         uint64_t n_max_seen = 0, i_l = 0, i_r = 0, i_n = 0, i_lr = 0, i_mn = 0;
         for (uint64_t i = 0; i < D; ++i) {
             lphq_uni_block* blk = w.at<lphq_uni_block>(h.off_uni) + i / E;
@@ -178,19 +210,33 @@ bool build_image(const LphFile& x, std::vector<uint8_t>& img, std::string& err) 
             const bool msb = x.root.bv.get(i);
             const bool lsb = msb ? x.max_none.bv.get(i_mn++) : x.left_right.bv.get(i_lr++);
             uint64_t size = 0, pos = 0;
+            uint64_t cbase;  // what the kernels' ctx_partitioned() makes of this minimizer (src/partitioned_mphf.cpp:297-336), for the tail table
+            uint32_t cmode = 0;
             if (!msb && !lsb) {  // LEFT
                 size = vals[i_l + 1] - vals[i_l];
+                cbase = base + vals[i_l];
                 ++i_l;
             } else if (!msb && lsb) {  // RIGHT_OR_COLLISION
                 size = vals[rcs + i_r + 1] - vals[rcs + i_r];
+                if (size == 0) {
+                    cbase = h.collision_base;
+                    cmode = 2;
+                } else {
+                    cbase = base + vals[rcs + i_r] + (uint64_t)(x.k - x.m);
+                    cmode = 1;
+                }
                 ++i_r;
             } else if (msb && !lsb) {  // MAXIMAL
+                cbase = (uint64_t)h.W * n_max_seen;
                 ++n_max_seen;
             } else {  // NONE
                 size = vals[nss + i_n + 1] - vals[nss + i_n];
                 pos = vals[nps + i_n + 1] - vals[nps + i_n];
+                cbase = base + vals[nss + i_n] + pos;
+                cmode = 1;
                 ++i_n;
             }
+            if (!tailf.put(i, cbase, cmode, err)) return false;
             if ((size >> P) || (pos >> P)) {
                 err = "stored size/position does not fit the plane width (value > k-m+1?)";
                 return false;
@@ -202,6 +248,10 @@ bool build_image(const LphFile& x, std::vector<uint8_t>& img, std::string& err) 
                 if ((size >> q) & 1) blk->w[2 * T + q * T + wi] |= bit;
                 if ((pos >> q) & 1) blk->w[2 * T + P * T + q * T + wi] |= bit;
             }
+        }
+        if (tailf.t != mm_free.size()) {
+            err = "minimizer_order free slots point beyond the minimizers";
+            return false;
         }
         if (i_l != n_left || i_r != n_right || i_n != n_none || n_max_seen != x.n_maximal) {
             err = "wavelet tree census does not match the region starts";
@@ -232,6 +282,17 @@ bool build_image(const LphFile& x, std::vector<uint8_t>& img, std::string& err) 
         h.collision_base = x.num_kmers_in_main_index;  // unpartitioned_mphf.cpp:198
         h.off_upair = w.reserve(((D + LPHQ_PAIR_PER_BLOCK - 1) / LPHQ_PAIR_PER_BLOCK + 1) * sizeof(lphq_plane_block));
         if (!fill_pair_blocks(w, h.off_upair, sz.data(), ps.data(), D, 0, h.P, err)) return false;
+        // tail entries: what ctx_unpartitioned() makes of a minimizer (src/unpartitioned_mphf.cpp:194-204)
+        h.off_tail = w.reserve((mm_free.size() ? mm_free.size() : 1) * 8);
+        TailFiller tailf{mm_free, w.at<uint64_t>(h.off_tail)};
+        for (uint64_t i = 0; i < D; ++i) {
+            const uint64_t size = sz[i + 1] - sz[i], pos = ps[i + 1] - ps[i];
+            if (!(size == 0 ? tailf.put(i, h.collision_base, 2, err) : tailf.put(i, sz[i] + pos, 1, err))) return false;
+        }
+        if (tailf.t != mm_free.size()) {
+            err = "minimizer_order free slots point beyond the minimizers";
+            return false;
+        }
     }
     img.resize((img.size() + 255) & ~(size_t)255, 0);
     h.total_bytes = img.size();
