@@ -247,28 +247,43 @@ __device__ __forceinline__ uint64_t fallback_hash(uint64_t lo, uint64_t hi, uint
 
 // debug::compute_minimizer_triplet   include/mphf_utils.hpp:118-137: scan the W m-mers from the right end,
 // `<=` keeps the LEFTMOST minimum; returns the m-mer and p = offset of the minimizer from the left.
+// Same result, scanned from the LEFT end with a strict `<` (the first of equal hashes stays): the k-mer is kept left-aligned, so the m-mer is
+// the top 2m bits (one shift, no mask), and hash and index are updated under ONE compare; the m-mer itself is cut out again afterwards.
+// ~31 instructions per m-mer instead of ~38 (k=63: 44 m-mers per lookup, and that kernel is bound by VALU issue, profiles/r02_c4_pmc_summary.txt).
 template <bool K128>
 __device__ __forceinline__ void minimizer_of(uint64_t lo, uint64_t hi, uint32_t k, uint32_t m, uint32_t W, uint64_t mm_seedx, uint64_t& mm, uint32_t& p) {
-    const uint64_t mask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
-    uint64_t min_hash = ~0ull;
-    uint32_t pos = 0;
-    mm = 0;
-#pragma unroll 2
-    for (uint32_t i = 0; i < W; ++i) {
-        const uint64_t mmer = lo & mask;
-        const uint64_t hsh = murmur8(mmer, mm_seedx);
-        if (hsh <= min_hash) {
-            min_hash = hsh;
-            mm = mmer;
-            pos = i;
-        }
-        lo >>= 2;
-        if (K128) {
-            lo |= hi << 62;
-            hi >>= 2;
-        }
+    const uint32_t top = 64u - 2u * m;  // m <= 32
+    uint64_t l, h;                      // the k-mer, first base in the top bits of h (K128) / l
+    if (K128) {
+        const uint32_t a = 128u - 2u * k;  // 2 .. 126
+        h = a >= 64u ? lo << (a - 64u) : ((hi << a) | (lo >> (64u - a)));
+        l = a >= 64u ? 0ull : lo << a;
+    } else {
+        h = 0;
+        l = lo << (64u - 2u * k);  // k <= 31
     }
-    p = k - (pos + m);
+    uint64_t min_hash = murmur8((K128 ? h : l) >> top, mm_seedx);  // W >= 1
+    uint32_t j_min = 0;
+#pragma unroll 2
+    for (uint32_t j = 1; j < W; ++j) {
+        if (K128) {
+            h = (h << 2) | (l >> 62);
+            l <<= 2;
+        } else {
+            l <<= 2;
+        }
+        const uint64_t hsh = murmur8((K128 ? h : l) >> top, mm_seedx);
+        const bool lt = hsh < min_hash;
+        min_hash = lt ? hsh : min_hash;
+        j_min = lt ? j : j_min;
+    }
+    const uint32_t s = 2u * (k - m - j_min);  // the minimizer starts j_min bases from the left: bits [s, s + 2m) of the k-mer
+    const uint64_t mask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
+    uint64_t v;
+    if (K128) v = s == 0u ? lo : (s < 64u ? ((lo >> s) | (hi << (64u - s))) : (hi >> (s - 64u)));
+    else v = lo >> s;
+    mm = v & mask;
+    p = j_min;  // == k - (pos + m) with pos counted from the right end, mphf_utils.hpp:136
 }
 
 // mphf::query (src/partitioned_mphf.cpp:292-339) / mphf_alt::query (src/unpartitioned_mphf.cpp:191-206):
