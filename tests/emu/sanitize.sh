@@ -3,7 +3,8 @@
 #   bash tests/emu/sanitize.sh [pytest -k expression]
 # LDS arrays are function-local statics here, so ASan's global redzones catch an out-of-range LDS index; host buffers are
 # numpy allocations, so its heap redzones catch a kernel reading or writing outside what the caller passed.
-# Last full run (round 2, after the read-batch kernel and k_extract_runs): 68 tests clean under both (ASan: ~7 min because of the pilot-search cases).
+# Last runs (round 2): 68 tests clean under both after the read-batch kernel and k_extract_runs (ASan: ~7 min because of the pilot-search cases);
+# 64 (all but the pilot-search cases) clean under both on the final tree of the round (tail table, trimmed streaming kernel, minimizer scan from the left).
 set -eu
 R=$(cd "$(dirname "$0")/../.." && pwd)
 cd "$R/tests/emu"
