@@ -91,6 +91,54 @@ __global__ __launch_bounds__(256) void k_pass_b(const lphq_image_header H, const
         __builtin_nontemporal_store(finish_hval<false>(img, H, c, lo, 0, it.p), out + it.idx);
     }
 }
+// XCD-SPATIAL variant of pass B: ONE launch, workgroup w serves slice w % 8 -- with the round-robin dispatch of workgroups over the 8 XCDs every XCD
+// reads only its eighth of the back dictionary (0.3 MB), which then stays in that XCD's L2.
+template <int G>
+__global__ __launch_bounds__(256) void k_pass_b_xcd(const lphq_image_header H, const uint8_t* __restrict__ img, const uint64_t* __restrict__ kmers,
+                                                    uint64_t* __restrict__ out, const Item* __restrict__ queues, const uint32_t* __restrict__ cnts, uint32_t n_regions) {
+    __shared__ uint32_t sm_pre[G + 1];
+    const uint32_t slice = blockIdx.x & 7u, r0 = (blockIdx.x >> 3) * G;
+    const Item* queue = queues + (size_t)slice * n_regions * 256;
+    const uint32_t* cnt = cnts + (size_t)slice * n_regions;
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int g = 0; g < G; ++g) {
+            sm_pre[g] = acc;
+            acc += (r0 + g < n_regions) ? cnt[r0 + g] : 0u;
+        }
+        sm_pre[G] = acc;
+    }
+    __syncthreads();
+    const uint32_t total = sm_pre[G];
+    for (uint32_t j = threadIdx.x; j < total; j += 256) {
+        uint32_t g = 0;
+#pragma unroll
+        for (int t = 1; t < G; ++t) g += (j >= sm_pre[t]);
+        const Item it = queue[(size_t)(r0 + g) * 256 + (j - sm_pre[g])];
+        const uint32_t h = (uint32_t)phf_position(img, H.mm, it.x);
+        uint32_t type, size, pos;
+        uint64_t base;
+        uni_lookup<4>(img, H.off_uni, H.W, h, type, base, size, pos);
+        const LookupCtx c = ctx_partitioned(H, type, base, size, pos);
+        uint64_t lo = 0;
+        if (c.mode == 2u) lo = kmers[it.idx];
+        __builtin_nontemporal_store(finish_hval<false>(img, H, c, lo, 0, it.p), out + it.idx);
+    }
+}
+float run_xcd(const lphq_image_header& H, const uint8_t* dimg, const uint64_t* k, size_t n, uint64_t* out, Item* q, size_t qcap, unsigned long long* qn, int reps) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    const unsigned nwg = (unsigned)((n + 255) / 256);
+    constexpr int G = 32;  // ~0.4 * 256 / 8 items per region -> ~400 per group
+    auto once = [&] {
+        k_pass_a<8><<<nwg, 256>>>(H, dimg, k, n, out, q, qcap, qn);
+        k_pass_b_xcd<G><<<8 * ((nwg + G - 1) / G), 256>>>(H, dimg, k, out, q, (const uint32_t*)qn, nwg);
+    };
+    once(); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int r = 0; r < reps; ++r) once();
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms / reps;
+}
 template <int S>
 float run(const lphq_image_header& H, const uint8_t* dimg, const uint64_t* k, size_t n, uint64_t* out, Item* q, size_t qcap, unsigned long long* qn, int reps) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -120,7 +168,7 @@ int main(int argc, char** argv) {
     const void* dimg; size_t dn; lphq_device_image(idx, &dimg, &dn);
     const size_t n = 1ull << 28, qcap = n;
     uint64_t *k, *out, *ref; CK(hipMalloc(&k, n * 8)); CK(hipMalloc(&out, n * 8)); CK(hipMalloc(&ref, n * 8));
-    Item* q; CK(hipMalloc(&q, 4 * qcap * sizeof(Item))); unsigned long long* qn; CK(hipMalloc(&qn, 4 * (n / 256) * 4 + 64));
+    Item* q; CK(hipMalloc(&q, 8 * qcap * sizeof(Item))); unsigned long long* qn; CK(hipMalloc(&qn, 8 * (n / 256) * 4 + 64));
     k_gen<<<4096, 256>>>(k, n); CK(hipDeviceSynchronize());
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     lphq_query_packed(idx, k, n, ref, nullptr); CK(hipDeviceSynchronize());
@@ -139,5 +187,6 @@ int main(int argc, char** argv) {
     CK(hipMemset(out, 0, n * 8)); printf("sliced, S = 2: %.3f ms\n", run<2>(H, (const uint8_t*)dimg, k, n, out, q, qcap, qn, 5)); check("S=2");
     CK(hipMemset(out, 0, n * 8)); printf("sliced, S = 3: %.3f ms\n", run<3>(H, (const uint8_t*)dimg, k, n, out, q, qcap, qn, 5)); check("S=3");
     CK(hipMemset(out, 0, n * 8)); printf("sliced, S = 4: %.3f ms\n", run<4>(H, (const uint8_t*)dimg, k, n, out, q, qcap, qn, 5)); check("S=4");
+    CK(hipMemset(out, 0, n * 8)); printf("XCD-spatial, 8 slices in one launch (workgroup w -> slice w %% 8): %.3f ms\n", run_xcd(H, (const uint8_t*)dimg, k, n, out, q, qcap, qn, 5)); check("XCD-spatial");
     return 0;
 }
