@@ -535,16 +535,17 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
                                                                  uint64_t tile_base /* first tile of this launch */) {
     const lphq_image_header& H = *(const lphq_image_header*)img;
     constexpr int kStreamPos = 4 * BLOCK, NW = tile_words(kStreamPos);
-    constexpr int NBADW = (NW + 8) / 2 + 2;  // 32-bit words of the bad-base bitmask (1 bit per base)
     constexpr int NDW = (NW + 1) * 4;        // dwords of sequence (4 bases each) the tile loads; NDW - BLOCK = 20 lanes of the last wave load two
     static_assert(NDW > BLOCK && NDW <= BLOCK + 64, "the dwords beyond the first BLOCK are loaded by the lanes of the last wave");
     __shared__ uint64_t sm_hash[hash_slots<BLOCK>()];  // phase B-C: minimizer hash per m-mer position (hslot order), or the blocks' prefix minima when W >= kBlockMinW; phase E-F: the leader's base
     __shared__ uint32_t sm_words[NW + 8];
-    __shared__ uint32_t sm_bad[NBADW];
+    __shared__ uint8_t sm_badb[NDW + 12];  // bad-base flags, one byte per sequence dword: bit i = base i of the dword is not a base of the batch (every entry is
+                                           // written by the lane that packs the dword, so the packing needs no barrier after an initialisation)
+    __shared__ uint32_t sm_anybad4[BLOCK / 64];  // per wave: one of its dwords holds a real non-ACGT base
     __shared__ uint16_t sm_queue[kStreamPos];
     __shared__ uint8_t sm_mode[kStreamPos];
     __shared__ uint8_t sm_off[hash_row<BLOCK>() + 3];  // phase B-C: where in its block each published prefix minimum sits
-    __shared__ uint32_t sm_rec[2], sm_count, sm_anybad;
+    __shared__ uint32_t sm_rec[2], sm_count;
     __shared__ uint64_t sm_roff[3];                // seq_off[rlo], seq_off[rlo+1], out_off[rlo]
     __shared__ uint64_t sm_rtab[2 * kRecCap + 1];  // multi-record tiles: the tile's slice of seq_off / out_off
     const uint32_t tid = threadIdx.x;
@@ -579,13 +580,12 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
             sm_roff[1] = e0;
             sm_roff[2] = out_off[r];
             sm_count = 0;
-            sm_anybad = 0;
         }
     }
-    for (int c = tid; c < NBADW; c += BLOCK) sm_bad[c] = (c < NDW / 8) ? 0u : 0xFFFFFFFFu;
+    if (tid < 12u) sm_badb[NDW + tid] = 0xFu;  // beyond the tile's dwords: not bases
     for (int c = NW + 1 + tid; c < NW + 8; c += BLOCK) sm_words[c] = 0;
-    __syncthreads();
-    if (sm_rec[0] != sm_rec[1]) load_record_table(sm_rtab, seq_off, out_off, sm_rec[0], sm_rec[1], tid);
+    // (no barrier here: the packing below touches only what its own lane loaded; the record search of wave 0 is awaited at the next barrier)
+    bool real_bad = false;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const uint32_t d = r == 0 ? tid : tid + 64u;
@@ -598,14 +598,19 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
                 if (!interior && (a < shift || a + 4u > shift + total))
                     for (int i = 0; i < 4; ++i)
                         if (a + i < shift || a + i >= shift + total) outside |= 1u << i;
-                if (b4 & ~outside) sm_anybad = 1u;  // a real non-ACGT base (any lane may write the same value)
+                real_bad = real_bad || (b4 & ~outside);  // a real non-ACGT base
                 b4 |= outside;
             }
             ((uint8_t*)sm_words)[(d & ~3u) + (3u - (d & 3u))] = (uint8_t)p8;  // first base in the top bits of each 32-bit word
-            if (b4) atomicOr(&sm_bad[d >> 3], b4 << (4 * (d & 7)));
+            sm_badb[d] = (uint8_t)b4;
         }
     }
+    {
+        const bool wave_bad = __any(real_bad);
+        if ((tid & 63u) == 0u) sm_anybad4[tid >> 6] = wave_bad ? 1u : 0u;
+    }
     __syncthreads();
+    if (sm_rec[0] != sm_rec[1]) load_record_table(sm_rtab, seq_off, out_off, sm_rec[0], sm_rec[1], tid);  // (visible to phase C through the barrier after phase B)
 
     // ---- B: hashes of the m-mers starting at local positions 4*lane .. 4*lane+3; block minima published for phase C ----
     BlockMin bmin;
@@ -646,7 +651,9 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
     const uint32_t a = 4u * tid;
     const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];
     const bool one_record = rlo == rhi;
-    const bool anybad = sm_anybad != 0u;
+    bool anybad = false;
+#pragma unroll
+    for (int wv = 0; wv < BLOCK / 64; ++wv) anybad = anybad || sm_anybad4[wv] != 0u;
     // one record: window i of the tile is a window of the record iff w_lo <= i < w_hi
     const uint32_t w_lo = t0 >= shift ? 0u : (uint32_t)(shift - t0);
     uint32_t w_hi = 0;
@@ -686,11 +693,11 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
         }
         if (anybad) {  // uniform over the workgroup
             const uint64_t kmask = (1ull << k) - 1ull;  // k <= 63
-            // bad-base bits [a, a + 96): a % 4 == 0, windows a..a+3 need bits up to a + 3 + 62
-            const uint32_t bw = a >> 5, bo = a & 31u;
-            const uint32_t b0 = sm_bad[bw], b1 = sm_bad[bw + 1], b2 = sm_bad[bw + 2], b3 = sm_bad[bw + 3];
-            const uint64_t blo = bo ? (((((uint64_t)b1 << 32) | b0) >> bo) | ((uint64_t)b2 << (64u - bo))) : ((((uint64_t)b1) << 32) | b0);
-            const uint32_t bhi = bo ? (uint32_t)(((((uint64_t)b3 << 32) | b2) >> bo)) : b2;
+            // bad-base bits [a, a + 68): windows a..a+3 need bits up to a + 3 + 62; one nibble per sequence dword, the lane's first dword is tid
+            uint64_t blo = 0;
+#pragma unroll
+            for (uint32_t d = 0; d < 16; ++d) blo |= (uint64_t)(sm_badb[tid + d] & 0xFu) << (4 * d);
+            const uint32_t bhi = sm_badb[tid + 16u] & 0xFu;
 #pragma unroll
             for (uint32_t jw = 0; jw < 4; ++jw) {
                 const uint64_t x = jw ? ((blo >> jw) | ((uint64_t)bhi << (64 - jw))) : blo;
