@@ -1,10 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native LPHash query engine.
 
-Workload (BASELINE.json configs[1], "C2"): partitioned LP-MPHF, k=31 m=20, 100 M k-mers; one *step* =
+Headline workload (BASELINE.json configs[1], "C2"): partitioned LP-MPHF, k=31 m=20, 100 M k-mers; one *step* =
 one batch of 2^28 random positive packed k-mer lookups per GPU (the reference's `streaming == false`
 branch, include/partitioned_mphf.hpp:185-195), inputs and outputs resident in HBM.  `--mode stream`
 measures C3 (all windows of the index FASTA, streaming kernel) instead.
+
+After the (unchanged) headline the default run measures the other BASELINE.json configurations the same way and
+reports them in a `secondary` list of the same JSON line: C3 (streaming, same index), C5 (unpartitioned), and the
+per-GPU work of C4 (k=63, 128-bit k-mers, 2 B k-mers) in random and in streaming mode -- each entry with its kernel
+time (HIP events), value, roofline, parity against the oracle and the oracle timed beside it.  `--no-secondary`
+skips them; a secondary that fails is reported in `secondary_errors` and never takes the headline with it.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -12,10 +18,15 @@ measures C3 (all windows of the index FASTA, streaming kernel) instead.
 
 Multi-GPU: the index is built once on rank 0, its flat device image is broadcast with RCCL
 (torch.distributed backend "nccl"), and every rank processes its own batch -- no data-path collective
- => weak scaling; value = lookups of all ranks / max-over-ranks time.
-Rank 0 prints ONE JSON line.
+ => weak scaling; value = lookups of all ranks / max-over-ranks time.  Every rank checks a
+slice of ITS OWN timed batch against the oracle, the verdicts are all-reduced, and a failure on any rank ends the
+whole job with exit code 3.  Rank 0 prints ONE JSON line.
+
+`--plan-only` (no GPU needed; gloo when WORLD_SIZE > 1) stops before the first GPU call: it resolves the workloads
+and cache paths, checks that every rank resolved the same plan and prints it -- what tests/test_dist_cpu.py runs.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -25,10 +36,71 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+# VALU issue peak in lane-instructions/s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (one wave64 instruction = 4 cycles of a SIMD)
+VALU_PEAK_LANE_INSTR = 256 * 4 * 16 * 2.4e9
+RECORD_KMERS = 100_000  # k-mers per synthetic record
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# the plan: pure functions of the arguments (no GPU, no torch) -- every rank must resolve the same one
+# ----------------------------------------------------------------------------------------------------------
+def make_workload(name, mode, kind, k, m, kmers, batch_log2, steps, warmup, cpu_sample_log2, gpu_build, nonmember_frac=0.0,
+                  shuffle_records=False, bbhash_gamma=1.0, headline=False):
+    n_records = max(1, kmers // RECORD_KMERS)
+    return {"name": name, "mode": mode, "kind": kind, "k": k, "m": m, "kmers": n_records * RECORD_KMERS, "n_records": n_records,
+            "rec_len": RECORD_KMERS + k - 1, "kmer_bits": 64 if k <= 31 else 128, "batch_log2": batch_log2, "steps": steps, "warmup": warmup,
+            "cpu_sample_log2": cpu_sample_log2, "gpu_build": bool(gpu_build), "nonmember_frac": nonmember_frac,
+            "shuffle_records": bool(shuffle_records), "bbhash_gamma": bbhash_gamma, "headline": headline}
+
+
+def config_name(wl):
+    if wl["kind"] == "bbhash":
+        return "BBHash competitor (SURVEY 8f-4)"
+    if wl["kind"] == "pthash":
+        return "PTHash competitor (SURVEY 8f-4)"
+    if wl["kind"] == "u":
+        return "C5"
+    return "C4" if wl["k"] > 31 else ("C2" if wl["mode"] == "random" else "C3")
+
+
+def index_path(cache_dir, wl):
+    g = wl["bbhash_gamma"] if wl["kind"] == "bbhash" else ""
+    return os.path.join(cache_dir, f"synth_seed1_{wl['kind']}{g}_k{wl['k']}_m{wl['m']}_n{wl['kmers']}_b{wl['kmer_bits']}.lph")
+
+
+def headline_workload(args):
+    wl = make_workload("headline", args.mode, args.kind, args.k, args.m, args.kmers, args.batch_log2, args.steps, args.warmup, args.cpu_sample_log2,
+                       args.gpu_build, args.nonmember_frac, args.shuffle_records, args.bbhash_gamma, headline=True)
+    wl["name"] = config_name(wl)
+    return wl
+
+
+def is_default_headline(wl):
+    return (wl["mode"], wl["kind"], wl["k"], wl["m"], wl["kmers"], wl["batch_log2"], wl["nonmember_frac"]) == ("random", "p", 31, 20, 100_000_000, 28, 0.0)
+
+
+def secondary_workloads(args, head):
+    """The other BASELINE.json configurations, measured after the headline of a default run (C2): same steps / warmup, a smaller oracle
+    sample (k=63 costs the oracle 4x more per k-mer), C4's 2 B-k-mer index built with the GPU pilot search (its bytes equal the
+    sequential build's: tests/test_zz_gpu_next.py; the sequential search would take minutes)."""
+    if args.no_secondary or args.no_cpu_baseline or not is_default_headline(head):  # (--no-cpu-baseline = profiling runs: the named workload only)
+        return []
+    st, wu = args.steps, args.warmup
+    c4 = args.secondary_c4_kmers
+    return [make_workload("C3", "stream", "p", 31, 20, 100_000_000, 0, st, wu, 22, args.gpu_build),
+            make_workload("C5", "random", "u", 31, 20, 100_000_000, 28, st, wu, 22, args.gpu_build),
+            make_workload("C4-random", "random", "p", 63, 20, c4, 28, st, wu, 21, True),
+            make_workload("C4-stream", "stream", "p", 63, 20, c4, 0, st, wu, 21, True)]
+
+
+def plan_of(args):
+    head = headline_workload(args)
+    wls = [head] + secondary_workloads(args, head)
+    return {"gpus": args.gpus, "cache_dir": args.cache_dir, "workloads": wls, "index_paths": [index_path(args.cache_dir, w) for w in wls]}
 
 
 def algorithmic_bytes_per_lookup(h, mode, k, W, partitioned):
@@ -112,147 +184,151 @@ def hbm_ceiling_gbs(torch, dev):
     return n * 8 / t_read / 1e9, 2 * n * 8 / t_copy / 1e9
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--mode", choices=["random", "stream"], default="random")
-    ap.add_argument("--kmers", type=int, default=100_000_000, help="k-mers in the index (C2: 100 M)")
-    ap.add_argument("--batch-log2", type=int, default=28, help="random mode: 2^x lookups per step per GPU")
-    ap.add_argument("--k", type=int, default=31)
-    ap.add_argument("--m", type=int, default=20)
-    ap.add_argument("--kind", choices=["p", "u", "pthash", "bbhash"], default="p",
-                    help="p / u: LPHash partitioned / unpartitioned; pthash / bbhash: the competitors of SURVEY 8(f)-4 over the same k-mers (random mode)")
-    ap.add_argument("--bbhash-gamma", type=float, default=1.0, help="--kind bbhash: load factor (the reference's ptbb_build default is 1)")
-    ap.add_argument("--build-threads", type=int, default=0)
-    ap.add_argument("--gpu-build", action="store_true",
-                    help="run the PTHash pilot search of the index build on the GPU (same file bytes; default is the sequential CPU search so that "
-                         "the measured query path does not depend on construction code)")
-    ap.add_argument("--cpu-sample-log2", type=int, default=24, help="oracle-timed sample size (rank 0, N=1)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--nonmember-frac", type=float, default=0.0,
-                    help="random mode: this fraction of the probes are uniformly random k-mers (non-members; SURVEY 8(d) secondary run)")
-    ap.add_argument("--shuffle-records", action="store_true", help="stream mode: the index records in a random order (SURVEY 8(d) variant)")
-    ap.add_argument("--cache-dir", default=os.environ.get("LPHQ_BENCH_CACHE", "/tmp/lphq_bench_cache"))
-    ap.add_argument("--no-hbm-probe", action="store_true", help="skip the in-run measurement of the HBM copy ceiling (roofline.peak_measured)")
-    ap.add_argument("--dist-single", action="store_true",
-                    help="with one rank, still initialise torch.distributed (RCCL) and run the image broadcast and the replica check: exercises the N > 1 code on a 1-GPU box")
-    ap.add_argument("--b1-records", type=int, default=300,
-                    help="records of the index set the reference-faithful driver baseline (B1: gz + parse inside the timer) reads; 0 = skip")
-    args = ap.parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # before anything initialises the GPU in this process
-        sys.exit(self_launch(args.gpus, sys.argv[1:]))
-    # Everything but the result line goes to stderr, also what native libraries print (RCCL writes a version banner to stdout with C stdio, flushed
-    # when the process ends, i.e. AFTER the JSON line): file descriptor 1 is pointed at stderr and the line is written to a copy of the original.
-    sys.stdout.flush()
-    result_out = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
-    global np, torch, L, synthetic_records
-    import numpy as np
-    import torch
+def plans_agree(dist, torch, dev, plan):
+    """Every rank resolved the same plan (arguments, workloads, cache paths)?  all-gather of a digest; collective, same verdict on every rank."""
+    digest = hashlib.sha256(json.dumps(plan, sort_keys=True).encode()).digest()
+    mine = torch.tensor(list(digest[:16]), dtype=torch.int64, device=dev)
+    every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, mine)
+    return all(bool(torch.equal(e, mine)) for e in every)
 
-    import lphash_amd as L
-    from lphash_amd.synth import synthetic_records
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        log(f"[bench] ERROR: WORLD_SIZE={world} but --gpus {args.gpus}")
-        sys.exit(2)
-    assert torch.cuda.is_available(), "bench.py needs a GPU: the query path has no CPU fallback"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1 or args.dist_single:
-        import torch.distributed as dist_mod
+def all_ranks_ok(dist, torch, dev, ok):
+    """Logical AND of a per-rank verdict (collective).  A rank that fails a check does not leave on its own -- the others would wait
+    for it in the next collective until the watchdog fires -- it reports here and every rank ends the job together."""
+    if dist is None:
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
 
-        dist = dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if world == 1:
-            os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    k, m = args.k, args.m
+class Job:
+    """What the workloads of one bench process share."""
+
+    def __init__(self, args, rank, local_rank, world, dev, dist, torch, np, L):
+        self.args, self.rank, self.local_rank, self.world, self.dev, self.dist = args, rank, local_rank, world, dev, dist
+        self.torch, self.np, self.L = torch, np, L
+        self._records = {}  # (n_records, rec_len) -> (flat, recs): the k=31 workloads share one set
+        self.hbm = None
+        self.valu = {}
+
+    def records(self, wl):
+        from lphash_amd.synth import synthetic_records
+
+        key = (wl["n_records"], wl["rec_len"])
+        if key not in self._records:
+            self._records.clear()  # one set at a time (C4's is 2 GB + the per-record copies)
+            t0 = time.time()
+            self._records[key] = synthetic_records(seed=1, n_records=wl["n_records"], length=wl["rec_len"])
+            log(f"[bench r{self.rank}] generated {wl['n_records']} records x {wl['rec_len']} bases in {time.time() - t0:.1f}s")
+        return self._records[key]
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def fail(self, code, msg):
+        log(f"[bench r{self.rank}] ERROR: {msg}")
+        if self.dist is not None:
+            try:
+                self.dist.destroy_process_group()
+            except Exception:
+                pass
+        sys.exit(code)
+
+
+def load_oracle(job, wl, path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc  # the checker: never on the measured path
+
+    if wl["kind"] == "pthash":
+        return orc.PtHash(path, wl["k"], wl["kmer_bits"])
+    return orc.Index(path, orc.PARTITIONED if wl["kind"] == "p" else orc.UNPARTITIONED, wl["kmer_bits"])
+
+
+def run_workload(job, wl):
+    """One workload on every rank: index (rank 0 builds / loads, RCCL broadcast of the image), per-rank batch resident in HBM, warmup, timed
+    steps between barriers, parity of the timed output against the oracle on every rank, CPU baseline on rank 0.  Returns the result
+    dictionary on rank 0 (None elsewhere)."""
+    args, rank, local_rank, world, dev, dist, torch, np, L = job.args, job.rank, job.local_rank, job.world, job.dev, job.dist, job.torch, job.np, job.L
+    k, m, mode = wl["k"], wl["m"], wl["mode"]
     W = k - m + 1
-    kmer_bits = 64 if k <= 31 else 128
-    kind = {"p": L.PARTITIONED, "u": L.UNPARTITIONED, "pthash": L.PTHASH, "bbhash": L.BBHASH}[args.kind]
+    kmer_bits = wl["kmer_bits"]
+    kind = {"p": L.PARTITIONED, "u": L.UNPARTITIONED, "pthash": L.PTHASH, "bbhash": L.BBHASH}[wl["kind"]]
     cls = {L.PARTITIONED: L.Mphf, L.UNPARTITIONED: L.MphfAlt, L.PTHASH: L.PtHash, L.BBHASH: L.BbHash}[kind]
     competitor = kind in (L.PTHASH, L.BBHASH)
     load = (lambda p_, dev_: cls.load(p_, k, kmer_bits=kmer_bits, device=dev_)) if competitor else (lambda p_, dev_: cls.load(p_, kmer_bits=kmer_bits, device=dev_))
-    if competitor and args.mode != "random":
-        sys.exit("--kind pthash / bbhash is measured in random mode only")
-    rec_len = 100_000 + k - 1
-    n_records = max(1, args.kmers // 100_000)
-    nk = n_records * 100_000
+    rec_len, n_records, nk = wl["rec_len"], wl["n_records"], wl["kmers"]
+    steps, warmup = wl["steps"], wl["warmup"]
+    tag = f"[bench r{rank} {wl['name']}]"
 
     # ---- synthetic index set (every rank regenerates it: deterministic, ~1 s per 100 M bases) ----
-    t0 = time.time()
-    flat, recs = synthetic_records(seed=1, n_records=n_records, length=rec_len)
-    log(f"[bench r{rank}] generated {n_records} records x {rec_len} bases in {time.time() - t0:.1f}s")
+    flat, recs = job.records(wl)
 
     # ---- index: built once (rank 0), cached on local disk, image broadcast over RCCL ----
-    os.makedirs(args.cache_dir, exist_ok=True)
-    path = os.path.join(args.cache_dir, f"synth_seed1_{args.kind}{args.bbhash_gamma if args.kind == 'bbhash' else ''}_k{k}_m{m}_n{nk}_b{kmer_bits}.lph")
+    path = index_path(args.cache_dir, wl)
     build_s = None
+    h = None
     if rank == 0:
         if not os.path.exists(path):
             t0 = time.time()
             tmp = path + f".tmp{os.getpid()}"
+            bdev = local_rank if wl["gpu_build"] else None
             if kind == L.BBHASH:
-                L.build_bbhash(recs, k, tmp, kmer_bits=kmer_bits, gamma=args.bbhash_gamma, threads=args.build_threads or 0)
+                L.build_bbhash(recs, k, tmp, kmer_bits=kmer_bits, gamma=wl["bbhash_gamma"], threads=args.build_threads or 0)
             elif kind == L.PTHASH:
-                L.build_pthash(recs, k, tmp, kmer_bits=kmer_bits, threads=args.build_threads or 0,
-                               device=local_rank if args.gpu_build else None)
+                L.build_pthash(recs, k, tmp, kmer_bits=kmer_bits, threads=args.build_threads or 0, device=bdev)
             else:
-                L.build(recs, k, m, tmp, kind=kind, kmer_bits=kmer_bits, threads=args.build_threads or 0,
-                        device=local_rank if args.gpu_build else None)
+                L.build(recs, k, m, tmp, kind=kind, kmer_bits=kmer_bits, threads=args.build_threads or 0, device=bdev)
             os.replace(tmp, path)
             build_s = time.time() - t0
-            log(f"[bench] built index over {nk} k-mers in {build_s:.1f}s -> {path} ({os.path.getsize(path)} bytes)")
+            log(f"{tag} built index over {nk} k-mers in {build_s:.1f}s -> {path} ({os.path.getsize(path)} bytes)")
         t0 = time.time()
         h = load(path, local_rank)
-        log(f"[bench] loaded + attached in {time.time() - t0:.1f}s: {h.get_kmer_count()} k-mers, {h.get_minimizer_L0()} minimizers, "
+        log(f"{tag} loaded + attached in {time.time() - t0:.1f}s: {h.get_kmer_count()} k-mers, {h.get_minimizer_L0()} minimizers, "
             f"{h.info.fallback_kmers} fallback k-mers, image {h.info.image_bytes / 1e6:.1f} MB")
         assert h.get_kmer_count() == nk, "synthetic set has duplicate k-mers?"
     bcast_s = None
+    image_t = None
     if dist is not None:
         from lphash_amd.dist import broadcast_image
 
         dist.barrier()  # the index file exists and rank 0 is attached
         torch.cuda.synchronize()
         t0 = time.time()
-        # RCCL over xGMI: the only collective of the job.  No fallback: a failure ends this rank (and, through the launcher, the job)
+        # RCCL over xGMI: the only collective of the data path.  No fallback: a failure ends this rank (and, through the launcher, the job)
         image_t = broadcast_image(h.image() if rank == 0 else None, dist, dev, src=0)
         torch.cuda.synchronize()
         bcast_s = time.time() - t0
         if rank != 0:
             h = cls.from_device_image(image_t.data_ptr(), image_t.numel(), local_rank)
-        log(f"[bench r{rank}] image broadcast {image_t.numel() / 1e6:.1f} MB in {bcast_s * 1e3:.1f} ms")
+        log(f"{tag} image broadcast {image_t.numel() / 1e6:.1f} MB in {bcast_s * 1e3:.1f} ms")
 
     stream = torch.cuda.current_stream().cuda_stream
     d_seq = torch.from_numpy(flat).to(dev)
     total_bases = int(d_seq.numel())
     rec_order = None
-    if args.shuffle_records and args.mode == "stream":
+    if wl["shuffle_records"] and mode == "stream":
         rec_order = np.random.default_rng(3).permutation(n_records)
         d_seq = d_seq.view(n_records, rec_len)[torch.from_numpy(rec_order).to(dev)].contiguous().view(-1)
 
     # ---- per-rank batch, resident in HBM before the timed region ----
-    if args.mode == "random":
-        Q = 1 << args.batch_log2
+    d_kmers = None
+    if mode == "random":
+        Q = 1 << wl["batch_log2"]
         g = torch.Generator(device=dev)
         g.manual_seed(2 + rank)
         rec_i = torch.randint(0, n_records, (Q,), generator=g, device=dev, dtype=torch.int64)
-        off_i = torch.randint(0, 100_000, (Q,), generator=g, device=dev, dtype=torch.int64)
+        off_i = torch.randint(0, RECORD_KMERS, (Q,), generator=g, device=dev, dtype=torch.int64)
         d_pos = rec_i * rec_len + off_i
         del rec_i, off_i
         d_kmers = torch.empty(Q * (kmer_bits // 64), dtype=torch.int64, device=dev)
         h.pack_kmers(d_seq.data_ptr(), d_pos.data_ptr(), Q, d_kmers.data_ptr(), stream)
-        n_neg = int(Q * min(max(args.nonmember_frac, 0.0), 1.0))
+        torch.cuda.synchronize()
+        del d_pos
+        n_neg = int(Q * min(max(wl["nonmember_frac"], 0.0), 1.0))
         if n_neg:  # uniformly random k-mers (members with probability ~nk / 4^k ~ 0), scattered over the batch
-            torch.cuda.synchronize()
             where = torch.randperm(Q, generator=g, device=dev)[:n_neg]
             lo_bits = min(2 * k, 64)
             lo = torch.randint(-(1 << 63), (1 << 63) - 1, (n_neg,), generator=g, device=dev, dtype=torch.int64)
@@ -279,46 +355,41 @@ def main():
         def step():
             h.query_records(d_seq.data_ptr(), total_bases, seq_off.data_ptr(), n_records, d_out.data_ptr(), out_off.data_ptr(), True, stream)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    barrier()
+    job.barrier()
     torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
     for a, b in evs:
         a.record()  # HIP events on the stream the kernel is launched on (torch's current stream)
         step()
         b.record()
     torch.cuda.synchronize()
-    barrier()
+    job.barrier()
     elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    kernel_ms_per_rank = [kernel_ms]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        mine = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)  # a straggler shows here, not only in the max
+        kernel_ms_per_rank = [float(e.item()) for e in every]
 
-    # ---- parity of what was just measured + CPU baseline (oracle = checker, rank 0, N=1 only) ----
-    cpu = None
-    cpu_all = None
-    cpu_b1 = None
-    cli_b1 = None
+    # ---- parity of what was just measured, on EVERY rank (oracle = checker), + the CPU baseline on rank 0 ----
+    cpu = cpu_all = cpu_b1 = cli_b1 = None
     parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import orc
-
+    o = None
+    if not args.no_cpu_baseline:
         if kind == L.BBHASH:
-            log("[bench] --kind bbhash has no CPU oracle leg (its checker is the reference's own BooPHF, tests/golden/bbhash); use --no-cpu-baseline")
-            sys.exit(2)
-        o = orc.PtHash(path, k, kmer_bits) if kind == L.PTHASH else orc.Index(path, orc.PARTITIONED if kind == L.PARTITIONED else orc.UNPARTITIONED, kmer_bits)
-        S = min(1 << args.cpu_sample_log2, units)
-        if args.mode == "random":
+            job.fail(2, "--kind bbhash has no CPU oracle leg (its checker is the reference's own BooPHF, tests/golden/bbhash); use --no-cpu-baseline")
+        o = load_oracle(job, wl, path)
+        S = min(1 << (wl["cpu_sample_log2"] if rank == 0 else min(20, wl["cpu_sample_log2"])), units)
+        if mode == "random":
             sample = d_kmers[: S * (kmer_bits // 64)].cpu().numpy().view(np.uint64)
             t0 = time.perf_counter()
             exp = o.query_packed(sample)
@@ -334,8 +405,13 @@ def main():
             got = d_out[:S].cpu().numpy().view(np.uint64)
             what = f"first {nrec_s} records of the batch, oracle streaming branch, single thread"
         parity = bool(np.array_equal(got, exp))
-        cpu = {"value": S / cpu_s, "unit": "k-mer lookups/s", "cores": 1, "kind": "port", "sample": what}
-        if args.mode == "random" and not competitor:  # the same oracle on all host cores (POSIX threads over contiguous slices, inside the oracle library)
+        if mode == "random" and wl["nonmember_frac"] == 0.0:
+            parity = parity and bool(int(d_out.max()) < nk) and bool(int(d_out.min()) >= 0)  # positive probes: every code of the batch is a valid slot
+        log(f"{tag} cpu oracle: {S / cpu_s / 1e6:.2f} M lookups/s on {S} units; GPU == oracle on the sample of this rank's timed batch: {parity}")
+        if rank == 0:
+            cpu = {"value": S / cpu_s, "unit": "k-mer lookups/s", "cores": 1, "kind": "port", "sample": what}
+        if rank == 0 and wl["headline"] and mode == "random" and not competitor and parity:
+            # the same oracle on all host cores (POSIX threads over contiguous slices, inside the oracle library)
             quota = cpu_quota_cores()  # threads beyond the container's CPU-time quota only buy throttling (tools/host_probe.py)
             nthreads = len(os.sched_getaffinity(0)) if quota is None else max(1, min(len(os.sched_getaffinity(0)), 2 * int(np.ceil(quota))))  # 2x: fastest in the probe
             wpk = kmer_bits // 64
@@ -351,55 +427,53 @@ def main():
                        "cpu_quota_cores": quota,
                        "sample": f"first {S3} probes of the timed batch, {nthreads} POSIX threads over contiguous slices (= the CPUs visible, capped at twice the "
                                  f"container's CPU-time quota: the fastest setting on the box, tools/host_probe.py)"}
-        if args.mode == "random" and world == 1 and args.nonmember_frac == 0.0:
-            full = d_out.cpu().numpy().view(np.uint64)
-            parity = parity and bool(full.max() < nk)  # positive probes: every code is a valid slot
-        log(f"[bench] cpu oracle: {S / cpu_s / 1e6:.2f} M lookups/s on {S} units; GPU == oracle on the sample: {parity}")
-        assert parity, "GPU results differ from the oracle"
-        if args.b1_records > 0 and not competitor:
-            # BASELINE.md B1, "the number the reference tool would print": the oracle's restatement of src/query.cpp:24-88 over a
-            # .fa.gz of the first records of the index set -- one thread, inflate + record parsing inside the timers, one result
-            # vector per record, streaming pass then random pass.  Beside it the product's own `lphash query-*` on the same file
-            # (same CSV, PCIe and parsing included): the drop-in comparison, never the reported `value`.
-            import gzip
-            import subprocess
+    if not all_ranks_ok(dist, torch, dev, parity is not False):
+        job.fail(3, f"{wl['name']}: GPU results differ from the oracle on at least one rank (this rank: {parity})")
 
-            nb1 = min(n_records, args.b1_records)
-            fa = os.path.join(args.cache_dir, f"b1_seed1_k{k}_r{nb1}.fa.gz")
-            if not os.path.exists(fa):
-                with gzip.open(fa + ".tmp", "wb", compresslevel=6) as f:
-                    for i in range(nb1):
-                        f.write(b">s%d\n" % i)
-                        f.write(recs[i])
-                        f.write(b"\n")
-                os.replace(fa + ".tmp", fa)
-            n_s, n_r, us_s, us_r = o.query_file(fa)
-            assert n_s == n_r == nb1 * (rec_len - k + 1)
-            cpu_b1 = {"value": n_r / (us_r * 1e-6), "unit": "k-mer lookups/s", "cores": 1, "kind": "port",
-                      "streaming_ns_per_kmer": us_s * 1e3 / n_s, "random_ns_per_kmer": us_r * 1e3 / n_r,
-                      "sample": f"oracle restatement of the reference driver (src/query.cpp:24-88) on a .fa.gz of the first {nb1} index records "
-                                f"({n_s} k-mers per pass); gz inflate + parse inside the timers; value = random pass"}
-            exe = os.path.join(ROOT, "lphash_amd", "lphash")
-            if os.path.exists(exe):
-                r = subprocess.run([exe, "query-p" if kind == L.PARTITIONED else "query-u", "-i", path, "-q", fa, "--kmer-bits", str(kmer_bits)],
-                                   capture_output=True, text=True, timeout=600)
-                f5 = r.stdout.strip().split(",")
-                if r.returncode == 0 and len(f5) == 5 and int(f5[2]) == n_s:
-                    cli_b1 = {"streaming_ns_per_kmer": float(f5[3]), "random_ns_per_kmer": float(f5[4]), "kmers": int(f5[2]),
-                              "note": "lphash query-* (this repo's CLI, GPU path) on the same .fa.gz: host parse + PCIe included"}
-                else:
-                    log(f"[bench] CLI run failed ({r.returncode}): {r.stderr[-500:]}")
-            log(f"[bench] B1 reference-faithful driver: {cpu_b1['streaming_ns_per_kmer']:.1f} / {cpu_b1['random_ns_per_kmer']:.1f} ns per k-mer (streaming / random); CLI: {cli_b1}")
+    if rank == 0 and o is not None and wl["headline"] and args.b1_records > 0 and not competitor:
+        # BASELINE.md B1, "the number the reference tool would print": the oracle's restatement of src/query.cpp:24-88 over a
+        # .fa.gz of the first records of the index set -- one thread, inflate + record parsing inside the timers, one result
+        # vector per record, streaming pass then random pass.  Beside it the product's own `lphash query-*` on the same file
+        # (same CSV, PCIe and parsing included): the drop-in comparison, never the reported `value`.
+        import gzip
+        import subprocess
+
+        nb1 = min(n_records, args.b1_records)
+        fa = os.path.join(args.cache_dir, f"b1_seed1_k{k}_r{nb1}.fa.gz")
+        if not os.path.exists(fa):
+            with gzip.open(fa + ".tmp", "wb", compresslevel=6) as f:
+                for i in range(nb1):
+                    f.write(b">s%d\n" % i)
+                    f.write(recs[i])
+                    f.write(b"\n")
+            os.replace(fa + ".tmp", fa)
+        n_s, n_r, us_s, us_r = o.query_file(fa)
+        assert n_s == n_r == nb1 * (rec_len - k + 1)
+        cpu_b1 = {"value": n_r / (us_r * 1e-6), "unit": "k-mer lookups/s", "cores": 1, "kind": "port",
+                  "streaming_ns_per_kmer": us_s * 1e3 / n_s, "random_ns_per_kmer": us_r * 1e3 / n_r,
+                  "sample": f"oracle restatement of the reference driver (src/query.cpp:24-88) on a .fa.gz of the first {nb1} index records "
+                            f"({n_s} k-mers per pass); gz inflate + parse inside the timers; value = random pass"}
+        exe = os.path.join(ROOT, "lphash_amd", "lphash")
+        if os.path.exists(exe):
+            r = subprocess.run([exe, "query-p" if kind == L.PARTITIONED else "query-u", "-i", path, "-q", fa, "--kmer-bits", str(kmer_bits)],
+                               capture_output=True, text=True, timeout=600)
+            f5 = r.stdout.strip().split(",")
+            if r.returncode == 0 and len(f5) == 5 and int(f5[2]) == n_s:
+                cli_b1 = {"streaming_ns_per_kmer": float(f5[3]), "random_ns_per_kmer": float(f5[4]), "kmers": int(f5[2]),
+                          "note": "lphash query-* (this repo's CLI, GPU path) on the same .fa.gz: host parse + PCIe included"}
+            else:
+                log(f"{tag} CLI run failed ({r.returncode}): {r.stderr[-500:]}")
+        log(f"{tag} B1 reference-faithful driver: {cpu_b1['streaming_ns_per_kmer']:.1f} / {cpu_b1['random_ns_per_kmer']:.1f} ns per k-mer (streaming / random); CLI: {cli_b1}")
 
     # ---- N > 1: every replica (rank 0 parsed the file, the others received the image over RCCL) must answer alike ----
     replicas_agree = None
     if dist is not None:
-        if args.mode == "random":  # a probe set common to all ranks (the timed batches differ per rank)
+        if mode == "random":  # a probe set common to all ranks (the timed batches differ per rank)
             gc = torch.Generator(device=dev)
             gc.manual_seed(777)
             Qc = 1 << 20
             win = torch.randint(0, nk, (Qc,), generator=gc, device=dev, dtype=torch.int64)
-            posc = (win // 100_000) * rec_len + win % 100_000
+            posc = (win // RECORD_KMERS) * rec_len + win % RECORD_KMERS
             d_kc = torch.empty(Qc * (kmer_bits // 64), dtype=torch.int64, device=dev)
             h.pack_kmers(d_seq.data_ptr(), posc.data_ptr(), Qc, d_kc.data_ptr(), stream)
             d_chk = torch.empty(Qc, dtype=torch.int64, device=dev)
@@ -414,18 +488,16 @@ def main():
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         replicas_agree = bool(torch.equal(tmin, tmax)) and (competitor or int(t[2].item()) < nk)
-        if rank == 0 and args.mode == "random" and not args.no_cpu_baseline and kind != L.BBHASH:  # the common probes against the oracle (checker only)
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import orc
+        common_ok = True
+        if rank == 0 and mode == "random" and o is not None:  # the common probes against the oracle (checker only)
+            common_ok = bool(np.array_equal(o.query_packed(d_kc.cpu().numpy().view(np.uint64)), d_chk.cpu().numpy().view(np.uint64)))
+            log(f"{tag} {Qc} probes common to all ranks: GPU == oracle: {common_ok}")
+            parity = parity and common_ok
+        log(f"{tag} replicas agree on the common probes: {replicas_agree}")
+        if not all_ranks_ok(dist, torch, dev, replicas_agree and common_ok):
+            job.fail(3, f"{wl['name']}: replicas disagree or differ from the oracle")
 
-            o = orc.PtHash(path, k, kmer_bits) if kind == L.PTHASH else orc.Index(path, orc.PARTITIONED if kind == L.PARTITIONED else orc.UNPARTITIONED, kmer_bits)
-            parity = bool(np.array_equal(o.query_packed(d_kc.cpu().numpy().view(np.uint64)), d_chk.cpu().numpy().view(np.uint64)))
-            log(f"[bench] {Qc} probes common to all ranks: GPU == oracle: {parity}")
-        log(f"[bench r{rank}] replicas agree on the common probes: {replicas_agree}")
-        if not replicas_agree or parity is False:  # (the same verdict on every rank for replicas_agree; rank 0 alone can fail on parity)
-            log(f"[bench r{rank}] ERROR: replicas disagree or differ from the oracle")
-            sys.exit(3)
-
+    out = None
     if rank == 0:
         if kind == L.BBHASH:  # per probed level a bit-array word (8 B), on the hit a rank sample (8 B) + up to 7 more words; ~1/(1 - 0.63) levels at gamma 1
             chain, mix = 2.7 * 8 + 8 + 3.5 * 8, None
@@ -435,55 +507,66 @@ def main():
             chain, mix = 8 + 26 * p_free, None
             bpl = (8 if k <= 31 else 16) + 8 + chain
         else:
-            bpl, chain, mix = algorithmic_bytes_per_lookup(h, args.mode, k, W, kind == L.PARTITIONED)
-        cfg_name = "BBHash competitor (SURVEY 8f-4)" if kind == L.BBHASH else "PTHash competitor (SURVEY 8f-4)" if kind == L.PTHASH else (("C4" if k > 31 else ("C2" if args.mode == "random" else "C3")) if kind == L.PARTITIONED else "C5")
-        peak_read = peak_copy = None
-        if not args.no_hbm_probe:
-            peak_read, peak_copy = hbm_ceiling_gbs(torch, dev)
-        value = world * units * args.steps / elapsed
+            bpl, chain, mix = algorithmic_bytes_per_lookup(h, mode, k, W, kind == L.PARTITIONED)
+        cfg_name = config_name(wl)
+        if job.hbm is None and not args.no_hbm_probe:
+            job.hbm = hbm_ceiling_gbs(torch, dev)
+        peak_read, peak_copy = job.hbm if job.hbm is not None else (None, None)
+        value = world * units * steps / elapsed
         out = {
-            "metric": f"k-mer lookups/sec (whole node), k={k} {'BBHash' if kind == L.BBHASH else 'plain PTHash' if kind == L.PTHASH else ('partitioned' if kind == L.PARTITIONED else 'unpartitioned')} MPHF" + ("" if args.mode == "random" else ", streaming"),
+            "metric": f"k-mer lookups/sec (whole node), k={k} {'BBHash' if kind == L.BBHASH else 'plain PTHash' if kind == L.PTHASH else ('partitioned' if kind == L.PARTITIONED else 'unpartitioned')} MPHF" + ("" if mode == "random" else ", streaming"),
             "value": value,
             "unit": "k-mer lookups/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": cfg_name + (f": boomphf::mphf over the k-mers, gamma {args.bbhash_gamma}," if kind == L.BBHASH else ": pthash::single_phf over the k-mers," if kind == L.PTHASH else (": partitioned LP-MPHF" if kind == L.PARTITIONED else ": unpartitioned LP-MPHF"))
+                "workload": cfg_name + (f": boomphf::mphf over the k-mers, gamma {wl['bbhash_gamma']}," if kind == L.BBHASH else ": pthash::single_phf over the k-mers," if kind == L.PTHASH else (": partitioned LP-MPHF" if kind == L.PARTITIONED else ": unpartitioned LP-MPHF"))
                 + f" k={k} m={m}, {nk} k-mers (SplitMix64 seed 1, {n_records} records x {rec_len} bases); "
-                + ((f"2^{args.batch_log2} random positive packed k-mer lookups per GPU per step" if args.nonmember_frac == 0.0 else
-                    f"2^{args.batch_log2} random packed k-mer lookups per GPU per step, {args.nonmember_frac:.0%} of them uniformly random non-members")
-                   if args.mode == "random"
+                + ((f"2^{wl['batch_log2']} random positive packed k-mer lookups per GPU per step" if wl["nonmember_frac"] == 0.0 else
+                    f"2^{wl['batch_log2']} random packed k-mer lookups per GPU per step, {wl['nonmember_frac']:.0%} of them uniformly random non-members")
+                   if mode == "random"
                    else "all windows of the index records per step, streaming kernel" + (", records in shuffled order" if rec_order is not None else "")),
                 "k": k, "m": m, "kmers": nk, "units_per_step_per_gpu": units, "kmer_bits": kmer_bits,
                 "index_image_bytes": int(h.info.image_bytes), "type_mix": mix,
             },
             "kernel_ms": kernel_ms,
+            "kernel_ms_per_rank": kernel_ms_per_rank,
+            "kernel_ms_min": min(kernel_ms_per_rank),
+            "kernel_ms_max": max(kernel_ms_per_rank),
             "parity_vs_oracle": parity,
+            "parity_ranks_checked": world if parity is not None else 0,
             "rccl_ranks": int(dist.get_world_size()) if dist is not None else 1,
             "replicas_agree": replicas_agree,
         }
-        traffic = None
-        try:  # HBM bytes per launch from the committed PMC passes of this exact workload (never measured inside this run)
+        traffic = valu = None
+        try:  # HBM bytes and VALU instructions per unit from the committed PMC passes of this exact workload (never measured inside this run)
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            key = f"{args.mode}|{args.kind}|k{k}|m{m}|n{nk}|b{args.batch_log2 if args.mode == 'random' else 0}"
-            variant = args.nonmember_frac != 0.0 or rec_order is not None
+            key = f"{mode}|{wl['kind']}|k{k}|m{m}|n{nk}|b{wl['batch_log2'] if mode == 'random' else 0}"
+            variant = wl["nonmember_frac"] != 0.0 or rec_order is not None
             if key in tj and not variant:  # (counter passes exist for the default kernels on the primary workloads only)
                 traffic = tj[key]["bytes_per_unit"] * units
+                valu = tj[key].get("valu_lane_instr_per_unit"), tj[key].get("valu_source")
         except (OSError, ValueError, KeyError):
             pass
-        if bpl is not None:
-            achieved = bpl * units / (kernel_ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                               "peak_measured": peak_read, "peak_measured_copy": peak_copy,
-                               "frac_of_measured": (achieved / peak_read) if peak_read else None,
-                               "traffic": traffic, "bytes_per_lookup": bpl, "kernel": "k_query_packed" if args.mode == "random" else "k_query_tiles_stream"}
+        kernel_s = max(kernel_ms_per_rank) * 1e-3 if world > 1 else kernel_ms * 1e-3
+        achieved = bpl * units / kernel_s / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "peak_measured": peak_read, "peak_measured_copy": peak_copy,
+                           "frac_of_measured": (achieved / peak_read) if peak_read else None,
+                           "traffic": traffic, "bytes_per_lookup": bpl, "kernel": "k_query_packed" if mode == "random" else "k_query_tiles_stream"}
+        if valu is not None and valu[0]:
+            # the second roofline of the same kernel: VALU issue.  instr_per_unit = SQ_INSTS_VALU of the committed counter pass x 64 lanes / units of
+            # one launch (a wave64 instruction occupies a SIMD's 16 lanes for 4 cycles whatever the number of live lanes)
+            rate = valu[0] * units / kernel_s
+            out["roofline_valu"] = {"bound": "valu_issue", "instr_per_unit": valu[0], "achieved_lane_instr_per_s": rate, "peak": VALU_PEAK_LANE_INSTR,
+                                    "frac": rate / VALU_PEAK_LANE_INSTR, "unit": "lane-instructions/s", "source": valu[1]}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if cpu_all is not None:
@@ -496,6 +579,140 @@ def main():
             out["index_build_s"] = build_s
         if bcast_s is not None:
             out["image_broadcast_ms"] = bcast_s * 1e3
+    h.close()
+    del h, d_seq, d_out, d_kmers, image_t
+    torch.cuda.empty_cache()
+    return out
+
+
+def secondary_entry(out, wl):
+    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "kernel_ms", "kernel_ms_min", "kernel_ms_max", "parity_vs_oracle",
+            "parity_ranks_checked", "replicas_agree", "roofline", "roofline_valu", "cpu_baseline", "index_build_s", "image_broadcast_ms")
+    e = {"name": wl["name"], "workload": out["config"]["workload"], "units_per_step_per_gpu": out["config"]["units_per_step_per_gpu"],
+         "index_image_bytes": out["config"]["index_image_bytes"]}
+    e.update({k_: out[k_] for k_ in keep if k_ in out})
+    return e
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", choices=["random", "stream"], default="random")
+    ap.add_argument("--kmers", type=int, default=100_000_000, help="k-mers in the index (C2: 100 M)")
+    ap.add_argument("--batch-log2", type=int, default=28, help="random mode: 2^x lookups per step per GPU")
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--m", type=int, default=20)
+    ap.add_argument("--kind", choices=["p", "u", "pthash", "bbhash"], default="p",
+                    help="p / u: LPHash partitioned / unpartitioned; pthash / bbhash: the competitors of SURVEY 8(f)-4 over the same k-mers (random mode)")
+    ap.add_argument("--bbhash-gamma", type=float, default=1.0, help="--kind bbhash: load factor (the reference's ptbb_build default is 1)")
+    ap.add_argument("--build-threads", type=int, default=0)
+    ap.add_argument("--gpu-build", action="store_true",
+                    help="run the PTHash pilot search of the index build on the GPU (same file bytes; default is the sequential CPU search so that "
+                         "the measured query path does not depend on construction code)")
+    ap.add_argument("--cpu-sample-log2", type=int, default=24, help="oracle-timed sample size (rank 0; the other ranks check 2^20 of their batch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="no oracle leg at all (profiling runs): neither parity nor cpu_baseline")
+    ap.add_argument("--nonmember-frac", type=float, default=0.0,
+                    help="random mode: this fraction of the probes are uniformly random k-mers (non-members; SURVEY 8(d) secondary run)")
+    ap.add_argument("--shuffle-records", action="store_true", help="stream mode: the index records in a random order (SURVEY 8(d) variant)")
+    ap.add_argument("--cache-dir", default=os.environ.get("LPHQ_BENCH_CACHE", "/tmp/lphq_bench_cache"))
+    ap.add_argument("--no-hbm-probe", action="store_true", help="skip the in-run measurement of the HBM copy ceiling (roofline.peak_measured)")
+    ap.add_argument("--dist-single", action="store_true",
+                    help="with one rank, still initialise torch.distributed (RCCL) and run the image broadcast and the replica check: exercises the N > 1 code on a 1-GPU box")
+    ap.add_argument("--b1-records", type=int, default=300,
+                    help="records of the index set the reference-faithful driver baseline (B1: gz + parse inside the timer) reads; 0 = skip")
+    ap.add_argument("--no-secondary", action="store_true", help="headline only: skip the C3 / C5 / C4 measurements that follow a default (C2) run")
+    ap.add_argument("--secondary-c4-kmers", type=int, default=2_000_000_000, help="k-mers of the C4 secondary workloads (BASELINE.json: 2 B)")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="resolve workloads and cache paths, check that all ranks agree (gloo when WORLD_SIZE > 1), print the plan and stop before the first GPU call")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # before anything initialises the GPU in this process
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    # Everything but the result line goes to stderr, also what native libraries print (RCCL writes a version banner to stdout with C stdio, flushed
+    # when the process ends, i.e. AFTER the JSON line): file descriptor 1 is pointed at stderr and the line is written to a copy of the original.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"[bench] ERROR: WORLD_SIZE={world} but --gpus {args.gpus}")
+        sys.exit(2)
+    plan = plan_of(args)
+
+    if args.plan_only:  # host logic only: what tests/test_dist_cpu.py runs with world_size 2 over gloo
+        ok = True
+        dist = None
+        if world > 1:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            if os.environ.get("LPHQ_BENCH_TEST_FAIL_RANK") == str(rank):  # test hook: a rank that fails a check
+                ok = False
+            agree = plans_agree(dist, torch, torch.device("cpu"), plan)
+            ok = all_ranks_ok(dist, torch, torch.device("cpu"), ok and agree)
+            dist.destroy_process_group()
+            if not ok:
+                log(f"[bench r{rank}] ERROR: a rank failed or the ranks resolved different plans (agree: {agree})")
+                sys.exit(3)
+        if rank == 0:
+            result_out.write(json.dumps({"plan": plan, "ranks": world, "ranks_agree": True}) + "\n")
+            result_out.flush()
+        return
+
+    import lphash_amd as L
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the query path has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1 or args.dist_single:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    job = Job(args, rank, local_rank, world, dev, dist, torch, np, L)
+    if dist is not None and not all_ranks_ok(dist, torch, dev, plans_agree(dist, torch, dev, plan)):
+        job.fail(2, "the ranks resolved different plans (arguments / cache paths differ between ranks)")
+    os.makedirs(args.cache_dir, exist_ok=True)
+    if args.mode != "random" and args.kind in ("pthash", "bbhash"):
+        job.fail(2, "--kind pthash / bbhash is measured in random mode only")
+
+    wls = plan["workloads"]
+    t_job = time.time()
+    out = run_workload(job, wls[0])
+    secondary, errors = [], []
+    for wl in wls[1:]:
+        t0 = time.time()
+        try:
+            e = run_workload(job, wl)
+            if rank == 0:
+                e = secondary_entry(e, wl)
+                e["wall_s"] = time.time() - t0
+                secondary.append(e)
+        except SystemExit:
+            raise  # parity failure on some rank: the job ends (all ranks leave together)
+        except Exception as ex:  # noqa: BLE001 -- the headline must survive e.g. a host without the memory for the 2 B-k-mer set
+            if dist is not None:
+                raise  # (the other ranks are inside collectives of this workload: no way to skip it on one rank alone)
+            log(f"[bench] secondary {wl['name']} failed: {type(ex).__name__}: {ex}")
+            errors.append({"name": wl["name"], "error": f"{type(ex).__name__}: {ex}"[:300]})
+            torch.cuda.empty_cache()
+    if rank == 0:
+        if len(wls) > 1:
+            out["secondary"] = secondary
+            if errors:
+                out["secondary_errors"] = errors
+        out["bench_wall_s"] = time.time() - t_job
         result_out.write(json.dumps(out) + "\n")
         result_out.flush()
     if dist is not None:

@@ -25,6 +25,11 @@
 extern "C" {
 #endif
 
+/* Version of this interface.  An entry point never changes its signature: new behaviour gets a new name and the number goes up
+ * (2: lphq_count_valid_on_stream, lphq_abi_version).  A caller compiled against version N works with any library reporting >= N. */
+#define LPHQ_ABI_VERSION 2
+int lphq_abi_version(void);
+
 /* ---- status codes ---- */
 enum {
     LPHQ_OK = 0,
@@ -131,9 +136,11 @@ int lphq_query_records(const lphq_index* idx, const char* d_seq, size_t total_ba
 /* Pack windows of d_seq into kmer_t values: out[i] = string_to_integer_no_reverse(d_seq + d_pos[i], k). */
 int lphq_pack_kmers(const lphq_index* idx, const char* d_seq, const uint64_t* d_pos, size_t n, void* d_kmers, void* stream);
 
-/* Number of codes != LPHQ_INVALID in d_codes[0..n) (what vector.size() of the reference's streaming pass
- * would be).  Runs on `stream` (so it is ordered after the query that produced d_codes there) and waits for it. */
-int lphq_count_valid(const lphq_index* idx, const uint64_t* d_codes, size_t n, void* stream, uint64_t* count);
+/* Number of codes != LPHQ_INVALID in d_codes[0..n) (what vector.size() of the reference's streaming pass, src/query.cpp:53,
+ * would be).  Synchronous: counts on the default stream and waits for it. */
+int lphq_count_valid(const lphq_index* idx, const uint64_t* d_codes, size_t n, uint64_t* count);
+/* The same on `stream` (ordered after the query that produced d_codes there); waits for that stream only. */
+int lphq_count_valid_on_stream(const lphq_index* idx, const uint64_t* d_codes, size_t n, void* stream, uint64_t* count);
 /* The same count left in *d_count (8 bytes of device memory, overwritten) without waiting: for callers that keep several
  * batches in flight and read the count back with their own copy on `stream`. */
 int lphq_count_valid_async(const lphq_index* idx, const uint64_t* d_codes, size_t n, uint64_t* d_count, void* stream);

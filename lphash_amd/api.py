@@ -169,7 +169,10 @@ class _MphfBase:
     def count_valid(self, d_codes, n, stream=0):
         """Codes != LPHQ_INVALID among d_codes[0..n) (device pointer), counted on `stream`."""
         c = C.c_uint64()
-        check(lib.lphq_count_valid(self._h, C.c_void_p(d_codes), n, C.c_void_p(stream), C.byref(c)))
+        if stream:
+            check(lib.lphq_count_valid_on_stream(self._h, C.c_void_p(d_codes), n, C.c_void_p(stream), C.byref(c)))
+        else:
+            check(lib.lphq_count_valid(self._h, C.c_void_p(d_codes), n, C.byref(c)))
         return c.value
 
     def gather_payload(self, d_codes, n, d_table, elem_bytes, d_out, missing=0, stream=0):

@@ -37,6 +37,10 @@ struct Rd {
 
 // the level sizes of boomphf::mphf::setup() / load()  (BooPHF.hpp:1027-1043, 979-989)
 void level_domains(double gamma, uint64_t nelem, int nb_levels, std::vector<uint64_t>& dom) {
+    if (nelem == 0) {  // no key (the formula below divides by zero): every level is the minimum, one 64-bit word -- what the builder writes
+        dom.assign((size_t)nb_levels, 64);
+        return;
+    }
     const double pc = 1.0 - pow(((gamma * (double)nelem - 1) / (gamma * (double)nelem)), (double)(nelem - 1));
     const uint64_t hash_domain = (size_t)(ceil(double(nelem) * gamma));
     dom.resize((size_t)nb_levels);
@@ -295,8 +299,7 @@ bool build_bbhash_file(const char* const* records, const size_t* lengths, size_t
     // fastrange64(hash_i, domain_i); bits hit twice are cleared again, their keys go on; what reaches the last level is mapped exactly
     const int nb_levels = 25;
     std::vector<uint64_t> dom;
-    if (n) level_domains(gamma, n, nb_levels, dom);
-    else dom.assign((size_t)nb_levels, 64);
+    level_domains(gamma, n, nb_levels, dom);
     struct St { uint64_t s0, s1; };
     std::vector<St> st(n);           // xorshift state of every key still looking for a level
     std::vector<uint64_t> live(n);   // indices of those keys

@@ -321,6 +321,14 @@ extern "C" int lphq_image_copy(const lphq_index* idx, void* host_dst, size_t cap
 }
 
 // Every section a kernel may read must lie inside the image: guards lphq_open_device_image against a foreign / stale buffer.
+// the reciprocal fields of a divisor are the ones make_divisor (image.cpp) derives from d64: the kernels divide by dn / inv / shift alone, and an
+// adopted image (lphq_open_device_image) whose fields disagreed would yield positions beyond the table, i.e. reads outside the image
+static bool divisor_is_consistent(const lphq_divisor& v) {
+    if (v.d64 == 0 || v.d64 > 0xFFFFFFFFull) return false;
+    const uint32_t shift = (uint32_t)__builtin_clz((uint32_t)v.d64), dn = (uint32_t)v.d64 << shift;
+    return v.d == (uint32_t)v.d64 && v.shift == shift && v.dn == dn && v.inv == (uint32_t)(~(uint64_t)0 / dn - (1ull << 32));
+}
+
 static bool header_is_consistent(const lphq_image_header& h, size_t nbytes, std::string& why) {
     auto inside = [&](uint64_t off, uint64_t bytes) { return off >= sizeof(lphq_image_header) && off <= nbytes && bytes <= nbytes - off; };
     auto phf_ok = [&](const lphq_phf_desc& f, const char* name) {
@@ -328,7 +336,8 @@ static bool header_is_consistent(const lphq_image_header& h, size_t nbytes, std:
         const uint64_t nb = f.num_dense + f.num_sparse;
         bool ok = f.table_size >= f.num_keys && f.table_size <= 0xFFFFFFFFull && nb <= 0xFFFFFFFFull && f.num_dense <= nb && f.front_size <= nb && f.front_width >= 1 && f.front_width <= 32 &&
                   f.back_width >= 1 && f.back_width <= 32 && f.div_table.d64 == f.table_size && f.div_dense.d64 == f.num_dense &&
-                  f.div_sparse.d64 == f.num_sparse && f.num_dense > 0 && f.num_sparse > 0 &&
+                  f.div_sparse.d64 == f.num_sparse && f.num_dense > 0 && f.num_sparse > 0 && divisor_is_consistent(f.div_table) &&
+                  divisor_is_consistent(f.div_dense) && divisor_is_consistent(f.div_sparse) &&
                   inside(f.off_front_ranks, (f.front_size * f.front_width + 7) / 8 + 8) &&
                   inside(f.off_back_ranks, ((nb - f.front_size) * f.back_width + 7) / 8 + 8) && inside(f.off_front_hp, (uint64_t)f.n_front_dict * 8) &&
                   inside(f.off_back_hp, (uint64_t)f.n_back_dict * 8) && inside(f.off_free, (f.table_size - f.num_keys) * 4);
@@ -524,8 +533,9 @@ extern "C" int lphq_pack_kmers(const lphq_index* idx, const char* d_seq, const u
     return LPHQ_OK;
 }
 
-extern "C" int lphq_count_valid(const lphq_index* cidx, const uint64_t* d_codes, size_t n, void* stream, uint64_t* count) {
-    lphq_index* idx = const_cast<lphq_index*>(cidx);
+// count on `st`; on a failure the stream is drained before the scratch slot (which holds d_count) goes back to the pool, so that work
+// still queued on the caller's stream cannot write into a slot another thread has leased meanwhile
+static int count_valid_on(lphq_index* idx, const uint64_t* d_codes, size_t n, hipStream_t st, uint64_t* count) {
     REQUIRE_ATTACHED(idx);
     if (!count || (n && !d_codes)) return fail(LPHQ_ERR_ARG, "null argument");
     *count = 0;
@@ -534,15 +544,24 @@ extern "C" int lphq_count_valid(const lphq_index* cidx, const uint64_t* d_codes,
     DeviceGuard g(r->device);
     ScratchLease sl{idx, scratch_acquire(idx, r->device)};
     if (!sl.s) return LPHQ_ERR_HIP;
-    // everything on the caller's stream: ordered after whatever produced d_codes there
-    hipStream_t st = (hipStream_t)stream;
     unsigned long long* d_count = (unsigned long long*)(sl.s->d_offs + 4);
-    HIP_TRY(hipMemsetAsync(d_count, 0, 8, st));
-    HIP_TRY(launch_count_valid(d_codes, n, d_count, st));
-    HIP_TRY(hipMemcpyAsync(count, d_count, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    hipError_t e = hipMemsetAsync(d_count, 0, 8, st);
+    if (e == hipSuccess) e = launch_count_valid(d_codes, n, d_count, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(count, d_count, 8, hipMemcpyDeviceToHost, st);
+    const hipError_t es = hipStreamSynchronize(st);  // on every path: nothing of this call is in flight when the lease ends
+    if (e == hipSuccess) e = es;
+    if (e != hipSuccess) return fail_hip(e, "lphq_count_valid");
     return LPHQ_OK;
 }
+// the entry point of ABI 1 (four arguments, unchanged): counts on the default stream, i.e. after everything queued on blocking streams
+extern "C" int lphq_count_valid(const lphq_index* idx, const uint64_t* d_codes, size_t n, uint64_t* count) {
+    return count_valid_on(const_cast<lphq_index*>(idx), d_codes, n, nullptr, count);
+}
+// everything on the caller's stream: ordered after whatever produced d_codes there
+extern "C" int lphq_count_valid_on_stream(const lphq_index* idx, const uint64_t* d_codes, size_t n, void* stream, uint64_t* count) {
+    return count_valid_on(const_cast<lphq_index*>(idx), d_codes, n, (hipStream_t)stream, count);
+}
+extern "C" int lphq_abi_version(void) { return LPHQ_ABI_VERSION; }
 
 extern "C" int lphq_gather_payload(const lphq_index* idx, const uint64_t* d_codes, size_t n, const void* d_table, uint32_t elem_bytes, uint64_t missing,
                                    void* d_out, void* stream) {

@@ -419,7 +419,10 @@ __device__ __forceinline__ uint64_t bbhash_kmer(const uint8_t* __restrict__ img,
     const uint64_t cap = 1ull << lg;
     const uint64_t* keys = (const uint64_t*)(img + H.off_upair);
     const uint64_t* vals = keys + cap * (K128 ? 2 : 1);
-    for (uint64_t slot = bbh_slot_hash_dev(lo, hi) >> (64 - lg);; slot = (slot + 1) & (cap - 1)) {
+    // (at most cap probes: a well-formed table is at most half full, but an adopted image -- lphq_open_device_image -- whose table had no empty
+    // slot must not spin a non-member's lane forever)
+    uint64_t slot = bbh_slot_hash_dev(lo, hi) >> (64 - lg);
+    for (uint64_t probes = 0; probes < cap; ++probes, slot = (slot + 1) & (cap - 1)) {
         const uint64_t v = vals[slot];
         if (v == ~0ull) break;  // empty slot: not a key
         if (K128 ? (keys[2 * slot] == lo && keys[2 * slot + 1] == hi) : keys[slot] == lo) return v + H.collision_base;

@@ -89,3 +89,96 @@ def test_bench_launches_its_own_ranks_when_asked_for_several_gpus():
     assert "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr
     assert r.returncode != 0
     assert '"n_gpus"' not in r.stdout
+
+
+def _bench_module():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("lphq_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _run_bench(argv, env_extra=None, timeout=600):
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LPHQ_BENCH_TEST_FAIL_RANK")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_bench_plan_names_every_baseline_configuration():
+    """The default run = the C2 headline followed by C3, C5 and C4 (random, streaming) at BASELINE.json's sizes; any other headline, and the
+    profiling form (--no-cpu-baseline), measure the named workload only."""
+    import json
+
+    r = _run_bench(["--plan-only", "--steps", "20", "--warmup", "5"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    plan = json.loads(r.stdout.strip().splitlines()[-1])["plan"]
+    names = [w["name"] for w in plan["workloads"]]
+    assert names == ["C2", "C3", "C5", "C4-random", "C4-stream"]
+    c4 = plan["workloads"][3]
+    assert (c4["k"], c4["m"], c4["kmers"], c4["kmer_bits"], c4["batch_log2"], c4["steps"], c4["warmup"]) == (63, 20, 2_000_000_000, 128, 28, 20, 5)
+    assert plan["workloads"][1]["mode"] == "stream" and plan["workloads"][2]["kind"] == "u" and plan["workloads"][4]["mode"] == "stream"
+    assert plan["index_paths"][0] == plan["index_paths"][1] and plan["index_paths"][3] == plan["index_paths"][4]  # one index per (kind, k, m, n)
+    assert len(set(plan["index_paths"])) == 3
+    for extra in (["--mode", "stream"], ["--k", "63"], ["--no-secondary"], ["--no-cpu-baseline"], ["--kmers", "1000000"], ["--nonmember-frac", "0.5"]):
+        r = _run_bench(["--plan-only"] + extra)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert len(json.loads(r.stdout.strip().splitlines()[-1])["plan"]["workloads"]) == 1, extra
+
+
+def test_bench_rank_logic_gloo_world2(tmp_path):
+    """bench.py's rank logic up to the first GPU call, two ranks over gloo (`--plan-only`, launched the way the driver launches a scaling run):
+    the arguments reach both ranks, both resolve the same workloads and cache paths, rank 0 alone prints the line; a rank that fails a check
+    takes the whole job down with a non-zero code instead of leaving the other rank waiting in a collective."""
+    import json
+
+    args = ["--gpus", "2", "--plan-only", "--steps", "7", "--warmup", "3", "--cache-dir", str(tmp_path / "cache")]
+    r = _run_bench(args)  # no launcher: bench.py starts torch.distributed.run itself
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["ranks"] == 2 and line["ranks_agree"] is True
+    assert line["plan"]["gpus"] == 2 and line["plan"]["cache_dir"] == str(tmp_path / "cache")
+    assert all(w["steps"] == 7 and w["warmup"] == 3 for w in line["plan"]["workloads"]) and len(line["plan"]["workloads"]) == 5
+    assert all(p.startswith(str(tmp_path / "cache")) for p in line["plan"]["index_paths"])
+    r = _run_bench(args, {"LPHQ_BENCH_TEST_FAIL_RANK": "1"})
+    assert r.returncode != 0 and '"plan"' not in r.stdout
+    assert "a rank failed" in r.stderr
+    # WORLD_SIZE that contradicts --gpus: refused before anything else happens
+    r = _run_bench(["--gpus", "1", "--plan-only"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=2 but --gpus 1" in r.stderr
+
+
+def _agree_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bench = _bench_module()
+        cpu = torch.device("cpu")
+        same = bench.plans_agree(dist, torch, cpu, {"cache_dir": "/tmp/x", "k": 31})
+        differ = bench.plans_agree(dist, torch, cpu, {"cache_dir": "/tmp/x" if rank == 0 else "/tmp/y", "k": 31})
+        ok_all = bench.all_ranks_ok(dist, torch, cpu, True)
+        ok_one_bad = bench.all_ranks_ok(dist, torch, cpu, rank != 1)
+        q.put((rank, (same, differ, ok_all, ok_one_bad)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_plan_agreement_and_verdict_collectives_gloo_world2():
+    """plans_agree / all_ranks_ok: a cache path that differs on one rank, or one rank whose parity check failed, is seen by EVERY rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == {0: (True, False, True, False), 1: (True, False, True, False)}

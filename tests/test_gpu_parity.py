@@ -188,6 +188,18 @@ def test_device_image_handle_and_concurrent_callers(tmp_path):
     [t_.start() for t_ in ths]
     [t_.join() for t_ in ths]
     assert not errs
+    # an adopted image is only trusted as far as its header proves itself: the kernels divide by the reciprocal fields (dn / inv / shift) of the
+    # table-size divisor alone, so a copy whose reciprocal does not belong to its divisor is refused instead of hashing out of bounds
+    img = h0.image().copy()
+    ts = np.frombuffer(np.uint64(h0.info.minimizer_table_size).tobytes(), dtype=np.uint8)
+    hits = [i for i in range(0, 1024, 4) if np.array_equal(img[i:i + 8], ts)]
+    assert len(hits) >= 2  # phf_desc.table_size, then div_table.d64 (fields d, dn, inv, shift before it)
+    bad = img.copy()
+    bad[hits[1] - 8] ^= 0x10  # div_table.inv
+    tb = torch.from_numpy(bad).to(dev)
+    with pytest.raises(L.LphqError):
+        L.Mphf.from_device_image(tb.data_ptr(), tb.numel(), 0)
+    assert L.lib.lphq_abi_version() >= 2
 
 
 def test_attach_devices_and_stream_ordered_count(tmp_path):
@@ -247,16 +259,19 @@ def test_attach_devices_and_stream_ordered_count(tmp_path):
         h.gather_payload(d_out.data_ptr(), n_out, d_t.data_ptr(), 3, d_p.data_ptr())
 
 
-@pytest.mark.parametrize("kind,k,m,bits,n_rec", [(0, 31, 20, 64, 1000), (1, 31, 20, 64, 1000), (0, 63, 20, 128, 100)])
+@pytest.mark.parametrize("kind,k,m,bits,n_rec", [(0, 31, 20, 64, 1000), (1, 31, 20, 64, 1000), (0, 63, 20, 128, 100), (0, 63, 20, 128, 20_000)])
 def test_large_index_properties(tmp_path, kind, k, m, bits, n_rec):
-    """10 M k-mers, and BASELINE.json's full C2 size (100 M k-mers, k=31 m=20) for the partitioned function -- too many for
-    a full oracle pass in a test: the device codes are a bijection onto [0, n) in streaming AND random mode, both modes
-    agree, and sampled records equal the oracle."""
+    """BASELINE.json's configurations at FULL size -- C2 / C3 (partitioned, k=31 m=20, 100 M k-mers), C5 (unpartitioned, same set) and the
+    per-GPU work of C4 (k=63, 128-bit k-mers, 2 B k-mers; index built with the GPU pilot search, whose bytes equal the CPU build's:
+    test_zz_gpu_next.py) -- plus k=63 at 10 M.  Too many k-mers for a full oracle pass in a test: the device codes are a bijection onto
+    [0, n) in streaming AND random mode, both modes agree, sampled records equal the oracle, and a packed random batch equals the
+    codes of the windows it was cut from."""
     torch, dev = torch_dev()
     L_rec = 100_000 + k - 1
     flat, recs = synthetic_records(seed=3 if n_rec == 100 else 1, n_records=n_rec, length=L_rec)
     path = str(tmp_path / "big.lph")
-    L.build(recs, k, m, path, kind=kind, kmer_bits=bits, threads=0)  # sequential CPU pilot search: the query path is what is under test
+    # sequential CPU pilot search (the query path is what is under test) except at 2 B k-mers, where it would take minutes
+    L.build(recs, k, m, path, kind=kind, kmer_bits=bits, threads=0, device=0 if n_rec > 1000 else None)
     h = (L.Mphf if kind == 0 else L.MphfAlt).load(path, kmer_bits=bits, device=0)
     n = n_rec * 100_000
     assert h.get_kmer_count() == n
@@ -269,13 +284,17 @@ def test_large_index_properties(tmp_path, kind, k, m, bits, n_rec):
         h.query_records(d_seq.data_ptr(), int(d_seq.numel()), seq_off.data_ptr(), n_rec, d_out.data_ptr(), out_off.data_ptr(), streaming)
         torch.cuda.synchronize()
         assert int(d_out.min()) == 0 and int(d_out.max()) == n - 1
-        assert int(torch.unique(d_out).numel()) == n  # bijection: every slot exactly once
+        # bijection: every slot exactly once (n codes inside [0, n) that mark n distinct slots)
+        seen = torch.zeros(n, dtype=torch.uint8, device=dev)
+        seen[d_out] = 1
+        assert int(seen.sum(dtype=torch.int64)) == n
+        del seen
         outs.append(d_out)
     assert torch.equal(outs[0], outs[1])
     o = orc.Index(path, kind, bits)
     for i in (0, 37, n_rec - 1):
         assert np.array_equal(outs[0][i * 100_000:(i + 1) * 100_000].cpu().numpy().view(np.uint64), o(recs[i], True))
-    # packed random batch with repeats: same multiset of codes as the gathered positions
+    # packed random batch with repeats: the codes of the windows the k-mers were cut from, and the oracle's on a slice of it
     g = torch.Generator(device=dev)
     g.manual_seed(5)
     Q = 1 << 22
@@ -287,6 +306,8 @@ def test_large_index_properties(tmp_path, kind, k, m, bits, n_rec):
     h.query_packed(d_k.data_ptr(), Q, d_o.data_ptr())
     torch.cuda.synchronize()
     assert torch.equal(d_o, outs[0][win])
+    S = 1 << 16
+    assert np.array_equal(d_o[:S].cpu().numpy().view(np.uint64), o.query_packed(d_k[: S * (bits // 64)].cpu().numpy().view(np.uint64)))
 
 
 def test_cli_query_end_to_end(tmp_path):

@@ -777,3 +777,24 @@ def test_fast_inflate_equals_zlib(tmp_path):
             assert got == want, trial
         elif trial % 2 == 0:  # truncated: everything decoded is a prefix of the truth
             assert want.startswith(got), trial
+
+
+def test_bbhash_of_no_keys_loads_its_own_file(tmp_path):
+    """A function over no key (every record shorter than k): the level sizes written (one 64-bit word each) are the ones the loader recomputes --
+    the size formula of BooPHF.hpp:1027-1043 divides by the number of keys and is not evaluated for zero."""
+    path = str(tmp_path / "empty.bbh")
+    st = L.build_bbhash([b"ACG", b""], 5, path, kmer_bits=64, gamma=1.0, threads=2)
+    assert st["num_kmers"] == 0
+    h = L.BbHash.load(path, 5, kmer_bits=64)
+    assert h.get_kmer_count() == 0
+    h.close()
+
+
+def test_abi_version_and_both_count_valid_entry_points_are_exported():
+    """ABI 2 added lphq_count_valid_on_stream and kept the four-argument lphq_count_valid of ABI 1 (a caller compiled against the first header must
+    keep working: an entry point never changes its signature)."""
+    assert L.lib.lphq_abi_version() == 2
+    hdr = open(os.path.join(ROOT, "include", "lphq.h")).read()
+    assert "#define LPHQ_ABI_VERSION 2" in hdr
+    assert "int lphq_count_valid(const lphq_index* idx, const uint64_t* d_codes, size_t n, uint64_t* count);" in hdr
+    assert "int lphq_count_valid_on_stream(const lphq_index* idx, const uint64_t* d_codes, size_t n, void* stream, uint64_t* count);" in hdr

@@ -8,6 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 import lphash_amd as L  # noqa: E402
+import orc  # noqa: E402  (the checker)
 from lphash_amd.synth import synthetic_records  # noqa: E402
 from util import dedup_records  # noqa: E402
 
@@ -23,7 +24,8 @@ def torch_dev():
                                                      (31, 15, 128, 0, 50, 60_000)])
 def test_gpu_pilot_search_build_is_byte_identical(tmp_path, k, m, bits, kind, nrec, rlen):
     """lphq_build_device (PTHash pilot search on the GPU: speculative window + in-order commit) must write exactly the
-    file the sequential first-fit search writes."""
+    file the sequential first-fit search writes -- and exactly the file the oracle's restatement of the reference's construction
+    (src/partitioned_mphf.cpp:33-268, src/unpartitioned_mphf.cpp:23-170, include/minimizer.hpp:11-319) writes."""
     _, recs = synthetic_records(seed=11 + k, n_records=nrec, length=rlen)
     recs = dedup_records(recs, k) if k < 25 else recs
     pc, pg = str(tmp_path / "cpu.lph"), str(tmp_path / "gpu.lph")
@@ -31,6 +33,9 @@ def test_gpu_pilot_search_build_is_byte_identical(tmp_path, k, m, bits, kind, nr
     sg = L.build(recs, k, m, pg, kind=kind, kmer_bits=bits, threads=8, device=0)
     assert sc == sg
     assert open(pc, "rb").read() == open(pg, "rb").read()
+    po = str(tmp_path / "oracle.lph")
+    orc.build(recs, k, m, po, kind=kind, kmer_bits=bits)
+    assert open(pg, "rb").read() == open(po, "rb").read(), "GPU-built file differs from the oracle's"
 
 
 @pytest.mark.parametrize("k,m,bits,kind", [(31, 20, 64, 0), (63, 20, 128, 0), (31, 15, 64, 1), (15, 9, 64, 0), (47, 32, 128, 0), (33, 5, 128, 0)])
@@ -56,6 +61,9 @@ def test_gpu_super_kmer_extraction_build_is_byte_identical(tmp_path, k, m, bits,
     want = open(pc, "rb").read()
     sg = L.build(recs, k, m, pg, kind=kind, kmer_bits=bits, threads=8, device=0)
     assert sg == sc and open(pg, "rb").read() == want
+    po = str(tmp_path / "oracle.lph")
+    orc.build(recs, k, m, po, kind=kind, kmer_bits=bits)  # the oracle's restatement of the reference's construction, directly
+    assert want == open(po, "rb").read(), "GPU-built file (extraction + sort + pilot search on the device) differs from the oracle's"
     os.environ["LPHQ_EXTRACT_INITIAL_CAP"] = "1000"  # the first launch runs out of room: the kernel only counts on, the second launch has the exact size
     try:
         sg = L.build(recs, k, m, pg, kind=kind, kmer_bits=bits, threads=8, device=0)
@@ -208,3 +216,7 @@ def test_bench_collective_path_with_one_rank(tmp_path, mode):
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["rccl_ranks"] == 1 and line["replicas_agree"] is True and line["parity_vs_oracle"] is True
     assert line["image_broadcast_ms"] > 0 and line["n_gpus"] == 1 and line["roofline"]["frac"] > 0
+    # what a scaling run reports per rank: the kernel time of every rank (a straggler must be visible, not only the max), how many ranks
+    # compared their own timed batch with the oracle, and the CPU baseline of rank 0 at any N
+    assert len(line["kernel_ms_per_rank"]) == 1 and line["kernel_ms_min"] == line["kernel_ms_max"] == line["kernel_ms_per_rank"][0] > 0
+    assert line["parity_ranks_checked"] == 1 and line["cpu_baseline"]["value"] > 0 and "secondary" not in line
