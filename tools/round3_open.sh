@@ -9,16 +9,18 @@ mkdir -p "$O"
 cd "$R"
 step() { echo "[$(date +%H:%M:%S)] $*" | tee -a "$O/log.txt"; }
 free -g | head -2 | tee -a "$O/log.txt"; nproc | tee -a "$O/log.txt"
+if [ "${SKIP_TESTS:-0}" = 1 ]; then step "tests skipped"; else
 step "1. pytest -m gpu"
 timeout 1500 python -m pytest tests/ -x -q -m gpu --durations=8 > "$O/pytest_gpu.txt" 2>&1
 echo "exit code $?" >> "$O/pytest_gpu.txt"
 tail -14 "$O/pytest_gpu.txt" | tee -a "$O/log.txt"
 step "2. smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee -a "$O/log.txt"
+fi
 step "3. default bench line (headline C2 + secondary C3 / C5 / C4-random / C4-stream), the driver's command"
-/usr/bin/time -v timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > "$O/bench_default.json" 2> "$O/bench_default.err"
+T0=$(date +%s); timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > "$O/bench_default.json" 2> "$O/bench_default.err"
 echo "exit code $?" | tee -a "$O/log.txt"
-grep -E "Elapsed|Maximum resident" "$O/bench_default.err" | tee -a "$O/log.txt"
+echo "bench wall $(( $(date +%s) - T0 )) s" | tee -a "$O/log.txt"; tail -3 "$O/bench_default.err" | cut -c1-300 | tee -a "$O/log.txt"
 python3 - "$O/bench_default.json" <<'P' | tee -a "$O/log.txt"
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
