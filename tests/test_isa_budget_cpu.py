@@ -38,7 +38,7 @@ SGPR_SPILLS = {"k_query_packed": 40}
 
 
 def resource_usage(src):
-    r = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", os.devnull],
+    r = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I.", "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", os.devnull],
                        cwd=CSRC, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     out, cur = {}, None
