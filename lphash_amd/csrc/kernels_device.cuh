@@ -389,8 +389,9 @@ struct BlockMin {  // a lane's suffix minima, alive from phase B to phase C
     uint64_t h1, h2, h3;  // S[1], S[2], S[3] (S[0] = M, re-read from LDS)
     uint32_t p;           // their positions within the block, 2 bits each: S[1] | S[2] << 2 | S[3] << 4
 };
-// byte published per lane: position (0..3) within the block of P[1] (bit 0), P[2] (bits 1-2), P[3] = M (bits 3-4)
-__device__ __forceinline__ uint32_t prefix_off(uint32_t ob, uint32_t c) { return c == 0u ? 0u : (c == 1u ? (ob & 1u) : (c == 2u ? ((ob >> 1) & 3u) : ((ob >> 3) & 3u))); }
+// byte published per lane: position (0..3) within the block of the prefix minimum P[c] in bits [2c, 2c + 2) (P[0] is position 0; P[3] = M):
+// one bit-field extract, no branches (the four-way select this replaces compiled to nested EXEC-masked branches, ~10 scalar instructions per window)
+__device__ __forceinline__ uint32_t prefix_off(uint32_t ob, uint32_t c) { return (ob >> (2u * c)) & 3u; }
 
 template <int BLOCK>
 __device__ __forceinline__ BlockMin publish_block_minima(uint64_t* __restrict__ sm_hash, uint8_t* __restrict__ sm_off, uint32_t tid, const uint64_t (&h)[4]) {
@@ -399,13 +400,13 @@ __device__ __forceinline__ BlockMin publish_block_minima(uint64_t* __restrict__ 
     sm_hash[tid] = p.h;
     take_if_less(p, h[1], 1);
     sm_hash[ROW + tid] = p.h;
-    uint32_t ob = p.p;
+    uint32_t ob = p.p << 2;
     take_if_less(p, h[2], 2);
     sm_hash[2 * ROW + tid] = p.h;
-    ob |= p.p << 1;
+    ob |= p.p << 4;
     take_if_less(p, h[3], 3);
     sm_hash[3 * ROW + tid] = p.h;
-    ob |= p.p << 3;
+    ob |= p.p << 6;
     sm_off[tid] = (uint8_t)ob;
     BlockMin s;
     s.h3 = h[3];
@@ -432,15 +433,18 @@ __device__ __forceinline__ void window_argmin4(const uint64_t* __restrict__ sm_h
     }
     const uint64_t m0 = colM[0];
     const uint32_t ob0 = sm_off[tid];
-    HashPos w[4] = {HashPos{m0, (ob0 >> 3) & 3u}, HashPos{s.h1, s.p & 3u}, HashPos{s.h2, (s.p >> 2) & 3u}, HashPos{s.h3, (s.p >> 4) & 3u}};
+    HashPos w[4] = {HashPos{m0, (ob0 >> 6) & 3u}, HashPos{s.h1, s.p & 3u}, HashPos{s.h2, (s.p >> 2) & 3u}, HashPos{s.h3, (s.p >> 4) & 3u}};
 #pragma unroll
     for (uint32_t j = 0; j < 4; ++j) {
         const uint32_t nf = (j + W - 4u) >> 2, hc = (j + W - 4u) & 3u;  // uniform over the wave
         if (nf0) take_if_less(w[j], r.h, r.p);
         if (nf > nf0) take_if_less(w[j], colM[nf], (nf << 2) | 3u);
         if (hc) take_if_less(w[j], sm_hash[(hc - 1u) * ROW + tid + nf + 1u], ((nf + 1u) << 2) | (hc - 1u));
-        const uint32_t t = w[j].p >> 2;
-        q[j] = 4u * tid + (t ? 4u * t + prefix_off(sm_off[tid + t], w[j].p & 3u) : w[j].p);
+        // the winner is column c of the block t lanes to the right (its place inside that block is in the block's byte), or -- t = 0 -- position c of the
+        // own block: one LDS byte read for every lane (t = 0 reads its own and ignores it) instead of a divergent branch
+        const uint32_t t = w[j].p >> 2, c = w[j].p & 3u;
+        const uint32_t off = prefix_off(sm_off[tid + t], c);
+        q[j] = 4u * (tid + t) + (t ? off : c);
     }
 }
 
