@@ -1,0 +1,134 @@
+// query_main.cpp -- the reference's query driver (template <typename MPHF> int query(argc, argv), src/query.cpp:24-88) over the
+// gpu_mphf<> binding of examples/gpu_mphf.hpp: what `lphash query-p | query-u` becomes once the two lines of INTEGRATION.md section 2 are
+// changed.  Restated here (same passes, same timers around the same loops, same CSV, same exit codes) so that the binding is compiled
+// with a plain host compiler against include/lphq.h and run by the tests; the record reader is this repository's kseq-equivalent
+// (lphash_amd/csrc/fastx.hpp) because the reference's external/kseq.h is not part of this tree.
+//
+//   g++ -std=c++17 -O2 -Iinclude -Ilphash_amd/csrc examples/query_main.cpp -Llphash_amd -llphq -lz -lpthread -o examples/query_example
+//   examples/query_example query-p|query-u -i index.lph -q queries.fa[.gz] [--dump prefix]     (--dump: codes of both passes as prefix.streaming.u64 / prefix.random.u64)
+//   examples/query_example build-p|build-u -i unitigs.fa[.gz] -k K -m M -o index.lph [-s seed] [-c c] [-t threads] [-d tmp] [--max-memory GB]
+//                          (the build side of the binding, src/build.cpp:24-28: same file as the reference's build-p / build-u)
+//   -DLPHASH_KMER64 selects `typedef uint64_t kmer_t` (include/compile_constants.tpd:2); the default is __uint128_t, as the reference ships.
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <string>
+
+#include "fastx.hpp"
+#include "gpu_mphf.hpp"
+
+#ifdef LPHASH_KMER64
+typedef uint64_t kmer_t;
+#else
+typedef __uint128_t kmer_t;
+#endif
+
+namespace lphash {
+
+template <typename MPHF>
+int query(const std::string& mphf_filename, const std::string& query_filename, const std::string& dump_prefix) {
+    MPHF hf;
+    hf.load(mphf_filename.c_str());  // essentials::load(hf, mphf_filename.c_str())                      src/query.cpp:37
+    uint64_t total[2] = {0, 0};
+    long long micros[2] = {0, 0};
+    for (int pass = 0; pass < 2; ++pass) {  // streaming_on = true (src/query.cpp:48-58), then streaming_off (:60-79)
+        const bool streaming = pass == 0;
+        lphq::FastxReader reader(query_filename.c_str());
+        if (!reader.ok()) {
+            std::cerr << "Unable to open the input file " << query_filename << "\n";
+            return 2;  // src/query.cpp:43-46
+        }
+        FILE* dump = nullptr;
+        if (!dump_prefix.empty()) {
+            dump = fopen((dump_prefix + (streaming ? ".streaming.u64" : ".random.u64")).c_str(), "wb");
+            if (!dump) return 2;
+        }
+        std::string seq;
+        const auto t0 = std::chrono::high_resolution_clock::now();
+        while (reader.next(seq)) {  // while (kseq_read(seq) >= 0)
+            auto hashes = hf(seq.data(), seq.size(), streaming);
+            total[pass] += hashes.size();
+            if (dump && !hashes.empty()) fwrite(hashes.data(), sizeof(uint64_t), hashes.size(), dump);  // (the reference: do_not_optimize_away, :54)
+        }
+        micros[pass] = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+        if (dump) fclose(dump);
+    }
+    if (total[0] != total[1]) std::cerr << "warning: the two passes disagree on the number of k-mers (non-ACGT bases in the input)\n";  // assert, :81
+    std::cout << query_filename << "," << mphf_filename << "," << total[0] << "," << static_cast<double>(micros[0] * 1000) / total[0] << ","
+              << static_cast<double>(micros[1] * 1000) / total[1] << std::endl;  // src/query.cpp:83-86
+    return 0;
+}
+
+// The kseq loop of mphf::build (src/partitioned_mphf.cpp:66-78, read again at :118-130) as the record source lphq_build_stream asks for:
+// one record per call is enough for the example (larger batches amortise the device copies).
+struct record_source {
+    std::string path;
+    lphq::FastxReader* reader = nullptr;
+    int pass = -1;
+    std::string seq;
+    const char* rec = nullptr;
+    size_t len = 0;
+    ~record_source() { delete reader; }
+};
+static int next_record(void* ctx, int pass, const char* const** records, const size_t** lengths, size_t* n) {
+    auto* s = static_cast<record_source*>(ctx);
+    if (s->pass != pass) {  // first call of a pass: (re)open, src/partitioned_mphf.cpp:66 / :118
+        delete s->reader;
+        s->reader = new lphq::FastxReader(s->path.c_str());
+        if (!s->reader->ok()) return -1;
+        s->pass = pass;
+    }
+    if (!s->reader->next(s->seq)) return 0;  // end of this pass
+    s->rec = s->seq.data();
+    s->len = s->seq.size();
+    *records = &s->rec;
+    *lengths = &s->len;
+    *n = 1;
+    return 1;
+}
+
+}  // namespace lphash
+
+int main(int argc, char** argv) {
+    std::string tool = argc > 1 ? argv[1] : "", mphf, queries, dump, out, tmp = ".";
+    int k = 0, m = 0, threads = 1;
+    uint64_t seed = 42, max_memory_gb = 0;
+    double c = 3.0;
+    for (int i = 2; i + 1 < argc; i += 2) {
+        const std::string a = argv[i], v = argv[i + 1];
+        if (a == "-i") mphf = v;
+        else if (a == "-q") queries = v;
+        else if (a == "--dump") dump = v;
+        else if (a == "-o") out = v;
+        else if (a == "-k") k = std::stoi(v);
+        else if (a == "-m") m = std::stoi(v);
+        else if (a == "-s") seed = std::stoull(v);
+        else if (a == "-c") c = std::stod(v);
+        else if (a == "-t") threads = std::stoi(v);
+        else if (a == "-d") tmp = v;
+        else if (a == "--max-memory") max_memory_gb = std::stoull(v);
+    }
+    const bool is_query = tool == "query-p" || tool == "query-u", is_build = tool == "build-p" || tool == "build-u";
+    if ((!is_query && !is_build) || mphf.empty() || (is_query && queries.empty()) || (is_build && (out.empty() || k <= 0 || m <= 0))) {
+        std::cerr << "usage: " << argv[0] << " query-p|query-u -i <mphf> -q <fasta|fastq[.gz]> [--dump prefix]\n"
+                  << "       " << argv[0] << " build-p|build-u -i <fasta[.gz]> -k K -m M -o <mphf> [-s seed] [-c c] [-t threads] [-d tmp] [--max-memory GB]\n";
+        return 1;  // ParseError, src/query.cpp:31-33
+    }
+    try {
+        if (is_build) {  // hf.build(config, res); essentials::save(hf, config.output_filename)   src/build.cpp:24-28
+            lphash::record_source src;
+            src.path = mphf;
+            lphq_build_stats st;
+            if (tool == "build-p") lphash::gpu_mphf<LPHQ_PARTITIONED, kmer_t>::build(lphash::next_record, &src, k, m, seed, c, threads, /*device*/ 0, tmp.c_str(), max_memory_gb << 30, out.c_str(), &st);
+            else lphash::gpu_mphf<LPHQ_UNPARTITIONED, kmer_t>::build(lphash::next_record, &src, k, m, seed, c, threads, /*device*/ 0, tmp.c_str(), max_memory_gb << 30, out.c_str(), &st);
+            std::cerr << "built " << out << ": " << st.num_kmers << " k-mers, " << st.distinct_minimizers << " minimizers\n";
+            return 0;
+        }
+        if (tool == "query-p") return lphash::query<lphash::gpu_mphf<LPHQ_PARTITIONED, kmer_t>>(mphf, queries, dump);
+        return lphash::query<lphash::gpu_mphf<LPHQ_UNPARTITIONED, kmer_t>>(mphf, queries, dump);
+    } catch (const std::exception& e) {
+        std::cerr << e.what() << "\n";
+        return 1;
+    }
+}

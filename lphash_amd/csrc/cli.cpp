@@ -414,7 +414,7 @@ int records_main(int argc, char** argv) {
     const size_t batch = a.get("--batch-bytes") ? (size_t)std::strtoull(a.get("--batch-bytes")->c_str(), nullptr, 10) : (size_t)512 << 20;
     const size_t min_piece = a.get("--min-piece") ? (size_t)std::strtoull(a.get("--min-piece")->c_str(), nullptr, 10) : (size_t)1 << 16;
     const int passes = a.get("--passes") ? std::max(1, std::atoi(a.get("--passes")->c_str())) : 1;  // later passes reuse the (warm) parse arenas
-    uint64_t n_rec = 0, n_bases = 0, h = 0, n_batches = 0, n_parallel = 0;
+    uint64_t n_rec = 0, n_bases = 0, h = 0, n_batches = 0, n_parallel = 0, window = 0;
     std::chrono::high_resolution_clock::time_point t0;
     for (int pass = 0; pass < passes; ++pass) {
     n_rec = n_bases = n_batches = n_parallel = 0;
@@ -464,11 +464,12 @@ int records_main(int argc, char** argv) {
             }
         }
         if (!rd.ok()) return 3;
+        window = rd.window_capacity();  // BGZF: bytes of inflated text held at once (0 for every other kind of input)
     }
     }
     auto t1 = std::chrono::high_resolution_clock::now();
     const double sec = std::chrono::duration<double>(t1 - t0).count();
-    std::cout << n_rec << "," << n_bases << "," << h << "," << n_batches << "," << n_parallel << "," << sec << std::endl;
+    std::cout << n_rec << "," << n_bases << "," << h << "," << n_batches << "," << n_parallel << "," << sec << "," << window << std::endl;
     return 0;
 }
 

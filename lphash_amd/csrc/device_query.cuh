@@ -270,12 +270,10 @@ __device__ __forceinline__ void minimizer_of(uint64_t lo, uint64_t hi, uint32_t 
             const uint32_t s = 2u * j0;            // < 126
             const uint64_t cur = s == 0u ? h : (s < 64u ? ((h << s) | (l >> (64u - s))) : (l << (s - 64u)));
             const uint32_t n = min(T, W - j0);
-#pragma unroll 2
             for (uint32_t t = 0; t < n; ++t) step((cur << (2u * t)) >> top, j0 + t);
         }
     } else {
         uint64_t l = lo << (64u - 2u * k);  // k <= 31: the k-mer left-aligned, the m-mer is its top 2m bits (one shift, no mask)
-#pragma unroll 2
         for (uint32_t j = 0; j < W; ++j) {
             step(l >> top, j);
             l <<= 2;

@@ -10,9 +10,11 @@
 // length of a record begun elsewhere -- makes the reader fall back, from the start of the current batch, to the serial
 // FastxReader for the rest of the file, so the records are the serial reader's in every case.  gzip input and files
 // that do not start with '>' or '@' take the serial reader from the beginning -- except BGZF (bgzip / htslib: gzip members of
-// <= 64 KiB whose compressed size is in the header's 'BC' extra field): its blocks are independent deflate streams, so the first
-// next() inflates all of them concurrently (raw inflate + CRC-32 and length check per block) into one buffer, which then stands in
-// for the mapped file.  A single-member .gz cannot be split and stays on the serial reader (zlib inflate, ~0.5 GB/s).
+// <= 64 KiB whose compressed size is in the header's 'BC' extra field): its blocks are independent deflate streams, so they are inflated
+// concurrently (raw inflate + CRC-32 and length check per block) into a WINDOW of text that stands in for the mapped file: the window
+// always covers the batch being cut plus what it takes to find the next record start, slides forward with the batches and is as large
+// as a few batches (one record larger than that grows it, as it grows the arenas) -- memory stays proportional to batch_bases however
+// large the file is, like the plain and the single-member paths.  A single-member .gz cannot be split and stays on the serial reader.
 //
 // A batch is a list of segments (bases in file order; a record may run across segments) plus the record lengths; segments
 // point into one of two arenas owned by the reader, used alternately, so a batch stays valid while the NEXT one is
@@ -90,7 +92,7 @@ public:
             void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd_, 0);
             if (m != MAP_FAILED) {
                 map_ = (const char*)m;
-                size_ = (size_t)st.st_size;
+                size_ = lim_ = (size_t)st.st_size;
                 (void)madvise(m, size_, MADV_SEQUENTIAL);
             }
         }
@@ -101,8 +103,8 @@ public:
     ~FastxBatchReader() {
         delete serial_;
         if (bgzf_) munmap((void*)bgzf_, bgzf_size_);
-        if (inflated_) {
-            free(inflated_);
+        if (wbuf_) {
+            free(wbuf_);
             map_ = nullptr;
         }
         if (map_) munmap((void*)map_, size_);
@@ -130,25 +132,34 @@ public:
     bool next(FastxBatch& b, size_t batch_bases) {
         b.clear();
         which_ ^= 1;
-        if (bgzf_ && !bgzf_inflate()) {  // first call on a BGZF file; on any irregularity the serial reader takes the whole file
+        if (bgzf_ && !windowed_ && !serial_ && !bgzf_index()) {  // first call on a BGZF file; on any irregularity the serial reader takes the whole file
             serial_ = new FastxReader(path_.c_str());
             if (!serial_->ok()) ok_ = false;
         }
         while (ok_ && parallel()) {
             if (off_ >= size_) return false;
             if (!next_parallel(b, batch_bases)) {
-                // a '+' line: the rest of the file goes through the serial reader, starting at this batch's first record
+                // a '+' line (or a damaged BGZF block): the rest of the file goes through the serial reader, starting at this batch's first record.
+                // Plain text: by offset.  BGZF: a fresh reader skips the records already handed out (by the equivalence of the two readers they are
+                // the first `emitted_` records of the serial one; seeking zlib to an uncompressed offset would drop what precedes a damaged block)
                 serial_ = new FastxReader(path_.c_str());
-                if (!serial_->ok() || !serial_->seek(off_)) ok_ = false;
+                if (!serial_->ok()) ok_ = false;
+                else if (!windowed_) ok_ = serial_->seek(off_);
+                else {
+                    std::string skip;
+                    for (uint64_t i = 0; i < emitted_ && serial_->next(skip); ++i) {}
+                }
                 b.clear();
                 break;
             }
+            emitted_ += b.lens.size();
             if (!b.lens.empty()) return true;  // (an empty window: a last header without a line end)
         }
         return ok_ && next_serial(b, batch_bases);
     }
 
-    bool bgzf() const { return inflated_ != nullptr; }  // (tests) the input was inflated block-parallel
+    bool bgzf() const { return windowed_; }  // (tests) the input is inflated block-parallel
+    size_t window_capacity() const { return wcap_; }  // (tests) bytes of inflated text held at once
 
 private:
     // ---- BGZF (SAM/BAM specification, section 4.1): gzip member = 10-byte header with FLG.FEXTRA, XLEN, extra subfields (one of them
@@ -188,75 +199,101 @@ private:
         bgzf_ = (const unsigned char*)m;
         bgzf_size_ = size;
     }
-    // inflate every block (threads_ threads); true = map_/size_ now describe the inflated text and it may be parsed in parallel
-    bool bgzf_inflate() {
+    // Index every member of the file (no inflation yet); true = it is BGZF from the first byte to the last, size_ is the length of its text and
+    // the first window is in place and begins like a FASTA / FASTQ file.
+    bool bgzf_index() {
         const unsigned char* f = bgzf_;
         const size_t size = bgzf_size_;
-        std::vector<BgzfBlock> blocks;
         size_t at = 0, total = 0;
-        bool good = true;
-        while (at < size && good) {
+        while (at < size) {
             size_t payload = 0;
             const size_t bs = bgzf_member(f, size, at, payload);
-            if (!bs) {
-                good = false;
-                break;
-            }
+            if (!bs) return false;
             BgzfBlock bl;
             bl.in = payload;
             bl.in_len = at + bs - 8 - payload;
             bl.crc = le32(f + at + bs - 8);
             bl.out = total;
             bl.out_len = le32(f + at + bs - 4);
+            if (bl.out_len > 65536) return false;
             total += bl.out_len;
-            blocks.push_back(bl);
+            blocks_.push_back(bl);
             at += bs;
         }
-        char* buf = good ? (char*)malloc(total ? total : 1) : nullptr;
-        if (good && buf) {
-            std::vector<int> bad((size_t)threads_, 0);
-            auto work = [&](int t) {
-                // every block through the own decoder (fast_inflate.hpp) into a private buffer -- the decoder writes a few bytes past what it has
-                // decoded, which must not land in a neighbour's part of the text -- then into place; CRC-32 and length as the member's trailer says
-                DeflateDecoder* dec = new DeflateDecoder();
-                std::vector<uint8_t> tmp((size_t)65536 + DeflateDecoder::kSlack + 64);
-                for (size_t i = (size_t)t; i < blocks.size(); i += (size_t)threads_) {
-                    const BgzfBlock& bl = blocks[i];
-                    bool okb = bl.out_len <= 65536;
-                    if (okb) {
-                        dec->reset(f + bl.in, f + bl.in + bl.in_len);
-                        size_t pos = 0;
-                        okb = dec->decode(tmp.data(), pos, 65536) == 1 && pos == bl.out_len && dec->stream_end() <= f + bl.in + bl.in_len &&
-                              crc32_slice16(0, tmp.data(), pos) == bl.crc;
-                        if (okb) memcpy(buf + bl.out, tmp.data(), pos);
-                    }
-                    if (!okb) {
-                        bad[(size_t)t] = 1;
-                        break;
-                    }
-                }
-                delete dec;
-            };
-            std::vector<std::thread> th;
-            for (int t = 1; t < threads_; ++t) th.emplace_back(work, t);
-            work(0);
-            for (auto& x : th) x.join();
-            for (int x : bad) good = good && !x;
-        } else {
-            good = false;
-        }
-        munmap((void*)bgzf_, bgzf_size_);
-        bgzf_ = nullptr;
-        if (!good || total == 0 || (buf[0] != '>' && buf[0] != '@')) {  // damaged, empty or headerless text: the serial reader decides
-            free(buf);
+        if (total == 0) return false;  // empty text: the serial reader decides
+        size_ = total;
+        windowed_ = true;
+        if (!bgzf_window(0, std::min<size_t>(total, 1 << 16)) || (map_[0] != '>' && map_[0] != '@')) {  // damaged or headerless text: the serial reader decides
+            windowed_ = false;
+            map_ = nullptr;
+            size_ = lim_ = 0;
             return false;
         }
-        inflated_ = buf;
-        map_ = buf;
-        size_ = total;
-        fastq_ = buf[0] == '@';
+        fastq_ = map_[0] == '@';
         return true;
     }
+    // Make the window hold the text [from, upto') with upto' >= min(upto, size_) (whole blocks).  Text before `from` is given up; what is
+    // already inflated beyond it is kept (moved to the front of the buffer only when the buffer would otherwise overflow, so that the copying
+    // is of the look-ahead tail, not of the batch).  The new blocks are inflated by threads_ threads.  false = a block is damaged.
+    bool bgzf_window(size_t from, size_t upto) {
+        upto = std::min(upto, size_);
+        size_t b_end = blk_next_;
+        size_t new_bytes = 0;
+        while (b_end < blocks_.size() && blocks_[b_end].out < upto) new_bytes += blocks_[b_end++].out_len;
+        if (b_end == blk_next_) return true;
+        if (from > wend_) from = wend_;
+        const size_t keep = wend_ - from;  // already inflated text that is still needed
+        if ((wend_ - wbase_) + new_bytes + kWindowSlack > wcap_) {  // slide: the retained tail to the front, and grow if that is not enough
+            if (keep + new_bytes + kWindowSlack > wcap_) {
+                const size_t cap = std::max<size_t>(2 * wcap_, keep + new_bytes + new_bytes / 2 + kWindowSlack);
+                char* nb = (char*)malloc(cap);
+                if (!nb) return false;
+                if (keep) memcpy(nb, wbuf_ + (from - wbase_), keep);
+                free(wbuf_);
+                wbuf_ = nb;
+                wcap_ = cap;
+            } else if (keep && from != wbase_) {
+                memmove(wbuf_, wbuf_ + (from - wbase_), keep);
+            }
+            wbase_ = from;
+        }
+        const unsigned char* f = bgzf_;
+        char* const base = wbuf_;
+        const size_t wbase = wbase_, b0 = blk_next_, nb = b_end - blk_next_;
+        const int T = (int)std::min<size_t>((size_t)threads_, nb);
+        std::vector<int> bad((size_t)T, 0);
+        auto work = [&](int t) {
+            // every block through the own decoder (fast_inflate.hpp) into a private buffer -- the decoder writes a few bytes past what it has
+            // decoded, which must not land in a neighbour's part of the text -- then into place; CRC-32 and length as the member's trailer says
+            DeflateDecoder* dec = new DeflateDecoder();
+            std::vector<uint8_t> tmp((size_t)65536 + DeflateDecoder::kSlack + 64);
+            for (size_t i = b0 + (size_t)t; i < b0 + nb; i += (size_t)T) {
+                const BgzfBlock& bl = blocks_[i];
+                dec->reset(f + bl.in, f + bl.in + bl.in_len);
+                size_t pos = 0;
+                const bool okb = dec->decode(tmp.data(), pos, 65536) == 1 && pos == bl.out_len && dec->stream_end() <= f + bl.in + bl.in_len &&
+                                 crc32_slice16(0, tmp.data(), pos) == bl.crc;
+                if (!okb) {
+                    bad[(size_t)t] = 1;
+                    break;
+                }
+                memcpy(base + (bl.out - wbase), tmp.data(), pos);
+            }
+            delete dec;
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+        for (int x : bad)
+            if (x) return false;
+        blk_next_ = b_end;
+        wend_ = blocks_[b_end - 1].out + blocks_[b_end - 1].out_len;
+        lim_ = wend_;
+        map_ = (const char*)((uintptr_t)wbuf_ - (uintptr_t)wbase_);  // map_[p] is the text at absolute position p for p in [wbase_, wend_)
+        return true;
+    }
+    static constexpr size_t kWindowSlack = 1 << 12;
 
     struct Piece {
         size_t begin, end;   // file span; begin is a line start
@@ -290,30 +327,31 @@ private:
 
     // first position p in [from, size_) with map_[p] == '>' and map_[p - 1] == '\n'; size_ if there is none
     // FASTQ: first line start p >= from with map_[p] == '@' whose next-but-one line begins with '+'; size_ if there is none
+    // (searches end at lim_: the end of the file for mapped text, the end of the inflated window for BGZF -- the caller extends the window and asks again)
     size_t next_fastq_record(size_t from) const {
         size_t p = from;
-        if (p > 0 && map_[p - 1] != '\n') p = next_line_start(p, size_);
-        while (p < size_) {
+        if (p > 0 && map_[p - 1] != '\n') p = next_line_start(p, lim_);
+        while (p < lim_) {
             if (map_[p] == '@') {
-                const size_t l1 = next_line_start(p, size_), l2 = l1 < size_ ? next_line_start(l1, size_) : size_;
-                if (l2 < size_ && map_[l2] == '+') return p;
+                const size_t l1 = next_line_start(p, lim_), l2 = l1 < lim_ ? next_line_start(l1, lim_) : lim_;
+                if (l2 < lim_ && map_[l2] == '+') return p;
             }
-            p = next_line_start(p, size_);
+            p = next_line_start(p, lim_);
         }
-        return size_;
+        return lim_;
     }
 
     size_t next_record_start(size_t from) const {
         if (fastq_) return next_fastq_record(from);
         size_t p = std::max<size_t>(from, 1);
-        while (p < size_) {
-            const char* q = (const char*)memchr(map_ + p, '>', size_ - p);
-            if (!q) return size_;
+        while (p < lim_) {
+            const char* q = (const char*)memchr(map_ + p, '>', lim_ - p);
+            if (!q) return lim_;
             p = (size_t)(q - map_);
             if (map_[p - 1] == '\n') return p;
             ++p;
         }
-        return size_;
+        return lim_;
     }
 
     // first line start in (from, end]; `end` if the rest holds no line end
@@ -431,7 +469,23 @@ private:
 
     bool next_parallel(FastxBatch& b, size_t batch_bases) {
         const size_t want = std::max<size_t>(batch_bases, 1);
-        const size_t end = want >= size_ - off_ ? size_ : next_record_start(off_ + want);
+        size_t end;
+        if (!windowed_) {
+            end = want >= size_ - off_ ? size_ : next_record_start(off_ + want);
+        } else {
+            // BGZF: the window must hold the batch and the start of the record after it; a search that runs into the end of the window while the
+            // file goes on asks for twice as much
+            for (size_t ahead = want + (1 << 16);; ahead *= 2) {
+                if (!bgzf_window(off_, ahead >= size_ - off_ ? size_ : off_ + ahead)) return false;  // damaged block: the serial reader takes over at off_
+                if (want >= size_ - off_) {
+                    end = size_;
+                    if (lim_ == size_) break;
+                    continue;
+                }
+                end = off_ + want < lim_ ? next_record_start(off_ + want) : lim_;
+                if (end < lim_ || lim_ == size_) break;
+            }
+        }
         // sized for a full batch from the start, so that a short first batch does not cause a second cold allocation
         if (!reserve(std::max(end - off_, std::min(want, size_ - off_)))) return true;
         char* const arena = arenas_[which_].p;
@@ -500,9 +554,15 @@ private:
     const char* map_ = nullptr;
     size_t size_ = 0, off_ = 0;
     bool fastq_ = false;                   // the mapped text begins with '@': four-line FASTQ pieces
-    const unsigned char* bgzf_ = nullptr;  // mapped BGZF file until the first next()
+    size_t lim_ = 0;                       // end of the text map_ can be read at: size_ for a mapped file, the end of the window for BGZF
+    const unsigned char* bgzf_ = nullptr;  // mapped BGZF file
     size_t bgzf_size_ = 0;
-    char* inflated_ = nullptr;             // its text afterwards (map_ points here)
+    std::vector<BgzfBlock> blocks_;        // its members (filled by the first next())
+    size_t blk_next_ = 0;                  // first member not inflated yet
+    char* wbuf_ = nullptr;                 // window of inflated text [wbase_, wend_); map_ = wbuf_ - wbase_
+    size_t wcap_ = 0, wbase_ = 0, wend_ = 0;
+    bool windowed_ = false;
+    uint64_t emitted_ = 0;                 // records handed out by the parallel path so far
     FastxReader* serial_ = nullptr;
     bool serial_done_ = false, ok_ = false;
     Arena arenas_[2];

@@ -437,7 +437,7 @@ __device__ __forceinline__ void window_argmin4(const uint64_t* __restrict__ sm_h
 #pragma unroll
     for (uint32_t j = 0; j < 4; ++j) {
         const uint32_t nf = (j + W - 4u) >> 2, hc = (j + W - 4u) & 3u;  // uniform over the wave
-        if (nf0) take_if_less(w[j], r.h, r.p);
+        take_if_less(w[j], r.h, r.p);  // (no full block: r.h = ~0, never smaller -- unconditional, a uniform `if` here compiled to three more selects per window)
         if (nf > nf0) take_if_less(w[j], colM[nf], (nf << 2) | 3u);
         if (hc) take_if_less(w[j], sm_hash[(hc - 1u) * ROW + tid + nf + 1u], ((nf + 1u) << 2) | (hc - 1u));
         // the winner is column c of the block t lanes to the right (its place inside that block is in the block's byte), or -- t = 0 -- position c of the

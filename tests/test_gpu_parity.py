@@ -446,3 +446,34 @@ def test_empty_and_tiny_indexes(tmp_path):
             else:   # nothing is indexed: only the number of codes is defined
                 for q in probes:
                     assert len(h(q, streaming=True)) == len(q) - k + 1
+
+
+# ---- files written by a real reference build (tests/golden/ref/README.md): skipped until one is supplied ----
+def test_reference_built_files_gpu_codes():
+    """For every case directory under tests/golden/ref that holds queries and code dumps: the gfx950 kernels, through the C ABI, answer the
+    REFERENCE's codes in streaming and in random mode."""
+    import ref_intake
+
+    found = [ref_intake.Case(d) for d in ref_intake.cases()]
+    found = [c for c in found if c.queries and c.codes]
+    if not found:
+        pytest.skip("no reference-built file supplied (tests/golden/ref/README.md has the recipe)")
+    torch_dev()
+    for c in found:
+        assert ref_intake.check_case_gpu(c, L), c.dir
+
+
+@pytest.mark.parametrize("kind,k,m,bits", [("p", 31, 20, 64), ("u", 31, 20, 64), ("p", 63, 17, 128)])
+def test_reference_intake_dry_run_gpu(tmp_path, kind, k, m, bits):
+    """The GPU half of the intake on an oracle-written case in a temporary directory (layout of README.md): both code dumps are reproduced by the
+    kernels; a corrupted dump fails."""
+    import ref_intake
+
+    torch_dev()
+    d = ref_intake.write_oracle_case(str(tmp_path / "case"), orc, kind=kind, k=k, m=m, kmer_bits=bits)
+    assert ref_intake.check_case_gpu(ref_intake.Case(d), L) == ["gpu-codes-streaming", "gpu-codes-random"]
+    codes = np.fromfile(os.path.join(d, "codes_streaming.u64"), dtype="<u8")
+    codes[3] += 1
+    codes.tofile(os.path.join(d, "codes_streaming.u64"))
+    with pytest.raises(AssertionError, match="GPU codes differ"):
+        ref_intake.check_case_gpu(ref_intake.Case(d), L)

@@ -2,6 +2,8 @@
 (byte-identical to the oracle's restatement of the reference build path), error behaviour.  No compute calls:
 the query path only exists on the GPU."""
 import ctypes as C
+import gzip
+import json
 import os
 import re
 import subprocess
@@ -647,7 +649,37 @@ def test_bgzf_input_is_inflated_block_parallel(tmp_path):
     p.write_bytes(bytes(broken))
     ser = subprocess.run([exe, "records", "-i", str(p), "--serial"], capture_output=True, text=True).stdout.strip().split(",")
     par = subprocess.run([exe, "records", "-i", str(p), "-t", "6"], capture_output=True, text=True).stdout.strip().split(",")
-    assert par[:3] == ser[:3] and int(par[4]) == 0  # whatever zlib makes of the damaged stream, both readers agree
+    assert par[:3] == ser[:3] and int(par[4]) == 0  # whatever zlib makes of the damaged stream, both readers agree (one batch: the damage is in its window)
+    # small batches: the windows before the damaged block are parsed in parallel, the serial reader takes over at the batch that meets it
+    par = subprocess.run([exe, "records", "-i", str(p), "-t", "6", "--batch-bytes", "50000", "--min-piece", "1"], capture_output=True, text=True).stdout.strip().split(",")
+    assert par[:3] == ser[:3] and 0 < int(par[4]) < int(par[3])
+
+
+def test_bgzf_window_is_bounded_by_the_batch_size(tmp_path):
+    """The inflated text of a BGZF file is held in a window of a few batches, not whole (a bgzip'd FASTQ of hundreds of GB must not need its
+    uncompressed size in RAM): 24 MB of text read in 1-MB batches keeps < 6 MB inflated at once, a record larger than the batch grows the window to
+    what that record needs, and the records are the serial reader's in every case (FASTA, FASTQ, many threads, any batch size)."""
+    exe = os.path.join(ROOT, "lphash_amd", "lphash")
+    recs = random_records(91, 300, 1000, 160_000)
+    fasta = b"".join(b">r%d\n" % i + b"\n".join(r[j:j + 80] for j in range(0, len(r), 80)) + b"\n" for i, r in enumerate(recs))
+    reads = random_records(92, 30_000, 100, 250)
+    fastq = b"".join(b"@q%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)) for i, r in enumerate(reads))
+    big = random_records(93, 1, 6_000_000, 6_000_000)[0]
+    one_big = b">small\nACGT\n>big\n" + b"\n".join(big[j:j + 70] for j in range(0, len(big), 70)) + b"\n>after\nGGCC\n"
+    for name, text, batch in (("fasta", fasta, 1 << 20), ("fastq", fastq, 1 << 20), ("fastq_tiny_batches", fastq, 3000), ("one_big_record", one_big, 1 << 20)):
+        p = tmp_path / f"{name}.gz"
+        p.write_bytes(bgzf_compress(text))
+        ser = subprocess.run([exe, "records", "-i", str(p), "--serial"], capture_output=True, text=True).stdout.strip().split(",")
+        for threads in ("1", "7"):
+            par = subprocess.run([exe, "records", "-i", str(p), "-t", threads, "--batch-bytes", str(batch), "--min-piece", "1000"], capture_output=True, text=True)
+            f = par.stdout.strip().split(",")
+            assert par.returncode == 0 and f[:3] == ser[:3], (name, threads, f, ser)
+            assert int(f[4]) == int(f[3]) > 0  # every batch came from the parallel path
+            window = int(f[6])
+            if name == "one_big_record":
+                assert len(one_big) <= window < 4 * len(one_big)
+            else:
+                assert 0 < window <= 6 * max(batch, 1 << 17) and window < len(text)
 
 
 BBHASH_REF = os.path.join(ROOT, "oracle", "_ref", "bbhash_ref")
@@ -798,3 +830,74 @@ def test_abi_version_and_both_count_valid_entry_points_are_exported():
     assert "#define LPHQ_ABI_VERSION 2" in hdr
     assert "int lphq_count_valid(const lphq_index* idx, const uint64_t* d_codes, size_t n, uint64_t* count);" in hdr
     assert "int lphq_count_valid_on_stream(const lphq_index* idx, const uint64_t* d_codes, size_t n, void* stream, uint64_t* count);" in hdr
+
+
+# ---- files written by a real reference build (tests/golden/ref/README.md): skipped until one is supplied ----
+def test_reference_built_files_pin_loader_oracle_and_builders():
+    """For every case directory under tests/golden/ref: the loader accepts the reference's file, the oracle reproduces the reference's codes,
+    both builders reproduce the file's bytes.  This is the test that turns "parity unpinned" into "pinned"."""
+    import ref_intake
+
+    found = ref_intake.cases()
+    if not found:
+        pytest.skip("no reference-built file supplied (tests/golden/ref/README.md has the recipe)")
+    for d in found:
+        ran = ref_intake.check_case_cpu(ref_intake.Case(d), L, orc)
+        assert "loader" in ran, d
+
+
+@pytest.mark.parametrize("kind,k,m,bits", [("p", 31, 20, 64), ("u", 31, 20, 64), ("p", 63, 17, 128)])
+def test_reference_intake_dry_run_cpu(tmp_path, kind, k, m, bits):
+    """The intake machinery itself, on a case the ORACLE wrote into a temporary directory in exactly the layout of README.md (gzip multi-line
+    FASTA input, query file, .u64 code dumps, meta.json): every check runs and passes; a corrupted code dump and a file of the wrong kind fail."""
+    import ref_intake
+
+    d = ref_intake.write_oracle_case(str(tmp_path / "case"), orc, kind=kind, k=k, m=m, kmer_bits=bits)
+    assert ref_intake.cases(str(tmp_path)) == [d]
+    ran = ref_intake.check_case_cpu(ref_intake.Case(d), L, orc)
+    assert ran == ["loader", "oracle-codes-streaming", "oracle-codes-random", "builder-bytes", "oracle-builder-bytes"]
+    codes = np.fromfile(os.path.join(d, "codes_random.u64"), dtype="<u8")
+    codes[len(codes) // 2] ^= 1
+    codes.tofile(os.path.join(d, "codes_random.u64"))
+    with pytest.raises(AssertionError, match="oracle codes differ"):
+        ref_intake.check_case_cpu(ref_intake.Case(d), L, orc)
+    meta = json.load(open(os.path.join(d, "meta.json")))
+    meta["kind"] = "u" if kind == "p" else "p"
+    json.dump(meta, open(os.path.join(d, "meta.json"), "w"))
+    with pytest.raises(L.LphqError):  # the loader's cross-checks refuse a file read as the other class
+        ref_intake.check_case_cpu(ref_intake.Case(d), L, orc)
+
+
+def test_reference_intake_fastx_reader_matches_the_product_reader(tmp_path):
+    """ref_intake.read_fastx (what feeds the builders in the intake) yields the records the product's reader -- pinned to the real kseq.h -- yields."""
+    import ref_intake
+
+    fa = tmp_path / "x.fa.gz"
+    with gzip.open(fa, "wb") as f:
+        f.write(b">a desc\nACGT\nACG\n>b\n\n>c\nTTTT\r\nGG\n")
+    assert ref_intake.read_fastx(str(fa)) == [b"ACGTACG", b"", b"TTTTGG"]
+    fq = tmp_path / "x.fq"
+    fq.write_bytes(b"@r1\nACGTN\n+\n@IIII\n@r2\nGGCC\n+r2\n>>>>\n")
+    assert ref_intake.read_fastx(str(fq)) == [b"ACGTN", b"GGCC"]
+    n, bases, _ = orc.file_digest(str(fa))
+    assert (n, bases) == (3, 13)
+
+
+def test_integration_stub_is_built_and_needs_a_gpu(tmp_path):
+    """examples/query_example{64,128}: the reference-side binding of INTEGRATION.md section 2 (examples/gpu_mphf.hpp + the reference's query<MPHF>
+    driver restated), compiled with the plain host compiler against include/lphq.h by `make`.  Without a GPU (here) it must fail loudly -- there
+    is no CPU path behind the C ABI -- and keep the reference's exit codes for usage errors."""
+    for bits in (64, 128):
+        exe = os.path.join(ROOT, "examples", f"query_example{bits}")
+        assert os.path.exists(exe), "make -C lphash_amd/csrc builds the examples"
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 1 and "usage" in r.stderr
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the GPU test runs the binding")
+    path = os.path.join(ROOT, "tests", "golden", "p_k31_m20_b64.lph")
+    fa = tmp_path / "q.fa"
+    fa.write_bytes(b">q\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n")
+    r = subprocess.run([os.path.join(ROOT, "examples", "query_example64"), "query-p", "-i", path, "-q", str(fa)], capture_output=True, text=True)
+    assert r.returncode == 1 and r.stdout == "" and "device" in r.stderr.lower()

@@ -220,3 +220,60 @@ def test_bench_collective_path_with_one_rank(tmp_path, mode):
     # compared their own timed batch with the oracle, and the CPU baseline of rank 0 at any N
     assert len(line["kernel_ms_per_rank"]) == 1 and line["kernel_ms_min"] == line["kernel_ms_max"] == line["kernel_ms_per_rank"][0] > 0
     assert line["parity_ranks_checked"] == 1 and line["cpu_baseline"]["value"] > 0 and "secondary" not in line
+
+
+@pytest.mark.parametrize("name", ["p_k31_m20_b64", "u_k31_m20_b64", "p_k63_m20_b128", "p_k21_m8_b64_fallback"])
+def test_integration_stub_query_driver(tmp_path, name):
+    """The reference-side binding of INTEGRATION.md as compiled code: examples/query_example (gpu_mphf<> over include/lphq.h under the reference's
+    query<MPHF> driver, built with g++) on a committed fixture -- the 5-field CSV of src/query.cpp:83-86 with the oracle's k-mer count, and the
+    codes of both passes equal to the oracle's."""
+    import subprocess
+
+    import numpy as np
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    z = np.load(os.path.join(root, "tests", "golden", name + ".npz"))
+    kind, bits = int(z["kind"]), int(z["kmer_bits"])
+    lph = os.path.join(root, "tests", "golden", name + ".lph")
+    queries = [bytes(z["queries"][z["q_off"][i]:z["q_off"][i + 1]]) for i in range(len(z["q_off"]) - 1)]
+    queries = [q for q in queries if q]  # (a FASTA file cannot carry the fixture's empty record as a record of its own)
+    fa = tmp_path / "q.fa"
+    with open(fa, "wb") as f:
+        for i, q in enumerate(queries):
+            f.write(b">q%d\n%s\n" % (i, q))
+    o = orc.Index(lph, kind, bits)
+    want_s = np.concatenate([o(q, True) for q in queries])
+    want_r = np.concatenate([o(q, False) for q in queries])
+    exe = os.path.join(root, "examples", f"query_example{bits}")
+    r = subprocess.run([exe, "query-p" if kind == 0 else "query-u", "-i", lph, "-q", str(fa), "--dump", str(tmp_path / "codes")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    f5 = r.stdout.strip().split(",")
+    assert len(f5) == 5 and f5[0] == str(fa) and f5[1] == lph and int(f5[2]) == len(want_s) and float(f5[3]) > 0 and float(f5[4]) > 0
+    assert np.array_equal(np.fromfile(str(tmp_path / "codes.streaming.u64"), dtype="<u8"), want_s)
+    assert np.array_equal(np.fromfile(str(tmp_path / "codes.random.u64"), dtype="<u8"), want_r)
+    # exit code 2 for a query file that cannot be opened (src/query.cpp:43-46)
+    r = subprocess.run([exe, "query-p" if kind == 0 else "query-u", "-i", lph, "-q", str(tmp_path / "missing.fa")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "Unable to open the input file" in r.stderr
+
+
+@pytest.mark.parametrize("tool,k,m,bits", [("build-p", 31, 20, 64), ("build-u", 31, 15, 64), ("build-p", 63, 20, 128)])
+def test_integration_stub_build_driver(tmp_path, tool, k, m, bits):
+    """The build side of the same binding (gpu_mphf<>::build = lphq_build_stream over a record source, replacing MPHF::build + essentials::save of
+    src/build.cpp:24-28): the file it writes is the oracle's, byte for byte."""
+    import subprocess
+
+    from util import random_records
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    recs = dedup_records(random_records(500 + k, 12, k - 1, 20_000), k)
+    fa = tmp_path / "in.fa"
+    with open(fa, "wb") as f:
+        for i, r in enumerate(recs):
+            f.write(b">r%d\n%s\n" % (i, r))
+    out = tmp_path / "x.lph"
+    r = subprocess.run([os.path.join(root, "examples", f"query_example{bits}"), tool, "-i", str(fa), "-k", str(k), "-m", str(m), "-o", str(out), "-t", "4", "-d", str(tmp_path)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    po = str(tmp_path / "o.lph")
+    orc.build(recs, k, m, po, kind=0 if tool == "build-p" else 1, kmer_bits=bits)
+    assert open(out, "rb").read() == open(po, "rb").read()
