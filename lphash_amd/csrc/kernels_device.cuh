@@ -771,14 +771,25 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream(const uint8_t* __r
             }
     }
     if (one_record) {
-        uint64_t* dst = out + (sm_roff[2] + (t0 + a - shift - sm_roff[0]));  // (wraps harmlessly when the lane has no valid window)
-        if (a >= w_lo && a + 4u <= w_hi) {
-            store_codes_nt(dst, hv[0], hv[1]);
-            store_codes_nt(dst + 2, hv[2], hv[3]);
-        } else {
+        // A lane holds 4 consecutive codes: stored from the registers, a 16-byte store of a wave covers 2 KB of memory half-filled (lane stride 32 B).
+        // Through LDS instead (the hash array is free once every lane has read its bases) they leave as fully coalesced stores: 1 KB contiguous per
+        // wave and instruction (the eight-per-lane kernel, where the stride is 64 B, gained 8 % from this: profiles/r03_stream8.txt).
+        __syncthreads();
+        ulonglong2* sm_out = (ulonglong2*)sm_hash;  // kStreamPos codes <= the hash array
+        static_assert(hash_slots<BLOCK>() >= (uint32_t)kStreamPos, "the staged codes fit the hash array");
+        sm_out[2u * tid] = make_ulonglong2(hv[0], hv[1]);
+        sm_out[2u * tid + 1u] = make_ulonglong2(hv[2], hv[3]);
+        __syncthreads();
+        uint64_t* const dst0 = out + (sm_roff[2] + (t0 - shift - sm_roff[0]));  // code of window 0 of the tile (wraps harmlessly for windows before the record)
 #pragma unroll
-            for (uint32_t jw = 0; jw < 4; ++jw)
-                if (code[jw] != 0xFFFEu) __builtin_nontemporal_store(hv[jw], dst + jw);
+        for (uint32_t i = 0; i < 2u; ++i) {
+            const uint32_t idx = i * 2u * (uint32_t)BLOCK + 2u * tid;  // windows idx, idx + 1
+            const ulonglong2 v = sm_out[idx / 2u];
+            if (idx >= w_lo && idx + 2u <= w_hi) store_codes_nt(dst0 + idx, v.x, v.y);
+            else {
+                if (idx >= w_lo && idx < w_hi) __builtin_nontemporal_store((uint64_t)v.x, dst0 + idx);
+                if (idx + 1u >= w_lo && idx + 1u < w_hi) __builtin_nontemporal_store((uint64_t)v.y, dst0 + idx + 1u);
+            }
         }
     } else {
         // the walk of phase C again, from the record found there: where each window's code goes

@@ -1,0 +1,378 @@
+// stream8_device.cuh -- the streaming kernel for WIDE windows (W = k - m + 1 >= kBlockMinW): eight m-mer positions and windows per lane.
+//
+// Same tile (1024 m-mer positions, windows cut as stream_tile_windows says), same phases A-F and same results as k_query_tiles_stream
+// (kernels_device.cuh; MPHF::operator()(.., streaming=true), include/partitioned_mphf.hpp:78-184), with 128 threads instead of 256: a lane owns
+// the block of 8 consecutive positions a .. a+7, a = 8 * tid.  Why: at W = 44 the 4-per-lane kernel issues 602 VALU instructions per wave of
+// which 96 are the hashes (profiles/r03_stream_phases_k63.txt) -- the rest is per-LANE and per-WAVE work (addressing, the block range every
+// window of a lane shares, ballots, barriers) that this shape pays once per 8 windows instead of once per 4:
+//   C  window a+j = own suffix S[j] + the blocks all eight windows cover (l+1 .. l+nf0, nf0 = (W-8)/8: 4 reads at W = 44, against 10 per four
+//      windows) + at most one more whole block + a prefix of the block after it
+//   D  one cross-lane move and one LDS atomic per 8 windows; two waves meet at the barriers instead of four
+// Ties keep the LEFT position throughout (candidates are taken left to right with a strict `<`), as the strict `>` comparisons of
+// include/partitioned_mphf.hpp:122,150-163 do.
+#pragma once
+#include "kernels_device.cuh"
+
+namespace lphq {
+
+constexpr uint32_t kStream8MinW = 24;                  // the launcher uses this kernel for W >= kStream8MinW (it needs W >= 8)
+constexpr int kS8Block = 128;                          // threads per workgroup
+constexpr int kS8Pos = 8 * kS8Block;                   // m-mer positions per tile (= 4 * kStreamBlockDefault: the tiles of both kernels coincide)
+constexpr uint32_t kS8Row = (uint32_t)kS8Block + 9u;   // blocks per row of prefix minima: a lane reads up to block l + 8 (W <= 62); the 9 beyond the tile hold ~0
+static_assert(kS8Pos == 4 * kStreamBlockDefault, "the launcher sizes the grid for one tile geometry");
+// slot of position i in phases E-F (the leader's base): column i % 8, block i / 8
+__device__ __forceinline__ uint32_t hslot8(uint32_t i) { return (i & 7u) * kS8Row + (i >> 3); }
+
+struct BlockMin8 {   // a lane's suffix minima S[1..7] over a+j .. a+7 (S[0] is the block minimum, re-read from LDS), alive from phase B to phase C
+    uint64_t h[7];
+    uint32_t p;      // their positions within the block, 3 bits each: S[1] | S[2] << 3 | ...
+};
+
+// Publishes (column c of sm_hash) the prefix minima P[c] over a .. a+c -- P[7] is the minimum M of the block -- and, 3 bits each in one word,
+// which position each of them is (P[0] is position 0); returns the suffix minima.
+__device__ __forceinline__ BlockMin8 publish_block_minima8(uint64_t* __restrict__ sm_hash, uint32_t* __restrict__ sm_off, uint32_t tid, const uint64_t (&h)[8]) {
+    HashPos p{h[0], 0};
+    sm_hash[tid] = p.h;
+    uint32_t ob = 0;
+#pragma unroll
+    for (uint32_t c = 1; c < 8; ++c) {
+        take_if_less(p, h[c], c);
+        sm_hash[c * kS8Row + tid] = p.h;
+        ob |= p.p << (3u * c);
+    }
+    sm_off[tid] = ob;
+    BlockMin8 s;
+    uint64_t cur = h[7];
+    uint32_t cp = 7;
+    s.h[6] = cur;
+    s.p = cp << 18;
+#pragma unroll
+    for (int j = 6; j >= 1; --j) {
+        const bool le = h[j] <= cur;  // `<=`: scanning from the right, the left one wins ties
+        cur = le ? h[j] : cur;
+        cp = le ? (uint32_t)j : cp;
+        s.h[j - 1] = cur;
+        s.p |= cp << (3u * (uint32_t)(j - 1));
+    }
+    return s;
+}
+
+// Leftmost minimum of the 8 consecutive windows starting at local positions a .. a+7, each W >= 8 positions wide -> q[0..7] (local positions).
+// id of a candidate: (t << 3) | c for column c of the block t lanes to the right; for the own block (t = 0) c is the position itself.
+__device__ __forceinline__ void window_argmin8(const uint64_t* __restrict__ sm_hash, const uint32_t* __restrict__ sm_off, uint32_t tid, uint32_t W, const BlockMin8& s,
+                                               uint32_t (&q)[8]) {
+    const uint64_t* colM = sm_hash + 7u * kS8Row + tid;  // M of the block t lanes to the right: colM[t]
+    const uint32_t nf0 = (W - 8u) >> 3;                  // blocks covered completely by all eight windows: l+1 .. l+nf0
+    HashPos r{~0ull, 0};
+    if (nf0) {
+        r = HashPos{colM[1], (1u << 3) | 7u};
+        for (uint32_t t = 2; t <= nf0; ++t) take_if_less(r, colM[t], (t << 3) | 7u);
+    }
+    const uint32_t ob0 = sm_off[tid];
+    HashPos w[8];
+    w[0] = HashPos{colM[0], (ob0 >> 21) & 7u};
+#pragma unroll
+    for (uint32_t j = 1; j < 8; ++j) w[j] = HashPos{s.h[j - 1], (s.p >> (3u * (j - 1u))) & 7u};
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) {
+        const uint32_t nf = (j + W - 8u) >> 3, hc = (j + W - 8u) & 7u;  // uniform over the wave
+        take_if_less(w[j], r.h, r.p);                                      // (no full block: r.h = ~0, never smaller)
+        if (nf > nf0) take_if_less(w[j], colM[nf], (nf << 3) | 7u);
+        if (hc) take_if_less(w[j], sm_hash[(hc - 1u) * kS8Row + tid + nf + 1u], ((nf + 1u) << 3) | (hc - 1u));
+        const uint32_t t = w[j].p >> 3, c = w[j].p & 7u;
+        const uint32_t off = (sm_off[tid + t] >> (3u * c)) & 7u;  // place of that block's P[c] (t = 0 reads the own word and ignores it)
+        q[j] = 8u * (tid + t) + (t ? off : c);
+    }
+}
+
+template <int KIND, bool K128, int P>
+__global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al, uint64_t shift, uint64_t total,
+                                                                  const uint64_t* __restrict__ seq_off, const uint64_t* __restrict__ out_off, uint32_t n_records,
+                                                                  uint64_t* __restrict__ out, uint64_t tile_base /* first tile of this launch */) {
+    const lphq_image_header& H = *(const lphq_image_header*)img;
+    constexpr int BLOCK = kS8Block, NW = tile_words(kS8Pos);
+    constexpr int NDW = (NW + 1) * 4;          // dwords of sequence (4 bases each) the tile loads: two per lane, the NDW - 2 * BLOCK beyond by lanes of the last wave
+    constexpr uint32_t NX = (uint32_t)(NDW - 2 * BLOCK);
+    static_assert(NDW > 2 * BLOCK && NX <= 64, "the dwords beyond the first 2 * BLOCK are loaded by the lanes of the last wave");
+    __shared__ uint64_t sm_hash[8 * kS8Row];   // phase B-C: prefix minima of every block (column c, block b at c * kS8Row + b); phase E-F: the leader's base
+    __shared__ uint32_t sm_words[NW + 8];
+    __shared__ uint8_t sm_badb[NDW + 12];      // bad-base flags, one byte per sequence dword (written by the lane that packs the dword)
+    __shared__ uint32_t sm_anybad[BLOCK / 64];
+    __shared__ uint16_t sm_queue[kS8Pos];
+    __shared__ uint8_t sm_mode[kS8Pos];
+    __shared__ uint32_t sm_off[kS8Row + 1];    // phase B-C: where in its block each published prefix minimum sits (3 bits each)
+    __shared__ uint32_t sm_rec[2], sm_count;
+    __shared__ uint64_t sm_roff[3];                // seq_off[rlo], seq_off[rlo+1], out_off[rlo]
+    __shared__ uint64_t sm_rtab[2 * kRecCap + 1];  // multi-record tiles: the tile's slice of seq_off / out_off
+    const uint32_t tid = threadIdx.x;
+    const uint32_t k = H.k, m = H.m, W = H.W;
+    const uint32_t TW = stream_tile_windows(W, kS8Pos);
+    const uint64_t t0 = (tile_base + blockIdx.x) * TW;  // shifted coordinate of the tile's first window start
+
+    // ---- A: sequence dwords first (no dependence on the record search), then the search, then pack into LDS ----
+    const bool interior = t0 >= shift && t0 + 4ull * (uint64_t)NDW <= shift + total;  // (uniform) every dword the tile loads lies inside the batch
+    const uint32_t dd[3] = {2u * tid, 2u * tid + 1u, 2u * (uint32_t)BLOCK + (tid - 64u)};
+    const bool live2 = tid >= 64u && tid - 64u < NX;
+    uint32_t xs[3] = {0u, 0u, 0u};
+    bool have[3];
+    if (interior) {
+        const uint2 v = *(const uint2*)(seq_al + t0 + 8ull * tid);  // (t0 and seq_al are 16-byte aligned)
+        xs[0] = v.x;
+        xs[1] = v.y;
+        have[0] = have[1] = true;
+        have[2] = live2;
+        if (live2) xs[2] = *(const uint32_t*)(seq_al + t0 + 4ull * dd[2]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const uint64_t a = t0 + 4ull * dd[r];
+            have[r] = (r < 2 || live2) && a < shift + total && a + 4u > shift;
+            if (have[r]) xs[r] = *(const uint32_t*)(seq_al + a);
+        }
+    }
+    if (tid < 64) {  // wave 0: record of the first base the tile can touch, and of the last
+        const uint64_t gfirst = t0 > shift ? t0 - shift : 0;
+        uint64_t glast = t0 + TW + 64 > shift ? t0 + TW + 64 - shift : 0;
+        if (glast >= total) glast = total ? total - 1 : 0;
+        const uint32_t r = find_record_wave(seq_off, n_records, gfirst);
+        const uint64_t s0 = seq_off[r], e0 = seq_off[r + 1];
+        const uint32_t r2 = glast < e0 ? r : find_record_wave(seq_off, n_records, glast);  // uniform over the wave
+        if (tid == 0) {
+            sm_rec[0] = r;
+            sm_rec[1] = r2;
+            sm_roff[0] = s0;
+            sm_roff[1] = e0;
+            sm_roff[2] = out_off[r];
+            sm_count = 0;
+        }
+    }
+    if (tid < 12u) sm_badb[NDW + tid] = 0xFu;  // beyond the tile's dwords: not bases
+    for (int c = NW + 1 + tid; c < NW + 8; c += BLOCK) sm_words[c] = 0;
+    bool real_bad = false;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        if (r < 2 || live2) {
+            const uint32_t d = dd[r];
+            const uint64_t a = t0 + 4ull * d;
+            uint32_t p8 = 0, b4 = 0xFu;
+            if (have[r]) {
+                p8 = pack4(xs[r], b4);
+                uint32_t outside = 0;  // bytes of the dword that are not bases of the batch
+                if (!interior && (a < shift || a + 4u > shift + total))
+                    for (int i = 0; i < 4; ++i)
+                        if (a + i < shift || a + i >= shift + total) outside |= 1u << i;
+                real_bad = real_bad || (b4 & ~outside);  // a real non-ACGT base
+                b4 |= outside;
+            }
+            ((uint8_t*)sm_words)[(d & ~3u) + (3u - (d & 3u))] = (uint8_t)p8;  // first base in the top bits of each 32-bit word
+            sm_badb[d] = (uint8_t)b4;
+        }
+    }
+    {
+        const bool wave_bad = __any(real_bad);
+        if ((tid & 63u) == 0u) sm_anybad[tid >> 6] = wave_bad ? 1u : 0u;
+    }
+    __syncthreads();
+    if (sm_rec[0] != sm_rec[1]) load_record_table(sm_rtab, seq_off, out_off, sm_rec[0], sm_rec[1], tid);  // (kRecCap + 1 <= BLOCK; visible to phase C through the next barrier)
+    static_assert(kRecCap + 1 <= kS8Block, "load_record_table: one lane per table entry");
+
+    // ---- B: hashes of the m-mers starting at local positions 8*lane .. 8*lane+7; prefix minima of the block published for phase C ----
+    const uint32_t a = 8u * tid;
+    BlockMin8 bmin;
+    {
+        const uint64_t mm_seedx = murmur_seedx(H.mm_seed);
+        const uint32_t w0 = a >> 4, o = (a & 15u) * 2u;  // o = 0 or 16
+        const uint32_t x0 = sm_words[w0], x1 = sm_words[w0 + 1], x2 = sm_words[w0 + 2], x3 = sm_words[w0 + 3];
+        const uint64_t A64 = ((uint64_t)x0 << 32) | x1, C64 = ((uint64_t)x2 << 32) | x3;
+        const uint64_t s0 = o ? ((A64 << o) | ((uint64_t)x2 >> (32 - o))) : A64;  // bits [0, 64) of the stream at base a
+        const uint64_t s1 = o ? (C64 << o) : C64;                                  // bits [64, 128): the top 14 are needed at most
+        const uint32_t sh = 64u - 2u * m;
+        const uint64_t mask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
+        uint64_t h[8];
+        if (m <= 25u) {  // (uniform) the eight m-mers end inside the first 64 bits: one shift each
+#pragma unroll
+            for (uint32_t r = 0; r < 8; ++r) h[r] = murmur8((s0 >> (sh - 2 * r)) & mask, mm_seedx);
+        } else {
+#pragma unroll
+            for (uint32_t r = 0; r < 8; ++r) {
+                const uint64_t v = r == 0 ? (s0 >> sh) : (((s0 << (2 * r)) | (s1 >> (64 - 2 * r))) >> sh);
+                h[r] = murmur8(v & mask, mm_seedx);
+            }
+        }
+        bmin = publish_block_minima8(sm_hash, sm_off, tid, h);
+        if (tid < 72u) sm_hash[(tid / 9u) * kS8Row + (uint32_t)BLOCK + tid % 9u] = ~0ull;  // blocks beyond the tile: never a minimum
+        if (tid < 10u) sm_off[(uint32_t)BLOCK + tid] = 0;
+    }
+    __syncthreads();
+
+    // ---- C + D: leftmost minimum of the lane's 8 windows, their validity, leaders -> queue ----
+    const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];
+    const bool one_record = rlo == rhi;
+    bool anybad = false;
+#pragma unroll
+    for (int wv = 0; wv < BLOCK / 64; ++wv) anybad = anybad || sm_anybad[wv] != 0u;
+    // one record: window i of the tile is a window of the record iff w_lo <= i < w_hi
+    const uint32_t w_lo = t0 >= shift ? 0u : (uint32_t)(shift - t0);
+    uint32_t w_hi = 0;
+    {
+        const uint64_t limit = sm_roff[1] + shift;  // shifted coordinate of the record's end
+        if (limit >= t0 + k) w_hi = (uint32_t)min((uint64_t)TW, limit - k - t0 + 1u);
+    }
+    uint32_t code[8];  // minimizer position of the window; 0xFFFF: holds a non-ACGT base; 0xFFFE: not a window of any record
+    uint32_t jrec = 0, jcur = 0;  // multi-record tiles: record (relative to rlo) of the lane's first in-batch window, and a cursor
+    {
+        uint32_t q[8];
+        window_argmin8(sm_hash, sm_off, tid, W, bmin, q);
+        if (one_record) {
+#pragma unroll
+            for (uint32_t jw = 0; jw < 8; ++jw) code[jw] = (a + jw >= w_lo && a + jw < w_hi) ? q[jw] : 0xFFFEu;
+        } else {
+            bool found = false;
+            uint64_t rs = 0, re = 0;
+#pragma unroll
+            for (uint32_t jw = 0; jw < 8; ++jw) {
+                const uint32_t i = a + jw;
+                const uint64_t ga = t0 + i;
+                uint32_t v = 0xFFFEu;
+                if (i < TW && ga >= shift && ga - shift + k <= total) {
+                    const uint64_t g = ga - shift;
+                    if (!found) {  // one search per lane; its record index is kept for phase F
+                        jrec = tile_record(sm_rtab, seq_off, rlo, rhi, g, rs, re);
+                        jcur = jrec;
+                        found = true;
+                    }
+                    rec_walk(sm_rtab, seq_off, rlo, rhi - rlo < (uint32_t)kRecCap, g, jcur, rs, re);
+                    if (g + k <= re) v = q[jw];
+                }
+                code[jw] = v;
+            }
+        }
+        if (anybad) {  // uniform over the workgroup
+            const uint64_t kmask = (1ull << k) - 1ull;  // k <= 63
+            // bad-base bits [a, a + 72): windows a..a+7 need bits up to a + 7 + 62; one nibble per sequence dword, the lane's first dword is 2 * tid
+            uint64_t blo = 0;
+#pragma unroll
+            for (uint32_t d = 0; d < 16; ++d) blo |= (uint64_t)(sm_badb[2u * tid + d] & 0xFu) << (4 * d);
+            const uint32_t bhi = (sm_badb[2u * tid + 16u] & 0xFu) | ((uint32_t)(sm_badb[2u * tid + 17u] & 0xFu) << 4);
+#pragma unroll
+            for (uint32_t jw = 0; jw < 8; ++jw) {
+                const uint64_t x = jw ? ((blo >> jw) | ((uint64_t)bhi << (64 - jw))) : blo;
+                if (code[jw] != 0xFFFEu && (x & kmask)) code[jw] = 0xFFFFu;
+            }
+        }
+    }
+    {
+        const uint32_t lane = tid & 63u;
+        uint32_t prev = __shfl(code[7], (int)((lane + 63u) & 63u), 64);  // last window of the lane to the left
+        if (lane == 0) prev = 0xFFFEu;                                     // it lives in another wave: queue the window regardless
+        bool lead[8];
+        uint64_t bal[8];
+        uint32_t total_leaders = 0;
+#pragma unroll
+        for (uint32_t jw = 0; jw < 8; ++jw) {
+            lead[jw] = code[jw] < 0xFFFEu && code[jw] != (jw ? code[jw - 1] : prev);
+            bal[jw] = __ballot(lead[jw]);
+            total_leaders += (uint32_t)__popcll(bal[jw]);
+        }
+        uint32_t base = 0;
+        if (lane == 0 && total_leaders) base = atomicAdd(&sm_count, total_leaders);
+        base = __shfl(base, 0, 64);
+        const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (uint32_t jw = 0; jw < 8; ++jw) {
+            if (lead[jw]) sm_queue[base + (uint32_t)__popcll(bal[jw] & lt)] = (uint16_t)code[jw];
+            base += (uint32_t)__popcll(bal[jw]);
+        }
+    }
+    __syncthreads();
+
+    // ---- E: one lookup per super-k-mer, dense lanes ----
+    const uint32_t nlead = sm_count;
+    for (uint32_t x = tid; x < nlead; x += BLOCK) {
+        const uint32_t q = sm_queue[x];
+        uint64_t mm, hi;
+        extract_kmer<false>(sm_words, q, m, mm, hi);
+        const LookupCtx c = lookup_ctx<KIND, K128, P>(img, H, mm);
+        sm_hash[hslot8(q)] = c.base;
+        sm_mode[q] = (uint8_t)c.mode;
+    }
+    __syncthreads();
+
+    // ---- F: the lane's eight codes ----
+    uint64_t hv[8];
+    uint32_t coll = 0;
+#pragma unroll
+    for (uint32_t jw = 0; jw < 8; ++jw) {
+        const uint32_t q = code[jw];
+        const bool valid = q < 0xFFFEu;
+        const uint32_t qq = valid ? q : a + jw;  // (any slot of the tile: the value read is discarded)
+        const uint64_t base = sm_hash[hslot8(qq)];
+        const uint32_t mode = sm_mode[qq];
+        const uint32_t p = qq - (a + jw);
+        const int32_t delta = mode == 0u ? (int32_t)p : -(int32_t)p;  // |p| < 2^16; (mode 2 is redone below)
+        const uint64_t hval = base + (uint64_t)(int64_t)delta;
+        hv[jw] = valid ? hval : ~0ull;  // LPHQ_INVALID
+        coll |= (valid && mode == 2u) ? 1u << jw : 0u;
+    }
+    if (__any(coll != 0u)) {  // windows under a colliding minimizer: the fallback function of the k-mer (src/partitioned_mphf.cpp:312-316)
+#pragma unroll
+        for (uint32_t jw = 0; jw < 8; ++jw)
+            if ((coll >> jw) & 1u) {
+                LookupCtx c;
+                c.base = sm_hash[hslot8(code[jw])];
+                c.mode = 2u;
+                uint64_t lo = 0, hi = 0;
+                extract_kmer<K128>(sm_words, a + jw, k, lo, hi);
+                hv[jw] = finish_hval<K128>(img, H, c, lo, hi, 0u);
+            }
+    }
+    if (one_record) {
+        // A lane holds 8 consecutive codes: stored from the registers, every 16-byte store of a wave would touch 64 different 64-byte segments (lane
+        // stride 64 B) -- measured, that made phase F 45 % slower than the 4-per-lane kernel's (profiles/r03_stream8.txt).  The codes go through LDS
+        // instead (the hash array is free once every lane has read its bases) and leave as four fully coalesced stores: 2 KB contiguous per wave each.
+        __syncthreads();
+        ulonglong2* sm_out = (ulonglong2*)sm_hash;  // kS8Pos codes = 8 KB <= sizeof(sm_hash)
+        static_assert(sizeof(uint64_t) * 8 * kS8Row >= sizeof(uint64_t) * kS8Pos, "the staged codes fit the hash array");
+#pragma unroll
+        for (uint32_t jw = 0; jw < 8; jw += 2) sm_out[4u * tid + jw / 2u] = make_ulonglong2(hv[jw], hv[jw + 1]);
+        __syncthreads();
+        uint64_t* const dst0 = out + (sm_roff[2] + (t0 - shift - sm_roff[0]));  // code of window 0 of the tile (wraps harmlessly for windows before the record)
+#pragma unroll
+        for (uint32_t i = 0; i < (uint32_t)kS8Pos / (2u * BLOCK); ++i) {
+            const uint32_t idx = i * 2u * BLOCK + 2u * tid;  // windows idx, idx + 1
+            const ulonglong2 v = sm_out[idx / 2u];
+            if (idx >= w_lo && idx + 2u <= w_hi) store_codes_nt(dst0 + idx, v.x, v.y);
+            else {
+                if (idx >= w_lo && idx < w_hi) __builtin_nontemporal_store((uint64_t)v.x, dst0 + idx);
+                if (idx + 1u >= w_lo && idx + 1u < w_hi) __builtin_nontemporal_store((uint64_t)v.y, dst0 + idx + 1u);
+            }
+        }
+    } else {
+        // the walk of phase C again, from the record found there: where each window's code goes
+        const bool cached = rhi - rlo < (uint32_t)kRecCap;
+        uint32_t j = jrec;
+        uint64_t rs = cached ? sm_rtab[j] : seq_off[rlo + j], re = cached ? sm_rtab[j + 1] : seq_off[rlo + j + 1];
+        uint64_t oidx[8];
+#pragma unroll
+        for (uint32_t jw = 0; jw < 8; ++jw) {
+            oidx[jw] = 0;
+            if (code[jw] == 0xFFFEu) continue;
+            const uint64_t g = t0 + a + jw - shift;
+            rec_walk(sm_rtab, seq_off, rlo, cached, g, j, rs, re);
+            oidx[jw] = tile_record_out(sm_rtab, out_off, rlo, rhi, j) + (g - rs);
+        }
+        bool all8 = oidx[7] == oidx[0] + 7u;
+#pragma unroll
+        for (uint32_t jw = 0; jw < 8; ++jw) all8 = all8 && code[jw] != 0xFFFEu;
+        if (all8) {  // eight windows of one record (the common case for reads)
+#pragma unroll
+            for (uint32_t jw = 0; jw < 8; jw += 2) store_codes_nt(out + oidx[0] + jw, hv[jw], hv[jw + 1]);
+        } else {
+#pragma unroll
+            for (uint32_t jw = 0; jw < 8; ++jw)
+                if (code[jw] != 0xFFFEu) __builtin_nontemporal_store(hv[jw], out + oidx[jw]);
+        }
+    }
+}
+
+}  // namespace lphq

@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "kernels_device.cuh"  // -Itests/emu resolves <hip/hip_runtime.h> to the stub
+#include "stream8_device.cuh"
 #include "extract_device.cuh"
 
 using namespace lphq;
@@ -52,13 +53,17 @@ extern "C" int emu_kernel_query_records(const uint8_t* img, size_t nbytes, const
     const uint8_t* seq_al = (const uint8_t*)seq - shift;
     const uint64_t span = shift + total;
     if (streaming && H.kind < 2) {
-        const uint64_t tw = stream_tile_windows(H.W, 4 * (block & 0xFFFF));
+        /* eight positions per lane (stream8_device.cuh): forced by 0x40000 for any W >= 8, or -- as the launcher does -- for wide windows unless a form is forced */
+        const bool s8 = H.W >= 8 && ((block & 0x40000) || (!(block & 0x30000) && H.W >= kBlockMinW && H.P == 6));
+        const uint64_t tw = stream_tile_windows(H.W, s8 ? kS8Pos : 4 * (block & 0xFFFF));
         const unsigned tiles = (unsigned)((span + tw - 1) / tw);
 #define CALL(KIND, K128, P)                                                                                                                             \
     do {                                                                                                                                                \
         const bool blk = (block & 0x10000) ? true : ((block & 0x20000) ? false : H.W >= kBlockMinW); /* forced either way, or as the launcher chooses */ \
         const int bs = block & 0xFFFF;                                                                                                                    \
-        if (H.W >= 4 && blk) {                                                                                                                            \
+        if (s8) {                                                                                                                                         \
+            emu::launch(tiles, kS8Block, [&] { k_query_tiles_stream8<KIND, K128, P>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0); });    \
+        } else if (H.W >= 4 && blk) {                                                                                                                            \
             if (bs == 128) emu::launch(tiles, 128, [&] { k_query_tiles_stream<KIND, K128, P, 128, true>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0); }); \
             else emu::launch(tiles, 256, [&] { k_query_tiles_stream<KIND, K128, P, 256, true>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0); });            \
         } else if (bs == 128) emu::launch(tiles, 128, [&] { k_query_tiles_stream<KIND, K128, P, 128, false>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0); }); \

@@ -142,7 +142,11 @@ def test_tile_kernels_on_the_emulator(emuk, tmp_path, k, m, bits, kind):
     batch += random_records(11, 150, 0, 5) + [recs[0][:k + 2]] + random_records(12, 40, k, k + 20) + [recs[1]]
     exp = [o(r, False) for r in batch]
     BLK, RAW = 0x10000, 0x20000  # window minima by block decomposition / in the direct form, whatever W (the launcher picks by W)
-    for streaming, mis, block in ((True, 0, 256), (True, 5, 256 | BLK), (True, 15, 128 | RAW), (False, 0, 256), (False, 9, 256), (True, 7, 256 | RAW), (True, 2, 128 | BLK)):
+    S8 = 0x40000                 # eight positions per lane (stream8_device.cuh), whatever W >= 8 (the launcher: W >= 24)
+    runs = [(True, 0, 256), (True, 5, 256 | BLK), (True, 15, 128 | RAW), (False, 0, 256), (False, 9, 256), (True, 7, 256 | RAW), (True, 2, 128 | BLK)]
+    if k - m + 1 >= 8:
+        runs += [(True, 0, 128 | S8), (True, 11, 128 | S8)]
+    for streaming, mis, block in runs:
         got = emu_records(emuk, h, batch, k, streaming, mis, block)
         for g, e in zip(got, exp):
             assert np.array_equal(g, e), (streaming, mis, block)
@@ -166,14 +170,15 @@ def test_tile_kernels_non_acgt_on_the_emulator(emuk, tmp_path):
     got_s = emu_records(emuk, h, batch, k, True)
     got_r = emu_records(emuk, h, batch, k, False)
     got_p = emu_records(emuk, h, batch, k, True, 3)  # another pointer alignment
-    for q, gs, gr, gp in zip(batch, got_s, got_r, got_p):
+    got_8 = emu_records(emuk, h, batch, k, True, 6, 128 | 0x40000)  # the eight-positions-per-lane kernel
+    for q, gs, gr, gp, g8 in zip(batch, got_s, got_r, got_p, got_8):
         exp = o(q, False)  # random mode reads a non-ACGT base as 'A' (mphf_utils.hpp:108)
         assert np.array_equal(gr, exp)
         bad = np.array([c not in b"ACGTUacgtu" for c in q])
         csum = np.concatenate([[0], np.cumsum(bad)])
         valid = (csum[k:] - csum[:-k]) == 0
         assert np.array_equal(gs[valid], exp[valid]) and np.all(gs[~valid] == np.uint64(L.INVALID))
-        assert np.array_equal(gp, gs)
+        assert np.array_equal(gp, gs) and np.array_equal(g8, gs)
         cnt = C.c_ulonglong()
         gs = np.ascontiguousarray(gs)
         assert emuk.emu_kernel_count_valid(gs.ctypes.data, len(gs), C.byref(cnt)) == 0 and cnt.value == int(valid.sum())
