@@ -134,18 +134,21 @@ __device__ __forceinline__ uint32_t find_record_wave(const uint64_t* __restrict_
 // they average < 17 bases; such tiles (and nothing else) keep searching the global offset arrays.  Layout of the table:
 // seq_off[rlo .. rlo + n] (n + 1 entries), then from entry kRecCap + 1 on out_off[rlo .. rlo + n - 1].
 constexpr int kRecCap = 64;
+// (CAP: records the table holds; the eight-per-lane kernel keeps 32 to leave LDS for one more workgroup per CU)
+template <int CAP = kRecCap>
 __device__ __forceinline__ void load_record_table(uint64_t* __restrict__ rtab, const uint64_t* __restrict__ seq_off, const uint64_t* __restrict__ out_off,
                                                   uint32_t rlo, uint32_t rhi, uint32_t tid) {
     const uint32_t n = rhi - rlo + 1u;
-    if (n > 1u && n <= (uint32_t)kRecCap) {
+    if (n > 1u && n <= (uint32_t)CAP) {
         if (tid <= n) rtab[tid] = seq_off[rlo + tid];
-        if (tid < n) rtab[kRecCap + 1 + tid] = out_off[rlo + tid];
+        if (tid < n) rtab[CAP + 1 + tid] = out_off[rlo + tid];
     }
 }
 // record of base g (rlo <= record <= rhi, rlo != rhi): index, first base and end
+template <int CAP = kRecCap>
 __device__ __forceinline__ uint32_t tile_record(const uint64_t* __restrict__ rtab, const uint64_t* __restrict__ seq_off, uint32_t rlo, uint32_t rhi, uint64_t g,
                                                 uint64_t& start, uint64_t& end) {
-    if (rhi - rlo < (uint32_t)kRecCap) {
+    if (rhi - rlo < (uint32_t)CAP) {
         const uint32_t j = find_record(rtab, 0, rhi - rlo, g);
         start = rtab[j];
         end = rtab[j + 1];
@@ -156,8 +159,9 @@ __device__ __forceinline__ uint32_t tile_record(const uint64_t* __restrict__ rta
     end = seq_off[r + 1];
     return r - rlo;
 }
+template <int CAP = kRecCap>
 __device__ __forceinline__ uint64_t tile_record_out(const uint64_t* __restrict__ rtab, const uint64_t* __restrict__ out_off, uint32_t rlo, uint32_t rhi, uint32_t j) {
-    return (rhi - rlo < (uint32_t)kRecCap) ? rtab[kRecCap + 1 + j] : out_off[rlo + j];
+    return (rhi - rlo < (uint32_t)CAP) ? rtab[CAP + 1 + j] : out_off[rlo + j];
 }
 
 // 2k bits starting at base q of the LDS-packed tile

@@ -18,6 +18,7 @@ namespace lphq {
 constexpr uint32_t kStream8MinW = 24;                  // the launcher uses this kernel for W >= kStream8MinW (it needs W >= 8)
 constexpr int kS8Block = 128;                          // threads per workgroup
 constexpr int kS8Pos = 8 * kS8Block;                   // m-mer positions per tile (= 4 * kStreamBlockDefault: the tiles of both kernels coincide)
+constexpr int kS8RecCap = 32;                          // records of a multi-record tile cached in LDS (more: the global offset arrays are searched)
 constexpr uint32_t kS8Row = (uint32_t)kS8Block + 9u;   // blocks per row of prefix minima: a lane reads up to block l + 8 (W <= 62); the 9 beyond the tile hold ~0
 static_assert(kS8Pos == 4 * kStreamBlockDefault, "the launcher sizes the grid for one tile geometry");
 // slot of position i in phases E-F (the leader's base): column i % 8, block i / 8
@@ -94,16 +95,18 @@ __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t*
     constexpr int NDW = (NW + 1) * 4;          // dwords of sequence (4 bases each) the tile loads: two per lane, the NDW - 2 * BLOCK beyond by lanes of the last wave
     constexpr uint32_t NX = (uint32_t)(NDW - 2 * BLOCK);
     static_assert(NDW > 2 * BLOCK && NX <= 64, "the dwords beyond the first 2 * BLOCK are loaded by the lanes of the last wave");
-    __shared__ uint64_t sm_hash[8 * kS8Row];   // phase B-C: prefix minima of every block (column c, block b at c * kS8Row + b); phase E-F: the leader's base
+    __shared__ uint64_t sm_hash[8 * kS8Row];   // phase B-C: prefix minima of every block (column c, block b at c * kS8Row + b); phase E-F: the leader's base | mode << 62
     __shared__ uint32_t sm_words[NW + 8];
     __shared__ uint8_t sm_badb[NDW + 12];      // bad-base flags, one byte per sequence dword (written by the lane that packs the dword)
     __shared__ uint32_t sm_anybad[BLOCK / 64];
-    __shared__ uint16_t sm_queue[kS8Pos];
-    __shared__ uint8_t sm_mode[kS8Pos];
+    // LDS is what limits the waves per CU of this kernel, and waves are what hide its latencies (measured: 13 -> 15 workgroups per CU = +7 %,
+    // profiles/r03_stream8.txt): the leader queue holds one round of BLOCK leaders (tiles with more take further rounds), the leader's mode rides in
+    // the top bits of its base, the record table holds kS8RecCap records -- 10.7 KB per workgroup, 15 workgroups (30 waves) per CU.
+    __shared__ uint16_t sm_queue[kS8Block];
     __shared__ uint32_t sm_off[kS8Row + 1];    // phase B-C: where in its block each published prefix minimum sits (3 bits each)
     __shared__ uint32_t sm_rec[2], sm_count;
-    __shared__ uint64_t sm_roff[3];                // seq_off[rlo], seq_off[rlo+1], out_off[rlo]
-    __shared__ uint64_t sm_rtab[2 * kRecCap + 1];  // multi-record tiles: the tile's slice of seq_off / out_off
+    __shared__ uint64_t sm_roff[3];                   // seq_off[rlo], seq_off[rlo+1], out_off[rlo]
+    __shared__ uint64_t sm_rtab[2 * kS8RecCap + 1];   // multi-record tiles: the tile's slice of seq_off / out_off
     const uint32_t tid = threadIdx.x;
     const uint32_t k = H.k, m = H.m, W = H.W;
     const uint32_t TW = stream_tile_windows(W, kS8Pos);
@@ -173,8 +176,8 @@ __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t*
         if ((tid & 63u) == 0u) sm_anybad[tid >> 6] = wave_bad ? 1u : 0u;
     }
     __syncthreads();
-    if (sm_rec[0] != sm_rec[1]) load_record_table(sm_rtab, seq_off, out_off, sm_rec[0], sm_rec[1], tid);  // (kRecCap + 1 <= BLOCK; visible to phase C through the next barrier)
-    static_assert(kRecCap + 1 <= kS8Block, "load_record_table: one lane per table entry");
+    if (sm_rec[0] != sm_rec[1]) load_record_table<kS8RecCap>(sm_rtab, seq_off, out_off, sm_rec[0], sm_rec[1], tid);  // (visible to phase C through the next barrier)
+    static_assert(kS8RecCap + 1 <= kS8Block, "load_record_table: one lane per table entry");
 
     // ---- B: hashes of the m-mers starting at local positions 8*lane .. 8*lane+7; prefix minima of the block published for phase C ----
     const uint32_t a = 8u * tid;
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t*
     }
     __syncthreads();
 
-    // ---- C + D: leftmost minimum of the lane's 8 windows, their validity, leaders -> queue ----
+    // ---- C + D: leftmost minimum of the lane's 8 windows, their validity; leaders -> queue (publish_leaders below) ----
     const uint32_t rlo = sm_rec[0], rhi = sm_rec[1];
     const bool one_record = rlo == rhi;
     bool anybad = false;
@@ -237,11 +240,11 @@ __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t*
                 if (i < TW && ga >= shift && ga - shift + k <= total) {
                     const uint64_t g = ga - shift;
                     if (!found) {  // one search per lane; its record index is kept for phase F
-                        jrec = tile_record(sm_rtab, seq_off, rlo, rhi, g, rs, re);
+                        jrec = tile_record<kS8RecCap>(sm_rtab, seq_off, rlo, rhi, g, rs, re);
                         jcur = jrec;
                         found = true;
                     }
-                    rec_walk(sm_rtab, seq_off, rlo, rhi - rlo < (uint32_t)kRecCap, g, jcur, rs, re);
+                    rec_walk(sm_rtab, seq_off, rlo, rhi - rlo < (uint32_t)kS8RecCap, g, jcur, rs, re);
                     if (g + k <= re) v = q[jw];
                 }
                 code[jw] = v;
@@ -261,42 +264,56 @@ __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t*
             }
         }
     }
-    {
+    // D: windows whose minimizer position differs from their left neighbour's lead a super-k-mer.  Leader number n of the tile (numbered wave by wave,
+    // window slot by window slot, lane by lane -- any order will do, lookups are independent) goes to queue entry n - r0 of the round that starts at r0.
+    uint32_t wbase = 0;  // number of the wave's first leader
+    auto publish_leaders = [&](uint32_t r0, bool first) {
         const uint32_t lane = tid & 63u;
         uint32_t prev = __shfl(code[7], (int)((lane + 63u) & 63u), 64);  // last window of the lane to the left
         if (lane == 0) prev = 0xFFFEu;                                     // it lives in another wave: queue the window regardless
-        bool lead[8];
-        uint64_t bal[8];
-        uint32_t total_leaders = 0;
+        auto leads = [&](uint32_t jw) { return code[jw] < 0xFFFEu && code[jw] != (jw ? code[jw - 1] : prev); };
+        if (first) {
+            uint32_t wave_leaders = 0;
 #pragma unroll
-        for (uint32_t jw = 0; jw < 8; ++jw) {
-            lead[jw] = code[jw] < 0xFFFEu && code[jw] != (jw ? code[jw - 1] : prev);
-            bal[jw] = __ballot(lead[jw]);
-            total_leaders += (uint32_t)__popcll(bal[jw]);
+            for (uint32_t jw = 0; jw < 8; ++jw) wave_leaders += (uint32_t)__popcll(__ballot(leads(jw)));
+            uint32_t b = 0;
+            if (lane == 0 && wave_leaders) b = atomicAdd(&sm_count, wave_leaders);
+            wbase = __shfl(b, 0, 64);
         }
-        uint32_t base = 0;
-        if (lane == 0 && total_leaders) base = atomicAdd(&sm_count, total_leaders);
-        base = __shfl(base, 0, 64);
-        const uint64_t lt = (1ull << lane) - 1ull;
+        uint32_t n = wbase - r0;  // (wraps for leaders of earlier rounds: their entry number is then >= BLOCK)
 #pragma unroll
-        for (uint32_t jw = 0; jw < 8; ++jw) {
-            if (lead[jw]) sm_queue[base + (uint32_t)__popcll(bal[jw] & lt)] = (uint16_t)code[jw];
-            base += (uint32_t)__popcll(bal[jw]);
+        for (uint32_t jw = 0; jw < 8; ++jw) {  // one ballot alive at a time (eight of them, with the flags, cost 10 more VGPRs in the rare later rounds)
+            const bool ld = leads(jw);
+            const uint64_t bal = __ballot(ld);
+            const uint32_t at = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            if (ld && at < (uint32_t)BLOCK) sm_queue[at] = (uint16_t)code[jw];
+            n += (uint32_t)__popcll(bal);
         }
-    }
+    };
+    publish_leaders(0, true);
     __syncthreads();
 
-    // ---- E: one lookup per super-k-mer, dense lanes ----
+    // ---- E: one lookup per super-k-mer, dense lanes; a round = up to BLOCK leaders, one per lane ----
     const uint32_t nlead = sm_count;
-    for (uint32_t x = tid; x < nlead; x += BLOCK) {
-        const uint32_t q = sm_queue[x];
-        uint64_t mm, hi;
-        extract_kmer<false>(sm_words, q, m, mm, hi);
-        const LookupCtx c = lookup_ctx<KIND, K128, P>(img, H, mm);
-        sm_hash[hslot8(q)] = c.base;
-        sm_mode[q] = (uint8_t)c.mode;
-    }
+    auto lookup_round = [&](uint32_t r0) {
+        if (r0 + tid < nlead) {
+            const uint32_t q = sm_queue[tid];
+            uint64_t mm, hi;
+            extract_kmer<false>(sm_words, q, m, mm, hi);
+            const LookupCtx c = lookup_ctx<KIND, K128, P>(img, H, mm);
+            sm_hash[hslot8(q)] = c.base | ((uint64_t)c.mode << LPHQ_TAIL_MODE_SHIFT);  // (bases are ranks < 2^62: the packing of the image's tail table)
+        }
+    };
+    lookup_round(0);
     __syncthreads();
+    if (__builtin_expect(nlead > (uint32_t)BLOCK, 0)) {  // (uniform) more leaders than lanes: further rounds (W >= 24: super-k-mers average >= 12 windows)
+        for (uint32_t r0 = (uint32_t)BLOCK; r0 < nlead; r0 += (uint32_t)BLOCK) {
+            publish_leaders(r0, false);
+            __syncthreads();
+            lookup_round(r0);
+            __syncthreads();
+        }
+    }
 
     // ---- F: the lane's eight codes ----
     uint64_t hv[8];
@@ -306,8 +323,9 @@ __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t*
         const uint32_t q = code[jw];
         const bool valid = q < 0xFFFEu;
         const uint32_t qq = valid ? q : a + jw;  // (any slot of the tile: the value read is discarded)
-        const uint64_t base = sm_hash[hslot8(qq)];
-        const uint32_t mode = sm_mode[qq];
+        const uint64_t packed = sm_hash[hslot8(qq)];
+        const uint64_t base = packed & LPHQ_TAIL_BASE_MASK;
+        const uint32_t mode = (uint32_t)(packed >> LPHQ_TAIL_MODE_SHIFT);
         const uint32_t p = qq - (a + jw);
         const int32_t delta = mode == 0u ? (int32_t)p : -(int32_t)p;  // |p| < 2^16; (mode 2 is redone below)
         const uint64_t hval = base + (uint64_t)(int64_t)delta;
@@ -319,7 +337,7 @@ __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t*
         for (uint32_t jw = 0; jw < 8; ++jw)
             if ((coll >> jw) & 1u) {
                 LookupCtx c;
-                c.base = sm_hash[hslot8(code[jw])];
+                c.base = sm_hash[hslot8(code[jw])] & LPHQ_TAIL_BASE_MASK;
                 c.mode = 2u;
                 uint64_t lo = 0, hi = 0;
                 extract_kmer<K128>(sm_words, a + jw, k, lo, hi);
@@ -349,7 +367,7 @@ __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t*
         }
     } else {
         // the walk of phase C again, from the record found there: where each window's code goes
-        const bool cached = rhi - rlo < (uint32_t)kRecCap;
+        const bool cached = rhi - rlo < (uint32_t)kS8RecCap;
         uint32_t j = jrec;
         uint64_t rs = cached ? sm_rtab[j] : seq_off[rlo + j], re = cached ? sm_rtab[j + 1] : seq_off[rlo + j + 1];
         uint64_t oidx[8];
@@ -359,7 +377,7 @@ __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t*
             if (code[jw] == 0xFFFEu) continue;
             const uint64_t g = t0 + a + jw - shift;
             rec_walk(sm_rtab, seq_off, rlo, cached, g, j, rs, re);
-            oidx[jw] = tile_record_out(sm_rtab, out_off, rlo, rhi, j) + (g - rs);
+            oidx[jw] = tile_record_out<kS8RecCap>(sm_rtab, out_off, rlo, rhi, j) + (g - rs);
         }
         bool all8 = oidx[7] == oidx[0] + 7u;
 #pragma unroll

@@ -45,6 +45,15 @@ static inline uint32_t __builtin_amdgcn_perm(uint32_t a, uint32_t b, uint32_t se
     }
     return r;
 }
+// v_mbcnt_lo / v_mbcnt_hi: bits of the mask below the calling lane (low / high half of the wave), added to `acc`
+static inline uint32_t __builtin_amdgcn_mbcnt_lo(uint32_t mask, uint32_t acc) {
+    const uint32_t lane = emu::thread_idx().x & 63u;
+    return acc + (uint32_t)__builtin_popcount(mask & (lane >= 32u ? ~0u : ((1u << lane) - 1u)));
+}
+static inline uint32_t __builtin_amdgcn_mbcnt_hi(uint32_t mask, uint32_t acc) {
+    const uint32_t lane = emu::thread_idx().x & 63u;
+    return acc + (lane > 32u ? (uint32_t)__builtin_popcount(mask & ((1u << (lane - 32u)) - 1u)) : 0u);
+}
 static inline int __popc(uint32_t v) { return __builtin_popcount(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
