@@ -105,13 +105,13 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
     for (uint64_t tile_base = 0; tile_base < tiles; tile_base += kMaxTiles) {
         const int grid = (int)std::min<uint64_t>(kMaxTiles, tiles - tile_base);
         if (stream_kernel) {
-            // window minima: direct form, four positions per lane; wide windows (W >= kBlockMinW; P == 6 <=> W > 15) by block decomposition, eight positions
-            // per lane (stream8_device.cuh; same tile geometry, 128 threads)
+            // W <= 15 (P == 4): four positions per lane, window minima in the direct form; W >= 16 (P == 6): eight positions per lane, block decomposition
+            // (stream8_device.cuh; same tile geometry, 128 threads).  The four-per-lane P == 6 variants remain reachable through LPHQ_STREAM8_MINW (A/B runs)
 #define LPHQ_STREAM_LAUNCH(KIND, K128) \
     do { \
-        if (H.W >= s8_min_w) { /* (>= 16, so P == 6) */ \
+        if (H.P == 6 && H.W >= s8_min_w) \
             k_query_tiles_stream8<KIND, K128, 6><<<grid, kS8Block, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
-        } else if (H.P != 6) k_query_tiles_stream<KIND, K128, 4, sblock, false><<<grid, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
+        else if (H.P != 6) k_query_tiles_stream<KIND, K128, 4, sblock, false><<<grid, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
         else if (H.W >= kBlockMinW) k_query_tiles_stream<KIND, K128, 6, sblock, true><<<grid, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
         else k_query_tiles_stream<KIND, K128, 6, sblock, false><<<grid, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
     } while (0)

@@ -1,4 +1,4 @@
-// stream8_device.cuh -- the streaming kernel for WIDE windows (W = k - m + 1 >= kBlockMinW): eight m-mer positions and windows per lane.
+// stream8_device.cuh -- the streaming kernel for windows of W = k - m + 1 >= 16 positions: eight m-mer positions and windows per lane.
 //
 // Same tile (1024 m-mer positions, windows cut as stream_tile_windows says), same phases A-F and same results as k_query_tiles_stream
 // (kernels_device.cuh; MPHF::operator()(.., streaming=true), include/partitioned_mphf.hpp:78-184), with 128 threads instead of 256: a lane owns
@@ -15,7 +15,8 @@
 
 namespace lphq {
 
-constexpr uint32_t kStream8MinW = 24;                  // the launcher uses this kernel for W >= kStream8MinW (it needs W >= 8)
+constexpr uint32_t kStream8MinW = 16;                  // the launcher uses this kernel for W >= kStream8MinW, i.e. whenever P == 6 (measured: W = 12 -1.6 %, W = 17 +7.5 %,
+                                                       // W = 24 +5 %, W = 31 +7 %, W = 44 +20 % against four positions per lane; profiles/r03_stream8.txt).  It needs W >= 8
 constexpr int kS8Block = 128;                          // threads per workgroup
 constexpr int kS8Pos = 8 * kS8Block;                   // m-mer positions per tile (= 4 * kStreamBlockDefault: the tiles of both kernels coincide)
 constexpr int kS8RecCap = 32;                          // records of a multi-record tile cached in LDS (more: the global offset arrays are searched)
