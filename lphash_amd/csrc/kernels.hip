@@ -88,11 +88,11 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
     const uint8_t* seq_al = (const uint8_t*)d_seq - shift;
     const uint64_t span = shift + total_bases;
     // windows at least this wide take the eight-positions-per-lane kernel (measured: profiles/r03_stream8.txt).  LPHQ_STREAM8_MINW (tuning aid, read once,
-    // clamped to [16, 64]; 64 = never) moves the threshold; it changes no result
+    // in [1, 64]; 64 = never) moves the threshold; it changes no result
     static const uint32_t s8_min_w = [] {
         const char* e = getenv("LPHQ_STREAM8_MINW");
         const long v = e ? atol(e) : 0;
-        return (uint32_t)((v >= 16 && v <= 64) ? v : kStream8MinW);
+        return (uint32_t)((v >= 1 && v <= 64) ? v : kStream8MinW);
     }();
     constexpr int sblock = kStreamBlockDefault;  // 256 threads measured best in both rounds (128: -4 %, 512: -6 %, profiles/r02_stream_v4_ab.txt)
     const bool stream_kernel = streaming && H.kind < 2;  // (the competitor harness has one kernel for both values of `streaming`)
@@ -105,13 +105,14 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
     for (uint64_t tile_base = 0; tile_base < tiles; tile_base += kMaxTiles) {
         const int grid = (int)std::min<uint64_t>(kMaxTiles, tiles - tile_base);
         if (stream_kernel) {
-            // W <= 15 (P == 4): four positions per lane, window minima in the direct form; W >= 16 (P == 6): eight positions per lane, block decomposition
-            // (stream8_device.cuh; same tile geometry, 128 threads).  The four-per-lane P == 6 variants remain reachable through LPHQ_STREAM8_MINW (A/B runs)
+            // W >= 8: eight positions per lane (stream8_device.cuh; same tile geometry, 128 threads); narrower windows, and anything below LPHQ_STREAM8_MINW in
+            // A/B runs: four positions per lane
 #define LPHQ_STREAM_LAUNCH(KIND, K128) \
     do { \
-        if (H.P == 6 && H.W >= s8_min_w) \
-            k_query_tiles_stream8<KIND, K128, 6><<<grid, kS8Block, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
-        else if (H.P != 6) k_query_tiles_stream<KIND, K128, 4, sblock, false><<<grid, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
+        if (H.W >= s8_min_w) { \
+            if (H.P == 6) k_query_tiles_stream8<KIND, K128, 6><<<grid, kS8Block, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
+            else k_query_tiles_stream8<KIND, K128, 4><<<grid, kS8Block, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
+        } else if (H.P != 6) k_query_tiles_stream<KIND, K128, 4, sblock, false><<<grid, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
         else if (H.W >= kBlockMinW) k_query_tiles_stream<KIND, K128, 6, sblock, true><<<grid, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
         else k_query_tiles_stream<KIND, K128, 6, sblock, false><<<grid, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
     } while (0)

@@ -1,4 +1,4 @@
-// stream8_device.cuh -- the streaming kernel for windows of W = k - m + 1 >= 16 positions: eight m-mer positions and windows per lane.
+// stream8_device.cuh -- the streaming kernel for windows of W = k - m + 1 >= 8 positions: eight m-mer positions and windows per lane.
 //
 // Same tile (1024 m-mer positions, windows cut as stream_tile_windows says), same phases A-F and same results as k_query_tiles_stream
 // (kernels_device.cuh; MPHF::operator()(.., streaming=true), include/partitioned_mphf.hpp:78-184), with 128 threads instead of 256: a lane owns
@@ -15,8 +15,10 @@
 
 namespace lphq {
 
-constexpr uint32_t kStream8MinW = 16;                  // the launcher uses this kernel for W >= kStream8MinW, i.e. whenever P == 6 (measured: W = 12 -1.6 %, W = 17 +7.5 %,
-                                                       // W = 24 +5 %, W = 31 +7 %, W = 44 +20 % against four positions per lane; profiles/r03_stream8.txt).  It needs W >= 8
+constexpr uint32_t kStream8MinW = 8;                   // the launcher uses this kernel for W >= kStream8MinW: window minima from the raw hashes for W <= 15 (P == 4), by
+                                                       // block decomposition from W = 16 on (P == 6).  Against four positions per lane (profiles/r03_stream8.txt):
+                                                       // W = 8 +1.6 %, W = 12 +3.3 %, W = 17 +7.5 %, W = 24 +5 %, W = 31 +7 %, W = 44 +20 %.  Narrower windows
+                                                       // (every other window leads a super-k-mer) stay with four per lane
 constexpr int kS8Block = 128;                          // threads per workgroup
 constexpr int kS8Pos = 8 * kS8Block;                   // m-mer positions per tile (= 4 * kStreamBlockDefault: the tiles of both kernels coincide)
 constexpr int kS8RecCap = 32;                          // records of a multi-record tile cached in LDS (more: the global offset arrays are searched)
@@ -87,7 +89,60 @@ __device__ __forceinline__ void window_argmin8(const uint64_t* __restrict__ sm_h
     }
 }
 
-template <int KIND, bool K128, int P>
+// The same for NARROW windows (W <= 15, i.e. P == 4) from the raw hashes (column c of sm_hash holds the hash of position 8 * block + c): a window spans at
+// most three blocks, so publishing prefix minima and decoding the winner's place would cost more than they save.  W >= 8: the positions a+7 .. a+W-1 are
+// common to the eight windows (the core); window a+j = the left suffix minimum over a+j .. a+6, the core, the right prefix minimum over a+W .. a+W+j-1 --
+// W + 7 LDS reads and W + 18 compare-selects per lane.  Ties keep the LEFT position (candidates left to right with a strict `<`; the suffix chain runs right
+// to left with `<=`).
+__device__ __forceinline__ void window_argmin8_raw(const uint64_t* __restrict__ sm_hash, uint32_t tid, uint32_t W, uint32_t (&q)[8]) {
+    auto H = [&](uint32_t c) { return sm_hash[(c & 7u) * kS8Row + tid + (c >> 3)]; };  // hash of position a + c
+    const uint32_t a = 8u * tid;
+    if (W >= 8u) {
+        uint64_t Lh[7];   // Lh[j]: leftmost minimum over offsets j .. 6; where it is: 3 bits each in Lp (one register instead of seven: this kernel's
+        uint32_t Lp;      // waves per CU are bounded by its VGPRs as much as by its LDS)
+        {
+            uint64_t cur = H(6);
+            uint32_t cp = 6;
+            Lh[6] = cur;
+            Lp = cp << 18;
+#pragma unroll
+            for (int j = 5; j >= 0; --j) {
+                const uint64_t h = H((uint32_t)j);
+                const bool le = h <= cur;  // `<=`: scanning from the right, the left one wins ties
+                cur = le ? h : cur;
+                cp = le ? (uint32_t)j : cp;
+                Lh[j] = cur;
+                Lp |= cp << (3u * (uint32_t)j);
+            }
+        }
+        HashPos c{H(7), 7};
+        for (uint32_t o = 8; o < W; ++o) take_if_less(c, H(o), o);
+        HashPos r{~0ull, 0};  // right prefix minimum over offsets W .. W + j - 1
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+            HashPos w = c;
+            if (j < 7u) {
+                w = HashPos{Lh[j < 7u ? j : 0], (Lp >> (3u * j)) & 7u};
+                take_if_less(w, c.h, c.p);
+            }
+            if (j > 0u) {
+                take_if_less(r, H(W + j - 1u), W + j - 1u);
+                take_if_less(w, r.h, r.p);
+            }
+            q[j] = a + w.p;
+        }
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+            HashPos c{H(j), j};
+            for (uint32_t t = 1; t < W; ++t) take_if_less(c, H(j + t), j + t);
+            q[j] = a + c.p;
+        }
+    }
+}
+
+// DIRECT: window minima from the raw hashes (narrow windows) instead of block prefix minima
+template <int KIND, bool K128, int P, bool DIRECT = (P == 4)>
 __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al, uint64_t shift, uint64_t total,
                                                                   const uint64_t* __restrict__ seq_off, const uint64_t* __restrict__ out_off, uint32_t n_records,
                                                                   uint64_t* __restrict__ out, uint64_t tile_base /* first tile of this launch */) {
@@ -101,11 +156,13 @@ __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t*
     __shared__ uint8_t sm_badb[NDW + 12];      // bad-base flags, one byte per sequence dword (written by the lane that packs the dword)
     __shared__ uint32_t sm_anybad[BLOCK / 64];
     // LDS is what limits the waves per CU of this kernel, and waves are what hide its latencies (measured: 13 -> 15 workgroups per CU = +7 %,
-    // profiles/r03_stream8.txt): the leader queue holds one round of BLOCK leaders (tiles with more take further rounds), the leader's mode rides in
-    // the top bits of its base, the record table holds kS8RecCap records -- 10.7 KB per workgroup, 15 workgroups (30 waves) per CU.
-    __shared__ uint16_t sm_queue[kS8Block];
+    // profiles/r03_stream8.txt): the leader queue holds QCAP leaders (a tile with more is redone slot by slot), the leader's mode rides in
+    // the top bits of its base, the record table holds kS8RecCap records -- 10.7 KB per workgroup (11.0 with the 256-entry queue of the narrow-window
+    // variant): LDS for 14-15 workgroups per CU; the 71 VGPRs allow 14 (28 waves).
+    constexpr uint32_t QCAP = DIRECT ? 2u * kS8Block : kS8Block;  // leaders per round: narrow windows have more super-k-mers per tile (W = 12: ~157 of 1024 positions)
+    __shared__ uint16_t sm_queue[QCAP];
     __shared__ uint32_t sm_off[kS8Row + 1];    // phase B-C: where in its block each published prefix minimum sits (3 bits each)
-    __shared__ uint32_t sm_rec[2], sm_count;
+    __shared__ uint32_t sm_rec[2], sm_count, sm_slot_count;  // (a counter of its own for the slot-by-slot path: lanes may still be reading sm_count)
     __shared__ uint64_t sm_roff[3];                   // seq_off[rlo], seq_off[rlo+1], out_off[rlo]
     __shared__ uint64_t sm_rtab[2 * kS8RecCap + 1];   // multi-record tiles: the tile's slice of seq_off / out_off
     const uint32_t tid = threadIdx.x;
@@ -203,7 +260,13 @@ __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t*
                 h[r] = murmur8(v & mask, mm_seedx);
             }
         }
-        bmin = publish_block_minima8(sm_hash, sm_off, tid, h);
+        if (DIRECT) {
+            bmin = BlockMin8{};
+#pragma unroll
+            for (uint32_t r = 0; r < 8; ++r) sm_hash[r * kS8Row + tid] = h[r];
+        } else {
+            bmin = publish_block_minima8(sm_hash, sm_off, tid, h);
+        }
         if (tid < 72u) sm_hash[(tid / 9u) * kS8Row + (uint32_t)BLOCK + tid % 9u] = ~0ull;  // blocks beyond the tile: never a minimum
         if (tid < 10u) sm_off[(uint32_t)BLOCK + tid] = 0;
     }
@@ -226,7 +289,8 @@ __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t*
     uint32_t jrec = 0, jcur = 0;  // multi-record tiles: record (relative to rlo) of the lane's first in-batch window, and a cursor
     {
         uint32_t q[8];
-        window_argmin8(sm_hash, sm_off, tid, W, bmin, q);
+        if (DIRECT) window_argmin8_raw(sm_hash, tid, W, q);
+        else window_argmin8(sm_hash, sm_off, tid, W, bmin, q);
         if (one_record) {
 #pragma unroll
             for (uint32_t jw = 0; jw < 8; ++jw) code[jw] = (a + jw >= w_lo && a + jw < w_hi) ? q[jw] : 0xFFFEu;
@@ -267,51 +331,64 @@ __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t*
     }
     // D: windows whose minimizer position differs from their left neighbour's lead a super-k-mer.  Leader number n of the tile (numbered wave by wave,
     // window slot by window slot, lane by lane -- any order will do, lookups are independent) goes to queue entry n - r0 of the round that starts at r0.
-    uint32_t wbase = 0;  // number of the wave's first leader
-    auto publish_leaders = [&](uint32_t r0, bool first) {
+    // (the first QCAP leaders go to the queue; a tile with more is redone slot by slot below)
+    uint32_t lmask = 0;  // bit jw: the lane's window jw leads a super-k-mer
+    {
         const uint32_t lane = tid & 63u;
         uint32_t prev = __shfl(code[7], (int)((lane + 63u) & 63u), 64);  // last window of the lane to the left
         if (lane == 0) prev = 0xFFFEu;                                     // it lives in another wave: queue the window regardless
-        auto leads = [&](uint32_t jw) { return code[jw] < 0xFFFEu && code[jw] != (jw ? code[jw - 1] : prev); };
-        if (first) {
-            uint32_t wave_leaders = 0;
+        uint32_t wave_leaders = 0;
 #pragma unroll
-            for (uint32_t jw = 0; jw < 8; ++jw) wave_leaders += (uint32_t)__popcll(__ballot(leads(jw)));
-            uint32_t b = 0;
-            if (lane == 0 && wave_leaders) b = atomicAdd(&sm_count, wave_leaders);
-            wbase = __shfl(b, 0, 64);
+        for (uint32_t jw = 0; jw < 8; ++jw) {
+            const bool ld = code[jw] < 0xFFFEu && code[jw] != (jw ? code[jw - 1] : prev);
+            lmask |= ld ? 1u << jw : 0u;
+            wave_leaders += (uint32_t)__popcll(__ballot(ld));
         }
-        uint32_t n = wbase - r0;  // (wraps for leaders of earlier rounds: their entry number is then >= BLOCK)
+        uint32_t b = 0;
+        if (lane == 0 && wave_leaders) b = atomicAdd(&sm_count, wave_leaders);
+        uint32_t n = __shfl(b, 0, 64);  // number of the wave's first leader
 #pragma unroll
-        for (uint32_t jw = 0; jw < 8; ++jw) {  // one ballot alive at a time (eight of them, with the flags, cost 10 more VGPRs in the rare later rounds)
-            const bool ld = leads(jw);
+        for (uint32_t jw = 0; jw < 8; ++jw) {  // one ballot alive at a time
+            const bool ld = (lmask >> jw) & 1u;
             const uint64_t bal = __ballot(ld);
             const uint32_t at = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-            if (ld && at < (uint32_t)BLOCK) sm_queue[at] = (uint16_t)code[jw];
+            if (ld && at < QCAP) sm_queue[at] = (uint16_t)code[jw];
             n += (uint32_t)__popcll(bal);
         }
-    };
-    publish_leaders(0, true);
+    }
     __syncthreads();
 
     // ---- E: one lookup per super-k-mer, dense lanes; a round = up to BLOCK leaders, one per lane ----
     const uint32_t nlead = sm_count;
-    auto lookup_round = [&](uint32_t r0) {
-        if (r0 + tid < nlead) {
-            const uint32_t q = sm_queue[tid];
+    auto lookup_queued = [&](uint32_t n) {  // the first n queue entries (n uniform)
+        for (uint32_t x = tid; x < n; x += (uint32_t)BLOCK) {
+            const uint32_t q = sm_queue[x];
             uint64_t mm, hi;
             extract_kmer<false>(sm_words, q, m, mm, hi);
             const LookupCtx c = lookup_ctx<KIND, K128, P>(img, H, mm);
             sm_hash[hslot8(q)] = c.base | ((uint64_t)c.mode << LPHQ_TAIL_MODE_SHIFT);  // (bases are ranks < 2^62: the packing of the image's tail table)
         }
     };
-    lookup_round(0);
-    __syncthreads();
-    if (__builtin_expect(nlead > (uint32_t)BLOCK, 0)) {  // (uniform) more leaders than lanes: further rounds (W >= 24: super-k-mers average >= 12 windows)
-        for (uint32_t r0 = (uint32_t)BLOCK; r0 < nlead; r0 += (uint32_t)BLOCK) {
-            publish_leaders(r0, false);
+    if (__builtin_expect(nlead <= QCAP, 1)) {  // (uniform) the common case: super-k-mers average (W + 1) / 2 windows
+        lookup_queued(nlead);
+        __syncthreads();
+    } else {
+        // More leaders than the queue holds: the tile is done window slot by window slot -- a lane leads at most once per slot, so the BLOCK leaders
+        // of a slot always fit.  Eight rounds of three barriers; rare, and it keeps this path out of the register budget of the common one.
+        for (uint32_t jw = 0; jw < 8; ++jw) {
+            if (tid == 0) sm_slot_count = 0;
             __syncthreads();
-            lookup_round(r0);
+            uint32_t cj = code[0];
+#pragma unroll
+            for (uint32_t t = 1; t < 8; ++t) cj = jw == t ? code[t] : cj;
+            const bool ld = (lmask >> jw) & 1u;
+            const uint64_t bal = __ballot(ld);
+            uint32_t b = 0;
+            if ((tid & 63u) == 0 && bal) b = atomicAdd(&sm_slot_count, (uint32_t)__popcll(bal));
+            b = __shfl(b, 0, 64);
+            if (ld) sm_queue[b + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint16_t)cj;
+            __syncthreads();
+            lookup_queued(sm_slot_count);
             __syncthreads();
         }
     }

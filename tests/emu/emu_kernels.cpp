@@ -53,8 +53,8 @@ extern "C" int emu_kernel_query_records(const uint8_t* img, size_t nbytes, const
     const uint8_t* seq_al = (const uint8_t*)seq - shift;
     const uint64_t span = shift + total;
     if (streaming && H.kind < 2) {
-        /* eight positions per lane (stream8_device.cuh): forced by 0x40000 for any W >= 8, or -- as the launcher does -- for wide windows unless a form is forced */
-        const bool s8 = H.W >= 8 && ((block & 0x40000) || (!(block & 0x30000) && H.W >= kStream8MinW && H.P == 6));
+        /* eight positions per lane (stream8_device.cuh): forced by 0x40000, or -- as the launcher does -- from W = kStream8MinW on unless a form is forced */
+        const bool s8 = (block & 0x40000) || (!(block & 0x30000) && H.W >= kStream8MinW);  /* (P == 4: window minima from the raw hashes, any W; P == 6: block form) */
         const uint64_t tw = stream_tile_windows(H.W, s8 ? kS8Pos : 4 * (block & 0xFFFF));
         const unsigned tiles = (unsigned)((span + tw - 1) / tw);
 #define CALL(KIND, K128, P)                                                                                                                             \

@@ -18,7 +18,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 BUDGET = {
     "k_query_packed": (64, 0),                # 8 waves / SIMD
     "k_query_tiles_stream": (64, 40 * 1024),
-    "k_query_tiles_stream8": (72, 11426),  # 128 threads, 8 positions per lane: <= 72 VGPRs (7 waves / SIMD) and LDS for 14 workgroups (28 waves) per CU  # 256 threads: 8 workgroups / CU need <= 64 VGPRs and <= 20 KB (512-thread build: 2x LDS)
+    "k_query_tiles_stream8": (72, 11702),  # 128 threads, 8 positions per lane: <= 72 VGPRs (7 waves / SIMD) and LDS for 14 workgroups (28 waves) per CU
     "k_query_tiles_random": (64, 10 * 1024),  # + the 8-KiB queue of k-mer window starts (read batches); 16 workgroups per CU still fit
     "k_pack_kmers": (64, 0),
     "k_count_valid": (64, 0),
