@@ -4,10 +4,13 @@
 // (kernels_device.cuh; MPHF::operator()(.., streaming=true), include/partitioned_mphf.hpp:78-184), with 128 threads instead of 256: a lane owns
 // the block of 8 consecutive positions a .. a+7, a = 8 * tid.  Why: at W = 44 the 4-per-lane kernel issues 602 VALU instructions per wave of
 // which 96 are the hashes (profiles/r03_stream_phases_k63.txt) -- the rest is per-LANE and per-WAVE work (addressing, the block range every
-// window of a lane shares, ballots, barriers) that this shape pays once per 8 windows instead of once per 4:
-//   C  window a+j = own suffix S[j] + the blocks all eight windows cover (l+1 .. l+nf0, nf0 = (W-8)/8: 4 reads at W = 44, against 10 per four
-//      windows) + at most one more whole block + a prefix of the block after it
+// window of a lane shares, ballots, barriers) that this shape pays once per 8 windows instead of once per 4.  What it took (profiles/r03_stream8.txt):
+//   C  W >= 16: window a+j = own suffix S[j] + the blocks all eight windows cover (l+1 .. l+nf0, nf0 = (W-8)/8: 4 reads at W = 44, against 10 per
+//      four windows) + at most one more whole block + a prefix of the block after it.  W <= 15: from the raw hashes (core + two edge chains)
 //   D  one cross-lane move and one LDS atomic per 8 windows; two waves meet at the barriers instead of four
+//   F  the codes leave through LDS: a lane's eight codes are 64 B from its neighbour's, and stores from the registers were what made the first
+//      version no faster than four per lane
+//   LDS and registers for 14 workgroups per CU (10.7-11.0 KB, <= 71 VGPRs): the kernel's time is nearly proportional to 1 / (waves per CU)
 // Ties keep the LEFT position throughout (candidates are taken left to right with a strict `<`), as the strict `>` comparisons of
 // include/partitioned_mphf.hpp:122,150-163 do.
 #pragma once
