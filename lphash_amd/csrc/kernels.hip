@@ -96,7 +96,9 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
     }();
     constexpr int sblock = kStreamBlockDefault;  // 256 threads measured best in both rounds (128: -4 %, 512: -6 %, profiles/r02_stream_v4_ab.txt)
     const bool stream_kernel = streaming && H.kind < 2;  // (the competitor harness has one kernel for both values of `streaming`)
-    const uint64_t tw = stream_kernel ? stream_tile_windows(H.W, 4 * sblock) : kTileW;
+    const bool s8 = stream_kernel && H.W >= s8_min_w;
+    const uint64_t tw = stream_kernel ? stream_tile_windows(H.W, 4 * sblock) : kTileW;  // (8 * kS8Block == 4 * sblock: both kernels cut the same tiles)
+    static_assert(8 * kS8Block == 4 * sblock, "one tile geometry");
     const uint64_t tiles = (span + tw - 1) / tw;
     if (n_records > 0xFFFFFFFFull) return hipErrorInvalidValue;
     // one workgroup per tile; HIP requires gridDim.x * blockDim.x < 2^32, so a batch of more than 2^24 - 1 tiles (~16 G bases) goes
@@ -109,7 +111,7 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
             // A/B runs: four positions per lane
 #define LPHQ_STREAM_LAUNCH(KIND, K128) \
     do { \
-        if (H.W >= s8_min_w) { \
+        if (s8) { \
             if (H.P == 6) k_query_tiles_stream8<KIND, K128, 6><<<grid, kS8Block, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
             else k_query_tiles_stream8<KIND, K128, 4><<<grid, kS8Block, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
         } else if (H.P != 6) k_query_tiles_stream<KIND, K128, 4, sblock, false><<<grid, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \

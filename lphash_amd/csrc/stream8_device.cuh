@@ -22,13 +22,15 @@ constexpr uint32_t kStream8MinW = 8;                   // the launcher uses this
                                                        // block decomposition from W = 16 on (P == 6).  Against four positions per lane (profiles/r03_stream8.txt):
                                                        // W = 8 +1.6 %, W = 12 +3.3 %, W = 17 +7.5 %, W = 24 +5 %, W = 31 +7 %, W = 44 +20 %.  Narrower windows
                                                        // (every other window leads a super-k-mer) stay with four per lane
-constexpr int kS8Block = 128;                          // threads per workgroup
-constexpr int kS8Pos = 8 * kS8Block;                   // m-mer positions per tile (= 4 * kStreamBlockDefault: the tiles of both kernels coincide)
+constexpr int kS8Block = 128;                          // threads per workgroup; 8 * BLOCK m-mer positions per tile (256 threads / 2048 positions: measured equal at W = 8, 12,
+                                                       // profiles/r03_stream8.txt (9); the template parameter stays for the emulator's coverage)
 constexpr int kS8RecCap = 32;                          // records of a multi-record tile cached in LDS (more: the global offset arrays are searched)
-constexpr uint32_t kS8Row = (uint32_t)kS8Block + 9u;   // blocks per row of prefix minima: a lane reads up to block l + 8 (W <= 62); the 9 beyond the tile hold ~0
-static_assert(kS8Pos == 4 * kStreamBlockDefault, "the launcher sizes the grid for one tile geometry");
+// blocks per row of prefix minima: a lane reads up to block l + 8 (W <= 62); the 9 beyond the tile hold ~0
+template <int BLOCK>
+constexpr uint32_t s8_row() { return (uint32_t)BLOCK + 9u; }
 // slot of position i in phases E-F (the leader's base): column i % 8, block i / 8
-__device__ __forceinline__ uint32_t hslot8(uint32_t i) { return (i & 7u) * kS8Row + (i >> 3); }
+template <int BLOCK>
+__device__ __forceinline__ uint32_t hslot8(uint32_t i) { return (i & 7u) * s8_row<BLOCK>() + (i >> 3); }
 
 struct BlockMin8 {   // a lane's suffix minima S[1..7] over a+j .. a+7 (S[0] is the block minimum, re-read from LDS), alive from phase B to phase C
     uint64_t h[7];
@@ -37,7 +39,9 @@ struct BlockMin8 {   // a lane's suffix minima S[1..7] over a+j .. a+7 (S[0] is 
 
 // Publishes (column c of sm_hash) the prefix minima P[c] over a .. a+c -- P[7] is the minimum M of the block -- and, 3 bits each in one word,
 // which position each of them is (P[0] is position 0); returns the suffix minima.
+template <int BLOCK>
 __device__ __forceinline__ BlockMin8 publish_block_minima8(uint64_t* __restrict__ sm_hash, uint32_t* __restrict__ sm_off, uint32_t tid, const uint64_t (&h)[8]) {
+    constexpr uint32_t kS8Row = s8_row<BLOCK>();
     HashPos p{h[0], 0};
     sm_hash[tid] = p.h;
     uint32_t ob = 0;
@@ -66,8 +70,10 @@ __device__ __forceinline__ BlockMin8 publish_block_minima8(uint64_t* __restrict_
 
 // Leftmost minimum of the 8 consecutive windows starting at local positions a .. a+7, each W >= 8 positions wide -> q[0..7] (local positions).
 // id of a candidate: (t << 3) | c for column c of the block t lanes to the right; for the own block (t = 0) c is the position itself.
+template <int BLOCK>
 __device__ __forceinline__ void window_argmin8(const uint64_t* __restrict__ sm_hash, const uint32_t* __restrict__ sm_off, uint32_t tid, uint32_t W, const BlockMin8& s,
                                                uint32_t (&q)[8]) {
+    constexpr uint32_t kS8Row = s8_row<BLOCK>();
     const uint64_t* colM = sm_hash + 7u * kS8Row + tid;  // M of the block t lanes to the right: colM[t]
     const uint32_t nf0 = (W - 8u) >> 3;                  // blocks covered completely by all eight windows: l+1 .. l+nf0
     HashPos r{~0ull, 0};
@@ -97,7 +103,9 @@ __device__ __forceinline__ void window_argmin8(const uint64_t* __restrict__ sm_h
 // common to the eight windows (the core); window a+j = the left suffix minimum over a+j .. a+6, the core, the right prefix minimum over a+W .. a+W+j-1 --
 // W + 7 LDS reads and W + 18 compare-selects per lane.  Ties keep the LEFT position (candidates left to right with a strict `<`; the suffix chain runs right
 // to left with `<=`).
+template <int BLOCK>
 __device__ __forceinline__ void window_argmin8_raw(const uint64_t* __restrict__ sm_hash, uint32_t tid, uint32_t W, uint32_t (&q)[8]) {
+    constexpr uint32_t kS8Row = s8_row<BLOCK>();
     auto H = [&](uint32_t c) { return sm_hash[(c & 7u) * kS8Row + tid + (c >> 3)]; };  // hash of position a + c
     const uint32_t a = 8u * tid;
     if (W >= 8u) {
@@ -145,12 +153,13 @@ __device__ __forceinline__ void window_argmin8_raw(const uint64_t* __restrict__ 
 }
 
 // DIRECT: window minima from the raw hashes (narrow windows) instead of block prefix minima
-template <int KIND, bool K128, int P, bool DIRECT = (P == 4)>
-__global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al, uint64_t shift, uint64_t total,
+template <int KIND, bool K128, int P, int BLOCK = kS8Block, bool DIRECT = (P == 4)>
+__global__ __launch_bounds__(BLOCK) void k_query_tiles_stream8(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al, uint64_t shift, uint64_t total,
                                                                   const uint64_t* __restrict__ seq_off, const uint64_t* __restrict__ out_off, uint32_t n_records,
                                                                   uint64_t* __restrict__ out, uint64_t tile_base /* first tile of this launch */) {
     const lphq_image_header& H = *(const lphq_image_header*)img;
-    constexpr int BLOCK = kS8Block, NW = tile_words(kS8Pos);
+    constexpr int kS8Pos = 8 * BLOCK, NW = tile_words(kS8Pos);
+    constexpr uint32_t kS8Row = s8_row<BLOCK>();
     constexpr int NDW = (NW + 1) * 4;          // dwords of sequence (4 bases each) the tile loads: two per lane, the NDW - 2 * BLOCK beyond by lanes of the last wave
     constexpr uint32_t NX = (uint32_t)(NDW - 2 * BLOCK);
     static_assert(NDW > 2 * BLOCK && NX <= 64, "the dwords beyond the first 2 * BLOCK are loaded by the lanes of the last wave");
@@ -162,7 +171,7 @@ __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t*
     // profiles/r03_stream8.txt): the leader queue holds QCAP leaders (a tile with more is redone slot by slot), the leader's mode rides in
     // the top bits of its base, the record table holds kS8RecCap records -- 10.7 KB per workgroup (11.0 with the 256-entry queue of the narrow-window
     // variant): LDS for 14-15 workgroups per CU; the 71 VGPRs allow 14 (28 waves).
-    constexpr uint32_t QCAP = DIRECT ? 2u * kS8Block : kS8Block;  // leaders per round: narrow windows have more super-k-mers per tile (W = 12: ~157 of 1024 positions)
+    constexpr uint32_t QCAP = DIRECT ? 2u * BLOCK : BLOCK;  // leaders per round: narrow windows have more super-k-mers per tile (W = 12: ~157 of 1024 positions)
     __shared__ uint16_t sm_queue[QCAP];
     __shared__ uint32_t sm_off[kS8Row + 1];    // phase B-C: where in its block each published prefix minimum sits (3 bits each)
     __shared__ uint32_t sm_rec[2], sm_count, sm_slot_count;  // (a counter of its own for the slot-by-slot path: lanes may still be reading sm_count)
@@ -175,8 +184,8 @@ __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t*
 
     // ---- A: sequence dwords first (no dependence on the record search), then the search, then pack into LDS ----
     const bool interior = t0 >= shift && t0 + 4ull * (uint64_t)NDW <= shift + total;  // (uniform) every dword the tile loads lies inside the batch
-    const uint32_t dd[3] = {2u * tid, 2u * tid + 1u, 2u * (uint32_t)BLOCK + (tid - 64u)};
-    const bool live2 = tid >= 64u && tid - 64u < NX;
+    const uint32_t dd[3] = {2u * tid, 2u * tid + 1u, 2u * (uint32_t)BLOCK + (tid - ((uint32_t)BLOCK - 64u))};
+    const bool live2 = tid >= (uint32_t)BLOCK - 64u && tid - ((uint32_t)BLOCK - 64u) < NX;
     uint32_t xs[3] = {0u, 0u, 0u};
     bool have[3];
     if (interior) {
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t*
     }
     __syncthreads();
     if (sm_rec[0] != sm_rec[1]) load_record_table<kS8RecCap>(sm_rtab, seq_off, out_off, sm_rec[0], sm_rec[1], tid);  // (visible to phase C through the next barrier)
-    static_assert(kS8RecCap + 1 <= kS8Block, "load_record_table: one lane per table entry");
+    static_assert(kS8RecCap + 1 <= BLOCK, "load_record_table: one lane per table entry");
 
     // ---- B: hashes of the m-mers starting at local positions 8*lane .. 8*lane+7; prefix minima of the block published for phase C ----
     const uint32_t a = 8u * tid;
@@ -268,7 +277,7 @@ __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t*
 #pragma unroll
             for (uint32_t r = 0; r < 8; ++r) sm_hash[r * kS8Row + tid] = h[r];
         } else {
-            bmin = publish_block_minima8(sm_hash, sm_off, tid, h);
+            bmin = publish_block_minima8<BLOCK>(sm_hash, sm_off, tid, h);
         }
         if (tid < 72u) sm_hash[(tid / 9u) * kS8Row + (uint32_t)BLOCK + tid % 9u] = ~0ull;  // blocks beyond the tile: never a minimum
         if (tid < 10u) sm_off[(uint32_t)BLOCK + tid] = 0;
@@ -292,8 +301,8 @@ __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t*
     uint32_t jrec = 0, jcur = 0;  // multi-record tiles: record (relative to rlo) of the lane's first in-batch window, and a cursor
     {
         uint32_t q[8];
-        if (DIRECT) window_argmin8_raw(sm_hash, tid, W, q);
-        else window_argmin8(sm_hash, sm_off, tid, W, bmin, q);
+        if (DIRECT) window_argmin8_raw<BLOCK>(sm_hash, tid, W, q);
+        else window_argmin8<BLOCK>(sm_hash, sm_off, tid, W, bmin, q);
         if (one_record) {
 #pragma unroll
             for (uint32_t jw = 0; jw < 8; ++jw) code[jw] = (a + jw >= w_lo && a + jw < w_hi) ? q[jw] : 0xFFFEu;
@@ -369,7 +378,7 @@ __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t*
             uint64_t mm, hi;
             extract_kmer<false>(sm_words, q, m, mm, hi);
             const LookupCtx c = lookup_ctx<KIND, K128, P>(img, H, mm);
-            sm_hash[hslot8(q)] = c.base | ((uint64_t)c.mode << LPHQ_TAIL_MODE_SHIFT);  // (bases are ranks < 2^62: the packing of the image's tail table)
+            sm_hash[hslot8<BLOCK>(q)] = c.base | ((uint64_t)c.mode << LPHQ_TAIL_MODE_SHIFT);  // (bases are ranks < 2^62: the packing of the image's tail table)
         }
     };
     if (__builtin_expect(nlead <= QCAP, 1)) {  // (uniform) the common case: super-k-mers average (W + 1) / 2 windows
@@ -404,7 +413,7 @@ __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t*
         const uint32_t q = code[jw];
         const bool valid = q < 0xFFFEu;
         const uint32_t qq = valid ? q : a + jw;  // (any slot of the tile: the value read is discarded)
-        const uint64_t packed = sm_hash[hslot8(qq)];
+        const uint64_t packed = sm_hash[hslot8<BLOCK>(qq)];
         const uint64_t base = packed & LPHQ_TAIL_BASE_MASK;
         const uint32_t mode = (uint32_t)(packed >> LPHQ_TAIL_MODE_SHIFT);
         const uint32_t p = qq - (a + jw);
@@ -418,7 +427,7 @@ __global__ __launch_bounds__(kS8Block) void k_query_tiles_stream8(const uint8_t*
         for (uint32_t jw = 0; jw < 8; ++jw)
             if ((coll >> jw) & 1u) {
                 LookupCtx c;
-                c.base = sm_hash[hslot8(code[jw])] & LPHQ_TAIL_BASE_MASK;
+                c.base = sm_hash[hslot8<BLOCK>(code[jw])] & LPHQ_TAIL_BASE_MASK;
                 c.mode = 2u;
                 uint64_t lo = 0, hi = 0;
                 extract_kmer<K128>(sm_words, a + jw, k, lo, hi);

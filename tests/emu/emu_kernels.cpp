@@ -55,14 +55,16 @@ extern "C" int emu_kernel_query_records(const uint8_t* img, size_t nbytes, const
     if (streaming && H.kind < 2) {
         /* eight positions per lane (stream8_device.cuh): forced by 0x40000, or -- as the launcher does -- from W = kStream8MinW on unless a form is forced */
         const bool s8 = (block & 0x40000) || (!(block & 0x30000) && H.W >= kStream8MinW);  /* (P == 4: window minima from the raw hashes, any W; P == 6: block form) */
-        const uint64_t tw = stream_tile_windows(H.W, s8 ? kS8Pos : 4 * (block & 0xFFFF));
+        const bool s8_256 = s8 && (block & 0xFFFF) == 256 && (block & 0x40000);  /* forced eight-per-lane with 256 threads: 2048 positions per tile */
+        const uint64_t tw = stream_tile_windows(H.W, s8 ? (s8_256 ? 8 * 256 : 8 * kS8Block) : 4 * (block & 0xFFFF));
         const unsigned tiles = (unsigned)((span + tw - 1) / tw);
 #define CALL(KIND, K128, P)                                                                                                                             \
     do {                                                                                                                                                \
         const bool blk = (block & 0x10000) ? true : ((block & 0x20000) ? false : H.W >= kBlockMinW); /* forced either way, or as the launcher chooses */ \
         const int bs = block & 0xFFFF;                                                                                                                    \
         if (s8) {                                                                                                                                         \
-            emu::launch(tiles, kS8Block, [&] { k_query_tiles_stream8<KIND, K128, P>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0); });    \
+            if (s8_256) emu::launch(tiles, 256, [&] { k_query_tiles_stream8<KIND, K128, P, 256>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0); }); \
+            else emu::launch(tiles, kS8Block, [&] { k_query_tiles_stream8<KIND, K128, P>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0); });    \
         } else if (H.W >= 4 && blk) {                                                                                                                            \
             if (bs == 128) emu::launch(tiles, 128, [&] { k_query_tiles_stream<KIND, K128, P, 128, true>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0); }); \
             else emu::launch(tiles, 256, [&] { k_query_tiles_stream<KIND, K128, P, 256, true>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0); });            \

@@ -144,7 +144,7 @@ def test_tile_kernels_on_the_emulator(emuk, tmp_path, k, m, bits, kind):
     BLK, RAW = 0x10000, 0x20000  # window minima by block decomposition / in the direct form, whatever W (the launcher picks by W)
     S8 = 0x40000                 # eight positions per lane (stream8_device.cuh), whatever W (the launcher picks by W)
     runs = [(True, 0, 256), (True, 5, 256 | BLK), (True, 15, 128 | RAW), (False, 0, 256), (False, 9, 256), (True, 7, 256 | RAW), (True, 2, 128 | BLK),
-            (True, 0, 128 | S8), (True, 11, 128 | S8)]
+            (True, 0, 128 | S8), (True, 11, 128 | S8), (True, 4, 256 | S8)]
     for streaming, mis, block in runs:
         got = emu_records(emuk, h, batch, k, streaming, mis, block)
         for g, e in zip(got, exp):
