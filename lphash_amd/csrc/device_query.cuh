@@ -362,7 +362,12 @@ __device__ __forceinline__ LookupCtx lookup_ctx(const uint8_t* __restrict__ img,
 }
 template <bool K128>
 __device__ __forceinline__ uint64_t finish_hval(const uint8_t* __restrict__ img, const lphq_image_header& H, const LookupCtx& c, uint64_t lo, uint64_t hi, uint32_t p) {
-    if (c.mode == 2u) return c.base + phf_position(img, H.fb, fallback_hash<K128>(lo, hi, H.fb.seed));
+    if (c.mode == 2u) {
+        // (rare) the fallback function's descriptor is read from the image, whatever copy of the header the caller holds: the random kernel takes the header
+        // by value, and 30 more scalar fields alive across its hot path were spilled to VGPR lanes and read back (v_readlane) by every wave
+        const lphq_phf_desc& fb = ((const lphq_image_header*)img)->fb;
+        return c.base + phf_position(img, fb, fallback_hash<K128>(lo, hi, fb.seed));
+    }
     return c.mode == 0u ? c.base + p : c.base - p;
 }
 
