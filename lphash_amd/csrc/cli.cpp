@@ -27,6 +27,7 @@
 #include "fastx.hpp"
 #include "fastx_batch.hpp"
 #include "host_cpus.hpp"
+#include "parallel_gz.hpp"
 
 namespace {
 
@@ -361,9 +362,9 @@ bool query_pass(lphq_index* idx, const lphq_info& info, const std::string& path,
 
 // diagnostic: the decompressed bytes of a .gz as the serial reader gets them (gz_source.hpp; --zlib: through gzread instead), to a file or nowhere
 int inflate_main(int argc, char** argv) {
-    Args a = parse(argc, argv, {"-i", "-o"}, {"--zlib"});
+    Args a = parse(argc, argv, {"-i", "-o", "--parallel", "--span"}, {"--zlib"});
     if (a.help || a.bad || !a.get("-i")) {
-        std::cerr << "Usage: " << argv[0] << " -i file.gz [-o output] [--zlib]\n";
+        std::cerr << "Usage: " << argv[0] << " -i file.gz [-o output] [--zlib | --parallel threads [--span bytes]]\n";
         return 1;
     }
     FILE* out = a.get("-o") ? fopen(a.get("-o")->c_str(), "wb") : nullptr;
@@ -383,6 +384,40 @@ int inflate_main(int argc, char** argv) {
         }
         error = n < 0;
         gzclose(fp);
+    } else if (a.get("--parallel")) {
+        // parallel_gz.hpp: every piece into one buffer that is written out whenever it holds 64 MiB; prints pieces taken from the pool / decoded serially
+        lphq::ParallelGzReader* src = lphq::ParallelGzReader::open(a.get("-i")->c_str(), std::atoi(a.get("--parallel")->c_str()),
+                                                                   a.get("--span") ? (size_t)std::atol(a.get("--span")->c_str()) : 0);
+        if (!src) {
+            std::cerr << "not a regular gzip file, or too small for its spans\n";
+            return 2;
+        }
+        src->prealloc();
+        std::vector<uint8_t> big((size_t)256 << 20, 1);  // (allocated and touched before the timer, like the reader's arenas)
+        const auto t1 = std::chrono::high_resolution_clock::now();
+        size_t used = 0;
+        auto drain = [&] {
+            src->flush();
+            if (out && used) fwrite(big.data(), 1, used, out);
+            total += used;
+            used = 0;
+        };
+        size_t n;
+        while ((n = src->next_len()) > 0) {
+            if (used + n > big.size()) {
+                drain();
+                if (n > big.size()) big.resize(n);
+            }
+            src->emit(big.data() + used);
+            used += n;
+        }
+        drain();
+        error = src->error();
+        const double sec = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t1).count();
+        if (out) fclose(out);
+        std::cout << total << "," << (error ? "error" : "ok") << "," << sec << "," << src->pieces_parallel() << "," << src->pieces_serial() << "," << src->span() << "\n";
+        delete src;
+        return error ? 3 : 0;
     } else {
         lphq::GzFastSource* src = lphq::GzFastSource::open(a.get("-i")->c_str());
         if (!src) {
@@ -414,10 +449,10 @@ int records_main(int argc, char** argv) {
     const size_t batch = a.get("--batch-bytes") ? (size_t)std::strtoull(a.get("--batch-bytes")->c_str(), nullptr, 10) : (size_t)512 << 20;
     const size_t min_piece = a.get("--min-piece") ? (size_t)std::strtoull(a.get("--min-piece")->c_str(), nullptr, 10) : (size_t)1 << 16;
     const int passes = a.get("--passes") ? std::max(1, std::atoi(a.get("--passes")->c_str())) : 1;  // later passes reuse the (warm) parse arenas
-    uint64_t n_rec = 0, n_bases = 0, h = 0, n_batches = 0, n_parallel = 0, window = 0;
+    uint64_t n_rec = 0, n_bases = 0, h = 0, n_batches = 0, n_parallel = 0, window = 0, n_pgz = 0;
     std::chrono::high_resolution_clock::time_point t0;
     for (int pass = 0; pass < passes; ++pass) {
-    n_rec = n_bases = n_batches = n_parallel = 0;
+    n_rec = n_bases = n_batches = n_parallel = n_pgz = 0;
     h = 1469598103934665603ull;  // FNV-1a over (length, bases) of every record
     const bool no_hash = a.has("--no-hash");  // timing of the reader alone
     auto mix = [&](const void* p, size_t n) {
@@ -444,6 +479,7 @@ int records_main(int argc, char** argv) {
         while (rd.next(b, batch)) {
             ++n_batches;
             n_parallel += rd.parallel();
+            n_pgz += rd.parallel_gz() && rd.parallel();  // ... of which: text that came from the span-parallel .gz decoder
             size_t si = 0, so = 0;  // walk the segments record by record
             for (uint64_t len : b.lens) {
                 mix(&len, 8);
@@ -464,12 +500,12 @@ int records_main(int argc, char** argv) {
             }
         }
         if (!rd.ok()) return 3;
-        window = rd.window_capacity();  // BGZF: bytes of inflated text held at once (0 for every other kind of input)
+        window = rd.window_capacity();  // BGZF and other .gz: bytes of inflated text held at once (0 for every other kind of input)
     }
     }
     auto t1 = std::chrono::high_resolution_clock::now();
     const double sec = std::chrono::duration<double>(t1 - t0).count();
-    std::cout << n_rec << "," << n_bases << "," << h << "," << n_batches << "," << n_parallel << "," << sec << "," << window << std::endl;
+    std::cout << n_rec << "," << n_bases << "," << h << "," << n_batches << "," << n_parallel << "," << sec << "," << window << "," << n_pgz << std::endl;
     return 0;
 }
 

@@ -1,8 +1,9 @@
-// fast_inflate.hpp -- a DEFLATE (RFC 1951) decoder and the gzip (RFC 1952) member framing around it, for the one input the parallel
-// readers cannot split: a single-member .gz (the format the reference's usage text names, src/query.cpp:14-22).  Such a stream is serial by
-// construction, so the only lever is the speed of the one decoder: zlib 1.2.11's inflate ran at ~490 MB/s of text on the GPU box and made the
-// whole `lphash query-*` call 2 ns per k-mer.  This decoder works on the whole compressed file in memory (mmap), which removes the input
-// refill logic, and is written for throughput:
+// fast_inflate.hpp -- a DEFLATE (RFC 1951) decoder and the gzip (RFC 1952) member framing around it, for a single-member .gz (the format
+// the reference's usage text names, src/query.cpp:14-22).  zlib 1.2.11's inflate ran at ~490 MB/s of text on the GPU box and made the whole
+// `lphash query-*` call 2 ns per k-mer.  This decoder works on the whole compressed file in memory (mmap), which removes the input refill
+// logic, and is written for throughput; it can start at any bit of the file and stop at the first block border at or after a given bit, and
+// it can write 16-bit symbols instead of bytes (a match then copies whatever stands in the 32 Ki symbols before it, known byte or
+// placeholder) -- the two things parallel_gz.hpp needs to decode one stream with many threads.  Per thread:
 //   * a 64-bit bit buffer refilled with one unaligned 8-byte load (no per-byte loop);
 //   * table-driven Huffman decoding: an 11-bit primary table for literals / lengths and an 8-bit one for distances, longer codes through
 //     second-level tables; one table entry carries the symbol's value (literal, length base, distance base), its extra-bit count and its
@@ -24,22 +25,43 @@ public:
     static constexpr size_t kSlack = 320;     // room past `limit` a call may write into: one match (258) and an 8-byte copy step, rounded up
 
     void reset(const uint8_t* in, const uint8_t* in_end) {
-        in_ = in;
+        base_ = in_ = in;
         end_ = in_end;
         bitbuf_ = 0;
         bitsleft_ = 0;
         state_ = kHeader;
         final_ = false;
         stored_left_ = 0;
+        stop_bit_ = ~(uint64_t)0;
+        blocks_ = 0;
     }
+    // start at bit `bit` of the data at `base` (bit 0 = least significant bit of base[0]: the order in which DEFLATE packs them)
+    void reset_at_bit(const uint8_t* base, uint64_t bit, const uint8_t* in_end) {
+        reset(base + (bit >> 3), in_end);
+        base_ = base;
+        if ((bit & 7) && need((int)(bit & 7))) take((int)(bit & 7));
+    }
+    // position of the next unread bit, counted like reset_at_bit's argument
+    uint64_t bit_position() const { return (uint64_t)(in_ - base_) * 8 - (uint64_t)bitsleft_; }
+    // decode() returns 3 instead of reading a block header at or beyond this bit
+    void set_stop_bit(uint64_t bit) { stop_bit_ = bit; }
+    // block headers read so far
+    uint32_t blocks_started() const { return blocks_; }
+    bool in_final_block() const { return final_; }
     // Decode into buf[pos ...): stops once pos > limit (the caller provides kSlack bytes of room past limit), at the end of the stream, or
     // on an error.  `hist` = valid bytes before buf + pos at the time of the call... a match may reach min(kWindow, bytes before its start).
     // Returns 0: out of room, call again with a new buffer whose first bytes repeat the last kWindow bytes; 1: the final block ended;
-    // -1: invalid or truncated stream.
-    int decode(uint8_t* buf, size_t& pos, size_t limit) {
+    // -1: invalid or truncated stream; 3: the next block would begin at or beyond the stop bit (set_stop_bit).
+    int decode(uint8_t* buf, size_t& pos, size_t limit) { return decode_as<uint8_t>(buf, pos, limit); }
+    // The same with T = uint16_t: one 16-bit symbol per byte of text.  Literals are 0..255; what a match copies is whatever the caller put (or this
+    // decoder wrote) in the symbols before it, so a caller that does not know the 32 KiB before its starting point puts 32 Ki distinct placeholder
+    // values >= 256 there and replaces them once the text before is known (parallel_gz.hpp).
+    template <typename T>
+    int decode_as(T* buf, size_t& pos, size_t limit) {
         for (;;) {
             if (state_ == kHeader) {
                 if (final_) return 1;
+                if (bit_position() >= stop_bit_) return 3;
                 if (!need(3)) return -1;
                 final_ = take(1) != 0;
                 const uint32_t type = take(2);
@@ -64,6 +86,7 @@ public:
                 } else {
                     return -1;
                 }
+                ++blocks_;
             }
             if (state_ == kStored) {
                 while (stored_left_) {
@@ -71,7 +94,9 @@ public:
                     size_t n = stored_left_;
                     if (n > limit + 1 - pos) n = limit + 1 - pos;
                     if ((size_t)(end_ - in_) < n) return -1;
-                    memcpy(buf + pos, in_, n);
+                    if (sizeof(T) == 1) memcpy(buf + pos, in_, n);
+                    else
+                        for (size_t i = 0; i < n; ++i) buf[pos + i] = (T)in_[i];
                     pos += n;
                     in_ += n;
                     stored_left_ -= (uint32_t)n;
@@ -79,7 +104,7 @@ public:
                 state_ = kHeader;
                 continue;
             }
-            const int r = huffman_block(buf, pos, limit);
+            const int r = huffman_block<T>(buf, pos, limit);
             if (r != 2) return r;  // 0: out of room, -1: error
             state_ = kHeader;      // 2: end of block
         }
@@ -87,7 +112,7 @@ public:
     // first byte after the deflate stream (valid once decode() returned 1): the bytes the bit buffer holds beyond the last symbol go back
     const uint8_t* stream_end() const { return in_ - (bitsleft_ >> 3); }
 
-private:
+protected:
     enum State { kHeader, kStored, kHuffman };
     // table entry: value << 16 | type << 12 | extra << 8 | nbits, nbits = the bits the symbol takes from the stream INCLUDING its extra bits
     // (one shift on the critical path; the extra bits are picked out of a copy of the buffer on the side)
@@ -304,9 +329,17 @@ private:
     }
 
     // ---- one Huffman-coded block: 2 = end of block, 0 = out of room, -1 = error ----
-    int huffman_block(uint8_t* buf, size_t& pos_io, size_t limit) {
-        uint8_t* out = buf + pos_io;
-        uint8_t* const stop = buf + limit;  // symbols may start while out <= stop
+    // four bytes -> four 16-bit symbols
+    static uint64_t widen4(uint32_t four) {
+        uint64_t x = four;
+        x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+        return (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    }
+    template <typename T>
+    int huffman_block(T* buf, size_t& pos_io, size_t limit) {
+        constexpr size_t E = 8 / sizeof(T);  // symbols per 8-byte copy step
+        T* out = buf + pos_io;
+        T* const stop = buf + limit;  // symbols may start while out <= stop
         const uint32_t lmask = (1u << kLitBits) - 1, dmask = (1u << kDistBits) - 1;
         int rc;
         // ---- the fast loop: bit state in registers; at its top the buffer holds >= 56 bits and the table entry of the next symbol is loaded
@@ -333,10 +366,15 @@ private:
                     do {
                         if (t == kLiterals) {
                             const uint32_t four = (uint32_t)(e >> 32);
-                            memcpy(out, &four, 4);  // (the bytes beyond the count are overwritten by what follows)
+                            if (sizeof(T) == 1) {
+                                memcpy(out, &four, 4);  // (the bytes beyond the count are overwritten by what follows)
+                            } else {
+                                const uint64_t w = widen4(four);
+                                memcpy(out, &w, 8);
+                            }
                             out += ((uint32_t)e >> 16) & 7u;
                         } else {
-                            *out++ = (uint8_t)(e >> 16);
+                            *out++ = (T)(uint8_t)(e >> 16);
                         }
                         bb >>= (e & 0xFFu);
                         bl -= (int)(e & 0xFFu);
@@ -352,7 +390,7 @@ private:
                     e = lit_[((uint32_t)e >> 16) + (uint32_t)(bb & ((1u << (((uint32_t)e >> 8) & 15u)) - 1))];
                     t = ((uint32_t)e >> 12) & 15u;
                     if (t == kLiteral) {
-                        *out++ = (uint8_t)(e >> 16);
+                        *out++ = (T)(uint8_t)(e >> 16);
                         bb >>= (e & 0xFFu);
                         bl -= (int)(e & 0xFFu);
                         LPHQ_REFILL();
@@ -386,22 +424,24 @@ private:
                     }
                     LPHQ_REFILL();
                     e = lit_[bb & lmask];  // the next symbol's entry travels while the bytes are copied
-                    const uint8_t* src = out - dist;
-                    uint8_t* const mend = out + len;
-                    if (dist >= 8) {
+                    const T* src = out - dist;
+                    T* const mend = out + len;
+                    if (dist >= E) {
                         memcpy(out, src, 8);
-                        memcpy(out + 8, src + 8, 8);
-                        if (len > 16) {
-                            out += 16;
-                            src += 16;
+                        memcpy(out + E, src + E, 8);
+                        if (len > 2 * E) {
+                            out += 2 * E;
+                            src += 2 * E;
                             do {
                                 memcpy(out, src, 8);
-                                out += 8;
-                                src += 8;
+                                out += E;
+                                src += E;
                             } while (out < mend);
                         }
                     } else if (dist == 1) {
-                        memset(out, *src, len);
+                        if (sizeof(T) == 1) memset(out, (int)*src, len);
+                        else
+                            for (uint32_t i = 0; i < len; ++i) out[i] = *src;
                     } else {
                         do *out++ = *src++;
                         while (out < mend);
@@ -454,9 +494,9 @@ private:
                     break;
                 }
                 if (type == kLiteral) {
-                    *out++ = (uint8_t)(e >> 16);
+                    *out++ = (T)(uint8_t)(e >> 16);
                 } else {
-                    for (uint32_t i = 0, cnt = ((uint32_t)e >> 16) & 7u; i < cnt; ++i) *out++ = (uint8_t)(e >> (32 + 8 * i));
+                    for (uint32_t i = 0, cnt = ((uint32_t)e >> 16) & 7u; i < cnt; ++i) *out++ = (T)(uint8_t)(e >> (32 + 8 * i));
                 }
                 continue;
             }
@@ -495,17 +535,19 @@ private:
                 rc = -1;
                 break;
             }
-            const uint8_t* src = out - dist;
-            uint8_t* const mend = out + len;
-            if (dist >= 8) {
+            const T* src = out - dist;
+            T* const mend = out + len;
+            if (dist >= E) {
                 do {
                     memcpy(out, src, 8);
-                    out += 8;
-                    src += 8;
+                    out += E;
+                    src += E;
                 } while (out < mend);
                 out = mend;
             } else if (dist == 1) {
-                memset(out, *src, len);
+                if (sizeof(T) == 1) memset(out, (int)*src, len);
+                else
+                    for (uint32_t i = 0; i < len; ++i) out[i] = *src;
                 out = mend;
             } else {
                 do *out++ = *src++;
@@ -516,7 +558,9 @@ private:
         return rc;
     }
 
-    const uint8_t *in_ = nullptr, *end_ = nullptr;
+    const uint8_t *in_ = nullptr, *end_ = nullptr, *base_ = nullptr;
+    uint64_t stop_bit_ = ~(uint64_t)0;
+    uint32_t blocks_ = 0;
     uint64_t bitbuf_ = 0;
     int bitsleft_ = 0;
     State state_ = kHeader;

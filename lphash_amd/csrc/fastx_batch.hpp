@@ -14,7 +14,10 @@
 // concurrently (raw inflate + CRC-32 and length check per block) into a WINDOW of text that stands in for the mapped file: the window
 // always covers the batch being cut plus what it takes to find the next record start, slides forward with the batches and is as large
 // as a few batches (one record larger than that grows it, as it grows the arenas) -- memory stays proportional to batch_bases however
-// large the file is, like the plain and the single-member paths.  A single-member .gz cannot be split and stays on the serial reader.
+// large the file is, like the plain path.  Any other regular .gz -- one member or several, what `gzip` and the reference's own inputs are --
+// is decoded by all threads as well (parallel_gz.hpp: spans of the compressed stream decoded from guessed block starts with placeholders for
+// the unknown history, accepted only where the chain of block borders confirms them) into the same sliding window; only its length is not
+// known before the end.  Non-regular files, one thread, tiny files: the serial reader (gz_source.hpp ahead of FastxReader).
 //
 // A batch is a list of segments (bases in file order; a record may run across segments) plus the record lengths; segments
 // point into one of two arenas owned by the reader, used alternately, so a batch stays valid while the NEXT one is
@@ -46,6 +49,7 @@
 #include <vector>
 
 #include "fastx.hpp"
+#include "parallel_gz.hpp"
 
 namespace lphq {
 
@@ -97,11 +101,16 @@ public:
             }
         }
         if (!map_ && fd_ >= 0 && fstat(fd_, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= 28) bgzf_detect((size_t)st.st_size);
-        if (!map_ && !bgzf_) serial_ = new FastxReader(path);
-        ok_ = map_ || bgzf_ || serial_->ok();
+        if (!map_ && !bgzf_ && fd_ >= 0 && !getenv("LPHQ_GZ_ZLIB") && !getenv("LPHQ_GZ_SERIAL")) {
+            const char* sp = getenv("LPHQ_GZ_SPAN");  // (tests) compressed bytes per span
+            pgz_ = ParallelGzReader::open(path, threads_, sp ? (size_t)atol(sp) : 0);
+        }
+        if (!map_ && !bgzf_ && !pgz_) serial_ = new FastxReader(path);
+        ok_ = map_ || bgzf_ || pgz_ || serial_->ok();
     }
     ~FastxBatchReader() {
         delete serial_;
+        delete pgz_;
         if (bgzf_) munmap((void*)bgzf_, bgzf_size_);
         if (wbuf_) {
             free(wbuf_);
@@ -123,6 +132,15 @@ public:
             which_ ^= 1;
             (void)reserve(want);
         }
+        if (pgz_ && !wbuf_) {  // the decoder's buffers and threads, and a window of one batch and a few pieces: allocated and touched here, nothing decoded
+            pgz_->prealloc();
+            const size_t cap = want + 16 * pgz_->span() + kWindowSlack;
+            wbuf_ = (char*)malloc(cap);
+            if (wbuf_) {
+                wcap_ = cap;
+                memset(wbuf_, 0, cap);
+            }
+        }
     }
     bool ok() const { return ok_; }
     bool parallel() const { return map_ != nullptr && serial_ == nullptr; }  // (tests) which path produced the last batch
@@ -136,12 +154,20 @@ public:
             serial_ = new FastxReader(path_.c_str());
             if (!serial_->ok()) ok_ = false;
         }
+        if (pgz_ && !windowed_ && !serial_ && !gz_begin()) {  // first call on any other .gz; text that does not begin like FASTA / FASTQ, or damage: the serial reader decides
+            delete pgz_;  // (its threads would go on decoding ahead)
+            pgz_ = nullptr;
+            serial_ = new FastxReader(path_.c_str());
+            if (!serial_->ok()) ok_ = false;
+        }
         while (ok_ && parallel()) {
             if (off_ >= size_) return false;
             if (!next_parallel(b, batch_bases)) {
                 // a '+' line (or a damaged BGZF block): the rest of the file goes through the serial reader, starting at this batch's first record.
                 // Plain text: by offset.  BGZF: a fresh reader skips the records already handed out (by the equivalence of the two readers they are
                 // the first `emitted_` records of the serial one; seeking zlib to an uncompressed offset would drop what precedes a damaged block)
+                delete pgz_;
+                pgz_ = nullptr;
                 serial_ = new FastxReader(path_.c_str());
                 if (!serial_->ok()) ok_ = false;
                 else if (!windowed_) ok_ = serial_->seek(off_);
@@ -158,7 +184,8 @@ public:
         return ok_ && next_serial(b, batch_bases);
     }
 
-    bool bgzf() const { return windowed_; }  // (tests) the input is inflated block-parallel
+    bool bgzf() const { return windowed_ && bgzf_ != nullptr; }  // (tests) the input is inflated block-parallel
+    bool parallel_gz() const { return windowed_ && pgz_ != nullptr; }  // (tests) ... or span-parallel (parallel_gz.hpp)
     size_t window_capacity() const { return wcap_; }  // (tests) bytes of inflated text held at once
 
 private:
@@ -242,21 +269,7 @@ private:
         while (b_end < blocks_.size() && blocks_[b_end].out < upto) new_bytes += blocks_[b_end++].out_len;
         if (b_end == blk_next_) return true;
         if (from > wend_) from = wend_;
-        const size_t keep = wend_ - from;  // already inflated text that is still needed
-        if ((wend_ - wbase_) + new_bytes + kWindowSlack > wcap_) {  // slide: the retained tail to the front, and grow if that is not enough
-            if (keep + new_bytes + kWindowSlack > wcap_) {
-                const size_t cap = std::max<size_t>(2 * wcap_, keep + new_bytes + new_bytes / 2 + kWindowSlack);
-                char* nb = (char*)malloc(cap);
-                if (!nb) return false;
-                if (keep) memcpy(nb, wbuf_ + (from - wbase_), keep);
-                free(wbuf_);
-                wbuf_ = nb;
-                wcap_ = cap;
-            } else if (keep && from != wbase_) {
-                memmove(wbuf_, wbuf_ + (from - wbase_), keep);
-            }
-            wbase_ = from;
-        }
+        if (!window_room(from, new_bytes)) return false;
         const unsigned char* f = bgzf_;
         char* const base = wbuf_;
         const size_t wbase = wbase_, b0 = blk_next_, nb = b_end - blk_next_;
@@ -294,6 +307,68 @@ private:
         return true;
     }
     static constexpr size_t kWindowSlack = 1 << 12;
+    // Room for new_bytes more bytes of text behind wend_, keeping [from, wend_): the retained tail slides to the front of the buffer only when
+    // the buffer would otherwise overflow (so that the copying is of the look-ahead tail, not of the batch), and the buffer grows if that is not enough.
+    bool window_room(size_t from, size_t new_bytes) {
+        const size_t keep = wend_ - from;  // already inflated text that is still needed
+        if ((wend_ - wbase_) + new_bytes + kWindowSlack > wcap_) {
+            if (keep + new_bytes + kWindowSlack > wcap_) {
+                const size_t cap = std::max<size_t>(2 * wcap_, keep + new_bytes + new_bytes / 2 + kWindowSlack);
+                char* nb = (char*)malloc(cap);
+                if (!nb) return false;
+                if (keep) memcpy(nb, wbuf_ + (from - wbase_), keep);
+                free(wbuf_);
+                wbuf_ = nb;
+                wcap_ = cap;
+            } else if (keep && from != wbase_) {
+                memmove(wbuf_, wbuf_ + (from - wbase_), keep);
+            }
+            wbase_ = from;
+        }
+        return true;
+    }
+    bool window_fill(size_t from, size_t upto) { return bgzf_ ? bgzf_window(from, upto) : (pgz_ ? gz_window(from, upto) : false); }
+
+    // ---- any other .gz: pieces of text from the span-parallel decoder (parallel_gz.hpp), appended to the window in order ----
+    static constexpr size_t kUnknownSize = ~(size_t)0 >> 2;
+    bool gz_begin() {
+        size_ = kUnknownSize;
+        windowed_ = true;
+        if (!gz_window(0, 1) || wend_ == 0 || (map_[0] != '>' && map_[0] != '@')) {
+            windowed_ = false;
+            map_ = nullptr;
+            size_ = lim_ = 0;
+            return false;
+        }
+        fastq_ = map_[0] == '@';
+        return true;
+    }
+    // Make the window hold the text [from, upto') with upto' >= upto, or up to the end of the data (size_ is known from then on).  The pieces are
+    // written into the window by the decoder's threads; false = the stream is damaged (or a CRC-32 / length is wrong).
+    bool gz_window(size_t from, size_t upto) {
+        if (from > wend_) from = wend_;
+        bool moved = false;
+        while (wend_ < upto && !gz_done_) {
+            const size_t n = pgz_->next_len();
+            if (n == 0) {
+                gz_done_ = true;
+                break;
+            }
+            if ((wend_ - wbase_) + n + kWindowSlack > wcap_) {  // the buffer is about to move: the pieces on their way into it first
+                if (!pgz_->flush()) return false;
+                if (!window_room(from, n)) return false;
+                moved = true;
+            }
+            pgz_->emit((uint8_t*)wbuf_ + (wend_ - wbase_));
+            wend_ += n;
+        }
+        (void)moved;
+        if (!pgz_->flush() || pgz_->error()) return false;
+        if (gz_done_) size_ = wend_;
+        lim_ = wend_;
+        map_ = (const char*)((uintptr_t)wbuf_ - (uintptr_t)wbase_);
+        return true;
+    }
 
     struct Piece {
         size_t begin, end;   // file span; begin is a line start
@@ -476,7 +551,7 @@ private:
             // BGZF: the window must hold the batch and the start of the record after it; a search that runs into the end of the window while the
             // file goes on asks for twice as much
             for (size_t ahead = want + (1 << 16);; ahead *= 2) {
-                if (!bgzf_window(off_, ahead >= size_ - off_ ? size_ : off_ + ahead)) return false;  // damaged block: the serial reader takes over at off_
+                if (!window_fill(off_, ahead >= size_ - off_ ? size_ : off_ + ahead)) return false;  // damaged block: the serial reader takes over at off_
                 if (want >= size_ - off_) {
                     end = size_;
                     if (lim_ == size_) break;
@@ -563,6 +638,8 @@ private:
     size_t wcap_ = 0, wbase_ = 0, wend_ = 0;
     bool windowed_ = false;
     uint64_t emitted_ = 0;                 // records handed out by the parallel path so far
+    ParallelGzReader* pgz_ = nullptr;      // a .gz that is not BGZF, decoded by all threads into the same window
+    bool gz_done_ = false;
     FastxReader* serial_ = nullptr;
     bool serial_done_ = false, ok_ = false;
     Arena arenas_[2];

@@ -6,6 +6,8 @@
 //   san_host build_stream <fasta> <k> <m> <kind> <kmer_bits> <threads> <out.lph> <max_memory_bytes> <tmp_dir>   lphq_build_stream, small batches
 //   san_host inflate <file.gz>                                                 the .gz through GzFastSource (decoder + ring + CRC thread)
 //   san_host inflate_fuzz <file.gz> <n> <seed>                                  n corrupted / truncated copies through DeflateDecoder
+//   san_host inflate_par <file.gz> <threads> <span>                            the .gz through ParallelGzReader (every piece into a heap block of its exact size)
+//   san_host inflate_par_fuzz <file.gz> <n> <seed> <threads> <span> <tmp>      n corrupted / truncated copies (written to <tmp>) through ParallelGzReader
 //   san_host load  <file.lph> <kind> <kmer_bits>                             parse + cross-check + flat image
 //   san_host fuzz  <file.lph> <kind> <kmer_bits> <n> <seed>                  n corrupted copies through the loader
 #include <cstdio>
@@ -19,6 +21,7 @@
 #include "../../include/lphq.h"
 #include "fastx_batch.hpp"
 #include "gz_source.hpp"
+#include "parallel_gz.hpp"
 #include "image.hpp"
 #include "lph_format.hpp"
 #include "extract.hpp"
@@ -141,6 +144,66 @@ int main(int argc, char** argv) {
         }
         printf("%llu,%016llx,%s\n", (unsigned long long)total, (unsigned long long)h, src->error() ? "error" : "ok");
         delete src;
+        return 0;
+    }
+    if ((cmd == "inflate_par" && argc == 5) || (cmd == "inflate_par_fuzz" && argc == 8)) {
+        // one file through the parallel decoder; pieces go into exact-size heap blocks (ASan sees a write past a piece), several pieces in flight
+        auto run = [&](const char* path, int threads, size_t span, uint64_t& total, uint64_t& h, bool& err) -> bool {
+            lphq::ParallelGzReader* src = lphq::ParallelGzReader::open(path, threads, span);
+            if (!src) return false;
+            src->prealloc();
+            total = 0;
+            h = 1469598103934665603ull;
+            std::vector<std::vector<uint8_t>> blocks;
+            auto drain = [&] {
+                src->flush();
+                for (auto& b : blocks)
+                    for (uint8_t c : b) h = (h ^ c) * 1099511628211ull;
+                blocks.clear();
+            };
+            size_t n;
+            while ((n = src->next_len()) > 0) {
+                blocks.emplace_back(n);
+                src->emit(blocks.back().data());
+                total += n;
+                if (blocks.size() >= 5) drain();
+            }
+            drain();
+            err = src->error();
+            delete src;
+            return true;
+        };
+        uint64_t total = 0, h = 0;
+        bool err = false;
+        if (cmd == "inflate_par") {
+            if (!run(argv[2], atoi(argv[3]), (size_t)atol(argv[4]), total, h, err)) return 3;
+            printf("%llu,%016llx,%s\n", (unsigned long long)total, (unsigned long long)h, err ? "error" : "ok");
+            return 0;
+        }
+        const std::vector<uint8_t> good = slurp(argv[2]);
+        uint64_t s = strtoull(argv[4], nullptr, 10) | 1;
+        auto rnd = [&] {
+            s ^= s << 13;
+            s ^= s >> 7;
+            s ^= s << 17;
+            return s;
+        };
+        int fine = 0, errors = 0, declined = 0;
+        for (int t = 0; t < atoi(argv[3]); ++t) {
+            std::vector<uint8_t> bad = good;
+            switch (rnd() % 3) {
+                case 0: bad.resize(18 + rnd() % (bad.size() - 17)); break;
+                case 1: for (int j = 0; j < 1 + (int)(rnd() % 6); ++j) bad[10 + rnd() % (bad.size() - 10)] ^= (uint8_t)(1u << (rnd() % 8)); break;
+                default: for (size_t j = 10 + rnd() % (bad.size() - 10), e = std::min(bad.size(), j + 1 + rnd() % 64); j < e; ++j) bad[j] = (uint8_t)rnd(); break;
+            }
+            {
+                std::ofstream f(argv[7], std::ios::binary | std::ios::trunc);
+                f.write((const char*)bad.data(), (std::streamsize)bad.size());
+            }
+            if (!run(argv[7], atoi(argv[5]), (size_t)atol(argv[6]), total, h, err)) ++declined;
+            else (err ? errors : fine)++;
+        }
+        printf("parallel inflate fuzz: %d fine, %d errors, %d declined\n", fine, errors, declined);
         return 0;
     }
     if (cmd == "inflate_fuzz" && argc == 5) {

@@ -572,6 +572,24 @@ def test_host_sources_under_sanitizers(tmp_path):
         f.write(fa.read_bytes()[:300_000])
     r = subprocess.run([exe, "inflate_fuzz", str(small), "400", "7"], capture_output=True, text=True, env=env)
     assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+    # the same stream through the span-parallel decoder (parallel_gz.hpp): same bytes (FNV of the text), then corrupted copies -- no report, no hang
+    want = subprocess.run([exe, "inflate", str(gz)], capture_output=True, text=True, env=env).stdout.split(",")[:2]
+    for threads, span in ((4, 40_000), (7, 9_000), (2, 0)):
+        r = subprocess.run([exe, "inflate_par", str(gz), str(threads), str(span)], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0 and r.stdout.strip().split(",") == want + ["ok"], (threads, span, r.stdout, r.stderr[-3000:])
+        assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
+    r = subprocess.run([exe, "inflate_par_fuzz", str(small), "120", "11", "4", "12000", str(tmp_path / "bad.gz")], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+    # ... and under ThreadSanitizer: the pool, the chain and the emits of the parallel decoder race-free
+    texe = str(tmp_path / "tsan_host")
+    cc = subprocess.run([gxx, "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-I" + csrc, os.path.join(ROOT, "tests", "san", "san_host.cpp"),
+                         os.path.join(csrc, "builder.cpp"), os.path.join(csrc, "lph_format.cpp"), os.path.join(csrc, "image.cpp"), "-o", texe, "-lz", "-lpthread"],
+                        capture_output=True, text=True)
+    if cc.returncode == 0:  # (a g++ without the TSan runtime: the ASan run above stands alone)
+        for threads, span in ((4, 40_000), (6, 9_000)):
+            r = subprocess.run([texe, "inflate_par", str(gz), str(threads), str(span)], capture_output=True, text=True, timeout=900)
+            assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+            assert r.returncode == 0 and r.stdout.strip().split(",") == want + ["ok"], (threads, span, r.stdout, r.stderr[-3000:])
 
 
 def test_ptbb_build_cli_and_file(tmp_path):
@@ -660,6 +678,58 @@ def test_bgzf_input_is_inflated_block_parallel(tmp_path):
     # small batches: the windows before the damaged block are parsed in parallel, the serial reader takes over at the batch that meets it
     par = subprocess.run([exe, "records", "-i", str(p), "-t", "6", "--batch-bytes", "50000", "--min-piece", "1"], capture_output=True, text=True).stdout.strip().split(",")
     assert par[:3] == ser[:3] and 0 < int(par[4]) < int(par[3])
+
+
+def test_plain_gzip_input_is_decoded_by_all_threads(tmp_path):
+    """An ordinary .gz -- one member, what `gzip` writes and what the reference's own query files are (data/queries/*.fasta.gz, read through
+    gzread inside the timer, src/query.cpp:43-58) -- is decoded by all threads (parallel_gz.hpp) into the sliding window the parallel parser works
+    on: the records are the serial reader's (= kseq's) for multi-line FASTA, FASTQ, several members, tiny batches (the window slides and stays far
+    smaller than the text), spans smaller than a deflate block; a '+' line, text that is no FASTA, a damaged or truncated stream hand the file to the
+    serial reader from the right record on."""
+    import gzip
+
+    exe = os.path.join(ROOT, "lphash_amd", "lphash")
+    recs = random_records(191, 120, 1000, 160_000)
+    fasta = b"".join(b">r%d some comment\n" % i + b"\n".join(r[j:j + 80] for j in range(0, len(r), 80)) + b"\n" for i, r in enumerate(recs))
+    reads = random_records(192, 30_000, 100, 250)
+    fastq = b"".join(b"@q%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)) for i, r in enumerate(reads))
+    cut = fasta.index(b"\n>", 3_000_000) + 1
+    plus = fasta[:cut] + b">odd\nACGT\n+\nIIII\n" + fasta[cut:]  # a quality line in the middle: from that batch on the serial reader
+    cases = {
+        "fasta": gzip.compress(fasta, 6),
+        "fasta_l1": gzip.compress(fasta, 1),
+        "fastq": gzip.compress(fastq, 6),
+        "members": b"".join(gzip.compress(fasta[i:i + 2_500_000], 6) for i in range(0, len(fasta), 2_500_000)),
+        "plus_line": gzip.compress(plus, 6),
+        "not_fasta": gzip.compress(b"no header here\n" + fasta, 6),
+    }
+    damaged = bytearray(cases["fasta"])
+    damaged[len(damaged) // 2] ^= 0x24
+    cases["damaged"] = bytes(damaged)
+    cases["truncated"] = cases["fasta"][: len(cases["fasta"]) * 2 // 3]
+    for name, blob in cases.items():
+        p = tmp_path / f"{name}.gz"
+        p.write_bytes(blob)
+        ser = subprocess.run([exe, "records", "-i", str(p), "--serial"], capture_output=True, text=True).stdout.strip().split(",")
+        if os.path.exists(KSEQ_DUMP) and name not in ("damaged", "truncated"):
+            assert ",".join(ser[:3]) == subprocess.run([KSEQ_DUMP, str(p)], capture_output=True, text=True).stdout.strip(), name
+        for threads, span, batch in (("6", "0", 1 << 29), ("6", "30000", 300_000), ("3", "200000", 1_000_000), ("8", "7000", 50_000)):
+            par = subprocess.run([exe, "records", "-i", str(p), "-t", threads, "--batch-bytes", str(batch), "--min-piece", "1000"], capture_output=True, text=True,
+                                 env=dict(os.environ, LPHQ_GZ_SPAN=span))
+            f = par.stdout.strip().split(",")
+            assert par.returncode == 0 and f[:3] == ser[:3], (name, threads, span, batch, f, ser)
+            n_batches, n_parallel, window, n_pgz = int(f[3]), int(f[4]), int(f[6]), int(f[7])
+            if name in ("fasta", "fasta_l1", "fastq", "members"):
+                assert n_pgz == n_batches == n_parallel > 0, (name, f)  # every batch: decoded by the pool, parsed by the parallel parser
+                if batch <= 1_000_000:
+                    assert window < len(fasta) // 2, (name, f)  # the text is never held whole
+            elif name == "not_fasta":
+                assert n_pgz == 0
+            elif batch <= 1_000_000:  # the batches before the '+' line / the damage came from the pool
+                assert 0 < n_pgz < n_batches, (name, f)
+    # the same file with the parallel decoder switched off is the serial path of old
+    par = subprocess.run([exe, "records", "-i", str(tmp_path / "fasta.gz"), "-t", "6"], capture_output=True, text=True, env=dict(os.environ, LPHQ_GZ_SERIAL="1"))
+    assert par.stdout.strip().split(",")[7] == "0"
 
 
 def test_bgzf_window_is_bounded_by_the_batch_size(tmp_path):
@@ -778,6 +848,8 @@ def test_fast_inflate_equals_zlib(tmp_path):
         "flags": _gzip_member(fasta[:50_000], name=b"x.fa", comment=b"made by a test", extra=b"AB\x02\x00xy", hcrc=True),
         "members": b"".join(_gzip_member(fasta[i:i + 77_777], level=int(rng.integers(0, 10))) for i in range(0, 1_500_000, 77_777)),
         "members_then_garbage": _gzip_member(text[:100_000]) + _gzip_member(b"") + _gzip_member(text[100_000:300_000]) + b"\x00garbage after the last member",
+        # a run of one letter longer than any span's cap of text (the N stretches of a chromosome; placeholders never die out inside it)
+        "poly_n": _gzip_member(fasta[:600_000] + b"N" * 40_000_000 + fasta[600_000:1_200_000], level=6),
     }
     plain = {"members_then_garbage": text[:300_000], "members": b"".join(fasta[i:i + 77_777] for i in range(0, 1_500_000, 77_777))}
     for name, blob in cases.items():
@@ -790,6 +862,19 @@ def test_fast_inflate_equals_zlib(tmp_path):
         r = subprocess.run([exe, "inflate", "-i", str(f), "-o", str(o)], capture_output=True, text=True)
         assert r.returncode == 0 and r.stdout.split(",")[:2] == [str(len(want)), "ok"], (name, r.stdout, r.stderr)
         assert o.read_bytes() == want, name
+        # the same stream decoded by several threads (parallel_gz.hpp): spans of the compressed file from guessed block starts, with placeholders for
+        # the unknown history; spans far smaller than a block, spans of many blocks, more spans than threads and fewer
+        for threads, span in ((2, 0), (3, 20_000), (8, 65_536), (8, 5_000), (5, 300_000)):
+            r = subprocess.run([exe, "inflate", "-i", str(f), "-o", str(o), "--parallel", str(threads)] + (["--span", str(span)] if span else []),
+                               capture_output=True, text=True)
+            if r.returncode == 2:  # a file of less than two spans is left to the serial decoder
+                assert len(blob) < 2 * max(span, 128 << 10), (name, threads, span)
+                continue
+            assert r.returncode == 0 and r.stdout.split(",")[:2] == [str(len(want)), "ok"], (name, threads, span, r.stdout, r.stderr)
+            assert o.read_bytes() == want, (name, threads, span)
+            n_par, n_ser = int(r.stdout.split(",")[3]), int(r.stdout.split(",")[4])
+            if name in ("level1", "level9_big", "huffman_only") and span >= 20_000:  # dynamic blocks throughout: the pool does the work
+                assert n_par >= 3 * n_ser, (name, threads, span, r.stdout)
     # the reader on top of it yields the records kseq / zlib yield (`lphash records --serial` with and without LPHQ_GZ_ZLIB)
     for name in ("level1", "fastq", "members"):
         a = subprocess.run([exe, "records", "-i", str(tmp_path / f"{name}.gz"), "--serial"], capture_output=True, text=True)
@@ -807,15 +892,16 @@ def test_fast_inflate_equals_zlib(tmp_path):
                 bad[int(rng.integers(10, len(bad)))] ^= 1 << int(rng.integers(0, 8))
         f, o = tmp_path / "bad.gz", tmp_path / "bad.out"
         f.write_bytes(bytes(bad))
-        r = subprocess.run([exe, "inflate", "-i", str(f), "-o", str(o)], capture_output=True, text=True)
-        if r.returncode == 2:  # not even a header left
-            continue
-        assert r.returncode in (0, 3), (trial, r.returncode, r.stderr)
-        got = o.read_bytes()
-        if r.returncode == 0:  # the damage was harmless (e.g. inside the trailing bytes that nothing reads): then the data must be right
-            assert got == want, trial
-        elif trial % 2 == 0:  # truncated: everything decoded is a prefix of the truth
-            assert want.startswith(got), trial
+        for par in ([], ["--parallel", "4", "--span", "30000"]):
+            r = subprocess.run([exe, "inflate", "-i", str(f), "-o", str(o)] + par, capture_output=True, text=True)
+            if r.returncode == 2:  # not even a header left (or, for the parallel decoder, less than two spans)
+                continue
+            assert r.returncode in (0, 3), (trial, par, r.returncode, r.stderr)
+            got = o.read_bytes()
+            if r.returncode == 0:  # the damage was harmless (e.g. inside the trailing bytes that nothing reads): then the data must be right
+                assert got == want, (trial, par)
+            elif trial % 2 == 0:  # truncated: everything decoded is a prefix of the truth
+                assert want.startswith(got), (trial, par)
 
 
 def test_bbhash_of_no_keys_loads_its_own_file(tmp_path):
