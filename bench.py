@@ -381,7 +381,7 @@ def run_workload(job, wl):
         kernel_ms_per_rank = [float(e.item()) for e in every]
 
     # ---- parity of what was just measured, on EVERY rank (oracle = checker), + the CPU baseline on rank 0 ----
-    cpu = cpu_all = cpu_b1 = cli_b1 = None
+    cpu = cpu_all = cpu_b1 = cli_b1 = binding_b1 = None
     parity = None
     o = None
     if not args.no_cpu_baseline:
@@ -463,6 +463,22 @@ def run_workload(job, wl):
                           "note": "lphash query-* (this repo's CLI, GPU path) on the same .fa.gz: host parse + PCIe included"}
             else:
                 log(f"{tag} CLI run failed ({r.returncode}): {r.stderr[-500:]}")
+        # the reference-side binding (examples/gpu_mphf.hpp under the reference's query<MPHF> driver, examples/query_main.cpp; INTEGRATION.md
+        # section 2) on the same file: batches of records through lphq_session_* (EVERY code comes back to the host: 8 B per k-mer over PCIe, which
+        # the CLI's default pass does not pay), and the reference's literal one-record-per-call loop over lphq_query_contig
+        exb = os.path.join(ROOT, "examples", f"query_example{kmer_bits}")
+        if os.path.exists(exb):
+            binding_b1 = {"note": "examples/query_example (gpu_mphf<> binding, compiled with g++ against include/lphq.h) on the same .fa.gz; batched = "
+                                  "submit / collect over lphq_session_*, all codes returned to the host; per_record = the reference's literal loop"}
+            for label, extra in (("batched", []), ("per_record", ["--per-record"])):
+                r = subprocess.run([exb, "query-p" if kind == L.PARTITIONED else "query-u", "-i", path, "-q", fa] + extra, capture_output=True, text=True, timeout=600)
+                f5 = r.stdout.strip().split(",")
+                if r.returncode == 0 and len(f5) == 5 and int(f5[2]) == n_s:
+                    binding_b1[label + "_streaming_ns_per_kmer"] = float(f5[3])
+                    binding_b1[label + "_random_ns_per_kmer"] = float(f5[4])
+                else:
+                    log(f"{tag} binding run ({label}) failed ({r.returncode}): {r.stderr[-500:]}")
+            log(f"{tag} binding: {binding_b1}")
         log(f"{tag} B1 reference-faithful driver: {cpu_b1['streaming_ns_per_kmer']:.1f} / {cpu_b1['random_ns_per_kmer']:.1f} ns per k-mer (streaming / random); CLI: {cli_b1}")
 
     # ---- N > 1: every replica (rank 0 parsed the file, the others received the image over RCCL) must answer alike ----
@@ -575,6 +591,8 @@ def run_workload(job, wl):
             out["cpu_baseline_reference_driver"] = cpu_b1
         if cli_b1 is not None:
             out["cli_end_to_end"] = cli_b1
+        if binding_b1 is not None:
+            out["binding_end_to_end"] = binding_b1
         if build_s is not None:
             out["index_build_s"] = build_s
         if bcast_s is not None:

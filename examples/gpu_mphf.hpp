@@ -2,10 +2,14 @@
 // lphash::mphf_alt in the reference's src/query.cpp and src/build.cpp that forwards to the C ABI (include/lphq.h).
 //
 // Inside the reference tree a maintainer adds this header, links -llphq (CMakeLists.txt:56) and changes two lines of src/lphash.cpp:28-31:
-//     return query<gpu_mphf<LPHQ_PARTITIONED>>(argc - 1, argv + 1);      // was query<mphf>
-//     return query<gpu_mphf<LPHQ_UNPARTITIONED>>(argc - 1, argv + 1);    // was query<mphf_alt>
+//     return query<gpu_mphf<LPHQ_PARTITIONED, kmer_t>>(argc - 1, argv + 1);      // was query<mphf>
+//     return query<gpu_mphf<LPHQ_UNPARTITIONED, kmer_t>>(argc - 1, argv + 1);    // was query<mphf_alt>
 // and, in query<MPHF>() (src/query.cpp:37), essentials::load(hf, name) -> hf.load(name).  examples/query_main.cpp is that driver,
 // restated, so that the binding is built and run by this repository's tests (tests/test_zz_gpu_next.py::test_integration_stub_*).
+//
+// Two ways to ask: operator()(contig, length, streaming) is the reference's call, one record at a time (two copies and two waits per record:
+// faithful, and ~200x below what the device does); submit() / collect() take MANY records per call and keep batches in flight
+// (lphq_session_*): that is the one a driver should loop over -- examples/query_main.cpp does, and keeps the literal loop as --per-record.
 //
 // Only lphq.h and the standard library are needed: plain pointers and sizes cross the boundary, no exception does.
 #pragma once
@@ -13,6 +17,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <string_view>
 #include <vector>
 
 #include "lphq.h"
@@ -25,10 +30,15 @@ public:
     gpu_mphf() = default;
     gpu_mphf(const gpu_mphf&) = delete;
     gpu_mphf& operator=(const gpu_mphf&) = delete;
-    ~gpu_mphf() { lphq_close(h_); }
+    ~gpu_mphf() {
+        lphq_session_close(s_);
+        lphq_close(h_);
+    }
 
     // replaces essentials::load(hf, path)                                   (src/query.cpp:37)
     void load(const char* path, int device = 0) {
+        lphq_session_close(s_);
+        s_ = nullptr;
         lphq_close(h_);
         h_ = nullptr;
         if (lphq_open(path, KIND, (int)sizeof(KmerT) * 8, &h_) != LPHQ_OK || lphq_attach(h_, device) != LPHQ_OK) throw std::runtime_error(lphq_last_error());
@@ -41,6 +51,51 @@ public:
         std::size_t n = 0;
         if (lphq_query_contig(h_, contig, length, streaming ? 1 : 0, res.data(), res.size(), &n) != LPHQ_OK) throw std::runtime_error(lphq_last_error());
         res.resize(n);
+        return res;
+    }
+
+    // ---- many records per call ----
+    // The codes of one batch: record r's codes are [begin(r), begin(r) + size(r)), in the session's pinned memory, valid until the next submit().
+    class batch {
+    public:
+        std::size_t records() const { return n_; }
+        const uint64_t* begin(std::size_t r) const { return codes_ + offs_[r]; }
+        std::size_t size(std::size_t r) const { return (std::size_t)(offs_[r + 1] - offs_[r]); }
+        std::size_t total() const { return n_ ? (std::size_t)offs_[n_] : 0; }
+        std::vector<uint64_t> operator[](std::size_t r) const { return std::vector<uint64_t>(begin(r), begin(r) + size(r)); }  // (a copy: what operator() returns)
+
+    private:
+        friend class gpu_mphf;
+        const uint64_t *codes_ = nullptr, *offs_ = nullptr;
+        std::size_t n_ = 0;
+    };
+    // Queue one batch (the records' memory must stay valid until the batch is collected; depth() batches may be in flight).
+    void submit(const char* const* records, const std::size_t* lengths, std::size_t n, bool streaming = true) {
+        if (!s_ && lphq_session_open(h_, kDepth, &s_) != LPHQ_OK) throw std::runtime_error(lphq_last_error());
+        if (lphq_session_submit(s_, records, lengths, n, streaming ? 1 : 0) != LPHQ_OK) throw std::runtime_error(lphq_last_error());
+    }
+    void submit(const std::vector<std::string_view>& records, bool streaming = true) {
+        ptrs_.resize(records.size());
+        lens_.resize(records.size());
+        for (std::size_t i = 0; i < records.size(); ++i) {
+            ptrs_[i] = records[i].data();
+            lens_[i] = records[i].size();
+        }
+        submit(ptrs_.data(), lens_.data(), records.size(), streaming);
+    }
+    // The oldest batch in flight.
+    batch collect() {
+        batch b;
+        if (lphq_session_collect(s_, &b.codes_, &b.offs_, &b.n_) != LPHQ_OK) throw std::runtime_error(lphq_last_error());
+        return b;
+    }
+    static constexpr int depth() { return kDepth; }
+    // MPHF::operator() over a whole batch: one vector per record, like a loop over operator() (and one copy more than submit / collect)
+    std::vector<std::vector<uint64_t>> operator()(const std::vector<std::string_view>& records, bool streaming = true) {
+        submit(records, streaming);
+        const batch b = collect();
+        std::vector<std::vector<uint64_t>> res(b.records());
+        for (std::size_t r = 0; r < b.records(); ++r) res[r] = b[r];
         return res;
     }
 
@@ -61,7 +116,11 @@ private:
         if (lphq_get_info(h_, &i) != LPHQ_OK) throw std::runtime_error(lphq_last_error());
         return i;
     }
+    static constexpr int kDepth = 2;
     lphq_index* h_ = nullptr;
+    lphq_session* s_ = nullptr;
+    std::vector<const char*> ptrs_;
+    std::vector<std::size_t> lens_;
 };
 
 }  // namespace lphash

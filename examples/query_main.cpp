@@ -5,7 +5,9 @@
 // (lphash_amd/csrc/fastx.hpp) because the reference's external/kseq.h is not part of this tree.
 //
 //   g++ -std=c++17 -O2 -Iinclude -Ilphash_amd/csrc examples/query_main.cpp -Llphash_amd -llphq -lz -lpthread -o examples/query_example
-//   examples/query_example query-p|query-u -i index.lph -q queries.fa[.gz] [--dump prefix]     (--dump: codes of both passes as prefix.streaming.u64 / prefix.random.u64)
+//   examples/query_example query-p|query-u -i index.lph -q queries.fa[.gz] [--dump prefix] [--per-record]
+//                          (--dump: codes of both passes as prefix.streaming.u64 / prefix.random.u64; --per-record: the reference's loop, literally --
+//                           one operator() per record; the default hands the binding batches of records and keeps two in flight)
 //   examples/query_example build-p|build-u -i unitigs.fa[.gz] -k K -m M -o index.lph [-s seed] [-c c] [-t threads] [-d tmp] [--max-memory GB]
 //                          (the build side of the binding, src/build.cpp:24-28: same file as the reference's build-p / build-u)
 //   -DLPHASH_KMER64 selects `typedef uint64_t kmer_t` (include/compile_constants.tpd:2); the default is __uint128_t, as the reference ships.
@@ -14,9 +16,12 @@
 #include <cstring>
 #include <iostream>
 #include <string>
+#include <vector>
 
 #include "fastx.hpp"
+#include "fastx_batch.hpp"
 #include "gpu_mphf.hpp"
+#include "host_cpus.hpp"
 
 #ifdef LPHASH_KMER64
 typedef uint64_t kmer_t;
@@ -26,14 +31,70 @@ typedef __uint128_t kmer_t;
 
 namespace lphash {
 
+// One pass with MANY records per call: the batch reader (all host threads: mapped text, BGZF and plain .gz alike) parses into page-locked arenas,
+// the binding copies a batch to the device while the previous one is being looked up and the one before is being consumed here.
 template <typename MPHF>
-int query(const std::string& mphf_filename, const std::string& query_filename, const std::string& dump_prefix) {
+bool batched_pass(MPHF& hf, const std::string& query_filename, bool streaming, FILE* dump, uint64_t& total, long long& micros) {
+    lphq::FastxBatchReader reader(query_filename.c_str(), lphq::usable_cpus() < 16 ? lphq::usable_cpus() : 16, &lphq_host_alloc, &lphq_host_free);
+    if (!reader.ok()) return false;
+    const size_t batch_bases = (size_t)16 << 20;
+    reader.prealloc(batch_bases);  // (set-up, like gzopen + kseq_init before t.start(), src/query.cpp:43-48)
+    lphq::FastxBatch bufs[2];
+    std::vector<const char*> ptrs[2];
+    std::vector<size_t> lens[2];
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    auto consume = [&] {
+        const auto b = hf.collect();
+        total += b.total();  // hashes.size() summed over the batch's records
+        if (dump && b.total()) fwrite(b.begin(0), sizeof(uint64_t), b.total(), dump);
+    };
+    int in_flight = 0;
+    for (int i = 0;; i ^= 1) {
+        // (the reader keeps the two most recent batches alive: batch i - 2's memory is reused now, so it must have been collected)
+        if (in_flight == 2) {
+            consume();
+            --in_flight;
+        }
+        if (!reader.next(bufs[i], batch_bases)) break;
+        bufs[i].compact();  // pieces parsed by different threads slide together: records are adjacent in memory, the binding copies them in one go
+        ptrs[i].clear();
+        lens[i].clear();
+        const char* p = bufs[i].segs.empty() ? nullptr : bufs[i].segs[0].p;
+        for (uint64_t len : bufs[i].lens) {
+            ptrs[i].push_back(p);
+            lens[i].push_back((size_t)len);
+            p += len;
+        }
+        hf.submit(ptrs[i].data(), lens[i].data(), ptrs[i].size(), streaming);
+        ++in_flight;
+    }
+    while (in_flight--) consume();
+    micros = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+    return true;
+}
+
+template <typename MPHF>
+int query(const std::string& mphf_filename, const std::string& query_filename, const std::string& dump_prefix, bool per_record) {
     MPHF hf;
     hf.load(mphf_filename.c_str());  // essentials::load(hf, mphf_filename.c_str())                      src/query.cpp:37
     uint64_t total[2] = {0, 0};
     long long micros[2] = {0, 0};
     for (int pass = 0; pass < 2; ++pass) {  // streaming_on = true (src/query.cpp:48-58), then streaming_off (:60-79)
         const bool streaming = pass == 0;
+        if (!per_record) {
+            FILE* dump = nullptr;
+            if (!dump_prefix.empty()) {
+                dump = fopen((dump_prefix + (streaming ? ".streaming.u64" : ".random.u64")).c_str(), "wb");
+                if (!dump) return 2;
+            }
+            const bool opened = batched_pass(hf, query_filename, streaming, dump, total[pass], micros[pass]);
+            if (dump) fclose(dump);
+            if (!opened) {
+                std::cerr << "Unable to open the input file " << query_filename << "\n";
+                return 2;  // src/query.cpp:43-46
+            }
+            continue;
+        }
         lphq::FastxReader reader(query_filename.c_str());
         if (!reader.ok()) {
             std::cerr << "Unable to open the input file " << query_filename << "\n";
@@ -95,8 +156,16 @@ int main(int argc, char** argv) {
     int k = 0, m = 0, threads = 1;
     uint64_t seed = 42, max_memory_gb = 0;
     double c = 3.0;
-    for (int i = 2; i + 1 < argc; i += 2) {
-        const std::string a = argv[i], v = argv[i + 1];
+    bool per_record = false;
+    for (int i = 2; i < argc; i += 2) {
+        const std::string a = argv[i];
+        if (a == "--per-record") {
+            per_record = true;
+            --i;
+            continue;
+        }
+        if (i + 1 >= argc) break;
+        const std::string v = argv[i + 1];
         if (a == "-i") mphf = v;
         else if (a == "-q") queries = v;
         else if (a == "--dump") dump = v;
@@ -111,7 +180,7 @@ int main(int argc, char** argv) {
     }
     const bool is_query = tool == "query-p" || tool == "query-u", is_build = tool == "build-p" || tool == "build-u";
     if ((!is_query && !is_build) || mphf.empty() || (is_query && queries.empty()) || (is_build && (out.empty() || k <= 0 || m <= 0))) {
-        std::cerr << "usage: " << argv[0] << " query-p|query-u -i <mphf> -q <fasta|fastq[.gz]> [--dump prefix]\n"
+        std::cerr << "usage: " << argv[0] << " query-p|query-u -i <mphf> -q <fasta|fastq[.gz]> [--dump prefix] [--per-record]\n"
                   << "       " << argv[0] << " build-p|build-u -i <fasta[.gz]> -k K -m M -o <mphf> [-s seed] [-c c] [-t threads] [-d tmp] [--max-memory GB]\n";
         return 1;  // ParseError, src/query.cpp:31-33
     }
@@ -125,8 +194,8 @@ int main(int argc, char** argv) {
             std::cerr << "built " << out << ": " << st.num_kmers << " k-mers, " << st.distinct_minimizers << " minimizers\n";
             return 0;
         }
-        if (tool == "query-p") return lphash::query<lphash::gpu_mphf<LPHQ_PARTITIONED, kmer_t>>(mphf, queries, dump);
-        return lphash::query<lphash::gpu_mphf<LPHQ_UNPARTITIONED, kmer_t>>(mphf, queries, dump);
+        if (tool == "query-p") return lphash::query<lphash::gpu_mphf<LPHQ_PARTITIONED, kmer_t>>(mphf, queries, dump, per_record);
+        return lphash::query<lphash::gpu_mphf<LPHQ_UNPARTITIONED, kmer_t>>(mphf, queries, dump, per_record);
     } catch (const std::exception& e) {
         std::cerr << e.what() << "\n";
         return 1;

@@ -26,8 +26,9 @@ extern "C" {
 #endif
 
 /* Version of this interface.  An entry point never changes its signature: new behaviour gets a new name and the number goes up
- * (2: lphq_count_valid_on_stream, lphq_abi_version).  A caller compiled against version N works with any library reporting >= N. */
-#define LPHQ_ABI_VERSION 2
+ * (2: lphq_count_valid_on_stream, lphq_abi_version; 3: lphq_session_*, lphq_host_alloc / lphq_host_free, lphq_replica_info).  A caller compiled
+ * against version N works with any library reporting >= N. */
+#define LPHQ_ABI_VERSION 3
 int lphq_abi_version(void);
 
 /* ---- status codes ---- */
@@ -162,6 +163,35 @@ int lphq_gather_payload(const lphq_index* idx, const uint64_t* d_codes, size_t n
  * between calls), so concurrent callers do not serialise on the library. */
 int lphq_query_contig(const lphq_index* idx, const char* contig, size_t length, int streaming,
                       uint64_t* out, size_t cap, size_t* n_out);
+
+/* ---- batched host-buffer queries: MPHF::operator() over MANY records per call, pipelined (ABI 3) ----
+ * lphq_query_contig pays two synchronous copies and two stream synchronisations per record; a driver that loops over records like
+ * src/query.cpp:48-59 gets 0.5-1 G k-mers/s from it.  A session keeps `depth` batches in flight on one stream of one device: submit copies the
+ * records of a batch to the device (one asynchronous copy per run of records that are adjacent in memory -- a batch parsed into one arena is one
+ * copy), runs the kernel and copies the codes into pinned host memory owned by the session, all without waiting; collect waits for the OLDEST
+ * batch in flight and hands out its codes.  Typical loop (depth 2): submit(A); submit(B); collect(A) ... use A ...; submit(C); collect(B); ...
+ *
+ * A session belongs to one thread at a time; any number of sessions (and other calls) may use one index concurrently.  The device is the calling
+ * thread's current HIP device at lphq_session_open if the index has a replica there, otherwise the primary one.
+ *
+ * submit: the records' memory must stay valid and unchanged until the batch is collected (pinned memory -- lphq_host_alloc -- makes the copies
+ *   truly asynchronous; pageable memory works, the runtime stages it).  LPHQ_ERR_STATE when `depth` batches are already in flight.
+ * collect: *codes holds the batch's codes record after record, record r at [(*offsets)[r], (*offsets)[r + 1]) -- (*offsets)[r + 1] - (*offsets)[r]
+ *   is what the reference's vector.size() would be: max(0, len_r - k + 1) windows, minus (streaming only) the windows that hold a non-ACGT base,
+ *   decided from the input bases as in lphq_query_contig.  The pointers are valid until the next lphq_session_submit on this session.
+ *   LPHQ_ERR_STATE when nothing is in flight. */
+typedef struct lphq_session lphq_session;
+int lphq_session_open(const lphq_index* idx, int depth /* 1..4 */, lphq_session** out);
+void lphq_session_close(lphq_session* s);
+int lphq_session_submit(lphq_session* s, const char* const* records, const size_t* lengths, size_t n_records, int streaming);
+int lphq_session_collect(lphq_session* s, const uint64_t** codes, const uint64_t** offsets /* n_records + 1 entries */, size_t* n_records);
+/* Page-locked host memory for record buffers handed to lphq_session_submit (hipHostMalloc); NULL when it cannot be had. */
+void* lphq_host_alloc(size_t bytes);
+void lphq_host_free(void* p);
+
+/* How replica i (attach order) got its image: 0 = uploaded from the host image, 1 = peer copy with peer access enabled (xGMI / PCIe P2P),
+ * 2 = peer copy staged by the runtime (no peer access between the two devices), 3 = adopted from device memory (lphq_open_device_image). */
+int lphq_replica_info(const lphq_index* idx, int i, int* device, int* how);
 
 /* ---- index construction (writes the reference's format) ----
  * In-memory build of a partitioned / unpartitioned LP-MPHF over the k-mers of the records

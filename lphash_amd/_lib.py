@@ -70,6 +70,13 @@ SIGNATURES = {
     "lphq_open_bbhash": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "lphq_build_bbhash": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_int, C.c_char_p,
                                     C.POINTER(BuildStats)]),
+    "lphq_session_open": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "lphq_session_close": (None, [C.c_void_p]),
+    "lphq_session_submit": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int]),
+    "lphq_session_collect": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_size_t)]),
+    "lphq_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "lphq_host_free": (None, [C.c_void_p]),
+    "lphq_replica_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lphq_open_pthash": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "lphq_build_pthash": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
                                     C.c_char_p, C.POINTER(BuildStats)]),

@@ -238,6 +238,19 @@ class _MphfBase:
         check(lib.lphq_query_contig(self._h, contig, len(contig), 1 if streaming else 0, out.ctypes.data, cap, C.byref(n)))
         return out[: n.value].copy()
 
+    # -- MPHF::operator() over many records per call, batches in flight (lphq_session_*) -----------
+    def session(self, depth=2):
+        return Session(self, depth)
+
+    def replica_info(self):
+        """[(device, how)] in attach order; how: 0 uploaded, 1 peer copy with peer access, 2 peer copy staged by the runtime, 3 adopted."""
+        out = []
+        for i in range(len(self.attached_devices())):
+            d, h = C.c_int(), C.c_int()
+            check(lib.lphq_replica_info(self._h, i, C.byref(d), C.byref(h)))
+            out.append((d.value, h.value))
+        return out
+
     # -- device-resident batches (pointers are raw device addresses, e.g. tensor.data_ptr()) -------
     def query_packed(self, d_kmers, n, d_out, stream=0):
         check(lib.lphq_query_packed(self._h, C.c_void_p(d_kmers), n, C.c_void_p(d_out), C.c_void_p(stream)))
@@ -248,6 +261,45 @@ class _MphfBase:
 
     def pack_kmers(self, d_seq, d_pos, n, d_kmers, stream=0):
         check(lib.lphq_pack_kmers(self._h, C.c_void_p(d_seq), C.c_void_p(d_pos), n, C.c_void_p(d_kmers), C.c_void_p(stream)))
+
+
+class Session:
+    """Batches of host records through one index, `depth` of them in flight (include/lphq.h: lphq_session_*).  submit() queues a batch (copy in,
+    kernel, copy out, nothing waited for); collect() waits for the oldest batch and returns one uint64 array per record -- what a loop over
+    MPHF::operator() would have returned."""
+
+    def __init__(self, mphf, depth=2):
+        self._s = C.c_void_p()
+        self._keep = []  # the records of the batches in flight (their memory must outlive the copies)
+        check(lib.lphq_session_open(mphf._h, depth, C.byref(self._s)))
+
+    def submit(self, records, streaming=True):
+        recs = [bytes(r) for r in records]
+        n = len(recs)
+        ptrs = (C.c_char_p * max(n, 1))(*recs)
+        lens = (C.c_size_t * max(n, 1))(*[len(r) for r in recs])
+        check(lib.lphq_session_submit(self._s, ptrs, lens, n, 1 if streaming else 0))
+        self._keep.append((recs, ptrs, lens))
+
+    def collect(self):
+        codes, offs, n = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)(), C.c_size_t()
+        check(lib.lphq_session_collect(self._s, C.byref(codes), C.byref(offs), C.byref(n)))
+        self._keep.pop(0)
+        o = np.ctypeslib.as_array(offs, shape=(n.value + 1,)).copy() if n.value else np.zeros(1, dtype=np.uint64)
+        total = int(o[-1])
+        flat = np.ctypeslib.as_array(codes, shape=(total,)).copy() if total else np.zeros(0, dtype=np.uint64)
+        return [flat[int(o[i]):int(o[i + 1])] for i in range(n.value)]
+
+    def close(self):
+        if self._s:
+            lib.lphq_session_close(self._s)
+            self._s = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Mphf(_MphfBase):

@@ -7,6 +7,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/lphq.h"
@@ -23,6 +24,7 @@ struct Replica {
     int device = -1;
     uint8_t* d_image = nullptr;
     bool owns = false;
+    int how = 0;  // lphq_replica_info: 0 uploaded, 1 peer copy with peer access, 2 peer copy staged by the runtime, 3 adopted
 };
 // Per-call scratch of the host-buffer path and of lphq_count_valid: buffers plus a private non-blocking stream, so that
 // concurrent callers neither serialise on a lock nor meet on the null stream.  Slots are recycled through a free list.
@@ -397,7 +399,8 @@ static int check_device(int device) {
 
 // Add a replica on `device`: from the host image when there is one and no replica exists yet, otherwise by a peer copy of
 // the primary replica (xGMI between GPUs of one node; the runtime stages through the host when peer access is unavailable).
-static int add_replica(lphq_index* idx, int device) {
+// With `stream` the peer copy is only queued there (lphq_attach_devices runs the copies to all devices concurrently and waits once).
+static int add_replica(lphq_index* idx, int device, hipStream_t* queued_on = nullptr) {
     for (const Replica& r : idx->reps)
         if (r.device == device) return LPHQ_OK;
     if (idx->reps.empty() && idx->image.empty()) return fail(LPHQ_ERR_STATE, "no host image to upload");
@@ -408,16 +411,38 @@ static int add_replica(lphq_index* idx, int device) {
     uint8_t* d = nullptr;
     HIP_TRY(hipMalloc((void**)&d, idx->image_bytes));
     hipError_t e;
-    if (idx->reps.empty()) e = hipMemcpy(d, idx->image.data(), idx->image_bytes, hipMemcpyHostToDevice);
-    else e = hipMemcpyPeer(d, device, idx->reps[0].d_image, idx->reps[0].device, idx->image_bytes);
+    int how = 0;
+    hipStream_t st = nullptr;
+    if (idx->reps.empty()) {
+        e = hipMemcpy(d, idx->image.data(), idx->image_bytes, hipMemcpyHostToDevice);
+    } else {
+        // peer access (destination device current): enabled once per pair; "already enabled" is fine, "not possible" leaves the staged path
+        const int src = idx->reps[0].device;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, device, src) == hipSuccess && can) {
+            const hipError_t pe = hipDeviceEnablePeerAccess(src, 0);
+            if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) how = 1;
+            (void)hipGetLastError();  // (clear the sticky "already enabled")
+        }
+        if (how == 0) how = 2;
+        if (queued_on) {
+            e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipMemcpyPeerAsync(d, device, idx->reps[0].d_image, src, idx->image_bytes, st);
+        } else {
+            e = hipMemcpyPeer(d, device, idx->reps[0].d_image, src, idx->image_bytes);
+        }
+    }
     if (e != hipSuccess) {
+        if (st) (void)hipStreamDestroy(st);
         (void)hipFree(d);
         return fail_hip(e, idx->reps.empty() ? "hipMemcpy(image)" : "hipMemcpyPeer(image)");
     }
+    if (queued_on) *queued_on = st;
     Replica r;
     r.device = device;
     r.d_image = d;
     r.owns = true;
+    r.how = how;
     idx->reps.push_back(r);
     return LPHQ_OK;
 }
@@ -427,13 +452,31 @@ extern "C" int lphq_attach(lphq_index* idx, int device) {
     return add_replica(idx, device);
 }
 
+// Upload to the first device, then one peer copy per further device, all in flight at once (each on a stream of its destination device: on a node
+// whose GPUs are fully connected over xGMI the N - 1 copies leave the primary over N - 1 different links), one wait per copy at the end.
 extern "C" int lphq_attach_devices(lphq_index* idx, const int* devices, int n) {
     if (!idx || (n > 0 && !devices)) return fail(LPHQ_ERR_ARG, "null argument");
     if (n <= 0) return fail(LPHQ_ERR_ARG, "no device given");
-    for (int i = 0; i < n; ++i) {
-        int rc = add_replica(idx, devices[i]);
-        if (rc) return rc;
+    std::vector<std::pair<int, hipStream_t>> pending;
+    int rc = LPHQ_OK;
+    for (int i = 0; i < n && rc == LPHQ_OK; ++i) {
+        hipStream_t st = nullptr;
+        rc = add_replica(idx, devices[i], &st);
+        if (st) pending.push_back({devices[i], st});
     }
+    for (auto& p : pending) {  // (also after a failure: nothing may still be writing into a replica when the caller closes the index)
+        DeviceGuard g(p.first);
+        const hipError_t e = hipStreamSynchronize(p.second);
+        (void)hipStreamDestroy(p.second);
+        if (e != hipSuccess && rc == LPHQ_OK) rc = fail_hip(e, "hipMemcpyPeerAsync(image)");
+    }
+    return rc;
+}
+
+extern "C" int lphq_replica_info(const lphq_index* idx, int i, int* device, int* how) {
+    if (!idx || i < 0 || (size_t)i >= idx->reps.size()) return fail(LPHQ_ERR_ARG, "no such replica");
+    if (device) *device = idx->reps[(size_t)i].device;
+    if (how) *how = idx->reps[(size_t)i].how;
     return LPHQ_OK;
 }
 
@@ -482,6 +525,7 @@ extern "C" int lphq_open_device_image(const void* d_image, size_t nbytes, int de
     r.device = device;
     r.d_image = (uint8_t*)d_image;
     r.owns = false;
+    r.how = 3;
     idx->reps.push_back(r);
     idx->image_bytes = nbytes;
     *out = idx;
@@ -649,5 +693,216 @@ extern "C" int lphq_query_contig(const lphq_index* cidx, const char* contig, siz
         }
     }
     *n_out = n;
+    return LPHQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// sessions: batches of host records, `depth` of them in flight (include/lphq.h, ABI 3)
+// ------------------------------------------------------------------------------------------
+struct SessionSlot {
+    char* d_seq = nullptr;
+    size_t d_seq_cap = 0;
+    uint64_t* d_out = nullptr;
+    size_t d_out_cap = 0;
+    uint64_t* d_offs = nullptr;  // n + 1 record offsets, n + 1 code offsets, 1 counter
+    size_t d_offs_cap = 0;
+    uint64_t* h_offs = nullptr;  // pinned: the same two offset arrays, then the counter's copy
+    size_t h_offs_cap = 0;
+    uint64_t* h_out = nullptr;  // pinned: the codes
+    size_t h_out_cap = 0;
+    hipEvent_t done = nullptr;
+    size_t n_records = 0, n_out = 0, total_bases = 0;
+    bool streaming = false, in_flight = false;
+    std::vector<const char*> recs;  // the caller's records (valid until collect): needed again only when the batch holds a non-ACGT byte
+    std::vector<size_t> lens;
+    std::vector<uint64_t> compact_offs;
+};
+struct lphq_session {
+    lphq_index* idx = nullptr;
+    const Replica* rep = nullptr;
+    hipStream_t stream = nullptr;
+    int depth = 2;
+    uint64_t submitted = 0, collected = 0;
+    SessionSlot slot[4];
+};
+
+extern "C" void* lphq_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+extern "C" void lphq_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
+extern "C" int lphq_session_open(const lphq_index* cidx, int depth, lphq_session** out) {
+    lphq_index* idx = const_cast<lphq_index*>(cidx);
+    REQUIRE_ATTACHED(idx);
+    if (!out) return fail(LPHQ_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (depth < 1 || depth > 4) return fail(LPHQ_ERR_ARG, "depth must be 1..4");
+    lphq_session* s = new (std::nothrow) lphq_session();
+    if (!s) return fail(LPHQ_ERR_ARG, "out of memory");
+    s->idx = idx;
+    s->rep = pick_replica(idx);
+    s->depth = depth;
+    DeviceGuard g(s->rep->device);
+    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    for (int i = 0; i < depth && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&s->slot[i].done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        lphq_session_close(s);
+        return fail_hip(e, "lphq_session_open");
+    }
+    *out = s;
+    return LPHQ_OK;
+}
+
+extern "C" void lphq_session_close(lphq_session* s) {
+    if (!s) return;
+    DeviceGuard g(s->rep->device);
+    if (s->stream) {
+        (void)hipStreamSynchronize(s->stream);
+        (void)hipStreamDestroy(s->stream);
+    }
+    for (SessionSlot& sl : s->slot) {
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.d_seq) (void)hipFree(sl.d_seq);
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        if (sl.d_offs) (void)hipFree(sl.d_offs);
+        if (sl.h_offs) (void)hipHostFree(sl.h_offs);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+    }
+    delete s;
+}
+
+template <typename T>
+static hipError_t grow_device(T*& p, size_t& cap, size_t want) {
+    if (want <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t n = want + want / 4 + 64;
+    const hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+    if (e == hipSuccess) cap = n;
+    return e;
+}
+template <typename T>
+static hipError_t grow_pinned(T*& p, size_t& cap, size_t want) {
+    if (want <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t n = want + want / 4 + 64;
+    const hipError_t e = hipHostMalloc((void**)&p, n * sizeof(T), hipHostMallocDefault);
+    if (e == hipSuccess) cap = n;
+    return e;
+}
+
+extern "C" int lphq_session_submit(lphq_session* s, const char* const* records, const size_t* lengths, size_t n, int streaming) {
+    if (!s || (n && (!records || !lengths))) return fail(LPHQ_ERR_ARG, "null argument");
+    if (n > 0xFFFFFFFFull) return fail(LPHQ_ERR_ARG, "more than 2^32-1 records in one batch");
+    if (s->submitted - s->collected >= (uint64_t)s->depth) return fail(LPHQ_ERR_STATE, "all batches of the session are in flight: collect one first");
+    lphq_index* idx = s->idx;
+    const uint32_t k = idx->hdr.k;
+    if (idx->hdr.kind >= LPHQ_PTHASH) streaming = 1;  // (as lphq_query_contig: the competitor functions yield nothing for windows holding a non-ACGT base)
+    SessionSlot& sl = s->slot[s->submitted % (uint64_t)s->depth];
+    DeviceGuard g(s->rep->device);
+    uint64_t so = 0, oo = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (lengths[i] && !records[i]) return fail(LPHQ_ERR_ARG, "null record");
+        so += lengths[i];
+        oo += lengths[i] >= k ? lengths[i] - k + 1 : 0;
+    }
+    HIP_TRY(grow_device(sl.d_seq, sl.d_seq_cap, (size_t)so + 64));
+    HIP_TRY(grow_device(sl.d_out, sl.d_out_cap, (size_t)oo + 16));
+    HIP_TRY(grow_device(sl.d_offs, sl.d_offs_cap, 2 * (n + 1) + 1));
+    HIP_TRY(grow_pinned(sl.h_offs, sl.h_offs_cap, 2 * (n + 1) + 1));
+    HIP_TRY(grow_pinned(sl.h_out, sl.h_out_cap, (size_t)oo + 16));
+    uint64_t a = 0, o = 0;
+    for (size_t i = 0; i < n; ++i) {
+        sl.h_offs[i] = a;
+        sl.h_offs[n + 1 + i] = o;
+        a += lengths[i];
+        o += lengths[i] >= k ? lengths[i] - k + 1 : 0;
+    }
+    sl.h_offs[n] = a;
+    sl.h_offs[2 * n + 1] = o;
+    sl.h_offs[2 * n + 2] = 0;
+    sl.recs.assign(records, records + n);
+    sl.lens.assign(lengths, lengths + n);
+    sl.n_records = n;
+    sl.n_out = (size_t)oo;
+    sl.total_bases = (size_t)so;
+    sl.streaming = streaming != 0;
+    // one copy per run of records that follow each other in the caller's memory
+    size_t at = 0;
+    for (size_t i = 0; i < n;) {
+        const char* run = records[i];
+        size_t len = lengths[i], j = i + 1;
+        while (j < n && (lengths[j] == 0 || records[j] == run + len)) len += lengths[j++];
+        if (len) HIP_TRY(hipMemcpyAsync(sl.d_seq + at, run, len, hipMemcpyHostToDevice, s->stream));
+        at += len;
+        i = j;
+    }
+    HIP_TRY(hipMemcpyAsync(sl.d_offs, sl.h_offs, (2 * (n + 1) + 1) * 8, hipMemcpyHostToDevice, s->stream));
+    if (oo) {
+        HIP_TRY(launch_query_records(idx->hdr, s->rep->d_image, sl.d_seq, so, sl.d_offs, sl.d_offs + n + 1, n, sl.d_out, streaming, s->stream));
+        if (streaming) {
+            HIP_TRY(launch_count_bad_bases(sl.d_seq, (size_t)so, (unsigned long long*)(sl.d_offs + 2 * n + 2), s->stream));
+            HIP_TRY(hipMemcpyAsync(sl.h_offs + 2 * n + 2, sl.d_offs + 2 * n + 2, 8, hipMemcpyDeviceToHost, s->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(sl.h_out, sl.d_out, (size_t)oo * 8, hipMemcpyDeviceToHost, s->stream));
+    }
+    HIP_TRY(hipEventRecord(sl.done, s->stream));
+    sl.in_flight = true;
+    ++s->submitted;
+    return LPHQ_OK;
+}
+
+extern "C" int lphq_session_collect(lphq_session* s, const uint64_t** codes, const uint64_t** offsets, size_t* n_records) {
+    if (!s || !codes || !offsets || !n_records) return fail(LPHQ_ERR_ARG, "null argument");
+    if (s->submitted == s->collected) return fail(LPHQ_ERR_STATE, "no batch in flight");
+    SessionSlot& sl = s->slot[s->collected % (uint64_t)s->depth];
+    DeviceGuard g(s->rep->device);
+    HIP_TRY(hipEventSynchronize(sl.done));
+    sl.in_flight = false;
+    ++s->collected;
+    const size_t n = sl.n_records;
+    const uint32_t k = s->idx->hdr.k;
+    *codes = sl.h_out;
+    *offsets = sl.h_offs + n + 1;
+    *n_records = n;
+    if (sl.streaming && sl.n_out && sl.h_offs[2 * n + 2] != 0) {
+        // some record holds a byte that is no base: its windows over that byte were not emitted by the reference (partitioned_mphf.hpp:179-183).
+        // Validity comes from the input bases (as in lphq_query_contig), the codes move down in place.
+        auto valid_base = [](unsigned char ch) {
+            switch (ch) {
+                case 'A': case 'a': case 'C': case 'c': case 'G': case 'g': case 'T': case 't': case 'U': case 'u': return true;
+                default: return false;
+            }
+        };
+        sl.compact_offs.assign(n + 1, 0);
+        size_t w = 0;
+        for (size_t r = 0; r < n; ++r) {
+            sl.compact_offs[r] = w;
+            const size_t len = sl.lens[r];
+            if (len < k) continue;
+            const uint64_t* src = sl.h_out + sl.h_offs[n + 1 + r];
+            const unsigned char* b = (const unsigned char*)sl.recs[r];
+            size_t last_bad = (size_t)-1;
+            for (size_t i = 0; i < len; ++i) {
+                if (!valid_base(b[i])) last_bad = i;
+                if (i + 1 >= k) {
+                    const size_t win = i + 1 - k;
+                    if (last_bad == (size_t)-1 || last_bad < win) sl.h_out[w++] = src[win];
+                }
+            }
+        }
+        sl.compact_offs[n] = w;
+        *offsets = sl.compact_offs.data();
+    }
     return LPHQ_OK;
 }

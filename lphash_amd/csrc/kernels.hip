@@ -67,6 +67,12 @@ hipError_t launch_count_valid(const uint64_t* d_codes, size_t n, unsigned long l
     return hipGetLastError();
 }
 
+hipError_t launch_count_bad_bases(const char* d_seq, size_t n, unsigned long long* d_count, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    k_count_bad_bases<><<<grid_for(n, kBlock * 16, 256 * 8), kBlock, 0, stream>>>((const uint8_t*)d_seq, n, d_count);
+    return hipGetLastError();
+}
+
 hipError_t launch_gather_payload(const uint64_t* d_codes, size_t n, const void* d_table, uint64_t n_slots, uint32_t elem_bytes, uint64_t missing, void* d_out,
                                  hipStream_t stream) {
     if (n == 0) return hipSuccess;

@@ -15,4 +15,5 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
 hipError_t launch_gather_payload(const uint64_t* d_codes, size_t n, const void* d_table, uint64_t n_slots, uint32_t elem_bytes, uint64_t missing, void* d_out,
                                  hipStream_t stream);
 hipError_t launch_count_valid(const uint64_t* d_codes, size_t n, unsigned long long* d_count, hipStream_t stream);
+hipError_t launch_count_bad_bases(const char* d_seq, size_t n, unsigned long long* d_count, hipStream_t stream);
 }  // namespace lphq

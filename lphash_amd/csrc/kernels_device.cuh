@@ -832,6 +832,17 @@ __global__ __launch_bounds__(kBlock) void k_count_valid(const uint64_t* __restri
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
 }
 
+// bytes of seq[0, n) that are no base (base_valid): the batched host-buffer path (lphq_session_*) asks this once per batch -- zero, the usual
+// answer, means that every window was emitted and the host has nothing to compact (the reference's streaming pass drops the windows that hold such a
+// byte, include/partitioned_mphf.hpp:179-183)
+template <int UNUSED = 0>
+__global__ __launch_bounds__(kBlock) void k_count_bad_bases(const uint8_t* __restrict__ seq, size_t n, unsigned long long* __restrict__ count) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    unsigned long long c = 0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) c += !base_valid(seq[i]);
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
 
 // ------------------------------------------------------------------------------------------
 // result consumer: payload[code] for every code -- the main downstream use of an MPHF

@@ -477,3 +477,64 @@ def test_reference_intake_dry_run_gpu(tmp_path, kind, k, m, bits):
     codes.tofile(os.path.join(d, "codes_streaming.u64"))
     with pytest.raises(AssertionError, match="GPU codes differ"):
         ref_intake.check_case_gpu(ref_intake.Case(d), L)
+
+
+@pytest.mark.parametrize("name", ["p_k31_m20_b64", "p_k63_m20_b128", "u_k31_m20_b64", "p_k21_m8_b64_fallback"])
+def test_session_batches_match_oracle(name):
+    """lphq_session_* (ABI 3): MPHF::operator() over many records per call with batches in flight.  Every record's codes == the oracle's in both
+    modes, for batches that mix long records, records shorter than k, empty records, records holding non-ACGT bytes (their windows are dropped in
+    streaming mode, read as 'A' in random mode) and lower case; batches are collected in submission order; the session refuses a third batch while two
+    are in flight and a collect when none is."""
+    golden = os.path.join(ROOT, "tests", "golden")
+    z = np.load(os.path.join(golden, name + ".npz"))
+    kind, bits = int(z["kind"]), int(z["kmer_bits"])
+    path = os.path.join(golden, name + ".lph")
+    o = orc.Index(path, kind, bits)
+    h = (L.Mphf if kind == 0 else L.MphfAlt).load(path, kmer_bits=bits, device=0)
+    k = h.k
+    base = [bytes(z["queries"][z["q_off"][i]:z["q_off"][i + 1]]) for i in range(len(z["q_off"]) - 1)]
+    rng = np.random.default_rng(5)
+    long_rec = b"".join(base)[:50_000]
+    dirty = bytearray(long_rec[:5000])
+    for pos in rng.integers(0, len(dirty), 12):
+        dirty[int(pos)] = ord("N")
+    dirty[100:130] = b"n" * 30
+    batches = [
+        base,
+        [long_rec, b"", b"ACGT", bytes(dirty), long_rec[:k], long_rec[:k - 1], long_rec.lower()[:3000], b"NNNN" * 40],
+        [bytes(dirty)],
+        [b"", b""],
+        [long_rec[i:i + 400] for i in range(0, 40_000, 400)],
+    ]
+
+    def want(rec, streaming):
+        if len(rec) < k:
+            return np.zeros(0, dtype=np.uint64)
+        exp = o(rec, False)  # non-ACGT read as 'A' (mphf_utils.hpp:108)
+        if not streaming:
+            return exp
+        bad = np.array([c not in b"ACGTUacgtu" for c in rec])
+        csum = np.concatenate([[0], np.cumsum(bad)])
+        return exp[(csum[k:] - csum[:-k]) == 0]  # streaming: one code per fully valid window (DESIGN section 7)
+
+    for streaming in (True, False):
+        s = h.session(depth=2)
+        with pytest.raises(L.LphqError):
+            s.collect()  # nothing in flight
+        s.submit(batches[0], streaming)
+        s.submit(batches[1], streaming)
+        with pytest.raises(L.LphqError):
+            s.submit(batches[2], streaming)  # both slots in flight
+        done = 0
+        for nxt in range(2, len(batches) + 2):
+            got = s.collect()
+            assert len(got) == len(batches[done])
+            for rec, g in zip(batches[done], got):
+                assert np.array_equal(g, want(rec, streaming)), (name, streaming, done, len(rec))
+            done += 1
+            if nxt < len(batches):
+                s.submit(batches[nxt], streaming)
+        assert done == len(batches)
+        s.close()
+    assert h.replica_info() == [(0, 0)]
+    h.close()

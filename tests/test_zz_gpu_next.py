@@ -245,12 +245,21 @@ def test_integration_stub_query_driver(tmp_path, name):
     want_s = np.concatenate([o(q, True) for q in queries])
     want_r = np.concatenate([o(q, False) for q in queries])
     exe = os.path.join(root, "examples", f"query_example{bits}")
-    r = subprocess.run([exe, "query-p" if kind == 0 else "query-u", "-i", lph, "-q", str(fa), "--dump", str(tmp_path / "codes")], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr
-    f5 = r.stdout.strip().split(",")
-    assert len(f5) == 5 and f5[0] == str(fa) and f5[1] == lph and int(f5[2]) == len(want_s) and float(f5[3]) > 0 and float(f5[4]) > 0
-    assert np.array_equal(np.fromfile(str(tmp_path / "codes.streaming.u64"), dtype="<u8"), want_s)
-    assert np.array_equal(np.fromfile(str(tmp_path / "codes.random.u64"), dtype="<u8"), want_r)
+    import gzip
+
+    gz = tmp_path / "q.fa.gz"
+    gz.write_bytes(gzip.compress(fa.read_bytes(), 6))
+    # the batched loop (gpu_mphf::submit / collect over lphq_session_*, the default), the reference's literal per-record loop, and the batched loop on a .gz
+    for q, extra in ((fa, []), (fa, ["--per-record"]), (gz, [])):
+        for f in ("codes.streaming.u64", "codes.random.u64"):
+            if (tmp_path / f).exists():
+                (tmp_path / f).unlink()
+        r = subprocess.run([exe, "query-p" if kind == 0 else "query-u", "-i", lph, "-q", str(q), "--dump", str(tmp_path / "codes")] + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        f5 = r.stdout.strip().split(",")
+        assert len(f5) == 5 and f5[0] == str(q) and f5[1] == lph and int(f5[2]) == len(want_s) and float(f5[3]) > 0 and float(f5[4]) > 0, (extra, f5)
+        assert np.array_equal(np.fromfile(str(tmp_path / "codes.streaming.u64"), dtype="<u8"), want_s), extra
+        assert np.array_equal(np.fromfile(str(tmp_path / "codes.random.u64"), dtype="<u8"), want_r), extra
     # exit code 2 for a query file that cannot be opened (src/query.cpp:43-46)
     r = subprocess.run([exe, "query-p" if kind == 0 else "query-u", "-i", lph, "-q", str(tmp_path / "missing.fa")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "Unable to open the input file" in r.stderr

@@ -39,9 +39,29 @@ with open("/tmp/reads150.fq", "wb") as f:  # 2 M reads of 150 bp sampled from th
     f.write(b"".join(chunks))
 idx = "/tmp/c2_cli.lph"
 t = time.time(); L.build(recs, 31, 20, idx, kmer_bits=64, threads=64, device=0); print("index built in %.1f s" % (time.time() - t))
-for q in ("/tmp/c2.fa", "/tmp/reads150.fq", "/tmp/c2_300.fa.gz", "/tmp/c2_300.bgzf.fa.gz"):
+with gzip.open("/tmp/c2_1000.fa.gz", "wb", compresslevel=6) as f:  # the whole index set as one gzip member (100 MB of text)
+    for i, r in enumerate(recs):
+        f.write(b">s%d\n" % i); f.write(r); f.write(b"\n")
+for q in ("/tmp/c2.fa", "/tmp/reads150.fq", "/tmp/c2_300.fa.gz", "/tmp/c2_1000.fa.gz", "/tmp/c2_300.bgzf.fa.gz"):
     for extra in ([], ["--threads", "8"], ["--threads", "32"], ["--pageable"], ["--batch-mb", "8"], ["--batch-mb", "128"]):
         t = time.time()
         r = subprocess.run(["lphash_amd/lphash", "query-p", "-i", idx, "-q", q, "--kmer-bits", "64"] + extra, capture_output=True, text=True)
         print(os.path.basename(q), extra, "k-mers, ns/k-mer streaming, random:", r.stdout.strip().split(",")[2:], "wall %.2f s" % (time.time() - t), r.stderr[-200:])
+# single-member .gz: the serial decoder (round 3) against the span-parallel one (round 4), CLI and decoder alone
+for q in ("/tmp/c2_300.fa.gz", "/tmp/c2_1000.fa.gz"):
+    r = subprocess.run(["lphash_amd/lphash", "query-p", "-i", idx, "-q", q, "--kmer-bits", "64"], capture_output=True, text=True, env=dict(os.environ, LPHQ_GZ_SERIAL="1"))
+    print(os.path.basename(q), "LPHQ_GZ_SERIAL=1 (serial decoder):", r.stdout.strip().split(",")[2:])
+    for span in ("131072", "262144", "524288", "1048576"):
+        r = subprocess.run(["lphash_amd/lphash", "query-p", "-i", idx, "-q", q, "--kmer-bits", "64"], capture_output=True, text=True, env=dict(os.environ, LPHQ_GZ_SPAN=span))
+        print(os.path.basename(q), "span", span, r.stdout.strip().split(",")[2:])
+    for args in (["--zlib"], [], ["--parallel", "4"], ["--parallel", "8"], ["--parallel", "16"], ["--parallel", "32"], ["--parallel", "16", "--span", "131072"],
+                 ["--parallel", "16", "--span", "262144"], ["--parallel", "16", "--span", "1048576"], ["--parallel", "32", "--span", "131072"]):
+        best = None
+        for rep in range(3):
+            r = subprocess.run(["lphash_amd/lphash", "inflate", "-i", q] + args, capture_output=True, text=True)
+            f = r.stdout.strip().split(",")
+            best = f if best is None or float(f[2]) < float(best[2]) else best
+        print("inflate", os.path.basename(q), args, "bytes, status, s (best of 3), pieces parallel / serial, span:", best, "-> %.2f GB/s" % (int(best[0]) / float(best[2]) / 1e9))
+r = subprocess.run(["lphash_amd/lphash", "inflate", "-i", "/tmp/c2_300.fa.gz", "--parallel", "16"], capture_output=True, text=True, env=dict(os.environ, LPHQ_PGZ_TRACE="1"))
+print(r.stderr)
 PY
