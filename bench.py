@@ -10,7 +10,8 @@ After the (unchanged) headline the default run measures the other BASELINE.json 
 reports them in a `secondary` list of the same JSON line: C3 (streaming, same index), C5 (unpartitioned), and the
 per-GPU work of C4 (k=63, 128-bit k-mers, 2 B k-mers) in random and in streaming mode -- each entry with its kernel
 time (HIP events), value, roofline, parity against the oracle and the oracle timed beside it.  `--no-secondary`
-skips them; a secondary that fails is reported in `secondary_errors` and never takes the headline with it.
+skips them; a secondary that fails is reported in `secondary_errors` and never takes the headline with it (a parity failure
+in one still prints the headline line, then ends the job with exit code 3).
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -34,6 +35,21 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def device_source_sha():
+    """sha256 (first 16 hex digits) over the device sources of the query kernels: what a counter pass in profiles/pmc_traffic.json is evidence for."""
+    import glob
+    import hashlib
+
+    hsh = hashlib.sha256()
+    csrc = os.path.join(ROOT, "lphash_amd", "csrc")
+    for pth in sorted(glob.glob(os.path.join(csrc, "*.cuh")) + glob.glob(os.path.join(csrc, "gfx950", "*.cuh")) +
+                      [os.path.join(csrc, "kernels.hip"), os.path.join(csrc, "image_layout.h")]):
+        hsh.update(os.path.basename(pth).encode())
+        hsh.update(open(pth, "rb").read())
+    return hsh.hexdigest()[:16]
+
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 # VALU issue peak in lane-instructions/s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (one wave64 instruction = 4 cycles of a SIMD)
@@ -203,6 +219,69 @@ def all_ranks_ok(dist, torch, dev, ok):
     return bool(int(t.item()))
 
 
+class RecordSet:
+    """The synthetic index records of one workload: n_records records of `length` bases.  With one rank they live in this process (one contiguous
+    array; a record is cut out when somebody asks for it).  With several ranks on a node, rank 0 generates the set ONCE and writes it to the cache
+    directory; the other ranks never hold it in host memory: they stream the file to their GPU in chunks (page cache is shared, not per-process) and
+    pread the few records their oracle sample needs.  Eight ranks at C4 (2 GB of bases) used to cost 8 x (2 GB + 2 GB of per-record copies) and
+    8 x the generation time."""
+    CHUNK = 64 << 20
+
+    def __init__(self, n_records, length, flat=None, path=None, source="generated"):
+        self.n_records, self.length, self.flat, self.path, self.source = n_records, length, flat, path, source
+
+    def __len__(self):
+        return self.n_records
+
+    def __getitem__(self, i):
+        if i < 0 or i >= self.n_records:
+            raise IndexError(i)
+        if self.flat is not None:
+            return self.flat[i * self.length:(i + 1) * self.length].tobytes()
+        with open(self.path, "rb") as f:
+            return os.pread(f.fileno(), self.length, i * self.length)
+
+    def __iter__(self):
+        return (self[i] for i in range(self.n_records))
+
+    def chunks(self):
+        """The bases in order, as uint8 arrays of at most CHUNK bytes (views of the array, or reads of the file into one reused buffer)."""
+        import numpy as np
+
+        total = self.n_records * self.length
+        if self.flat is not None:
+            for a in range(0, total, self.CHUNK):
+                yield self.flat[a:a + self.CHUNK]
+            return
+        buf = np.empty(min(self.CHUNK, total), dtype=np.uint8)
+        with open(self.path, "rb", buffering=0) as f:
+            done = 0
+            while done < total:
+                n = f.readinto(memoryview(buf)[: min(self.CHUNK, total - done)])
+                if not n:
+                    raise IOError(f"{self.path} is shorter than {total} bytes")
+                yield buf[:n]
+                done += n
+
+    def to_device(self, torch, dev):
+        total = self.n_records * self.length
+        d = torch.empty(total, dtype=torch.uint8, device=dev)
+        at = 0
+        for c in self.chunks():
+            d[at:at + len(c)].copy_(torch.from_numpy(c))
+            at += len(c)
+        return d
+
+    def checksum(self):
+        """CRC-32 of the bases as this rank reads them (what the ranks compare in --plan-only --plan-records)."""
+        import zlib
+
+        acc = 0
+        for c in self.chunks():
+            acc = zlib.crc32(memoryview(c), acc)
+        return acc
+
+
 class Job:
     """What the workloads of one bench process share."""
 
@@ -218,10 +297,29 @@ class Job:
 
         key = (wl["n_records"], wl["rec_len"])
         if key not in self._records:
-            self._records.clear()  # one set at a time (C4's is 2 GB + the per-record copies)
+            self._records.clear()  # one set at a time (C4's is 2 GB)
             t0 = time.time()
-            self._records[key] = synthetic_records(seed=1, n_records=wl["n_records"], length=wl["rec_len"])
-            log(f"[bench r{self.rank}] generated {wl['n_records']} records x {wl['rec_len']} bases in {time.time() - t0:.1f}s")
+            n, ln = key
+            path = os.path.join(self.args.cache_dir, f"records_seed1_{n}x{ln}.u8") if self.world > 1 else None
+            rs = None
+            if self.rank == 0:
+                flat, _ = synthetic_records(seed=1, n_records=n, length=ln, views=False)
+                rs = RecordSet(n, ln, flat=flat, source="generated")
+                log(f"[bench r{self.rank}] generated {n} records x {ln} bases in {time.time() - t0:.1f}s")
+                if path is not None and not (os.path.exists(path) and os.path.getsize(path) == n * ln):
+                    os.makedirs(self.args.cache_dir, exist_ok=True)
+                    tmp = path + f".tmp{os.getpid()}"
+                    with open(tmp, "wb") as f:
+                        for c in rs.chunks():
+                            f.write(memoryview(c))
+                    os.replace(tmp, path)
+                    log(f"[bench r{self.rank}] wrote {path} for the other ranks in {time.time() - t0:.1f}s")
+            self.barrier()  # the file is complete
+            if rs is None:
+                if not (os.path.exists(path) and os.path.getsize(path) == n * ln):
+                    self.fail(2, f"{path} is missing or short: the ranks of one node must share --cache-dir")
+                rs = RecordSet(n, ln, path=path, source="shared_file")
+            self._records[key] = rs
         return self._records[key]
 
     def barrier(self):
@@ -263,8 +361,8 @@ def run_workload(job, wl):
     steps, warmup = wl["steps"], wl["warmup"]
     tag = f"[bench r{rank} {wl['name']}]"
 
-    # ---- synthetic index set (every rank regenerates it: deterministic, ~1 s per 100 M bases) ----
-    flat, recs = job.records(wl)
+    # ---- synthetic index set: generated by rank 0 (deterministic, ~1 s per 100 M bases); further ranks read rank 0's copy from the cache directory ----
+    recs = job.records(wl)
 
     # ---- index: built once (rank 0), cached on local disk, image broadcast over RCCL ----
     path = index_path(args.cache_dir, wl)
@@ -306,7 +404,7 @@ def run_workload(job, wl):
         log(f"{tag} image broadcast {image_t.numel() / 1e6:.1f} MB in {bcast_s * 1e3:.1f} ms")
 
     stream = torch.cuda.current_stream().cuda_stream
-    d_seq = torch.from_numpy(flat).to(dev)
+    d_seq = recs.to_device(torch, dev)
     total_bases = int(d_seq.numel())
     rec_order = None
     if wl["shuffle_records"] and mode == "stream":
@@ -561,22 +659,47 @@ def run_workload(job, wl):
             "rccl_ranks": int(dist.get_world_size()) if dist is not None else 1,
             "replicas_agree": replicas_agree,
         }
-        traffic = valu = None
+        traffic = valu = traffic_stale = traffic_src = None
         try:  # HBM bytes and VALU instructions per unit from the committed PMC passes of this exact workload (never measured inside this run)
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             key = f"{mode}|{wl['kind']}|k{k}|m{m}|n{nk}|b{wl['batch_log2'] if mode == 'random' else 0}"
             variant = wl["nonmember_frac"] != 0.0 or rec_order is not None
             if key in tj and not variant:  # (counter passes exist for the default kernels on the primary workloads only)
-                traffic = tj[key]["bytes_per_unit"] * units
-                valu = tj[key].get("valu_lane_instr_per_unit"), tj[key].get("valu_source")
+                # the passes are evidence for the kernels they were taken on: an entry whose device sources are not the ones in this tree is reported
+                # as stale and contributes no number
+                if tj[key].get("tree") == device_source_sha():
+                    traffic = tj[key]["bytes_per_unit"] * units
+                    traffic_src = tj[key].get("source")
+                    valu = tj[key].get("valu_lane_instr_per_unit"), tj[key].get("valu_source")
+                else:
+                    traffic_stale = {"counters_taken_on_tree": tj[key].get("tree"), "this_tree": device_source_sha(), "source": tj[key].get("source"),
+                                     "note": "the committed counter passes predate a change of the device sources: traffic / instr_per_unit withheld"}
         except (OSError, ValueError, KeyError):
             pass
         kernel_s = max(kernel_ms_per_rank) * 1e-3 if world > 1 else kernel_ms * 1e-3
         achieved = bpl * units / kernel_s / 1e9
+        # The strict lower bound beside the algorithmic figure: only what MUST cross HBM once -- the input (8 / 16 B per packed k-mer, 1 B
+        # per base when streaming) and the 8-byte code -- as if the index cost nothing.  An image below the 256-MiB Infinity Cache does stay on chip
+        # between steps, so for it the index part of `achieved` is fabric traffic, not HBM traffic, and frac_compulsory is the honest HBM fraction.
+        compulsory = ((8 if k <= 31 else 16) + 8) if mode == "random" else (1.0 * (units + n_records * (k - 1)) / units + 8)
+        image_bytes = int(h.info.image_bytes)
+        if mode == "random":
+            kernel_name = "k_query_packed"
+        else:
+            kernel_name = "k_query_tiles_stream8" if W >= 8 else "k_query_tiles_stream"  # (kStream8MinW, lphash_amd/csrc/stream8_device.cuh)
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "peak_measured": peak_read, "peak_measured_copy": peak_copy,
                            "frac_of_measured": (achieved / peak_read) if peak_read else None,
-                           "traffic": traffic, "bytes_per_lookup": bpl, "kernel": "k_query_packed" if mode == "random" else "k_query_tiles_stream"}
+                           "traffic": traffic, "traffic_source": traffic_src, "bytes_per_lookup": bpl, "kernel": kernel_name,
+                           "compulsory_bytes_per_lookup": compulsory, "achieved_compulsory": compulsory * units / kernel_s / 1e9,
+                           "frac_compulsory": compulsory * units / kernel_s / 1e9 / HBM_PEAK_GBS,
+                           "index_residency": ("infinity_cache" if image_bytes < (256 << 20) else "hbm"),
+                           "index_residency_note": (f"the {image_bytes / 1e6:.1f}-MB image is smaller than the 256-MiB Infinity Cache: its lines are re-read from on-chip "
+                                                    "memory, `traffic` counts fabric requests, and the HBM proper carries the compulsory stream only"
+                                                    if image_bytes < (256 << 20) else
+                                                    f"the {image_bytes / 1e6:.1f}-MB image exceeds the 256-MiB Infinity Cache: index lines come from HBM")}
+        if traffic_stale is not None:
+            out["roofline"]["traffic_stale"] = traffic_stale
         if valu is not None and valu[0]:
             # the second roofline of the same kernel: VALU issue.  instr_per_unit = SQ_INSTS_VALU of the committed counter pass x 64 lanes / units of
             # one launch (a wave64 instruction occupies a SIMD's 16 lanes for 4 cycles whatever the number of live lanes)
@@ -642,6 +765,9 @@ def main():
                     help="records of the index set the reference-faithful driver baseline (B1: gz + parse inside the timer) reads; 0 = skip")
     ap.add_argument("--no-secondary", action="store_true", help="headline only: skip the C3 / C5 / C4 measurements that follow a default (C2) run")
     ap.add_argument("--secondary-c4-kmers", type=int, default=2_000_000_000, help="k-mers of the C4 secondary workloads (BASELINE.json: 2 B)")
+    ap.add_argument("--plan-records", action="store_true",
+                    help="with --plan-only: also run the record-set logic of the first workload (rank 0 generates and shares through --cache-dir, the other "
+                         "ranks stream the file) and report source, CRC-32 and peak RSS per rank")
     ap.add_argument("--plan-only", action="store_true",
                     help="resolve workloads and cache paths, check that all ranks agree (gloo when WORLD_SIZE > 1), print the plan and stop before the first GPU call")
     args = ap.parse_args()
@@ -675,12 +801,33 @@ def main():
                 ok = False
             agree = plans_agree(dist, torch, torch.device("cpu"), plan)
             ok = all_ranks_ok(dist, torch, torch.device("cpu"), ok and agree)
-            dist.destroy_process_group()
             if not ok:
+                dist.destroy_process_group()
                 log(f"[bench r{rank}] ERROR: a rank failed or the ranks resolved different plans (agree: {agree})")
                 sys.exit(3)
+        records_report = None
+        if args.plan_records:
+            # the host side of "every rank has the index records": rank 0 generates and shares them through the cache directory, the others stream
+            # the file (what to_device does, minus the device) -- per rank: where the bases came from, their CRC-32, the process's peak RSS
+            import resource
+
+            job = Job(args, rank, local_rank, world, None, dist, torch, np, None)
+            rs = job.records(plan["workloads"][0])
+            mine = {"rank": rank, "source": rs.source, "crc32": rs.checksum(), "first_record_crc32": __import__("zlib").crc32(rs[0]),
+                    "maxrss_mb": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0}
+            if dist is not None:
+                gathered = [None] * world
+                dist.all_gather_object(gathered, mine)
+                records_report = gathered
+            else:
+                records_report = [mine]
+        if dist is not None:
+            dist.destroy_process_group()
         if rank == 0:
-            result_out.write(json.dumps({"plan": plan, "ranks": world, "ranks_agree": True}) + "\n")
+            line = {"plan": plan, "ranks": world, "ranks_agree": True}
+            if records_report is not None:
+                line["records"] = records_report
+            result_out.write(json.dumps(line) + "\n")
             result_out.flush()
         return
 
@@ -709,6 +856,7 @@ def main():
     t_job = time.time()
     out = run_workload(job, wls[0])
     secondary, errors = [], []
+    exit_code = 0
     for wl in wls[1:]:
         t0 = time.time()
         try:
@@ -717,8 +865,13 @@ def main():
                 e = secondary_entry(e, wl)
                 e["wall_s"] = time.time() - t0
                 secondary.append(e)
-        except SystemExit:
-            raise  # parity failure on some rank: the job ends (all ranks leave together)
+        except SystemExit as ex:
+            # a parity failure (every rank reaches job.fail together: the verdict is a collective) ends the job with that code -- but the headline was
+            # measured and checked before: rank 0 still prints it, with the failed workload named in secondary_errors
+            exit_code = ex.code if isinstance(ex.code, int) and ex.code else 3
+            errors.append({"name": wl["name"], "error": "GPU results differ from the oracle (see stderr)", "parity_vs_oracle": False})
+            dist = None  # (job.fail has torn the process group down)
+            break
         except Exception as ex:  # noqa: BLE001 -- the headline must survive e.g. a host without the memory for the 2 B-k-mer set
             if dist is not None:
                 raise  # (the other ranks are inside collectives of this workload: no way to skip it on one rank alone)
@@ -736,6 +889,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

@@ -69,6 +69,11 @@ public:
         const uint64_t *codes_ = nullptr, *offs_ = nullptr;
         std::size_t n_ = 0;
     };
+    // Set-up before a timer starts: the session and its buffers for batches of up to total_bases bases in n_records records (optional).
+    void reserve(std::size_t total_bases, std::size_t n_records) {
+        if (!s_ && lphq_session_open(h_, kDepth, &s_) != LPHQ_OK) throw std::runtime_error(lphq_last_error());
+        if (lphq_session_reserve(s_, total_bases, n_records) != LPHQ_OK) throw std::runtime_error(lphq_last_error());
+    }
     // Queue one batch (the records' memory must stay valid until the batch is collected; depth() batches may be in flight).
     void submit(const char* const* records, const std::size_t* lengths, std::size_t n, bool streaming = true) {
         if (!s_ && lphq_session_open(h_, kDepth, &s_) != LPHQ_OK) throw std::runtime_error(lphq_last_error());

@@ -39,6 +39,7 @@ bool batched_pass(MPHF& hf, const std::string& query_filename, bool streaming, F
     if (!reader.ok()) return false;
     const size_t batch_bases = (size_t)16 << 20;
     reader.prealloc(batch_bases);  // (set-up, like gzopen + kseq_init before t.start(), src/query.cpp:43-48)
+    hf.reserve(batch_bases + batch_bases / 4, (size_t)1 << 16);  // ... and the binding's device and page-locked result buffers
     lphq::FastxBatch bufs[2];
     std::vector<const char*> ptrs[2];
     std::vector<size_t> lens[2];

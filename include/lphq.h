@@ -183,6 +183,10 @@ int lphq_query_contig(const lphq_index* idx, const char* contig, size_t length, 
 typedef struct lphq_session lphq_session;
 int lphq_session_open(const lphq_index* idx, int depth /* 1..4 */, lphq_session** out);
 void lphq_session_close(lphq_session* s);
+/* Allocate now what batches of up to total_bases bases in up to n_records records need (device buffers and the pinned result buffer of EVERY
+ * slot): page-locked allocations are slow (tens of ms for hundreds of MB), a caller with a timer does them before it starts the timer, like the
+ * reference's gzopen + kseq_init before t.start() (src/query.cpp:43-48).  Optional: submit grows the buffers when a batch needs more. */
+int lphq_session_reserve(lphq_session* s, size_t total_bases, size_t n_records);
 int lphq_session_submit(lphq_session* s, const char* const* records, const size_t* lengths, size_t n_records, int streaming);
 int lphq_session_collect(lphq_session* s, const uint64_t** codes, const uint64_t** offsets /* n_records + 1 entries */, size_t* n_records);
 /* Page-locked host memory for record buffers handed to lphq_session_submit (hipHostMalloc); NULL when it cannot be had. */

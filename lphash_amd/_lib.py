@@ -72,6 +72,7 @@ SIGNATURES = {
                                     C.POINTER(BuildStats)]),
     "lphq_session_open": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "lphq_session_close": (None, [C.c_void_p]),
+    "lphq_session_reserve": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t]),
     "lphq_session_submit": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int]),
     "lphq_session_collect": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_size_t)]),
     "lphq_host_alloc": (C.c_void_p, [C.c_size_t]),

@@ -273,6 +273,9 @@ class Session:
         self._keep = []  # the records of the batches in flight (their memory must outlive the copies)
         check(lib.lphq_session_open(mphf._h, depth, C.byref(self._s)))
 
+    def reserve(self, total_bases, n_records):
+        check(lib.lphq_session_reserve(self._s, total_bases, n_records))
+
     def submit(self, records, streaming=True):
         recs = [bytes(r) for r in records]
         n = len(recs)

@@ -801,6 +801,21 @@ static hipError_t grow_pinned(T*& p, size_t& cap, size_t want) {
     return e;
 }
 
+extern "C" int lphq_session_reserve(lphq_session* s, size_t total_bases, size_t n_records) {
+    if (!s) return fail(LPHQ_ERR_ARG, "null argument");
+    if (s->submitted != s->collected) return fail(LPHQ_ERR_STATE, "batches in flight: collect them first");
+    DeviceGuard g(s->rep->device);
+    for (int i = 0; i < s->depth; ++i) {
+        SessionSlot& sl = s->slot[i];
+        HIP_TRY(grow_device(sl.d_seq, sl.d_seq_cap, total_bases + 64));
+        HIP_TRY(grow_device(sl.d_out, sl.d_out_cap, total_bases + 16));  // (windows <= bases)
+        HIP_TRY(grow_device(sl.d_offs, sl.d_offs_cap, 2 * (n_records + 1) + 1));
+        HIP_TRY(grow_pinned(sl.h_offs, sl.h_offs_cap, 2 * (n_records + 1) + 1));
+        HIP_TRY(grow_pinned(sl.h_out, sl.h_out_cap, total_bases + 16));
+    }
+    return LPHQ_OK;
+}
+
 extern "C" int lphq_session_submit(lphq_session* s, const char* const* records, const size_t* lengths, size_t n, int streaming) {
     if (!s || (n && (!records || !lengths))) return fail(LPHQ_ERR_ARG, "null argument");
     if (n > 0xFFFFFFFFull) return fail(LPHQ_ERR_ARG, "more than 2^32-1 records in one batch");

@@ -14,6 +14,8 @@
 // Ties keep the LEFT position throughout (candidates are taken left to right with a strict `<`), as the strict `>` comparisons of
 // include/partitioned_mphf.hpp:122,150-163 do.
 #pragma once
+#include <gfx950/wave_scan.cuh>
+
 #include "kernels_device.cuh"
 
 namespace lphq {
@@ -24,13 +26,19 @@ constexpr uint32_t kStream8MinW = 8;                   // the launcher uses this
                                                        // (every other window leads a super-k-mer) stay with four per lane
 constexpr int kS8Block = 128;                          // threads per workgroup; 8 * BLOCK m-mer positions per tile (256 threads / 2048 positions: measured equal at W = 8, 12,
                                                        // profiles/r03_stream8.txt (9); the template parameter stays for the emulator's coverage)
-constexpr int kS8RecCap = 32;                          // records of a multi-record tile cached in LDS (more: the global offset arrays are searched)
-// blocks per row of prefix minima: a lane reads up to block l + 8 (W <= 62); the 9 beyond the tile hold ~0
+constexpr int kS8RecCap = 16;                          // records of a multi-record tile cached in LDS (more: the global offset arrays are searched)
+// Blocks per row of prefix minima.  A lane reads up to block l + 8 (W <= 62), i.e. past its row's BLOCK entries -- but only for windows that begin at or
+// beyond TW = stream_tile_windows(W, 8 * BLOCK): a window the tile emits ends at position <= 8 * BLOCK - 1, inside block BLOCK - 1.  What such a read
+// returns is discarded with the window (code 0xFFFE), so the rows need no ~0 padding of their own: a read past row c lands in row c + 1 (the rows are
+// one array; the odd row length keeps the eight columns of a block in different banks), and kS8Tail entries behind the last row keep the furthest
+// one inside the array.  Round 4: 9 padded blocks per row -> 1, 448 B of LDS less per workgroup.
 template <int BLOCK>
-constexpr uint32_t s8_row() { return (uint32_t)BLOCK + 9u; }
-// slot of position i in phases E-F (the leader's base): column i % 8, block i / 8
+constexpr uint32_t s8_row() { return (uint32_t)BLOCK + 1u; }
+constexpr uint32_t kS8Tail = 8u;
+// slot of position i in phases E-F (the leader's base): the position itself (round 4; the column-major slot of phases B-C cost three instructions per
+// window in phase F for nothing: neighbouring lanes read the same leader or one a few slots away)
 template <int BLOCK>
-__device__ __forceinline__ uint32_t hslot8(uint32_t i) { return (i & 7u) * s8_row<BLOCK>() + (i >> 3); }
+__device__ __forceinline__ uint32_t hslot8(uint32_t i) { return i; }
 
 struct BlockMin8 {   // a lane's suffix minima S[1..7] over a+j .. a+7 (S[0] is the block minimum, re-read from LDS), alive from phase B to phase C
     uint64_t h[7];
@@ -68,33 +76,38 @@ __device__ __forceinline__ BlockMin8 publish_block_minima8(uint64_t* __restrict_
     return s;
 }
 
-// Leftmost minimum of the 8 consecutive windows starting at local positions a .. a+7, each W >= 8 positions wide -> q[0..7] (local positions).
-// id of a candidate: (t << 3) | c for column c of the block t lanes to the right; for the own block (t = 0) c is the position itself.
+// Leftmost minimum of the 8 consecutive windows starting at local positions a .. a+7, each W >= 16 positions wide -> q[0..7] (local positions).
+// Window a+j = own suffix S[j] (a+j .. a+7), the blocks every window covers (l+1 .. l+nf0, nf0 = (W - 8) / 8), then -- by (j + W - 8) / 8 and % 8, uniform
+// over the wave -- block l+nf0+1 whole and a prefix of block l+nf0+2, or only a prefix of block l+nf0+1.  Every candidate carries its POSITION relative to
+// a from the start (round 4): the own block's come out of the 3-bit fields of s.p / sm_off[tid]; the two blocks behind the common ones are at uniform
+// distances, so their words of sm_off are read once per lane and a field of them is one v_bfe_u32 per candidate; only the winner of the common blocks
+// needs a data-dependent read.  Before, every window carried a (block, column) id through its chain and decoded it afterwards with a dependent LDS read,
+// a variable shift and a select: 8 decodes of ~11 instructions per lane, now 1.
 template <int BLOCK>
 __device__ __forceinline__ void window_argmin8(const uint64_t* __restrict__ sm_hash, const uint32_t* __restrict__ sm_off, uint32_t tid, uint32_t W, const BlockMin8& s,
                                                uint32_t (&q)[8]) {
     constexpr uint32_t kS8Row = s8_row<BLOCK>();
     const uint64_t* colM = sm_hash + 7u * kS8Row + tid;  // M of the block t lanes to the right: colM[t]
-    const uint32_t nf0 = (W - 8u) >> 3;                  // blocks covered completely by all eight windows: l+1 .. l+nf0
-    HashPos r{~0ull, 0};
-    if (nf0) {
-        r = HashPos{colM[1], (1u << 3) | 7u};
-        for (uint32_t t = 2; t <= nf0; ++t) take_if_less(r, colM[t], (t << 3) | 7u);
-    }
+    const uint32_t nf0 = (W - 8u) >> 3;                  // blocks covered completely by all eight windows: l+1 .. l+nf0 (>= 1: W >= 16)
+    HashPos r{colM[1], 1u};
+    for (uint32_t t = 2; t <= nf0; ++t) take_if_less(r, colM[t], t);
+    r.p = (r.p << 3) + ((sm_off[tid + r.p] >> 21) & 7u);  // position relative to a: 8 t + where block t's minimum sits
+    const uint32_t wA = sm_off[tid + nf0 + 1u], wB = sm_off[tid + nf0 + 2u];
+    const uint32_t relA = (nf0 + 1u) << 3, relB = relA + 8u;  // (uniform)
+    const HashPos mA{colM[nf0 + 1u], relA + ((wA >> 21) & 7u)};
     const uint32_t ob0 = sm_off[tid];
-    HashPos w[8];
-    w[0] = HashPos{colM[0], (ob0 >> 21) & 7u};
-#pragma unroll
-    for (uint32_t j = 1; j < 8; ++j) w[j] = HashPos{s.h[j - 1], (s.p >> (3u * (j - 1u))) & 7u};
+    const uint32_t a = 8u * tid;
 #pragma unroll
     for (uint32_t j = 0; j < 8; ++j) {
+        HashPos w = j == 0 ? HashPos{colM[0], (ob0 >> 21) & 7u} : HashPos{s.h[j ? j - 1 : 0], (s.p >> (3u * (j ? j - 1u : 0u))) & 7u};
         const uint32_t nf = (j + W - 8u) >> 3, hc = (j + W - 8u) & 7u;  // uniform over the wave
-        take_if_less(w[j], r.h, r.p);                                      // (no full block: r.h = ~0, never smaller)
-        if (nf > nf0) take_if_less(w[j], colM[nf], (nf << 3) | 7u);
-        if (hc) take_if_less(w[j], sm_hash[(hc - 1u) * kS8Row + tid + nf + 1u], ((nf + 1u) << 3) | (hc - 1u));
-        const uint32_t t = w[j].p >> 3, c = w[j].p & 7u;
-        const uint32_t off = (sm_off[tid + t] >> (3u * c)) & 7u;  // place of that block's P[c] (t = 0 reads the own word and ignores it)
-        q[j] = 8u * (tid + t) + (t ? off : c);
+        take_if_less(w, r.h, r.p);
+        if (nf > nf0) take_if_less(w, mA.h, mA.p);
+        if (hc) {
+            const uint32_t word = nf > nf0 ? wB : wA, rel = nf > nf0 ? relB : relA;
+            take_if_less(w, sm_hash[(hc - 1u) * kS8Row + tid + nf + 1u], rel + ((word >> (3u * (hc - 1u))) & 7u));
+        }
+        q[j] = a + w.p;
     }
 }
 
@@ -154,7 +167,9 @@ __device__ __forceinline__ void window_argmin8_raw(const uint64_t* __restrict__ 
 
 // DIRECT: window minima from the raw hashes (narrow windows) instead of block prefix minima
 template <int KIND, bool K128, int P, int BLOCK = kS8Block, bool DIRECT = (P == 4)>
-__global__ __launch_bounds__(BLOCK) void k_query_tiles_stream8(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al, uint64_t shift, uint64_t total,
+// (second launch bound = waves per SIMD the register allocation must leave room for: 8 = 64 VGPRs for the wide-window variant, whose LDS now allows the
+// 16 workgroups per CU that takes; the narrow-window variant stays at its 71)
+__global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al, uint64_t shift, uint64_t total,
                                                                   const uint64_t* __restrict__ seq_off, const uint64_t* __restrict__ out_off, uint32_t n_records,
                                                                   uint64_t* __restrict__ out, uint64_t tile_base /* first tile of this launch */) {
     const lphq_image_header& H = *(const lphq_image_header*)img;
@@ -163,7 +178,7 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream8(const uint8_t* __
     constexpr int NDW = (NW + 1) * 4;          // dwords of sequence (4 bases each) the tile loads: two per lane, the NDW - 2 * BLOCK beyond by lanes of the last wave
     constexpr uint32_t NX = (uint32_t)(NDW - 2 * BLOCK);
     static_assert(NDW > 2 * BLOCK && NX <= 64, "the dwords beyond the first 2 * BLOCK are loaded by the lanes of the last wave");
-    __shared__ uint64_t sm_hash[8 * kS8Row];   // phase B-C: prefix minima of every block (column c, block b at c * kS8Row + b); phase E-F: the leader's base | mode << 62
+    __shared__ uint64_t sm_hash[8 * kS8Row + kS8Tail];  // phase B-C: prefix minima of every block (column c, block b at c * kS8Row + b); phase E-F: the leader's base | mode << 62
     __shared__ uint32_t sm_words[NW + 8];
     __shared__ uint8_t sm_badb[NDW + 12];      // bad-base flags, one byte per sequence dword (written by the lane that packs the dword)
     __shared__ uint32_t sm_anybad[BLOCK / 64];
@@ -172,8 +187,8 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream8(const uint8_t* __
     // the top bits of its base, the record table holds kS8RecCap records -- 10.7 KB per workgroup (11.0 with the 256-entry queue of the narrow-window
     // variant): LDS for 14-15 workgroups per CU; the 71 VGPRs allow 14 (28 waves).
     constexpr uint32_t QCAP = DIRECT ? 2u * BLOCK : BLOCK;  // leaders per round: narrow windows have more super-k-mers per tile (W = 12: ~157 of 1024 positions)
-    __shared__ uint16_t sm_queue[QCAP];
-    __shared__ uint32_t sm_off[kS8Row + 1];    // phase B-C: where in its block each published prefix minimum sits (3 bits each)
+    __shared__ uint16_t sm_queue[QCAP + 8];  // (8 of slack: a lane whose first leader fits writes all of its leaders)
+    __shared__ uint32_t sm_off[kS8Row + kS8Tail];  // phase B-C: where in its block each published prefix minimum sits (3 bits each); read up to 8 blocks past a lane's own
     __shared__ uint32_t sm_rec[2], sm_count, sm_slot_count;  // (a counter of its own for the slot-by-slot path: lanes may still be reading sm_count)
     __shared__ uint64_t sm_roff[3];                   // seq_off[rlo], seq_off[rlo+1], out_off[rlo]
     __shared__ uint64_t sm_rtab[2 * kS8RecCap + 1];   // multi-record tiles: the tile's slice of seq_off / out_off
@@ -279,8 +294,7 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream8(const uint8_t* __
         } else {
             bmin = publish_block_minima8<BLOCK>(sm_hash, sm_off, tid, h);
         }
-        if (tid < 72u) sm_hash[(tid / 9u) * kS8Row + (uint32_t)BLOCK + tid % 9u] = ~0ull;  // blocks beyond the tile: never a minimum
-        if (tid < 10u) sm_off[(uint32_t)BLOCK + tid] = 0;
+        // (blocks beyond the tile are read by windows the tile does not emit only: see s8_row)
     }
     __syncthreads();
 
@@ -349,23 +363,26 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream8(const uint8_t* __
         const uint32_t lane = tid & 63u;
         uint32_t prev = __shfl(code[7], (int)((lane + 63u) & 63u), 64);  // last window of the lane to the left
         if (lane == 0) prev = 0xFFFEu;                                     // it lives in another wave: queue the window regardless
-        uint32_t wave_leaders = 0;
 #pragma unroll
         for (uint32_t jw = 0; jw < 8; ++jw) {
             const bool ld = code[jw] < 0xFFFEu && code[jw] != (jw ? code[jw - 1] : prev);
             lmask |= ld ? 1u << jw : 0u;
-            wave_leaders += (uint32_t)__popcll(__ballot(ld));
         }
+        // Round 4: the lane's leaders are numbered by ONE prefix sum of popcount(lmask) over the wave (six DPP adds, gfx950/wave_scan.cuh) and written
+        // one after the other -- leaders in lane order instead of slot order, which the lookups do not care about.  Round 3 took a ballot, a population
+        // count and an mbcnt pair per window slot, twice.
+        const uint32_t mine = (uint32_t)__popc(lmask);
+        const uint32_t incl = wave_inclusive_add(mine);
+        const uint32_t wave_leaders = __shfl(incl, 63, 64);
         uint32_t b = 0;
         if (lane == 0 && wave_leaders) b = atomicAdd(&sm_count, wave_leaders);
-        uint32_t n = __shfl(b, 0, 64);  // number of the wave's first leader
+        uint32_t at = __shfl(b, 0, 64) + incl - mine;  // queue entry of the lane's first leader
+        if (at < QCAP) {  // (a lane writes at most 8 entries from there: the queue has 8 entries of slack; a tile with more than QCAP leaders is redone below)
 #pragma unroll
-        for (uint32_t jw = 0; jw < 8; ++jw) {  // one ballot alive at a time
-            const bool ld = (lmask >> jw) & 1u;
-            const uint64_t bal = __ballot(ld);
-            const uint32_t at = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-            if (ld && at < QCAP) sm_queue[at] = (uint16_t)code[jw];
-            n += (uint32_t)__popcll(bal);
+            for (uint32_t jw = 0; jw < 8; ++jw) {
+                if ((lmask >> jw) & 1u) sm_queue[at] = (uint16_t)code[jw];
+                at += (lmask >> jw) & 1u;
+            }
         }
     }
     __syncthreads();
@@ -407,12 +424,12 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream8(const uint8_t* __
 
     // ---- F: the lane's eight codes ----
     uint64_t hv[8];
-    uint32_t coll = 0;
+    uint32_t modes = 0;  // OR of the mode fields of the lane's windows (bit 1: a colliding minimizer)
 #pragma unroll
     for (uint32_t jw = 0; jw < 8; ++jw) {
         const uint32_t q = code[jw];
         const bool valid = q < 0xFFFEu;
-        const uint32_t qq = valid ? q : a + jw;  // (any slot of the tile: the value read is discarded)
+        const uint32_t qq = q & (uint32_t)(kS8Pos - 1);  // (an invalid window reads some slot of the tile: the value is discarded)
         const uint64_t packed = sm_hash[hslot8<BLOCK>(qq)];
         const uint64_t base = packed & LPHQ_TAIL_BASE_MASK;
         const uint32_t mode = (uint32_t)(packed >> LPHQ_TAIL_MODE_SHIFT);
@@ -420,9 +437,13 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream8(const uint8_t* __
         const int32_t delta = mode == 0u ? (int32_t)p : -(int32_t)p;  // |p| < 2^16; (mode 2 is redone below)
         const uint64_t hval = base + (uint64_t)(int64_t)delta;
         hv[jw] = valid ? hval : ~0ull;  // LPHQ_INVALID
-        coll |= (valid && mode == 2u) ? 1u << jw : 0u;
+        modes |= valid ? mode : 0u;  // (what an invalid window read is whatever phases B-C left in that slot)
     }
-    if (__any(coll != 0u)) {  // windows under a colliding minimizer: the fallback function of the k-mer (src/partitioned_mphf.cpp:312-316)
+    if (__any((modes & 2u) != 0u)) {  // windows under a colliding minimizer: the fallback function of the k-mer (src/partitioned_mphf.cpp:312-316)
+        uint32_t coll = 0;            // which of the lane's windows (worked out here, off the common path)
+#pragma unroll
+        for (uint32_t jw = 0; jw < 8; ++jw)
+            if (code[jw] < 0xFFFEu && (uint32_t)(sm_hash[hslot8<BLOCK>(code[jw])] >> LPHQ_TAIL_MODE_SHIFT) == 2u) coll |= 1u << jw;
 #pragma unroll
         for (uint32_t jw = 0; jw < 8; ++jw)
             if ((coll >> jw) & 1u) {
@@ -440,7 +461,7 @@ __global__ __launch_bounds__(BLOCK) void k_query_tiles_stream8(const uint8_t* __
         // instead (the hash array is free once every lane has read its bases) and leave as four fully coalesced stores: 2 KB contiguous per wave each.
         __syncthreads();
         ulonglong2* sm_out = (ulonglong2*)sm_hash;  // kS8Pos codes = 8 KB <= sizeof(sm_hash)
-        static_assert(sizeof(uint64_t) * 8 * kS8Row >= sizeof(uint64_t) * kS8Pos, "the staged codes fit the hash array");
+        static_assert(sizeof(uint64_t) * (8 * kS8Row + kS8Tail) >= sizeof(uint64_t) * kS8Pos, "the staged codes fit the hash array");
 #pragma unroll
         for (uint32_t jw = 0; jw < 8; jw += 2) sm_out[4u * tid + jw / 2u] = make_ulonglong2(hv[jw], hv[jw + 1]);
         __syncthreads();

@@ -32,7 +32,8 @@ def random_bases(seed, n, chunk_words=1 << 22):
     return out[:n]
 
 
-def synthetic_records(seed, n_records, length):
-    """n_records records of `length` bases each, as one contiguous uint8 array + the list of bytes views."""
+def synthetic_records(seed, n_records, length, views=True):
+    """n_records records of `length` bases each, as one contiguous uint8 array + the list of per-record bytes (views=False: None instead of the
+    list -- a second copy of the set that a caller who cuts records out on demand does not need)."""
     flat = random_bases(seed, n_records * length)
-    return flat, [flat[i * length:(i + 1) * length].tobytes() for i in range(n_records)]
+    return flat, ([flat[i * length:(i + 1) * length].tobytes() for i in range(n_records)] if views else None)

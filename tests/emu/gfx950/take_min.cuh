@@ -10,5 +10,4 @@ static inline void take_min_uniform(uint64_t& mh, uint32_t& mp, uint64_t h, uint
         mp = p;
     }
 }
-static inline void take_min_lane(uint64_t& mh, uint32_t& mp, uint64_t h, uint32_t p) { take_min_uniform(mh, mp, h, p); }
 }  // namespace lphq

@@ -26,7 +26,8 @@ for B in 128 64; do
   (cd "$REF" && g++ -std=c++17 -O3 -march=native -pthread -I. "$HERE/dump_codes.cpp" $SRCS -lz -o "$W/dump_codes$B")
 done
 restore
-zcat "$REF/data/queries/salmonella_enterica.fasta.gz" | head -c 200100 | gzip > "$W/q.fa.gz"
+# (no `zcat | head -c`: head leaves early, zcat dies of SIGPIPE and `set -o pipefail` would end the script here)
+python3 -c 'import gzip, sys; sys.stdout.buffer.write(gzip.open(sys.argv[1]).read(200100))' "$REF/data/queries/salmonella_enterica.fasta.gz" | gzip > "$W/q.fa.gz"
 case_dir() { # name tool bits k m input
   local d="$HERE/$1" tool=$2 bits=$3 k=$4 m=$5 in=$6 kind
   mkdir -p "$d"

@@ -154,6 +154,33 @@ def test_bench_rank_logic_gloo_world2(tmp_path):
     assert r.returncode == 2 and "WORLD_SIZE=2 but --gpus 1" in r.stderr
 
 
+def test_bench_record_set_is_shared_not_regenerated_gloo_world8(tmp_path):
+    """The first 8-GPU run, minus the GPUs (`--plan-only --plan-records`, eight ranks over gloo, launched as the driver launches a scaling run): rank 0
+    generates the synthetic records once and shares them through the cache directory; ranks 1-7 stream that file and never hold the set -- same CRC-32
+    on every rank, `shared_file` as their source, and a peak RSS well below rank 0's (which holds the array).  At C4 this is 2 GB of bases: eight
+    private copies plus eight per-record copies were 32 GB of host memory and eight generations."""
+    import json
+
+    kmers = 300_000_000  # 3000 records x 100030 bases = 300 MB of bases
+    args = ["--gpus", "8", "--plan-only", "--plan-records", "--kmers", str(kmers), "--no-secondary", "--cache-dir", str(tmp_path / "cache")]
+    r = _run_bench(args, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["ranks"] == 8 and line["ranks_agree"] is True and len(line["plan"]["workloads"]) == 1
+    rec = sorted(line["records"], key=lambda e: e["rank"])
+    assert [e["rank"] for e in rec] == list(range(8))
+    assert rec[0]["source"] == "generated" and all(e["source"] == "shared_file" for e in rec[1:])
+    assert len({e["crc32"] for e in rec}) == 1 and len({e["first_record_crc32"] for e in rec}) == 1
+    size_mb = 3000 * 100030 / 1e6
+    assert rec[0]["maxrss_mb"] > size_mb  # rank 0 holds the array
+    for e in rec[1:]:
+        assert e["maxrss_mb"] < rec[0]["maxrss_mb"] - 0.6 * size_mb, rec  # the others hold one 64-MB chunk of it at a time
+    shared = tmp_path / "cache" / "records_seed1_3000x100030.u8"
+    assert shared.exists() and shared.stat().st_size == 3000 * 100030
+
+
 def _agree_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

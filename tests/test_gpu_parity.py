@@ -519,6 +519,8 @@ def test_session_batches_match_oracle(name):
 
     for streaming in (True, False):
         s = h.session(depth=2)
+        if streaming:
+            s.reserve(100_000, 64)  # (optional set-up; the random pass lets submit grow the buffers)
         with pytest.raises(L.LphqError):
             s.collect()  # nothing in flight
         s.submit(batches[0], streaming)
