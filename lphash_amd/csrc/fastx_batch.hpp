@@ -50,6 +50,7 @@
 
 #include "fastx.hpp"
 #include "parallel_gz.hpp"
+#include "work_pool.hpp"
 
 namespace lphq {
 
@@ -111,6 +112,7 @@ public:
     ~FastxBatchReader() {
         delete serial_;
         delete pgz_;
+        delete pool_;
         if (bgzf_) munmap((void*)bgzf_, bgzf_size_);
         if (wbuf_) {
             free(wbuf_);
@@ -132,6 +134,7 @@ public:
             which_ ^= 1;
             (void)reserve(want);
         }
+        if (!pool_ && threads_ > 1 && !serial_) pool_ = new WorkPool(threads_);  // the parse threads, parked
         if (pgz_ && !wbuf_) {  // the decoder's buffers and threads, and a window of one batch and a few pieces: allocated and touched here, nothing decoded
             pgz_->prealloc();
             const size_t cap = want + 16 * pgz_->span() + kWindowSlack;
@@ -294,10 +297,7 @@ private:
             }
             delete dec;
         };
-        std::vector<std::thread> th;
-        for (int t = 1; t < T; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto& x : th) x.join();
+        pool().run((size_t)T, [&](size_t t) { work((int)t); });
         for (int x : bad)
             if (x) return false;
         blk_next_ = b_end;
@@ -549,8 +549,10 @@ private:
             end = want >= size_ - off_ ? size_ : next_record_start(off_ + want);
         } else {
             // BGZF: the window must hold the batch and the start of the record after it; a search that runs into the end of the window while the
-            // file goes on asks for twice as much
-            for (size_t ahead = want + (1 << 16);; ahead *= 2) {
+            // file goes on asks for more
+            // (a quarter more each time, not twice as much: the window is filled synchronously for BGZF, and for a plain .gz waiting for text nobody needs
+            // yet delays the batch that could already be on its way to the GPU)
+            for (size_t ahead = want + (1 << 16);; ahead += std::max<size_t>(ahead / 4, (size_t)1 << 16)) {
                 if (!window_fill(off_, ahead >= size_ - off_ ? size_ : off_ + ahead)) return false;  // damaged block: the serial reader takes over at off_
                 if (want >= size_ - off_) {
                     end = size_;
@@ -578,13 +580,7 @@ private:
             pieces.push_back(std::move(pc));
             from = to;
         }
-        if (pieces.size() == 1) parse_piece(pieces[0]);
-        else {
-            std::vector<std::thread> th;
-            for (size_t i = 1; i < pieces.size(); ++i) th.emplace_back([this, &pieces, i] { parse_piece(pieces[i]); });
-            parse_piece(pieces[0]);
-            for (auto& t : th) t.join();
-        }
+        pool().run(pieces.size(), [&](size_t i) { parse_piece(pieces[i]); });
         for (const Piece& pc : pieces)
             if (pc.unsafe) return false;
         for (const Piece& pc : pieces) {
@@ -638,6 +634,11 @@ private:
     size_t wcap_ = 0, wbase_ = 0, wend_ = 0;
     bool windowed_ = false;
     uint64_t emitted_ = 0;                 // records handed out by the parallel path so far
+    WorkPool* pool_ = nullptr;             // the parse (and BGZF inflate) threads: created by prealloc() or at the first batch that needs them
+    WorkPool& pool() {
+        if (!pool_) pool_ = new WorkPool(threads_);
+        return *pool_;
+    }
     ParallelGzReader* pgz_ = nullptr;      // a .gz that is not BGZF, decoded by all threads into the same window
     bool gz_done_ = false;
     FastxReader* serial_ = nullptr;

@@ -14,6 +14,7 @@
 // Ties keep the LEFT position throughout (candidates are taken left to right with a strict `<`), as the strict `>` comparisons of
 // include/partitioned_mphf.hpp:122,150-163 do.
 #pragma once
+#include <gfx950/shift_in.cuh>
 #include <gfx950/wave_scan.cuh>
 
 #include "kernels_device.cuh"
@@ -311,13 +312,21 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
         const uint64_t limit = sm_roff[1] + shift;  // shifted coordinate of the record's end
         if (limit >= t0 + k) w_hi = (uint32_t)min((uint64_t)TW, limit - k - t0 + 1u);
     }
+    // (uniform) a PLAIN tile: inside one record from its first window to its last (w_lo = 0, w_hi = TW) and without a non-ACGT base -- all tiles of a long
+    // record but its first and last.  Its windows are valid or not by whole lanes (TW is a multiple of 16), so what the general path decides per window
+    // (round 3: ~55 instructions per lane in phases C, D and F) is one compare per lane here.
+    const bool plain = one_record && !anybad && w_lo == 0u && w_hi == TW;
     uint32_t code[8];  // minimizer position of the window; 0xFFFF: holds a non-ACGT base; 0xFFFE: not a window of any record
     uint32_t jrec = 0, jcur = 0;  // multi-record tiles: record (relative to rlo) of the lane's first in-batch window, and a cursor
     {
         uint32_t q[8];
         if (DIRECT) window_argmin8_raw<BLOCK>(sm_hash, tid, W, q);
         else window_argmin8<BLOCK>(sm_hash, sm_off, tid, W, bmin, q);
-        if (one_record) {
+        if (plain) {  // every window below TW (a multiple of 8: whole lanes) is a window of the record
+            const bool lane_in = a < TW;
+#pragma unroll
+            for (uint32_t jw = 0; jw < 8; ++jw) code[jw] = lane_in ? q[jw] : 0xFFFEu;
+        } else if (one_record) {
 #pragma unroll
             for (uint32_t jw = 0; jw < 8; ++jw) code[jw] = (a + jw >= w_lo && a + jw < w_hi) ? q[jw] : 0xFFFEu;
         } else {
@@ -363,10 +372,16 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
         const uint32_t lane = tid & 63u;
         uint32_t prev = __shfl(code[7], (int)((lane + 63u) & 63u), 64);  // last window of the lane to the left
         if (lane == 0) prev = 0xFFFEu;                                     // it lives in another wave: queue the window regardless
+        if (plain) {  // whole lanes are windows of the record or not: the validity of a leader is the lane's (gfx950/shift_in.cuh: 2 instructions per window)
 #pragma unroll
-        for (uint32_t jw = 0; jw < 8; ++jw) {
-            const bool ld = code[jw] < 0xFFFEu && code[jw] != (jw ? code[jw - 1] : prev);
-            lmask |= ld ? 1u << jw : 0u;
+            for (int jw = 7; jw >= 0; --jw) shift_in_ne(lmask, code[jw], jw ? code[jw - 1] : prev);
+            lmask = a < TW ? lmask : 0u;
+        } else {
+#pragma unroll
+            for (uint32_t jw = 0; jw < 8; ++jw) {
+                const bool ld = code[jw] < 0xFFFEu && code[jw] != (jw ? code[jw - 1] : prev);
+                lmask |= ld ? 1u << jw : 0u;
+            }
         }
         // Round 4: the lane's leaders are numbered by ONE prefix sum of popcount(lmask) over the wave (six DPP adds, gfx950/wave_scan.cuh) and written
         // one after the other -- leaders in lane order instead of slot order, which the lookups do not care about.  Round 3 took a ballot, a population
@@ -398,18 +413,22 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
             sm_hash[hslot8<BLOCK>(q)] = c.base | ((uint64_t)c.mode << LPHQ_TAIL_MODE_SHIFT);  // (bases are ranks < 2^62: the packing of the image's tail table)
         }
     };
-    if (__builtin_expect(nlead <= QCAP, 1)) {  // (uniform) the common case: super-k-mers average (W + 1) / 2 windows
-        lookup_queued(nlead);
-        __syncthreads();
-    } else {
-        // More leaders than the queue holds: the tile is done window slot by window slot -- a lane leads at most once per slot, so the BLOCK leaders
-        // of a slot always fit.  Eight rounds of three barriers; rare, and it keeps this path out of the register budget of the common one.
-        for (uint32_t jw = 0; jw < 8; ++jw) {
+    // (uniform) the common case: one round over the queue as phase D filled it (super-k-mers average (W + 1) / 2 windows).  More leaders than the queue
+    // holds: the tile is done window slot by window slot -- a lane leads at most once per slot, so the BLOCK leaders of a slot always fit -- eight rounds of
+    // three barriers.  ONE copy of the lookup serves both (round 3 had two, and the rare one's registers were what the compiler spilled).
+    const bool overflow = nlead > QCAP;
+    const uint32_t rounds = overflow ? 8u : 1u;
+#pragma unroll 1
+    for (uint32_t jw = 0; jw < rounds; ++jw) {
+        uint32_t n = nlead;
+        if (overflow) {
             if (tid == 0) sm_slot_count = 0;
             __syncthreads();
-            uint32_t cj = code[0];
+            // window slot jw's code is code[0] of an array rotated by one per round (eight rounds put it back as it was: phase F reads it again)
+            const uint32_t cj = code[0];
 #pragma unroll
-            for (uint32_t t = 1; t < 8; ++t) cj = jw == t ? code[t] : cj;
+            for (uint32_t t = 0; t < 7; ++t) code[t] = code[t + 1];
+            code[7] = cj;
             const bool ld = (lmask >> jw) & 1u;
             const uint64_t bal = __ballot(ld);
             uint32_t b = 0;
@@ -417,27 +436,44 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
             b = __shfl(b, 0, 64);
             if (ld) sm_queue[b + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint16_t)cj;
             __syncthreads();
-            lookup_queued(sm_slot_count);
-            __syncthreads();
+            n = sm_slot_count;
         }
+        lookup_queued(n);
+        __syncthreads();
     }
 
     // ---- F: the lane's eight codes ----
     uint64_t hv[8];
     uint32_t modes = 0;  // OR of the mode fields of the lane's windows (bit 1: a colliding minimizer)
+    if (plain) {
+        // the codes of lanes at or beyond TW are never stored (the stores below are bounded by w_hi = TW): nothing to invalidate per window
 #pragma unroll
-    for (uint32_t jw = 0; jw < 8; ++jw) {
-        const uint32_t q = code[jw];
-        const bool valid = q < 0xFFFEu;
-        const uint32_t qq = q & (uint32_t)(kS8Pos - 1);  // (an invalid window reads some slot of the tile: the value is discarded)
-        const uint64_t packed = sm_hash[hslot8<BLOCK>(qq)];
-        const uint64_t base = packed & LPHQ_TAIL_BASE_MASK;
-        const uint32_t mode = (uint32_t)(packed >> LPHQ_TAIL_MODE_SHIFT);
-        const uint32_t p = qq - (a + jw);
-        const int32_t delta = mode == 0u ? (int32_t)p : -(int32_t)p;  // |p| < 2^16; (mode 2 is redone below)
-        const uint64_t hval = base + (uint64_t)(int64_t)delta;
-        hv[jw] = valid ? hval : ~0ull;  // LPHQ_INVALID
-        modes |= valid ? mode : 0u;  // (what an invalid window read is whatever phases B-C left in that slot)
+        for (uint32_t jw = 0; jw < 8; ++jw) {
+            const uint32_t qq = code[jw] & (uint32_t)(kS8Pos - 1);
+            const uint64_t packed = sm_hash[hslot8<BLOCK>(qq)];
+            const uint64_t base = packed & LPHQ_TAIL_BASE_MASK;
+            const uint32_t mode = (uint32_t)(packed >> LPHQ_TAIL_MODE_SHIFT);
+            const uint32_t p = qq - (a + jw);
+            const int32_t delta = mode == 0u ? (int32_t)p : -(int32_t)p;
+            hv[jw] = base + (uint64_t)(int64_t)delta;
+            modes |= mode;
+        }
+        modes = a < TW ? modes : 0u;  // (what a lane beyond TW read is whatever phases B-C left in slot 1022)
+    } else {
+#pragma unroll
+        for (uint32_t jw = 0; jw < 8; ++jw) {
+            const uint32_t q = code[jw];
+            const bool valid = q < 0xFFFEu;
+            const uint32_t qq = q & (uint32_t)(kS8Pos - 1);  // (an invalid window reads some slot of the tile: the value is discarded)
+            const uint64_t packed = sm_hash[hslot8<BLOCK>(qq)];
+            const uint64_t base = packed & LPHQ_TAIL_BASE_MASK;
+            const uint32_t mode = (uint32_t)(packed >> LPHQ_TAIL_MODE_SHIFT);
+            const uint32_t p = qq - (a + jw);
+            const int32_t delta = mode == 0u ? (int32_t)p : -(int32_t)p;  // |p| < 2^16; (mode 2 is redone below)
+            const uint64_t hval = base + (uint64_t)(int64_t)delta;
+            hv[jw] = valid ? hval : ~0ull;  // LPHQ_INVALID
+            modes |= valid ? mode : 0u;  // (what an invalid window read is whatever phases B-C left in that slot)
+        }
     }
     if (__any((modes & 2u) != 0u)) {  // windows under a colliding minimizer: the fallback function of the k-mer (src/partitioned_mphf.cpp:312-316)
         uint32_t coll = 0;            // which of the lane's windows (worked out here, off the common path)

@@ -161,7 +161,7 @@ def test_bench_record_set_is_shared_not_regenerated_gloo_world8(tmp_path):
     private copies plus eight per-record copies were 32 GB of host memory and eight generations."""
     import json
 
-    kmers = 300_000_000  # 3000 records x 100030 bases = 300 MB of bases
+    kmers = 160_000_000  # 1600 records x 100030 bases = 160 MB of bases
     args = ["--gpus", "8", "--plan-only", "--plan-records", "--kmers", str(kmers), "--no-secondary", "--cache-dir", str(tmp_path / "cache")]
     r = _run_bench(args, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -173,12 +173,12 @@ def test_bench_record_set_is_shared_not_regenerated_gloo_world8(tmp_path):
     assert [e["rank"] for e in rec] == list(range(8))
     assert rec[0]["source"] == "generated" and all(e["source"] == "shared_file" for e in rec[1:])
     assert len({e["crc32"] for e in rec}) == 1 and len({e["first_record_crc32"] for e in rec}) == 1
-    size_mb = 3000 * 100030 / 1e6
+    size_mb = 1600 * 100030 / 1e6
     assert rec[0]["maxrss_mb"] > size_mb  # rank 0 holds the array
     for e in rec[1:]:
         assert e["maxrss_mb"] < rec[0]["maxrss_mb"] - 0.6 * size_mb, rec  # the others hold one 64-MB chunk of it at a time
-    shared = tmp_path / "cache" / "records_seed1_3000x100030.u8"
-    assert shared.exists() and shared.stat().st_size == 3000 * 100030
+    shared = tmp_path / "cache" / "records_seed1_1600x100030.u8"
+    assert shared.exists() and shared.stat().st_size == 1600 * 100030
 
 
 def _agree_worker(rank, world, port, q):
