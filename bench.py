@@ -706,6 +706,12 @@ def run_workload(job, wl):
             rate = valu[0] * units / kernel_s
             out["roofline_valu"] = {"bound": "valu_issue", "instr_per_unit": valu[0], "achieved_lane_instr_per_s": rate, "peak": VALU_PEAK_LANE_INSTR,
                                     "frac": rate / VALU_PEAK_LANE_INSTR, "unit": "lane-instructions/s", "source": valu[1]}
+            if mode == "random" and not competitor:
+                # distance to the floor: a lookup hashes W m-mers; MurmurHash2_64 of one word is 24 VALU instructions on gfx950 and cannot be
+                # fewer, the scan spends 29 per m-mer (24 + 2 to cut the m-mer out + 3 for min / argmin); everything else is the measured rest
+                out["roofline_valu"].update({"hash_floor_instr_per_unit": 24 * W, "scan_instr_per_unit": 29 * W, "rest_instr_per_unit": valu[0] - 29 * W,
+                                             "floor_instr_per_unit": valu[0] - 5 * W,
+                                             "above_floor": valu[0] / (valu[0] - 5 * W) - 1.0})
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if cpu_all is not None:

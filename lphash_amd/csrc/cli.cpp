@@ -210,10 +210,19 @@ bool query_pass(lphq_index* idx, const lphq_info& info, const std::string& path,
         err = "out of host memory";
         return true;
     }
+    // ... and the device buffers of both slots of every GPU for a whole batch (its share of it): allocation is set-up too
+    for (GpuWorker& g : gpus) {
+        const size_t share = batch_bases / gpus.size() + batch_bases / 8 + (1 << 16);
+        if (hipSetDevice(g.device) != hipSuccess) continue;
+        for (GpuWorker::Slot& s : g.slot)
+            if (!s.busy) (void)GpuWorker::ensure(s, share, 1024, share, sink != nullptr);
+    }
     auto t0 = std::chrono::high_resolution_clock::now();
     lphq::FastxBatch bufs[2];
     total_kmers = 0;
     const size_t ng = gpus.size();
+    const bool trace = getenv("LPHQ_CLI_TRACE") != nullptr;  // per-batch timeline on stderr (ms since the pass's timer started)
+    auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count(); };
     // wait for slot `si` of every GPU: its count is in, its buffers are free; with --output its codes go to the sink (in GPU
     // order = record order)
     auto retire = [&](int si) -> bool {
@@ -301,6 +310,7 @@ bool query_pass(lphq_index* idx, const lphq_info& info, const std::string& path,
             s.h_offs[2 * nr + 1] = o;
             uint64_t left = so;
             size_t at = 0;
+            if (trace) fprintf(stderr, "[cli]   flush: buffers ready at %.2f ms\n", ms());
             while (left) {  // one copy per parsed piece, compacting on the way
                 const size_t take = (size_t)std::min<uint64_t>(left, b.segs[seg_i].n - seg_o);
                 if (take && hipMemcpyAsync(s.d_seq + at, b.segs[seg_i].p + seg_o, take, hipMemcpyHostToDevice, g.stream) != hipSuccess) {
@@ -321,10 +331,12 @@ bool query_pass(lphq_index* idx, const lphq_info& info, const std::string& path,
                 return false;
             }
             s.busy = true;
+            if (trace) fprintf(stderr, "[cli]   flush: copies queued at %.2f ms\n", ms());
             if (lphq_query_records(idx, s.d_seq, so, s.d_offs, nr, s.d_out, s.d_offs + nr + 1, streaming, g.stream) != LPHQ_OK) {
                 err = lphq_last_error();
                 return false;
             }
+            if (trace) fprintf(stderr, "[cli]   flush: kernel queued at %.2f ms\n", ms());
             // hashes.size() of the reference: counted on the device, read back when the slot is retired
             s.n_out = oo;
             if (lphq_count_valid_async(idx, s.d_out, oo, s.d_count, g.stream) != LPHQ_OK) {
@@ -341,7 +353,14 @@ bool query_pass(lphq_index* idx, const lphq_info& info, const std::string& path,
     };
     // batch i+1 is parsed (by `threads` threads) while batch i is copied to the devices and looked up; the reader keeps
     // both batches' bases alive (fastx_batch.hpp), and bufs[i] may be parsed into again once slot i's copies are done
-    auto parse = [&](int i) { return std::async(std::launch::async, [&rd, &bufs, i, batch_bases] { return rd.next(bufs[i], batch_bases); }); };
+    auto parse = [&](int i) {
+        return std::async(std::launch::async, [&rd, &bufs, i, batch_bases, trace, &ms] {
+            const double a = trace ? ms() : 0;
+            const bool r = rd.next(bufs[i], batch_bases);
+            if (trace) fprintf(stderr, "[cli] next(): %.2f -> %.2f ms, %zu bases in %zu records, %zu pieces\n", a, ms(), bufs[i].bases, bufs[i].lens.size(), bufs[i].segs.size());
+            return r;
+        });
+    };
     std::future<bool> pending = parse(0);
     bool ok = true;
     int last = 1;  // slot of the most recent batch
@@ -349,11 +368,16 @@ bool query_pass(lphq_index* idx, const lphq_info& info, const std::string& path,
         if (!pending.get()) break;
         arena_released(i ^ 1);
         pending = parse(i ^ 1);
-        ok = retire(i) && flush(bufs[i], i);
+        const double a = trace ? ms() : 0;
+        ok = retire(i);
+        const double b = trace ? ms() : 0;
+        ok = ok && flush(bufs[i], i);
+        if (trace) fprintf(stderr, "[cli] batch of %zu bases: retire %.2f -> %.2f, queued at %.2f ms\n", bufs[i].bases, a, b, ms());
         last = i;
         if (!ok) pending.wait();
     }
     ok = ok && retire(last ^ 1) && retire(last);  // the older batch first: the sink keeps record order
+    if (trace) fprintf(stderr, "[cli] all retired at %.2f ms\n", ms());
     if (ok && !rd.ok()) err = "out of host memory while reading the query file";
     auto t1 = std::chrono::high_resolution_clock::now();
     elapsed_us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count();

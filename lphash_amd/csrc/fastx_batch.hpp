@@ -567,7 +567,10 @@ private:
         if (!reserve(std::max(end - off_, std::min(want, size_ - off_)))) return true;
         char* const arena = arenas_[which_].p;
         // cut [off_, end) into pieces at line starts
-        const int T = (int)std::min<size_t>((size_t)threads_, std::max<size_t>(1, (end - off_) / min_piece_));
+        // (text that is still being decoded by a pool of its own: pieces of >= 1 MB -- the decoder's threads hold the cores, and waking sixteen parse
+        // threads for a 4-MB batch cost more than the parsing; the tests' tiny min_piece_ still cuts finely)
+        const size_t piece = (pgz_ && windowed_ && !gz_done_) ? std::max<size_t>(min_piece_ < (1 << 16) ? min_piece_ : (size_t)1 << 20, 1) : min_piece_;
+        const int T = (int)std::min<size_t>((size_t)threads_, std::max<size_t>(1, (end - off_) / piece));
         std::vector<Piece> pieces;
         size_t from = off_;
         for (int t = 1; t <= T && from < end; ++t) {

@@ -280,12 +280,14 @@ private:
         // this thread's share of the slots: allocated and touched once (first-touch page faults cost more than decoding into warm memory)
         for (size_t i = (size_t)t; i < depth_; i += (size_t)threads_) {
             Slot& s = slots_[i];
-            const size_t n = W + est_text() + kSlack;
-            s.sym = (uint16_t*)malloc(n * 2);
+            // (placeholders die out after ~0.5 M symbols on DNA text: the 16-bit buffer starts at 1.5 M symbols and grows if a span needs more)
+            const size_t n = W + est_text() + kSlack, n16 = W + std::min<size_t>(est_text(), (size_t)3 << 19) + kSlack;
+            s.sym = (uint16_t*)malloc(n16 * 2);
             s.text = (uint8_t*)malloc(n);
             if (s.sym && s.text) {
-                s.sym_cap = s.text_cap = n;
-                memset(s.sym, 0, n * 2);
+                s.sym_cap = n16;
+                s.text_cap = n;
+                memset(s.sym, 0, n16 * 2);
                 memset(s.text, 0, n);
                 for (size_t k = 0; k < W; ++k) s.sym[k] = (uint16_t)(256 + k);
             } else {

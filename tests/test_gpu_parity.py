@@ -292,7 +292,7 @@ def test_large_index_properties(tmp_path, kind, k, m, bits, n_rec):
         outs.append(d_out)
     assert torch.equal(outs[0], outs[1])
     o = orc.Index(path, kind, bits)
-    for i in (0, 37, n_rec - 1):
+    for i in sorted({0, 1, 37, n_rec // 3, n_rec // 2, n_rec - 2, n_rec - 1}):  # 700 K windows against the oracle's streaming branch
         assert np.array_equal(outs[0][i * 100_000:(i + 1) * 100_000].cpu().numpy().view(np.uint64), o(recs[i], True))
     # packed random batch with repeats: the codes of the windows the k-mers were cut from, and the oracle's on a slice of it
     g = torch.Generator(device=dev)
@@ -306,8 +306,12 @@ def test_large_index_properties(tmp_path, kind, k, m, bits, n_rec):
     h.query_packed(d_k.data_ptr(), Q, d_o.data_ptr())
     torch.cuda.synchronize()
     assert torch.equal(d_o, outs[0][win])
-    S = 1 << 16
+    # 2^20 probes against the oracle's random branch: at C4's fallback rate (0.14 % of the k-mers sit under colliding minimizers) that is ~1,400 lookups
+    # through the fallback function, where round 3's 2^16 probes met ~90
+    S = 1 << 20
     assert np.array_equal(d_o[:S].cpu().numpy().view(np.uint64), o.query_packed(d_k[: S * (bits // 64)].cpu().numpy().view(np.uint64)))
+    expect_fallback = S * h.info.fallback_kmers / n
+    assert n_rec <= 1000 or expect_fallback > 500, expect_fallback
 
 
 def test_cli_query_end_to_end(tmp_path):

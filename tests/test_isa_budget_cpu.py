@@ -18,9 +18,9 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 BUDGET = {
     "k_query_packed": (64, 0),                # 8 waves / SIMD
     "k_query_tiles_stream": (64, 40 * 1024),
-    # 128 threads, 8 positions per lane.  Round 4: the wide-window variant (P == 6) fits 64 VGPRs and 10 KB of LDS = 16 workgroups (32 waves, the CU's cap)
-    # per CU; the narrow-window one stays at <= 72 VGPRs (7 waves / SIMD).  Checked per variant in test_stream8_variants_fit_their_occupancy_targets.
-    "k_query_tiles_stream8": (72, 10240),
+    # 128 threads, 8 positions per lane.  Round 4: 64 VGPRs and <= 10 KB of LDS for BOTH variants = 16 workgroups (32 waves, the CU's cap) per CU, no scratch
+    # (one copy of the lookup code for the common and the overflow rounds: the duplicated copy was what cost the registers).
+    "k_query_tiles_stream8": (64, 10240),
     "k_query_tiles_random": (64, 10 * 1024),  # + the 8-KiB queue of k-mer window starts (read batches); 16 workgroups per CU still fit
     "k_pack_kmers": (64, 0),
     "k_count_valid": (64, 0),
@@ -38,7 +38,7 @@ BUDGET = {
 }
 # SGPR spills go to VGPR lanes, not to memory.  k_query_packed takes the 1.2-KB header by value (measured 2 % faster than reading the header from the
 # image); since round 3 the fallback function's descriptor is read from the image in the rare path that needs it and nothing spills.
-SGPR_SPILLS = {"k_query_packed": 0, "k_query_tiles_stream8": 16}  # (stream8: lane slots of one VGPR, all inside the rare overflow path of the wide-window variant)
+SGPR_SPILLS = {"k_query_packed": 0}
 
 
 _CACHE = {}
@@ -85,30 +85,24 @@ def _kernel_body(asm, mangled_fragment):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_stream8_variants_fit_their_occupancy_targets(kernels_asm):
-    """The eight-positions-per-lane streaming kernel: every wide-window instantiation (P == 6: C4's W = 44) within 64 VGPRs and 10240 B of LDS -- 16
-    workgroups of two waves per CU, the hardware's 32-wave cap -- with at most the 16 bytes of scratch its once-in-a-thousand-tiles overflow path spills
-    (the common path keeps everything in registers: no scratch instruction before the overflow loop is checked below); every narrow-window one
-    (P == 4, W <= 15: C3) within 72 VGPRs and no scratch."""
+    """The eight-positions-per-lane streaming kernel: every instantiation -- wide windows (P == 6: C4's W = 44) and narrow ones (P == 4: C3's W = 12) --
+    within 64 VGPRs and 10240 B of LDS, i.e. 16 workgroups of two waves per CU (the hardware's 32-wave cap), and without a byte of scratch; its leader
+    numbering is the DPP scan of gfx950/wave_scan.cuh and its plain-tile leader mask the v_cmp + v_addc pair of gfx950/shift_in.cuh."""
     usage, asm = kernels_asm
     seen = 0
     for name, u in usage.items():
         if "k_query_tiles_stream8" not in name:
             continue
         seen += 1
-        wide = "ELi6ELi128ELb0E" in name or "ELi6ELi256ELb0E" in name
-        if wide:
-            assert u["VGPRs"] <= 64 and u.get("LDS Size", 0) <= 10240 and u.get("ScratchSize", 0) <= 16, (name, u)
-        else:
-            assert u["VGPRs"] <= 72 and u.get("ScratchSize", 0) == 0 and u.get("VGPRs Spill", 0) == 0, (name, u)
+        assert u["VGPRs"] <= 64 and u.get("LDS Size", 0) <= 10240 and u.get("ScratchSize", 0) == 0 and u.get("VGPRs Spill", 0) == 0, (name, u)
+        assert u.get("Occupancy", 8) == 8, (name, u)
     assert seen >= 8
-    body = _kernel_body(asm, "k_query_tiles_stream8ILi0ELb1ELi6ELi128ELb0E")
-    # the leader numbering is the DPP scan of gfx950/wave_scan.cuh ...
-    for ctrl in ("row_shr:1", "row_shr:2", "row_shr:4", "row_shr:8", "row_bcast:15", "row_bcast:31"):
-        assert ctrl in body, ctrl
-    # ... and whatever is spilled is spilled behind the common path: after the barrier that ends phase E's common branch
-    first_scratch = body.find("scratch_")
-    if first_scratch >= 0:
-        assert body[:first_scratch].count("s_barrier") >= 6, "a scratch access on the common path of the streaming kernel"
+    for frag in ("k_query_tiles_stream8ILi0ELb1ELi6ELi128ELb0E", "k_query_tiles_stream8ILi0ELb0ELi4ELi128ELb1E"):
+        body = _kernel_body(asm, frag)
+        for ctrl in ("row_shr:1", "row_shr:2", "row_shr:4", "row_shr:8", "row_bcast:15", "row_bcast:31"):
+            assert ctrl in body, (frag, ctrl)
+        assert len(re.findall(r"v_cmp_ne_u32[^\n]*\n\s*v_addc_co_u32", body)) >= 8, frag
+        assert "scratch_" not in body
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
@@ -125,7 +119,6 @@ def test_minimizer_scan_uses_the_exec_masked_take_min(kernels_asm):
 @pytest.mark.parametrize("src", ["kernels.hip", "search.hip", "extract.hip"])
 def test_kernels_fit_their_register_and_lds_budget(src):
     usage = resource_usage(src)
-    stream8_scratch = 16  # (the wide-window variant's rare overflow path: test_stream8_variants_fit_their_occupancy_targets)
     assert usage, "no kernel-resource-usage remarks in the compiler output"
     seen = set()
     for name, u in usage.items():
@@ -137,10 +130,7 @@ def test_kernels_fit_their_register_and_lds_budget(src):
         assert key in BUDGET, f"kernel {key} has no budget entry"
         seen.add(key)
         vg, lds = BUDGET[key]
-        if key == "k_query_tiles_stream8":
-            assert u.get("ScratchSize", 0) <= stream8_scratch, (name, u)
-        else:
-            assert u.get("ScratchSize", 0) == 0 and u.get("VGPRs Spill", 0) == 0, (name, u)
+        assert u.get("ScratchSize", 0) == 0 and u.get("VGPRs Spill", 0) == 0, (name, u)
         assert u.get("SGPRs Spill", 0) <= SGPR_SPILLS.get(key, 0), (name, u)
         assert u["VGPRs"] + u.get("AGPRs", 0) <= vg, (name, u)
         assert u.get("LDS Size", 0) <= lds, (name, u)
