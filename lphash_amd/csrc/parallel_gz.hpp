@@ -617,6 +617,14 @@ private:
     // The caller's thread decodes from the known bit with the known window to the end of span j (or to the end of the member, or to the cap).
     bool serial_piece(size_t j) {
         ++n_fallback_;
+        if (n_fallback_ >= 64 && n_accepted_ < n_fallback_ / 4 && !stop_claims_) {
+            // a stream the pool cannot help with (thousands of small members, stored blocks throughout): its threads would go on decoding spans that
+            // are thrown away -- from here on the caller's thread alone
+            std::lock_guard<std::mutex> g(mu_);
+            stop_claims_ = true;
+            for (size_t i = 0; i < depth_; ++i)
+                if (slots_[i].state == kBusy) slots_[i].abandon = true;
+        }
         FbBuf* fb = nullptr;
         {
             std::lock_guard<std::mutex> g(mu_);

@@ -848,10 +848,12 @@ def test_fast_inflate_equals_zlib(tmp_path):
         "flags": _gzip_member(fasta[:50_000], name=b"x.fa", comment=b"made by a test", extra=b"AB\x02\x00xy", hcrc=True),
         "members": b"".join(_gzip_member(fasta[i:i + 77_777], level=int(rng.integers(0, 10))) for i in range(0, 1_500_000, 77_777)),
         "members_then_garbage": _gzip_member(text[:100_000]) + _gzip_member(b"") + _gzip_member(text[100_000:300_000]) + b"\x00garbage after the last member",
+        # hundreds of small members: nothing for the pool to do (it stops itself after 64 pieces decoded by the caller's thread)
+        "many_members": b"".join(_gzip_member(fasta[i:i + 9_000], level=6) for i in range(0, 2_700_000, 9_000)),
         # a run of one letter longer than any span's cap of text (the N stretches of a chromosome; placeholders never die out inside it)
         "poly_n": _gzip_member(fasta[:600_000] + b"N" * 40_000_000 + fasta[600_000:1_200_000], level=6),
     }
-    plain = {"members_then_garbage": text[:300_000], "members": b"".join(fasta[i:i + 77_777] for i in range(0, 1_500_000, 77_777))}
+    plain = {"members_then_garbage": text[:300_000], "members": b"".join(fasta[i:i + 77_777] for i in range(0, 1_500_000, 77_777)), "many_members": fasta[:2_700_000]}
     for name, blob in cases.items():
         f, o = tmp_path / f"{name}.gz", tmp_path / f"{name}.out"
         f.write_bytes(blob)
