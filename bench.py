@@ -45,7 +45,7 @@ def device_source_sha():
     hsh = hashlib.sha256()
     csrc = os.path.join(ROOT, "lphash_amd", "csrc")
     for pth in sorted(glob.glob(os.path.join(csrc, "*.cuh")) + glob.glob(os.path.join(csrc, "gfx950", "*.cuh")) +
-                      [os.path.join(csrc, "kernels.hip"), os.path.join(csrc, "image_layout.h")]):
+                      [os.path.join(csrc, "kernels.hip"), os.path.join(csrc, "stream8.hip"), os.path.join(csrc, "image_layout.h")]):
         hsh.update(os.path.basename(pth).encode())
         hsh.update(open(pth, "rb").read())
     return hsh.hexdigest()[:16]

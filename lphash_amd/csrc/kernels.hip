@@ -6,7 +6,6 @@
 
 #include "kernels.hpp"
 #include "kernels_device.cuh"
-#include "stream8_device.cuh"
 
 namespace lphq {
 
@@ -104,7 +103,7 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
     const bool stream_kernel = streaming && H.kind < 2;  // (the competitor harness has one kernel for both values of `streaming`)
     const bool s8 = stream_kernel && H.W >= s8_min_w;
     const uint64_t tw = stream_kernel ? stream_tile_windows(H.W, 4 * sblock) : kTileW;  // (8 * kS8Block == 4 * sblock: both kernels cut the same tiles)
-    static_assert(8 * kS8Block == 4 * sblock, "one tile geometry");
+    static_assert(8 * 128 == 4 * sblock, "one tile geometry (stream8_device.cuh: kS8Block = 128 threads, eight positions each)");
     const uint64_t tiles = (span + tw - 1) / tw;
     if (n_records > 0xFFFFFFFFull) return hipErrorInvalidValue;
     // one workgroup per tile; HIP requires gridDim.x * blockDim.x < 2^32, so a batch of more than 2^24 - 1 tiles (~16 G bases) goes
@@ -115,12 +114,15 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
         if (stream_kernel) {
             // W >= 8: eight positions per lane (stream8_device.cuh; same tile geometry, 128 threads); narrower windows, and anything below LPHQ_STREAM8_MINW in
             // A/B runs: four positions per lane
+            if (s8) {
+                const hipError_t e8 = H.kind == 0 ? launch_query_tiles_stream8_p(H, d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base, grid, stream)
+                                                  : launch_query_tiles_stream8_u(H, d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base, grid, stream);
+                if (e8 != hipSuccess) return e8;
+                continue;
+            }
 #define LPHQ_STREAM_LAUNCH(KIND, K128) \
     do { \
-        if (s8) { \
-            if (H.P == 6) k_query_tiles_stream8<KIND, K128, 6><<<grid, kS8Block, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
-            else k_query_tiles_stream8<KIND, K128, 4><<<grid, kS8Block, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
-        } else if (H.P != 6) k_query_tiles_stream<KIND, K128, 4, sblock, false><<<grid, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
+        if (H.P != 6) k_query_tiles_stream<KIND, K128, 4, sblock, false><<<grid, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
         else if (H.W >= kBlockMinW) k_query_tiles_stream<KIND, K128, 6, sblock, true><<<grid, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
         else k_query_tiles_stream<KIND, K128, 6, sblock, false><<<grid, sblock, 0, stream>>>(d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, d_out, tile_base); \
     } while (0)

@@ -16,4 +16,11 @@ hipError_t launch_gather_payload(const uint64_t* d_codes, size_t n, const void* 
                                  hipStream_t stream);
 hipError_t launch_count_valid(const uint64_t* d_codes, size_t n, unsigned long long* d_count, hipStream_t stream);
 hipError_t launch_count_bad_bases(const char* d_seq, size_t n, unsigned long long* d_count, hipStream_t stream);
+// stream8.hip (one object per function kind): the eight-positions-per-lane streaming kernel over the tiles [tile_base, tile_base + grid)
+hipError_t launch_query_tiles_stream8_p(const lphq_image_header& H, const uint8_t* d_img, const uint8_t* seq_al, uint64_t shift, uint64_t total_bases,
+                                        const uint64_t* d_seq_off, const uint64_t* d_out_off, uint32_t n_records, uint64_t* d_out, uint64_t tile_base, int grid,
+                                        hipStream_t stream);
+hipError_t launch_query_tiles_stream8_u(const lphq_image_header& H, const uint8_t* d_img, const uint8_t* seq_al, uint64_t shift, uint64_t total_bases,
+                                        const uint64_t* d_seq_off, const uint64_t* d_out_off, uint32_t n_records, uint64_t* d_out, uint64_t tile_base, int grid,
+                                        hipStream_t stream);
 }  // namespace lphq

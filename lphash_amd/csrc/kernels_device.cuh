@@ -347,6 +347,10 @@ __device__ __forceinline__ void store_codes_nt(uint64_t* dst, uint64_t c0, uint6
     __builtin_nontemporal_store(v, (u64x2*)dst);
 }
 constexpr int kStreamBlockDefault = 256;  // threads per workgroup of the streaming kernel; 4 m-mer positions per lane
+constexpr uint32_t kStream8MinW = 8;                   // the launcher uses this kernel for W >= kStream8MinW: window minima from the raw hashes for W <= 15 (P == 4), by
+                                                       // block decomposition from W = 16 on (P == 6).  Against four positions per lane (profiles/r03_stream8.txt):
+                                                       // W = 8 +1.6 %, W = 12 +3.3 %, W = 17 +7.5 %, W = 24 +5 %, W = 31 +7 %, W = 44 +20 %.  Narrower windows
+                                                       // (every other window leads a super-k-mer) stay with four per lane
 __host__ __device__ inline uint32_t stream_tile_windows(uint32_t W, int npos) { return (uint32_t)(npos - (int)W + 1) & ~15u; }
 
 struct HashPos {

@@ -21,10 +21,6 @@
 
 namespace lphq {
 
-constexpr uint32_t kStream8MinW = 8;                   // the launcher uses this kernel for W >= kStream8MinW: window minima from the raw hashes for W <= 15 (P == 4), by
-                                                       // block decomposition from W = 16 on (P == 6).  Against four positions per lane (profiles/r03_stream8.txt):
-                                                       // W = 8 +1.6 %, W = 12 +3.3 %, W = 17 +7.5 %, W = 24 +5 %, W = 31 +7 %, W = 44 +20 %.  Narrower windows
-                                                       // (every other window leads a super-k-mer) stay with four per lane
 constexpr int kS8Block = 128;                          // threads per workgroup; 8 * BLOCK m-mer positions per tile (256 threads / 2048 positions: measured equal at W = 8, 12,
                                                        // profiles/r03_stream8.txt (9); the template parameter stays for the emulator's coverage)
 constexpr int kS8RecCap = 16;                          // records of a multi-record tile cached in LDS (more: the global offset arrays are searched)
@@ -84,12 +80,17 @@ __device__ __forceinline__ BlockMin8 publish_block_minima8(uint64_t* __restrict_
 // distances, so their words of sm_off are read once per lane and a field of them is one v_bfe_u32 per candidate; only the winner of the common blocks
 // needs a data-dependent read.  Before, every window carried a (block, column) id through its chain and decoded it afterwards with a dependent LDS read,
 // a variable shift and a select: 8 decodes of ~11 instructions per lane, now 1.
-template <int BLOCK>
+// W8 = (W - 8) % 8 as a compile-time constant (the launcher has one instantiation per value), or -1: taken from W at run time.  Which of the eight windows
+// take block l+nf0+1 whole, and how long a prefix of the block behind it each of them takes, depends on W only through that remainder; with it fixed at
+// compile time every per-window decision below is resolved by the compiler: no scalar branches, LDS offsets as immediates (measured with W fixed
+// altogether: -4.8 % VALU, -32 % SALU instructions, -2.5 % kernel time at C4, profiles/r04_stream8.txt).
+template <int BLOCK, int W8>
 __device__ __forceinline__ void window_argmin8(const uint64_t* __restrict__ sm_hash, const uint32_t* __restrict__ sm_off, uint32_t tid, uint32_t W, const BlockMin8& s,
                                                uint32_t (&q)[8]) {
     constexpr uint32_t kS8Row = s8_row<BLOCK>();
     const uint64_t* colM = sm_hash + 7u * kS8Row + tid;  // M of the block t lanes to the right: colM[t]
     const uint32_t nf0 = (W - 8u) >> 3;                  // blocks covered completely by all eight windows: l+1 .. l+nf0 (>= 1: W >= 16)
+    const uint32_t w8 = W8 >= 0 ? (uint32_t)W8 : ((W - 8u) & 7u);
     HashPos r{colM[1], 1u};
     for (uint32_t t = 2; t <= nf0; ++t) take_if_less(r, colM[t], t);
     r.p = (r.p << 3) + ((sm_off[tid + r.p] >> 21) & 7u);  // position relative to a: 8 t + where block t's minimum sits
@@ -101,12 +102,13 @@ __device__ __forceinline__ void window_argmin8(const uint64_t* __restrict__ sm_h
 #pragma unroll
     for (uint32_t j = 0; j < 8; ++j) {
         HashPos w = j == 0 ? HashPos{colM[0], (ob0 >> 21) & 7u} : HashPos{s.h[j ? j - 1 : 0], (s.p >> (3u * (j ? j - 1u : 0u))) & 7u};
-        const uint32_t nf = (j + W - 8u) >> 3, hc = (j + W - 8u) & 7u;  // uniform over the wave
+        const bool second = j + w8 >= 8u;   // (uniform; a constant when W8 is) the window takes block l+nf0+1 whole and a prefix of block l+nf0+2
+        const uint32_t hc = (j + w8) & 7u;  // ... of that many positions
         take_if_less(w, r.h, r.p);
-        if (nf > nf0) take_if_less(w, mA.h, mA.p);
+        if (second) take_if_less(w, mA.h, mA.p);
         if (hc) {
-            const uint32_t word = nf > nf0 ? wB : wA, rel = nf > nf0 ? relB : relA;
-            take_if_less(w, sm_hash[(hc - 1u) * kS8Row + tid + nf + 1u], rel + ((word >> (3u * (hc - 1u))) & 7u));
+            const uint32_t word = second ? wB : wA, rel = second ? relB : relA;
+            take_if_less(w, sm_hash[(hc - 1u) * kS8Row + tid + nf0 + (second ? 2u : 1u)], rel + ((word >> (3u * (hc - 1u))) & 7u));
         }
         q[j] = a + w.p;
     }
@@ -167,7 +169,7 @@ __device__ __forceinline__ void window_argmin8_raw(const uint64_t* __restrict__ 
 }
 
 // DIRECT: window minima from the raw hashes (narrow windows) instead of block prefix minima
-template <int KIND, bool K128, int P, int BLOCK = kS8Block, bool DIRECT = (P == 4)>
+template <int KIND, bool K128, int P, int BLOCK = kS8Block, bool DIRECT = (P == 4), int W8 = -1>
 // (second launch bound = waves per SIMD the register allocation must leave room for: 8 = 64 VGPRs for the wide-window variant, whose LDS now allows the
 // 16 workgroups per CU that takes; the narrow-window variant stays at its 71)
 __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al, uint64_t shift, uint64_t total,
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
     {
         uint32_t q[8];
         if (DIRECT) window_argmin8_raw<BLOCK>(sm_hash, tid, W, q);
-        else window_argmin8<BLOCK>(sm_hash, sm_off, tid, W, bmin, q);
+        else window_argmin8<BLOCK, W8>(sm_hash, sm_off, tid, W, bmin, q);
         if (plain) {  // every window below TW (a multiple of 8: whole lanes) is a window of the record
             const bool lane_in = a < TW;
 #pragma unroll
@@ -539,5 +541,19 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
         }
     }
 }
+
+// CALL(W8) for the value of (W - 8) % 8 at hand: what the launcher (stream8.hip) and the wave emulator (tests/emu) use to pick the instantiation of the
+// wide-window variant
+#define LPHQ_S8_SWITCH_W8(W, CALL) \
+    switch (((W) - 8u) & 7u) {     \
+        case 0: CALL(0); break;    \
+        case 1: CALL(1); break;    \
+        case 2: CALL(2); break;    \
+        case 3: CALL(3); break;    \
+        case 4: CALL(4); break;    \
+        case 5: CALL(5); break;    \
+        case 6: CALL(6); break;    \
+        default: CALL(7); break;   \
+    }
 
 }  // namespace lphq

@@ -58,13 +58,18 @@ extern "C" int emu_kernel_query_records(const uint8_t* img, size_t nbytes, const
         const bool s8_256 = s8 && (block & 0xFFFF) == 256 && (block & 0x40000);  /* forced eight-per-lane with 256 threads: 2048 positions per tile */
         const uint64_t tw = stream_tile_windows(H.W, s8 ? (s8_256 ? 8 * 256 : 8 * kS8Block) : 4 * (block & 0xFFFF));
         const unsigned tiles = (unsigned)((span + tw - 1) / tw);
+#define EMU_S8_W8(W8V) emu::launch(tiles, kS8Block, [&] { k_query_tiles_stream8<KIND_, K128_, 6, kS8Block, false, W8V>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0); });
 #define CALL(KIND, K128, P)                                                                                                                             \
     do {                                                                                                                                                \
+        constexpr int KIND_ = KIND;                                                                                                                     \
+        constexpr bool K128_ = K128;                                                                                                                    \
         const bool blk = (block & 0x10000) ? true : ((block & 0x20000) ? false : H.W >= kBlockMinW); /* forced either way, or as the launcher chooses */ \
         const int bs = block & 0xFFFF;                                                                                                                    \
         if (s8) {                                                                                                                                         \
             if (s8_256) emu::launch(tiles, 256, [&] { k_query_tiles_stream8<KIND, K128, P, 256>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0); }); \
-            else emu::launch(tiles, kS8Block, [&] { k_query_tiles_stream8<KIND, K128, P>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0); });    \
+            else if (P == 6 && H.W >= 16) { /* the wide-window variant as the launcher picks it: one instantiation per (W - 8) % 8 */                          \
+                LPHQ_S8_SWITCH_W8(H.W, EMU_S8_W8)                                                                                                                \
+            } else emu::launch(tiles, kS8Block, [&] { k_query_tiles_stream8<KIND, K128, P>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0); });  \
         } else if (H.W >= 4 && blk) {                                                                                                                            \
             if (bs == 128) emu::launch(tiles, 128, [&] { k_query_tiles_stream<KIND, K128, P, 128, true>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0); }); \
             else emu::launch(tiles, 256, [&] { k_query_tiles_stream<KIND, K128, P, 256, true>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0); });            \
@@ -73,6 +78,7 @@ extern "C" int emu_kernel_query_records(const uint8_t* img, size_t nbytes, const
     } while (0)
         EMU_DISPATCH(CALL);
 #undef CALL
+#undef EMU_S8_W8
     } else {
         const unsigned tiles = (unsigned)((span + kTileW - 1) / kTileW);
 #define CALL(KIND, K128, P) emu::launch(tiles, kBlock, [&] { k_query_tiles_random<KIND, K128, P>(img, seq_al, shift, total, seq_off, out_off, n_records, out, 0); })

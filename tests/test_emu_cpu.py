@@ -128,7 +128,8 @@ def emu_records(lib, h, recs, k, streaming, misalign=0, block=256):
 
 @pytest.mark.parametrize("k,m,bits,kind", [(31, 20, 64, 0), (63, 20, 128, 0), (31, 20, 64, 1), (21, 8, 64, 0), (47, 17, 128, 1), (31, 31, 64, 0), (15, 9, 64, 0), (9, 7, 64, 0),
                                            (63, 32, 128, 0), (33, 5, 128, 0), (15, 8, 64, 0),  # (15, 8): W = 8, > 200 leaders per tile: the eight-per-lane kernel's further queue rounds
-                                           (35, 20, 128, 0), (31, 15, 64, 0)])  # W = 16, 17: the block-form variant (P == 6) with ~120 leaders for its queue of 128 -- slot-by-slot path
+                                           (35, 20, 128, 0), (31, 15, 64, 0),  # W = 16, 17: the block-form variant (P == 6) with ~120 leaders for its queue of 128 -- slot-by-slot path
+                                           (37, 20, 128, 0), (38, 20, 128, 1), (41, 20, 128, 0)])  # W = 18, 19, 22: with the cases above every (W - 8) % 8 instantiation of the wide variant
 def test_tile_kernels_on_the_emulator(emuk, tmp_path, k, m, bits, kind):
     """k_query_tiles_stream / k_query_tiles_random over ragged multi-record batches: members, non-members, records shorter than
     k, empty records, tile-straddling records, every pointer alignment class, both workgroup sizes."""

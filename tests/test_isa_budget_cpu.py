@@ -50,6 +50,8 @@ def resource_usage(src, asm_path=None):
     if key in _CACHE:
         return _CACHE[key]
     out_args = ["--cuda-device-only", "-S", "-o", asm_path] if asm_path else ["-c", "-o", os.devnull]
+    if src == "stream8.hip":
+        out_args = ["-DLPHQ_S8_KIND=0"] + out_args  # (the partitioned half; the unpartitioned one is the same kernels with a smaller lookup)
     r = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I.", "-Rpass-analysis=kernel-resource-usage", src] + out_args,
                        cwd=CSRC, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -75,6 +77,14 @@ def kernels_asm(tmp_path_factory):
     return usage, open(path).read()
 
 
+@pytest.fixture(scope="module")
+def stream8_asm(tmp_path_factory):
+    """... and of stream8.hip (the eight-per-lane streaming kernel's translation unit)."""
+    path = str(tmp_path_factory.mktemp("isa8") / "stream8.s")
+    usage = resource_usage("stream8.hip", path)
+    return usage, open(path).read()
+
+
 def _kernel_body(asm, mangled_fragment):
     """text of the first kernel whose symbol contains the fragment"""
     m = re.search(r"^(_Z\S*" + re.escape(mangled_fragment) + r"\S*):", asm, re.M)
@@ -84,11 +94,12 @@ def _kernel_body(asm, mangled_fragment):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-def test_stream8_variants_fit_their_occupancy_targets(kernels_asm):
+def test_stream8_variants_fit_their_occupancy_targets(stream8_asm):
     """The eight-positions-per-lane streaming kernel: every instantiation -- wide windows (P == 6: C4's W = 44) and narrow ones (P == 4: C3's W = 12) --
     within 64 VGPRs and 10240 B of LDS, i.e. 16 workgroups of two waves per CU (the hardware's 32-wave cap), and without a byte of scratch; its leader
-    numbering is the DPP scan of gfx950/wave_scan.cuh and its plain-tile leader mask the v_cmp + v_addc pair of gfx950/shift_in.cuh."""
-    usage, asm = kernels_asm
+    numbering is the DPP scan of gfx950/wave_scan.cuh and its plain-tile leader mask the v_cmp + v_addc pair of gfx950/shift_in.cuh; the wide variant exists
+    once per (W - 8) % 8 and, with that remainder a compile-time constant, carries fewer scalar branches than the narrow one."""
+    usage, asm = stream8_asm
     seen = 0
     for name, u in usage.items():
         if "k_query_tiles_stream8" not in name:
@@ -96,8 +107,8 @@ def test_stream8_variants_fit_their_occupancy_targets(kernels_asm):
         seen += 1
         assert u["VGPRs"] <= 64 and u.get("LDS Size", 0) <= 10240 and u.get("ScratchSize", 0) == 0 and u.get("VGPRs Spill", 0) == 0, (name, u)
         assert u.get("Occupancy", 8) == 8, (name, u)
-    assert seen >= 8
-    for frag in ("k_query_tiles_stream8ILi0ELb1ELi6ELi128ELb0E", "k_query_tiles_stream8ILi0ELb0ELi4ELi128ELb1E"):
+    assert seen == 2 * (8 + 1)  # 64- and 128-bit k-mers x (eight wide-window instantiations, one per (W - 8) % 8, + the narrow-window one)
+    for frag in ("k_query_tiles_stream8ILi0ELb1ELi6ELi128ELb0ELi4E", "k_query_tiles_stream8ILi0ELb0ELi4ELi128ELb1ELin1E"):
         body = _kernel_body(asm, frag)
         for ctrl in ("row_shr:1", "row_shr:2", "row_shr:4", "row_shr:8", "row_bcast:15", "row_bcast:31"):
             assert ctrl in body, (frag, ctrl)
@@ -116,7 +127,7 @@ def test_minimizer_scan_uses_the_exec_masked_take_min(kernels_asm):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-@pytest.mark.parametrize("src", ["kernels.hip", "search.hip", "extract.hip"])
+@pytest.mark.parametrize("src", ["kernels.hip", "stream8.hip", "search.hip", "extract.hip"])
 def test_kernels_fit_their_register_and_lds_budget(src):
     usage = resource_usage(src)
     assert usage, "no kernel-resource-usage remarks in the compiler output"
@@ -134,7 +145,7 @@ def test_kernels_fit_their_register_and_lds_budget(src):
         assert u.get("SGPRs Spill", 0) <= SGPR_SPILLS.get(key, 0), (name, u)
         assert u["VGPRs"] + u.get("AGPRs", 0) <= vg, (name, u)
         assert u.get("LDS Size", 0) <= lds, (name, u)
-    where = {"k_search": "search.hip", "k_claim": "search.hip", "k_validate": "search.hip", "k_commit": "search.hip", "k_advance": "search.hip",
+    where = {"k_query_tiles_stream8": "stream8.hip", "k_search": "search.hip", "k_claim": "search.hip", "k_validate": "search.hip", "k_commit": "search.hip", "k_advance": "search.hip",
              "k_extract_runs": "extract.hip", "k_assemble_runs": "extract.hip", "k_group_flags": "extract.hip", "k_group_scatter": "extract.hip"}
     expected = {k for k in BUDGET if where.get(k, "kernels.hip") == src}
     assert seen == expected, (seen, expected)
