@@ -37,12 +37,15 @@ with open("/tmp/reads150.fq", "wb") as f:  # 2 M reads of 150 bp sampled from th
         if len(chunks) == 100000:
             f.write(b"".join(chunks)); chunks = []
     f.write(b"".join(chunks))
+import itertools
+with gzip.open("/tmp/reads150_500k.fq.gz", "wb", compresslevel=6) as f, open("/tmp/reads150.fq", "rb") as g:
+    f.writelines(itertools.islice(g, 4 * 500_000))  # what a user's input usually is: reads as ONE gzip member (0.5 M reads of 150 bp, ~160 MB of text)
 idx = "/tmp/c2_cli.lph"
 t = time.time(); L.build(recs, 31, 20, idx, kmer_bits=64, threads=64, device=0); print("index built in %.1f s" % (time.time() - t))
 with gzip.open("/tmp/c2_1000.fa.gz", "wb", compresslevel=6) as f:  # the whole index set as one gzip member (100 MB of text)
     for i, r in enumerate(recs):
         f.write(b">s%d\n" % i); f.write(r); f.write(b"\n")
-for q in ("/tmp/c2.fa", "/tmp/reads150.fq", "/tmp/c2_300.fa.gz", "/tmp/c2_1000.fa.gz", "/tmp/c2_300.bgzf.fa.gz"):
+for q in ("/tmp/c2.fa", "/tmp/reads150.fq", "/tmp/c2_300.fa.gz", "/tmp/c2_1000.fa.gz", "/tmp/reads150_500k.fq.gz", "/tmp/c2_300.bgzf.fa.gz"):
     for extra in ([], ["--threads", "8"], ["--threads", "32"], ["--pageable"], ["--batch-mb", "8"], ["--batch-mb", "128"]):
         t = time.time()
         r = subprocess.run(["lphash_amd/lphash", "query-p", "-i", idx, "-q", q, "--kmer-bits", "64"] + extra, capture_output=True, text=True)
