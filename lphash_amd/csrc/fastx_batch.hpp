@@ -347,7 +347,6 @@ private:
     // written into the window by the decoder's threads; false = the stream is damaged (or a CRC-32 / length is wrong).
     bool gz_window(size_t from, size_t upto) {
         if (from > wend_) from = wend_;
-        bool moved = false;
         while (wend_ < upto && !gz_done_) {
             const size_t n = pgz_->next_len();
             if (n == 0) {
@@ -357,12 +356,10 @@ private:
             if ((wend_ - wbase_) + n + kWindowSlack > wcap_) {  // the buffer is about to move: the pieces on their way into it first
                 if (!pgz_->flush()) return false;
                 if (!window_room(from, n)) return false;
-                moved = true;
             }
             pgz_->emit((uint8_t*)wbuf_ + (wend_ - wbase_));
             wend_ += n;
         }
-        (void)moved;
         if (!pgz_->flush() || pgz_->error()) return false;
         if (gz_done_) size_ = wend_;
         lim_ = wend_;
