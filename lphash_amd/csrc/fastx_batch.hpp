@@ -41,7 +41,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -539,7 +541,11 @@ private:
         pc.n = (size_t)(out - pc.out);
     }
 
+    // (LPHQ_READER_TRACE: where a batch's time goes, on stderr)
+    static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     bool next_parallel(FastxBatch& b, size_t batch_bases) {
+        static const bool trace = getenv("LPHQ_READER_TRACE") != nullptr;
+        const double t_in = trace ? now_ms() : 0;
         const size_t want = std::max<size_t>(batch_bases, 1);
         size_t end;
         if (!windowed_) {
@@ -560,6 +566,7 @@ private:
                 if (end < lim_ || lim_ == size_) break;
             }
         }
+        const double t_text = trace ? now_ms() : 0;
         // sized for a full batch from the start, so that a short first batch does not cause a second cold allocation
         if (!reserve(std::max(end - off_, std::min(want, size_ - off_)))) return true;
         char* const arena = arenas_[which_].p;
@@ -580,7 +587,11 @@ private:
             pieces.push_back(std::move(pc));
             from = to;
         }
+        const double t_cut = trace ? now_ms() : 0;
         pool().run(pieces.size(), [&](size_t i) { parse_piece(pieces[i]); });
+        if (trace)
+            fprintf(stderr, "[reader] batch of %zu bytes of text: text ready after %.2f ms, cut into %zu pieces after %.2f, parsed after %.2f\n", end - off_, t_text - t_in,
+                    pieces.size(), t_cut - t_in, now_ms() - t_in);
         for (const Piece& pc : pieces)
             if (pc.unsafe) return false;
         for (const Piece& pc : pieces) {
