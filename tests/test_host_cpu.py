@@ -732,6 +732,48 @@ def test_plain_gzip_input_is_decoded_by_all_threads(tmp_path):
     assert par.stdout.strip().split(",")[7] == "0"
 
 
+def test_plain_gzip_reader_fuzz_against_the_serial_reader(tmp_path):
+    """Random FASTA / FASTQ texts (line widths, CR LF, empty lines and records, a quality line in a FASTA, no final newline, two members) as .gz through
+    the span-parallel decoder + parse-while-decoding reader with random thread counts, span sizes, batch sizes and piece sizes: the records are the serial
+    reader's every time (the serial reader is the one pinned to kseq.h)."""
+    import gzip
+    import random
+
+    exe = os.path.join(ROOT, "lphash_amd", "lphash")
+    rng = random.Random(20261002)
+    gz = tmp_path / "t.gz"
+    for it in range(30):
+        kind = rng.choice(["fasta", "fasta", "fastq", "crlf", "weird"])
+        big = rng.random() < 0.3
+        out = []
+        for i in range(rng.randint(1, 300)):
+            ln = rng.randint(0, 60000 if big else 3000)
+            seq = "".join(rng.choice("ACGT") for _ in range(ln))
+            if kind == "fastq":
+                out.append("@r%d x\n%s\n+\n%s\n" % (i, seq, "I" * ln))
+            else:
+                w = rng.choice([60, 70, 80, 100, 100000])
+                nl = "\r\n" if kind == "crlf" else "\n"
+                out.append(">r%d some comment%s%s%s" % (i, nl, nl.join(seq[j:j + w] for j in range(0, ln, w)), nl if (ln > 0 or rng.random() < 0.5) else ""))
+                if kind == "weird" and rng.random() < 0.1:
+                    out.append("\n\n")
+                if kind == "weird" and rng.random() < 0.03:
+                    out.append(">q\nACGT\n+\nIIII\n")
+        text = "".join(out).encode()
+        if rng.random() < 0.2:
+            text = text.rstrip(b"\n")
+        if rng.random() < 0.2 and len(text) > 1000:
+            gz.write_bytes(gzip.compress(text[: len(text) // 2], 6) + gzip.compress(text[len(text) // 2:], 6))
+        else:
+            gz.write_bytes(gzip.compress(text, rng.choice([1, 6, 9])))
+        ser = subprocess.run([exe, "records", "-i", str(gz), "--serial"], capture_output=True, text=True).stdout.strip().split(",")[:3]
+        for threads, span, batch in ((4, rng.choice([3000, 20000, 100000]), rng.choice([5000, 100000, 2000000, 1 << 29])), (7, 0, rng.choice([30000, 1 << 29]))):
+            env = dict(os.environ, LPHQ_GZ_SPAN=str(span)) if span else dict(os.environ)
+            r = subprocess.run([exe, "records", "-i", str(gz), "-t", str(threads), "--batch-bytes", str(batch), "--min-piece", str(rng.choice([1, 1000, 65536]))],
+                               capture_output=True, text=True, env=env)
+            assert r.returncode == 0 and r.stdout.strip().split(",")[:3] == ser, (it, kind, len(text), threads, span, batch, ser, r.stdout, r.stderr[-500:])
+
+
 def test_bgzf_window_is_bounded_by_the_batch_size(tmp_path):
     """The inflated text of a BGZF file is held in a window of a few batches, not whole (a bgzip'd FASTQ of hundreds of GB must not need its
     uncompressed size in RAM): 24 MB of text read in 1-MB batches keeps < 6 MB inflated at once, a record larger than the batch grows the window to
