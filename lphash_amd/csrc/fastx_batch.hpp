@@ -541,78 +541,12 @@ private:
         pc.n = (size_t)(out - pc.out);
     }
 
-    // Last position in (from, lim] where a piece may end while only the text below lim is in place: a line start (FASTA: any will do), or the start of a
-    // four-line FASTQ record whose '+' line lies below lim as well; `from` if there is none.  (lim_ == lim on entry: the searches stop there.)
-    size_t early_cut(size_t from, size_t lim) const {
-        if (!fastq_) {
-            const char* q = (const char*)memrchr(map_ + from, '\n', lim - from);
-            return q ? (size_t)(q - map_) + 1 : from;
-        }
-        const size_t back = lim - from > 8192 ? lim - 8192 : from;  // a record start a few reads before the end of what is there
-        const size_t r = next_fastq_record(back);
-        return r < lim && r > from ? r : from;
-    }
-
     // (LPHQ_READER_TRACE: where a batch's time goes, on stderr)
     static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     bool next_parallel(FastxBatch& b, size_t batch_bases) {
         static const bool trace = getenv("LPHQ_READER_TRACE") != nullptr;
         const double t_in = trace ? now_ms() : 0;
         const size_t want = std::max<size_t>(batch_bases, 1);
-        // A plain .gz is decoded while it is read and the decoder is the slowest stage: instead of waiting in next_len() for the next piece of text and
-        // parsing everything afterwards, this thread parses what has already LANDED in the window (up to the last line / record start below the batch's
-        // target size) between two pieces.  What is left for the threads of the pool at the end is the tail behind the last landed cut.
-        std::vector<Piece> early;
-        size_t parsed = off_;
-        if (pgz_ && windowed_ && !gz_done_ && want <= ((size_t)1 << 30)) {  // (a caller that asks for everything at once: the length is not known before the end)
-            if (!reserve(std::min(want, size_ - off_))) return true;
-            char* const arena0 = arenas_[which_].p;
-            const size_t target = want >= size_ - off_ ? size_ : off_ + want;
-            std::vector<size_t> ends;  // text offset behind every piece handed to the decoder's pool since its last flush
-            size_t landed = wend_;     // (what the window holds on entry is in place: gz_window left it flushed)
-            for (;;) {
-                const size_t lim = std::min(landed, target);
-                if (lim > parsed && lim - parsed >= std::min<size_t>(min_piece_, (size_t)1 << 18)) {
-                    lim_ = lim;
-                    const size_t cut = early_cut(parsed, lim);
-                    if (cut > parsed) {
-                        Piece pc;
-                        pc.begin = parsed;
-                        pc.end = cut;
-                        pc.out = arena0 + (parsed - off_);
-                        parse_piece(pc);
-                        if (pc.unsafe) {
-                            (void)pgz_->flush();
-                            return false;
-                        }
-                        early.push_back(std::move(pc));
-                        parsed = cut;
-                    }
-                }
-                if (wend_ >= target + ((size_t)1 << 16)) break;
-                const size_t n = pgz_->next_len();  // (blocks until the next piece is decoded)
-                if (n == 0) {
-                    gz_done_ = true;
-                    break;
-                }
-                if ((wend_ - wbase_) + n + kWindowSlack > wcap_) {  // the buffer is about to move: the pieces on their way into it first
-                    if (!pgz_->flush()) return false;
-                    ends.clear();
-                    landed = wend_;
-                    if (!window_room(off_, n)) return false;
-                    map_ = (const char*)((uintptr_t)wbuf_ - (uintptr_t)wbase_);
-                }
-                pgz_->emit((uint8_t*)wbuf_ + (wend_ - wbase_));
-                wend_ += n;
-                ends.push_back(wend_);
-                map_ = (const char*)((uintptr_t)wbuf_ - (uintptr_t)wbase_);
-                const size_t done = pgz_->emits_completed();
-                if (done) landed = ends[done - 1];
-            }
-            if (!pgz_->flush() || pgz_->error()) return false;
-            if (gz_done_) size_ = wend_;
-            lim_ = wend_;
-        }
         size_t end;
         if (!windowed_) {
             end = want >= size_ - off_ ? size_ : next_record_start(off_ + want);
@@ -634,22 +568,17 @@ private:
         }
         const double t_text = trace ? now_ms() : 0;
         // sized for a full batch from the start, so that a short first batch does not cause a second cold allocation
-        {
-            const char* const before = arenas_[which_].p;
-            if (!reserve(std::max(end - off_, std::min(want, size_ - off_)), parsed - off_)) return true;
-            if (arenas_[which_].p != before)  // (a record that runs far beyond the target: the arena grew and took the early pieces' bases along)
-                for (Piece& pc : early) pc.out = arenas_[which_].p + (pc.begin - off_);
-        }
+        if (!reserve(std::max(end - off_, std::min(want, size_ - off_)))) return true;
         char* const arena = arenas_[which_].p;
         // cut [off_, end) into pieces at line starts
         // (text that is still being decoded by a pool of its own: pieces of >= 1 MB -- the decoder's threads hold the cores, and waking sixteen parse
         // threads for a 4-MB batch cost more than the parsing; the tests' tiny min_piece_ still cuts finely)
         const size_t piece = (pgz_ && windowed_ && !gz_done_) ? std::max<size_t>(min_piece_ < (1 << 16) ? min_piece_ : (size_t)1 << 20, 1) : min_piece_;
-        const int T = (int)std::min<size_t>((size_t)threads_, std::max<size_t>(1, (end - parsed) / piece));
+        const int T = (int)std::min<size_t>((size_t)threads_, std::max<size_t>(1, (end - off_) / piece));
         std::vector<Piece> pieces;
-        size_t from = parsed;
+        size_t from = off_;
         for (int t = 1; t <= T && from < end; ++t) {
-            size_t to = t == T ? end : (fastq_ ? std::min(end, next_fastq_record(parsed + (end - parsed) / T * t)) : next_line_start(parsed + (end - parsed) / T * t, end));
+            size_t to = t == T ? end : (fastq_ ? std::min(end, next_fastq_record(off_ + (end - off_) / T * t)) : next_line_start(off_ + (end - off_) / T * t, end));
             if (to <= from) continue;
             Piece pc;
             pc.begin = from;
@@ -661,12 +590,11 @@ private:
         const double t_cut = trace ? now_ms() : 0;
         pool().run(pieces.size(), [&](size_t i) { parse_piece(pieces[i]); });
         if (trace)
-            fprintf(stderr, "[reader] batch of %zu bytes of text: text ready after %.2f ms (%zu bytes parsed meanwhile, in %zu pieces), rest cut into %zu pieces after %.2f, parsed after %.2f\n",
-                    end - off_, t_text - t_in, parsed - off_, early.size(), pieces.size(), t_cut - t_in, now_ms() - t_in);
+            fprintf(stderr, "[reader] batch of %zu bytes of text: text ready after %.2f ms, cut into %zu pieces after %.2f, parsed after %.2f\n", end - off_, t_text - t_in,
+                    pieces.size(), t_cut - t_in, now_ms() - t_in);
         for (const Piece& pc : pieces)
             if (pc.unsafe) return false;
-        for (Piece& pc : pieces) early.push_back(std::move(pc));
-        for (const Piece& pc : early) {
+        for (const Piece& pc : pieces) {
             if (pc.n) b.segs.push_back({pc.out, pc.n});
             if (pc.head) {
                 if (b.lens.empty()) return false;  // cannot happen: the batch begins with a header (defensive)

@@ -136,7 +136,7 @@ public:
     void emit(uint8_t* dst) {
         if (!have_piece_) return;
         have_piece_ = false;
-        records_.push_back(Record{0, piece_.nsym + piece_.ntext, piece_.ends_member, piece_.want_crc, piece_.want_isize, true, false});
+        records_.push_back(Record{0, piece_.nsym + piece_.ntext, piece_.ends_member, piece_.want_crc, piece_.want_isize});
         EmitTask t;
         t.p = piece_;
         t.dst = dst;
@@ -167,18 +167,6 @@ public:
         return !error_;
     }
     bool error() const { return error_; }
-    // How many of the emit() calls since the last flush() have completed, counted from the first: the text of those pieces is in place (a caller that
-    // parses the text while the rest is being decoded asks this instead of waiting in flush()).
-    size_t emits_completed() {
-        std::lock_guard<std::mutex> g(mu_);
-        size_t n = 0;
-        for (const Record& r : records_) {
-            if (!r.from_emit) continue;
-            if (!r.done) break;
-            ++n;
-        }
-        return n;
-    }
     // (tests, diagnostics) pieces taken from the pool / decoded by the caller's thread
     uint64_t pieces_parallel() const { return n_accepted_; }
     uint64_t pieces_serial() const { return n_fallback_; }
@@ -225,7 +213,6 @@ private:
         size_t len;
         bool ends_member;
         uint32_t want_crc, want_isize;
-        bool from_emit = false, done = false;  // (emits_completed)
     };
     struct EmitTask {
         Piece p;
@@ -329,7 +316,6 @@ private:
                 g.lock();
                 if (task.p.slot) task.p.slot->state = kFree;
                 if (task.p.fb) task.p.fb->busy = false;
-                task.rec->done = true;
                 --emits_pending_;
                 g.unlock();
                 cv_.notify_all();
