@@ -200,10 +200,10 @@ int default_parse_threads() { return std::min(16, lphq::usable_cpus()); }
 // include/lphq.h: lphq_attach_devices); per GPU: copy in (async, from the pinned parse arena), kernel, count, all on that GPU's
 // stream.  The host only waits when it needs a slot or an arena back, so parsing of batch i+1, the copies of batch i and the
 // kernels of batch i-1 overlap.
-bool query_pass(lphq_index* idx, const lphq_info& info, const std::string& path, int streaming, size_t batch_bases, int threads, bool pinned,
+bool query_pass(lphq_index* idx, const lphq_info& info, const std::string& path, int streaming, size_t batch_bases, int threads, int gz_threads, bool pinned,
                 std::vector<GpuWorker>& gpus, uint64_t& total_kmers, uint64_t& elapsed_us, std::string& err, FILE* sink) {
     g_arenas.pinned = pinned;
-    lphq::FastxBatchReader rd(path.c_str(), threads, &arena_alloc, &arena_free);
+    lphq::FastxBatchReader rd(path.c_str(), threads, &arena_alloc, &arena_free, 1 << 16, gz_threads);
     if (!rd.ok()) return false;
     rd.prealloc(batch_bases);  // set-up, like the reference's gzopen + kseq_init before t.start() (src/query.cpp:43-48)
     if (!rd.ok()) {
@@ -581,6 +581,7 @@ int query_main(int kind, int argc, char** argv) {
     // 32 MB batches: the parse arenas stay small and warm, and parsing overlaps the device side (see query_pass)
     const size_t batch_bases = (size_t)(a.get("--batch-mb") ? std::max(1l, std::atol(a.get("--batch-mb")->c_str())) : 32) << 20;
     const int threads = a.get("--threads") ? std::max(1, std::atoi(a.get("--threads")->c_str())) : default_parse_threads();
+    const int gz_threads = a.get("--threads") ? threads : lphq::usable_cpus();  // (the .gz decoder scales further than the parser: fastx_batch.hpp)
     const bool pinned = !a.has("--pageable");  // parse arenas in pinned host memory (default): copies to the devices are asynchronous
     // --gpus N: replicas on devices 0..N-1, every batch sharded over them; --device D: that one device
     std::vector<int> devices;
@@ -623,7 +624,7 @@ int query_main(int kind, int argc, char** argv) {
         return 2;
     }
     for (int pass = 0; pass < 2; ++pass) {
-        bool opened = query_pass(idx, info, query_filename, pass == 0, batch_bases, threads, pinned, gpus, pass == 0 ? total_on : total_off,
+        bool opened = query_pass(idx, info, query_filename, pass == 0, batch_bases, threads, gz_threads, pinned, gpus, pass == 0 ? total_on : total_off,
                                  pass == 0 ? t_on : t_off, err, pass == 0 ? sink : nullptr);
         if (!opened) {
             std::cerr << "Unable to open the input file " << query_filename << "\n";
@@ -1062,6 +1063,7 @@ int ptbb_query_main(int argc, char** argv) {
     if (!device_list(a, device, devices)) return 1;
     const size_t batch_bases = (size_t)(a.get("--batch-mb") ? std::max(1l, std::atol(a.get("--batch-mb")->c_str())) : 32) << 20;
     const int threads = a.get("--threads") ? std::max(1, std::atoi(a.get("--threads")->c_str())) : default_parse_threads();
+    const int gz_threads = a.get("--threads") ? threads : lphq::usable_cpus();  // (the .gz decoder scales further than the parser: fastx_batch.hpp)
     // one timed pass per function given (ptbb_query.cpp:40-72), each ",<file>,<ns per k-mer>", else ",,"
     for (const char* flag : {"-p", "-b"}) {
         if (!a.get(flag)) {
@@ -1096,7 +1098,7 @@ int ptbb_query_main(int argc, char** argv) {
         }
         uint64_t total = 0, us = 0;
         std::string err;
-        const bool opened = query_pass(idx, info, input, 1, batch_bases, threads, !a.has("--pageable"), gpus, total, us, err, nullptr);
+        const bool opened = query_pass(idx, info, input, 1, batch_bases, threads, gz_threads, !a.has("--pageable"), gpus, total, us, err, nullptr);
         for (GpuWorker& g : gpus) g.destroy();
         lphq_close(idx);
         if (!opened) {

@@ -27,8 +27,8 @@ def run(env, extra=()):
     r = subprocess.run(["lphash_amd/lphash", "query-p", "-i", idx, "-q", "/tmp/c2_300.fa.gz", "--kmer-bits", "64", *extra], capture_output=True, text=True, env=dict(os.environ, **env))
     b = throttled()
     return r.stdout.strip().split(",")[2:] + [f"throttled +{b[0] - a[0]} periods, +{(b[1] - a[1]) / 1000:.1f} ms"], r.stderr
-for rep in range(8):
-    print("default", run({})[0][1:3], "| HSA_ENABLE_INTERRUPT=0", run({"HSA_ENABLE_INTERRUPT": "0"})[0][1:3], "| 32 threads", run({}, ["--threads", "32"])[0][1:3], "| serial", run({"LPHQ_GZ_SERIAL": "1"})[0][1:3])
+for rep in range(10):
+    print("default (decoder: usable cpus, parser: 16)", run({})[0][1:3], "| --threads 16", run({}, ["--threads", "16"])[0][1:3], "| --threads 32", run({}, ["--threads", "32"])[0][1:3], "| HSA_ENABLE_INTERRUPT=0", run({"HSA_ENABLE_INTERRUPT": "0"})[0][1:3])
 for rep in range(2):
     out, err = run({"LPHQ_CLI_TRACE": "1", "LPHQ_READER_TRACE": "1"})
     print(out); print("\n".join(l for l in err.splitlines() if l.startswith(("[cli]", "[reader]"))))
