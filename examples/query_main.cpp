@@ -35,7 +35,8 @@ namespace lphash {
 // the binding copies a batch to the device while the previous one is being looked up and the one before is being consumed here.
 template <typename MPHF>
 bool batched_pass(MPHF& hf, const std::string& query_filename, bool streaming, FILE* dump, uint64_t& total, long long& micros) {
-    lphq::FastxBatchReader reader(query_filename.c_str(), lphq::usable_cpus() < 16 ? lphq::usable_cpus() : 16, &lphq_host_alloc, &lphq_host_free);
+    lphq::FastxBatchReader reader(query_filename.c_str(), lphq::usable_cpus() < 16 ? lphq::usable_cpus() : 16, &lphq_host_alloc, &lphq_host_free, 1 << 16,
+                                  lphq::usable_cpus());  // (parser: at most 16 threads; .gz decoder: every usable CPU -- fastx_batch.hpp)
     if (!reader.ok()) return false;
     const size_t batch_bases = (size_t)16 << 20;
     reader.prealloc(batch_bases);  // (set-up, like gzopen + kseq_init before t.start(), src/query.cpp:43-48)
