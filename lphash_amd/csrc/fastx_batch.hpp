@@ -118,6 +118,7 @@ public:
         delete serial_;
         delete pgz_;
         delete pool_;
+        delete inflate_pool_;
         if (bgzf_) munmap((void*)bgzf_, bgzf_size_);
         if (wbuf_) {
             free(wbuf_);
@@ -140,6 +141,7 @@ public:
             (void)reserve(want);
         }
         if (!pool_ && threads_ > 1 && !serial_) pool_ = new WorkPool(threads_);  // the parse threads, parked
+        if (bgzf_ && !serial_) (void)inflate_pool();
         if (pgz_ && !wbuf_) {  // the decoder's buffers and threads, and a window of one batch and a few pieces: allocated and touched here, nothing decoded
             pgz_->prealloc();
             const size_t cap = want + 16 * pgz_->span() + kWindowSlack;
@@ -281,7 +283,7 @@ private:
         const unsigned char* f = bgzf_;
         char* const base = wbuf_;
         const size_t wbase = wbase_, b0 = blk_next_, nb = b_end - blk_next_;
-        const int T = (int)std::min<size_t>((size_t)threads_, nb);
+        const int T = (int)std::min<size_t>((size_t)gz_threads_, nb);  // (inflating is compute-bound like the span decoder: the larger of the two thread counts)
         std::vector<int> bad((size_t)T, 0);
         auto work = [&](int t) {
             // every block through the own decoder (fast_inflate.hpp) into a private buffer -- the decoder writes a few bytes past what it has
@@ -302,7 +304,7 @@ private:
             }
             delete dec;
         };
-        pool().run((size_t)T, [&](size_t t) { work((int)t); });
+        inflate_pool().run((size_t)T, [&](size_t t) { work((int)t); });
         for (int x : bad)
             if (x) return false;
         blk_next_ = b_end;
@@ -652,6 +654,12 @@ private:
     WorkPool& pool() {
         if (!pool_) pool_ = new WorkPool(threads_);
         return *pool_;
+    }
+    WorkPool* inflate_pool_ = nullptr;     // BGZF blocks: gz_threads_ threads when that is more than the parser's
+    WorkPool& inflate_pool() {
+        if (gz_threads_ <= threads_) return pool();
+        if (!inflate_pool_) inflate_pool_ = new WorkPool(gz_threads_);
+        return *inflate_pool_;
     }
     ParallelGzReader* pgz_ = nullptr;      // a .gz that is not BGZF, decoded by all threads into the same window
     bool gz_done_ = false;
