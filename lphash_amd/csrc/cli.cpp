@@ -5,8 +5,9 @@
 // Same flags, same CSV on stdout, same exit codes (1 usage/parse error, 2 cannot open the query file).
 // Extra flags (all optional, defaults keep the reference behaviour): --kmer-bits 64|128 (the reference's
 // compile-time kmer_t, default 128 like include/compile_constants.tpd:1; 64 reproduces a `uint64_t` build),
-// --device N or --gpus N (replicas on devices 0..N-1, every batch sharded over them), --batch-mb N, --threads N (FASTA parsing
-// threads of the query tools), --pageable (parse into ordinary instead of pinned host memory).  The work itself runs on the GPU through the C ABI (include/lphq.h).
+// --device N or --gpus N (replicas on devices 0..N-1, every batch sharded over them), --batch-mb N, --threads N (host threads of the
+// query tools for .gz / BGZF decoding and for FASTA / FASTQ parsing; default: 16 for parsing, every usable CPU for decoding), --pageable (parse into
+// ordinary instead of pinned host memory).  The work itself runs on the GPU through the C ABI (include/lphq.h).
 //   lphash records -i <fasta|fastq[.gz]> [-t N] [--serial] [--batch-bytes N] [--min-piece N]
 // is a diagnostic: it prints the record count, base count and a checksum of what the reader yields (tests compare the
 // multi-threaded reader with the serial one through it).
