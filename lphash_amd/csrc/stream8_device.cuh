@@ -37,15 +37,11 @@ constexpr uint32_t kS8Tail = 8u;
 template <int BLOCK>
 __device__ __forceinline__ uint32_t hslot8(uint32_t i) { return i; }
 
-struct BlockMin8 {   // a lane's suffix minima S[1..7] over a+j .. a+7 (S[0] is the block minimum, re-read from LDS), alive from phase B to phase C
-    uint64_t h[7];
-    uint32_t p;      // their positions within the block, 3 bits each: S[1] | S[2] << 3 | ...
-};
-
 // Publishes (column c of sm_hash) the prefix minima P[c] over a .. a+c -- P[7] is the minimum M of the block -- and, 3 bits each in one word,
-// which position each of them is (P[0] is position 0); returns the suffix minima.
+// which position each of them is (P[0] is position 0).  (The suffix minima a window needs of its own block are formed in phase C, in one chain with the
+// minimum of the blocks all eight windows share: window_argmin8.)
 template <int BLOCK>
-__device__ __forceinline__ BlockMin8 publish_block_minima8(uint64_t* __restrict__ sm_hash, uint32_t* __restrict__ sm_off, uint32_t tid, const uint64_t (&h)[8]) {
+__device__ __forceinline__ void publish_block_minima8(uint64_t* __restrict__ sm_hash, uint32_t* __restrict__ sm_off, uint32_t tid, const uint64_t (&h)[8]) {
     constexpr uint32_t kS8Row = s8_row<BLOCK>();
     HashPos p{h[0], 0};
     sm_hash[tid] = p.h;
@@ -57,20 +53,6 @@ __device__ __forceinline__ BlockMin8 publish_block_minima8(uint64_t* __restrict_
         ob |= p.p << (3u * c);
     }
     sm_off[tid] = ob;
-    BlockMin8 s;
-    uint64_t cur = h[7];
-    uint32_t cp = 7;
-    s.h[6] = cur;
-    s.p = cp << 18;
-#pragma unroll
-    for (int j = 6; j >= 1; --j) {
-        const bool le = h[j] <= cur;  // `<=`: scanning from the right, the left one wins ties
-        cur = le ? h[j] : cur;
-        cp = le ? (uint32_t)j : cp;
-        s.h[j - 1] = cur;
-        s.p |= cp << (3u * (uint32_t)(j - 1));
-    }
-    return s;
 }
 
 // Leftmost minimum of the 8 consecutive windows starting at local positions a .. a+7, each W >= 16 positions wide -> q[0..7] (local positions).
@@ -85,7 +67,7 @@ __device__ __forceinline__ BlockMin8 publish_block_minima8(uint64_t* __restrict_
 // compile time every per-window decision below is resolved by the compiler: no scalar branches, LDS offsets as immediates (measured with W fixed
 // altogether: -4.8 % VALU, -32 % SALU instructions, -2.5 % kernel time at C4, profiles/r04_stream8.txt).
 template <int BLOCK, int W8>
-__device__ __forceinline__ void window_argmin8(const uint64_t* __restrict__ sm_hash, const uint32_t* __restrict__ sm_off, uint32_t tid, uint32_t W, const BlockMin8& s,
+__device__ __forceinline__ void window_argmin8(const uint64_t* __restrict__ sm_hash, const uint32_t* __restrict__ sm_off, uint32_t tid, uint32_t W, const uint64_t (&h)[8],
                                                uint32_t (&q)[8]) {
     constexpr uint32_t kS8Row = s8_row<BLOCK>();
     const uint64_t* colM = sm_hash + 7u * kS8Row + tid;  // M of the block t lanes to the right: colM[t]
@@ -97,14 +79,19 @@ __device__ __forceinline__ void window_argmin8(const uint64_t* __restrict__ sm_h
     const uint32_t wA = sm_off[tid + nf0 + 1u], wB = sm_off[tid + nf0 + 2u];
     const uint32_t relA = (nf0 + 1u) << 3, relB = relA + 8u;  // (uniform)
     const HashPos mA{colM[nf0 + 1u], relA + ((wA >> 21) & 7u)};
-    const uint32_t ob0 = sm_off[tid];
     const uint32_t a = 8u * tid;
+    // Window a+j needs the leftmost minimum of its own positions j .. 7 AND of the common blocks: ONE chain from the right -- start at the common blocks'
+    // minimum, take position 7, 6, ... with `<=` (scanning leftwards, the left one wins ties) -- yields both for all eight windows in 8 compare-selects,
+    // where a suffix chain over the own block (6) plus one comparison with the common minimum per window (8) took 14 (round 4, last step).
+    HashPos cur = r;
 #pragma unroll
-    for (uint32_t j = 0; j < 8; ++j) {
-        HashPos w = j == 0 ? HashPos{colM[0], (ob0 >> 21) & 7u} : HashPos{s.h[j ? j - 1 : 0], (s.p >> (3u * (j ? j - 1u : 0u))) & 7u};
-        const bool second = j + w8 >= 8u;   // (uniform; a constant when W8 is) the window takes block l+nf0+1 whole and a prefix of block l+nf0+2
-        const uint32_t hc = (j + w8) & 7u;  // ... of that many positions
-        take_if_less(w, r.h, r.p);
+    for (int j = 7; j >= 0; --j) {
+        const bool le = h[j] <= cur.h;
+        cur.h = le ? h[j] : cur.h;
+        cur.p = le ? (uint32_t)j : cur.p;
+        HashPos w = cur;
+        const bool second = (uint32_t)j + w8 >= 8u;   // (uniform; a constant when W8 is) the window takes block l+nf0+1 whole and a prefix of block l+nf0+2
+        const uint32_t hc = ((uint32_t)j + w8) & 7u;  // ... of that many positions
         if (second) take_if_less(w, mA.h, mA.p);
         if (hc) {
             const uint32_t word = second ? wB : wA, rel = second ? relB : relA;
@@ -269,7 +256,7 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
 
     // ---- B: hashes of the m-mers starting at local positions 8*lane .. 8*lane+7; prefix minima of the block published for phase C ----
     const uint32_t a = 8u * tid;
-    BlockMin8 bmin;
+    uint64_t h[8];  // the lane's eight hashes: the wide-window variant uses them again in phase C (its own block's part of every window)
     {
         const uint64_t mm_seedx = murmur_seedx(H.mm_seed);
         const uint32_t w0 = a >> 4, o = (a & 15u) * 2u;  // o = 0 or 16
@@ -279,7 +266,6 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
         const uint64_t s1 = o ? (C64 << o) : C64;                                  // bits [64, 128): the top 14 are needed at most
         const uint32_t sh = 64u - 2u * m;
         const uint64_t mask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
-        uint64_t h[8];
         if (m <= 25u) {  // (uniform) the eight m-mers end inside the first 64 bits: one shift each
 #pragma unroll
             for (uint32_t r = 0; r < 8; ++r) h[r] = murmur8((s0 >> (sh - 2 * r)) & mask, mm_seedx);
@@ -291,11 +277,10 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
             }
         }
         if (DIRECT) {
-            bmin = BlockMin8{};
 #pragma unroll
             for (uint32_t r = 0; r < 8; ++r) sm_hash[r * kS8Row + tid] = h[r];
         } else {
-            bmin = publish_block_minima8<BLOCK>(sm_hash, sm_off, tid, h);
+            publish_block_minima8<BLOCK>(sm_hash, sm_off, tid, h);
         }
         // (blocks beyond the tile are read by windows the tile does not emit only: see s8_row)
     }
@@ -323,7 +308,7 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
     {
         uint32_t q[8];
         if (DIRECT) window_argmin8_raw<BLOCK>(sm_hash, tid, W, q);
-        else window_argmin8<BLOCK, W8>(sm_hash, sm_off, tid, W, bmin, q);
+        else window_argmin8<BLOCK, W8>(sm_hash, sm_off, tid, W, h, q);
         if (plain) {  // every window below TW (a multiple of 8: whole lanes) is a window of the record
             const bool lane_in = a < TW;
 #pragma unroll
