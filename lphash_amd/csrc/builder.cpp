@@ -323,25 +323,16 @@ void dict_encode(Dictionary& d, const uint64_t* v, uint64_t n) {  // pthash::dic
     cv_build(d.dict, dict);
 }
 
-// hashes[i] = hash.second() of key i (table position, duplicate check); firsts = hash.first() (bucket) for hash128 hashers,
-// nullptr for hash64 hashers, whose first() == second()
-bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed, double c, double alpha, int threads, int device, std::string& err,
-               const std::vector<uint64_t>* firsts = nullptr) {
+// Parameters of a single_phf over n keys (single_phf::build_in_internal_memory, skew_bucketer::init); false = too large for this builder.
+bool phf_setup(SinglePhf& f, uint64_t n, uint64_t seed, double c, double alpha, uint64_t& num_buckets, std::string& err) {
     f = SinglePhf();
     f.seed = seed;
-    const bool verbose = getenv("LPHQ_BUILD_VERBOSE") != nullptr;
-    auto tprev = std::chrono::steady_clock::now();
-    auto lap = [&](const char* what) {
-        auto now = std::chrono::steady_clock::now();
-        if (verbose) fprintf(stderr, "[lphq_build]   pthash: %-34s %8.3f s\n", what, std::chrono::duration<double>(now - tprev).count());
-        tprev = now;
-    };
-    const uint64_t n = hashes.size();
     f.num_keys = n;
+    num_buckets = 0;
     if (n == 0) return true;  // all-zero function; the reference never builds one
     uint64_t table_size = (uint64_t)((double)n / alpha);
     if ((table_size & (table_size - 1)) == 0) table_size += 1;
-    const uint64_t num_buckets = n < 2 ? 6 : (uint64_t)std::ceil((c * (double)n) / std::log2((double)n));
+    num_buckets = n < 2 ? 6 : (uint64_t)std::ceil((c * (double)n) / std::log2((double)n));
     f.table_size = table_size;
     f.M = compute_M_u64(table_size);
     f.num_dense = (uint64_t)(0.3 * (double)num_buckets);
@@ -352,6 +343,132 @@ bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed,
         err = "pthash build: more than 2^32-1 keys/buckets is not supported by this builder";
         return false;
     }
+    return true;
+}
+
+// First-fit pilot search, one bucket after the other in the order given: the first pilot whose table positions are free and distinct.
+// `taken` (bit p of word p/64, words_for(table_size) + 1 words) is carried from call to call, so that a search may come in pieces.
+// The CPU search is sequential: a speculative in-order-commit pool never beat one thread (1.05 us/key on 64 threads = sequential
+// speed), and a CPU port of the GPU's window/claim/commit scheme got slower with every thread added (profiles/r01_builder_stages.txt).
+// The parallel search is the GPU's (search.hip).
+struct CpuPilotSearch {
+    static constexpr uint64_t kCache = 1ull << 20;
+    // XOR displacement keeps the low bits of a hash: with a tiny table whose size has a power-of-two factor a bucket can
+    // be unplaceable for every pilot (PTHash itself would spin forever there); give up instead of hanging
+    static constexpr uint64_t kPilotCap = 1ull << 28;
+    std::vector<uint64_t> hp_cache;
+    uint64_t seed = 0;
+    void prepare(uint64_t seed_, int threads) {
+        if (!hp_cache.empty() && seed == seed_) return;
+        seed = seed_;
+        hp_cache.resize(kCache);
+        parallel_for(kCache >> 12, threads, [&](size_t t) {
+            for (uint64_t p = t << 12; p < (t + 1) << 12; ++p) hp_cache[p] = murmur64a_u64(p, seed);
+        });
+    }
+    bool run(const SinglePhf& f, const uint64_t* hs, const uint64_t* bstart, const uint32_t* order, uint64_t n_order, std::vector<uint64_t>& taken,
+             uint64_t* pilots_by_bucket, std::string& err) const {
+        const u128 M = f.M;
+        const uint64_t table_size = f.table_size;
+        std::vector<uint64_t> pos(16);
+        for (uint64_t oi = 0; oi < n_order; ++oi) {
+            const uint32_t b = order[oi];
+            const uint64_t* keys = hs + bstart[b];
+            const uint64_t s = bstart[b + 1] - bstart[b];
+            if (s == 0) continue;
+            if (pos.size() < s) pos.resize(s);
+            uint64_t pilot = 0;
+            for (;; ++pilot) {
+                if (pilot >= kPilotCap) {
+                    err = "pthash search: no pilot below 2^28 for some bucket (degenerate tiny key set: XOR displacement cannot separate keys that share "
+                          "their low bits when the table size has a power-of-two factor; the reference's PTHash does not terminate on it either)";
+                    return false;
+                }
+                const uint64_t hp = pilot < kCache ? hp_cache[pilot] : murmur64a_u64(pilot, seed);
+                uint64_t j = 0;
+                for (; j < s; ++j) {
+                    const uint64_t p = fastmod_u64(keys[j] ^ hp, M, table_size);
+                    if ((taken[p >> 6] >> (p & 63)) & 1) break;
+                    pos[j] = p;
+                }
+                if (j < s) continue;
+                bool d2 = false;
+                for (uint64_t a = 1; a < s && !d2; ++a)
+                    for (uint64_t q = 0; q < a; ++q)
+                        if (pos[a] == pos[q]) {
+                            d2 = true;
+                            break;
+                        }
+                if (!d2) break;
+            }
+            for (uint64_t j = 0; j < s; ++j) taken[pos[j] >> 6] |= 1ULL << (pos[j] & 63);
+            pilots_by_bucket[b] = pilot;
+        }
+        return true;
+    }
+};
+
+// What follows the search: dual<dictionary, dictionary>::encode of the pilots, and for a minimal function fill_free_slots + ef_sequence<false>.
+bool phf_finalize(SinglePhf& f, uint64_t num_buckets, const std::vector<uint64_t>& pilots, const std::vector<uint64_t>& taken_plain, std::string& err) {
+    const uint64_t n = f.num_keys, table_size = f.table_size;
+    auto is_taken = [&](uint64_t p) { return (taken_plain[p >> 6] >> (p & 63)) & 1; };
+    {  // the search must have placed every key exactly once: everything below relies on it (free-slot fill, minimality)
+        uint64_t ones = 0;
+        for (uint64_t p = 0; p < table_size; ++p) ones += is_taken(p);
+        if (ones != n) {
+            err = "pthash search: internal error (occupied slots != keys)";
+            return false;
+        }
+    }
+    // front = first 0.3 * num_buckets pilots
+    const uint64_t front_size = (uint64_t)((double)num_buckets * 0.3);
+    dict_encode(f.front, pilots.data(), front_size);
+    dict_encode(f.back, pilots.data() + front_size, num_buckets - front_size);
+    if (n < table_size) {
+        std::vector<uint64_t> fs;
+        fs.reserve(table_size - n);
+        uint64_t next_used_slot = n, last_free_slot = 0, last_valid_free_slot = 0;
+        for (;;) {
+            while (last_free_slot < n && is_taken(last_free_slot)) ++last_free_slot;
+            if (last_free_slot == n) break;
+            while (next_used_slot < table_size && !is_taken(next_used_slot)) {
+                fs.push_back(last_free_slot);
+                ++next_used_slot;
+            }
+            if (next_used_slot >= table_size) {  // cannot happen when exactly n slots are occupied (checked above)
+                err = "pthash: inconsistent slot bitmap";
+                return false;
+            }
+            fs.push_back(last_free_slot);
+            last_valid_free_slot = last_free_slot;
+            ++next_used_slot;
+            ++last_free_slot;
+        }
+        while (next_used_slot != table_size) {
+            fs.push_back(last_valid_free_slot);
+            ++next_used_slot;
+        }
+        ef_encode(f.free_slots, fs.size(), fs.back(), false, [&](uint64_t i) { return fs[i]; });
+    }
+    return true;
+}
+
+// hashes[i] = hash.second() of key i (table position, duplicate check); firsts = hash.first() (bucket) for hash128 hashers,
+// nullptr for hash64 hashers, whose first() == second()
+bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed, double c, double alpha, int threads, int device, std::string& err,
+               const std::vector<uint64_t>* firsts = nullptr) {
+    const bool verbose = getenv("LPHQ_BUILD_VERBOSE") != nullptr;
+    auto tprev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        auto now = std::chrono::steady_clock::now();
+        if (verbose) fprintf(stderr, "[lphq_build]   pthash: %-34s %8.3f s\n", what, std::chrono::duration<double>(now - tprev).count());
+        tprev = now;
+    };
+    const uint64_t n = hashes.size();
+    uint64_t num_buckets = 0;
+    if (!phf_setup(f, n, seed, c, alpha, num_buckets, err)) return false;
+    if (n == 0) return true;
+    const uint64_t table_size = f.table_size;
 
     // group hashes by bucket (counting sort), hashes sorted inside each bucket
     std::vector<uint32_t> bucket_id(n);
@@ -425,139 +542,14 @@ bool phf_build(SinglePhf& f, const std::vector<uint64_t>& hashes, uint64_t seed,
     }
     const bool used_gpu = searched;
     if (!searched) {
-        std::vector<std::atomic<uint64_t>> taken(words_for(table_size) + 1);
-        for (auto& x : taken) x.store(0, std::memory_order_relaxed);
-        const uint64_t HP_CACHE = 1ull << 20;
-        std::vector<uint64_t> hp_cache(HP_CACHE);
-        parallel_for(HP_CACHE >> 12, threads, [&](size_t t) {
-            for (uint64_t p = t << 12; p < (t + 1) << 12; ++p) hp_cache[p] = murmur64a_u64(p, seed);
-        });
-        std::atomic<uint64_t> next_commit{0};
-        std::atomic<bool> gave_up{false};
-        // XOR displacement keeps the low bits of a hash: with a tiny table whose size has a power-of-two factor a bucket can
-        // be unplaceable for every pilot (PTHash itself would spin forever there); give up instead of hanging
-        const uint64_t kPilotCap = 1ull << 28;
-        const u128 M = f.M;
-        auto is_taken = [&](uint64_t p) { return (taken[p >> 6].load(std::memory_order_relaxed) >> (p & 63)) & 1; };
-        // The CPU search is sequential: the speculative in-order-commit pool below never beat one thread (1.05 us/key on 64
-        // threads = sequential speed), and a CPU port of the GPU's window/claim/commit scheme got slower with every thread
-        // added (profiles/r01_builder_stages.txt).  The parallel search is the GPU's (search.hip).
-        const int T = 1;
-        (void)threads;
-        auto worker = [&](int tid) {
-            std::vector<uint64_t> pos(max_size ? max_size : 1);
-            for (uint64_t oi = (uint64_t)tid; oi < n_nonempty; oi += (uint64_t)T) {
-                const uint32_t b = order[oi];
-                const uint64_t* keys = hs.data() + bstart[b];
-                const uint64_t s = bstart[b + 1] - bstart[b];
-                uint64_t pilot = 0;
-                bool my_turn = false;
-                for (;;) {
-                    // first pilot (>= current) whose positions are free under the bits visible now
-                    for (;; ++pilot) {
-                        if (pilot >= kPilotCap || gave_up.load(std::memory_order_relaxed)) {
-                            gave_up.store(true);
-                            break;
-                        }
-                        const uint64_t hp = pilot < HP_CACHE ? hp_cache[pilot] : murmur64a_u64(pilot, seed);
-                        uint64_t j = 0;
-                        for (; j < s; ++j) {
-                            const uint64_t p = fastmod_u64(keys[j] ^ hp, M, table_size);
-                            if (is_taken(p)) break;
-                            pos[j] = p;
-                        }
-                        if (j < s) continue;
-                        bool d2 = false;
-                        for (uint64_t a = 1; a < s && !d2; ++a)
-                            for (uint64_t q = 0; q < a; ++q)
-                                if (pos[a] == pos[q]) {
-                                    d2 = true;
-                                    break;
-                                }
-                        if (!d2) break;
-                    }
-                    if (my_turn || gave_up.load()) break;  // searched under the exact table: done
-                    while (next_commit.load(std::memory_order_acquire) != oi && !gave_up.load(std::memory_order_relaxed)) std::this_thread::yield();
-                    if (gave_up.load()) break;
-                    my_turn = true;
-                    bool still_free = true;
-                    for (uint64_t j = 0; j < s; ++j)
-                        if (is_taken(pos[j])) {
-                            still_free = false;
-                            break;
-                        }
-                    if (still_free) break;
-                    // else: keep scanning from this pilot, now under the exact table
-                }
-                if (gave_up.load()) {
-                    next_commit.store(n_nonempty, std::memory_order_release);
-                    return;
-                }
-                for (uint64_t j = 0; j < s; ++j) taken[pos[j] >> 6].fetch_or(1ULL << (pos[j] & 63), std::memory_order_relaxed);
-                pilots[b] = pilot;
-                next_commit.store(oi + 1, std::memory_order_release);
-            }
-        };
-        if (T == 1) {
-            worker(0);
-        } else {
-            std::vector<std::thread> pool;
-            for (int t = 0; t < T; ++t) pool.emplace_back(worker, t);
-            for (auto& th : pool) th.join();
-        }
-        if (gave_up.load()) {
-            err = "pthash search: no pilot below 2^28 for some bucket (degenerate tiny key set: XOR displacement cannot separate keys that share "
-                  "their low bits when the table size has a power-of-two factor; the reference's PTHash does not terminate on it either)";
-            return false;
-        }
-        taken_plain.resize(taken.size());
-        for (size_t i = 0; i < taken.size(); ++i) taken_plain[i] = taken[i].load(std::memory_order_relaxed);
+        taken_plain.assign(words_for(table_size) + 1, 0);
+        CpuPilotSearch cpu;
+        cpu.prepare(seed, threads);
+        if (!cpu.run(f, hs.data(), bstart.data(), order.data(), n_nonempty, taken_plain, pilots.data(), err)) return false;
     }
-    auto is_taken = [&](uint64_t p) { return (taken_plain[p >> 6] >> (p & 63)) & 1; };
     lap(used_gpu ? "pilot search (GPU)" : "pilot search (CPU)");
-    {  // the search must have placed every key exactly once: everything below relies on it (free-slot fill, minimality)
-        uint64_t ones = 0;
-        for (uint64_t p = 0; p < table_size; ++p) ones += is_taken(p);
-        if (ones != n) {
-            err = "pthash search: internal error (occupied slots != keys)";
-            return false;
-        }
-    }
-
-    // dual<dictionary, dictionary>::encode: front = first 0.3 * num_buckets pilots
-    const uint64_t front_size = (uint64_t)((double)num_buckets * 0.3);
-    dict_encode(f.front, pilots.data(), front_size);
-    dict_encode(f.back, pilots.data() + front_size, num_buckets - front_size);
-
-    lap("dictionary encode");
-    // minimal: fill_free_slots + ef_sequence<false>::encode
-    if (n < table_size) {
-        std::vector<uint64_t> fs;
-        fs.reserve(table_size - n);
-        uint64_t next_used_slot = n, last_free_slot = 0, last_valid_free_slot = 0;
-        for (;;) {
-            while (last_free_slot < n && is_taken(last_free_slot)) ++last_free_slot;
-            if (last_free_slot == n) break;
-            while (next_used_slot < table_size && !is_taken(next_used_slot)) {
-                fs.push_back(last_free_slot);
-                ++next_used_slot;
-            }
-            if (next_used_slot >= table_size) {  // cannot happen when exactly n slots are occupied (checked above)
-                err = "pthash: inconsistent slot bitmap";
-                return false;
-            }
-            fs.push_back(last_free_slot);
-            last_valid_free_slot = last_free_slot;
-            ++next_used_slot;
-            ++last_free_slot;
-        }
-        while (next_used_slot != table_size) {
-            fs.push_back(last_valid_free_slot);
-            ++next_used_slot;
-        }
-        ef_encode(f.free_slots, fs.size(), fs.back(), false, [&](uint64_t i) { return fs[i]; });
-    }
-    lap("free slots");
+    if (!phf_finalize(f, num_buckets, pilots, taken_plain, err)) return false;
+    lap("dictionary encode, free slots");
     return true;
 }
 
@@ -726,75 +718,110 @@ struct CallbackSource : RecordSource {  // lphq_build_stream
 };
 
 // ---------------------------------------------------------------------------------------------
-// super-k-mer records beyond the memory limit: sorted pieces on disk, merged by a heap
+// records beyond the memory limit: sorted pieces on disk, merged by a heap
 // (include/external_memory_vector.hpp:43-109: push_back -> sort_and_flush, const_iterator = heap over the files)
+// T = a trivially copyable record, Vec = the vector type the caller fills, Key()(record) = the 64-bit sort key
 // ---------------------------------------------------------------------------------------------
-struct RunFileReader {
-    FILE* f = nullptr;
-    RunVec buf;
-    size_t at = 0, n = 0;
-    bool failed = false;
-    bool open(const std::string& path, size_t buf_records) {
-        f = fopen(path.c_str(), "rb");
-        buf.resize(std::max<size_t>(1, buf_records));
-        return f != nullptr;
-    }
-    bool next(Run& r) {
-        if (at == n) {
-            if (!f) return false;
-            n = fread(buf.data(), sizeof(Run), buf.size(), f);
-            at = 0;
-            if (n == 0) {
-                failed = ferror(f) != 0;
-                fclose(f);
-                f = nullptr;
-                return false;
-            }
-        }
-        r = buf[at++];
-        return true;
-    }
-    ~RunFileReader() {
-        if (f) fclose(f);
-    }
-};
-
-struct RunSpill {
+template <typename T, typename Vec, typename Key>
+struct Spill {
     std::string dir;
+    const char* kind = "runs";  // file-name suffix (several instances live side by side in one directory)
     std::vector<std::string> files;
-    uint64_t serial = 0;
     static constexpr size_t kMaxPieces = 64;  // more sorted pieces than this are first merged into one (open files and read buffers stay bounded)
-    ~RunSpill() {
+    ~Spill() { drop(); }
+    void drop() {
         for (const std::string& f : files) ::remove(f.c_str());
+        files.clear();
     }
-    std::string fresh_name() { return dir + "/lphash.tmp." + std::to_string((long)getpid()) + "." + std::to_string(serial++) + ".runs"; }
-    // every record of `paths`, ascending by minimizer (ties in no particular order), to fn; false on a read error
-    template <typename Fn>
-    static bool merge(const std::vector<std::string>& paths, size_t buf_records, std::string& err, Fn fn) {
-        std::vector<RunFileReader> rd(paths.size());
-        typedef std::pair<uint64_t, uint32_t> Head;  // (minimizer, piece)
-        std::priority_queue<Head, std::vector<Head>, std::greater<Head>> heap;
-        RunVec cur(paths.size());
-        for (size_t i = 0; i < paths.size(); ++i) {
-            if (!rd[i].open(paths[i], buf_records)) {
-                err = "cannot reopen the temporary file " + paths[i];
-                return false;
-            }
-            if (rd[i].next(cur[i])) heap.emplace(cur[i].mm, (uint32_t)i);
+    std::string fresh_name() {
+        static std::atomic<uint64_t> serial{0};
+        return dir + "/lphash.tmp." + std::to_string((long)getpid()) + "." + std::to_string(serial.fetch_add(1)) + "." + kind;
+    }
+    struct Reader {
+        FILE* f = nullptr;
+        Vec buf;
+        size_t at = 0, n = 0;
+        bool failed = false;
+        bool open(const std::string& path, size_t buf_records) {
+            f = fopen(path.c_str(), "rb");
+            buf.resize(std::max<size_t>(1, buf_records));
+            return f != nullptr;
         }
-        while (!heap.empty()) {
+        bool next(T& r) {
+            if (at == n) {
+                if (!f) return false;
+                n = fread((void*)buf.data(), sizeof(T), buf.size(), f);
+                at = 0;
+                if (n == 0) {
+                    failed = ferror(f) != 0;
+                    fclose(f);
+                    f = nullptr;
+                    return false;
+                }
+            }
+            r = buf[at++];
+            return true;
+        }
+        ~Reader() {
+            if (f) fclose(f);
+        }
+    };
+    // every record of `paths`, ascending by key (ties in no particular order), one next() at a time
+    struct Merger {
+        typedef std::pair<uint64_t, uint32_t> Head;  // (key, piece)
+        std::vector<Reader> rd;
+        std::priority_queue<Head, std::vector<Head>, std::greater<Head>> heap;
+        Vec cur;
+        const std::vector<std::string>* paths = nullptr;
+        bool failed = false;
+        std::string err;
+        bool open(const std::vector<std::string>& p, size_t buf_records) {
+            paths = &p;
+            rd = std::vector<Reader>(p.size());
+            cur.resize(p.size());
+            for (size_t i = 0; i < p.size(); ++i) {
+                if (!rd[i].open(p[i], buf_records)) {
+                    err = "cannot reopen the temporary file " + p[i];
+                    return !(failed = true);
+                }
+                if (rd[i].next(cur[i])) heap.emplace(Key()(cur[i]), (uint32_t)i);
+                else if (rd[i].failed) {
+                    err = "read error on the temporary file " + p[i];
+                    return !(failed = true);
+                }
+            }
+            return true;
+        }
+        bool next(T& out) {  // false: the end, or (failed) an error
+            if (failed || heap.empty()) return false;
             const uint32_t i = heap.top().second;
             heap.pop();
-            if (!fn(cur[i])) return false;
-            if (rd[i].next(cur[i])) heap.emplace(cur[i].mm, i);
+            out = cur[i];
+            if (rd[i].next(cur[i])) heap.emplace(Key()(cur[i]), i);
             else if (rd[i].failed) {
-                err = "read error on the temporary file " + paths[i];
-                return false;
+                err = "read error on the temporary file " + (*paths)[i];
+                failed = true;  // (the record just taken is good; the next call reports the failure)
             }
+            return true;
+        }
+    };
+    template <typename Fn>
+    static bool merge(const std::vector<std::string>& paths, size_t buf_records, std::string& err, Fn fn) {
+        Merger mg;
+        if (!mg.open(paths, buf_records)) {
+            err = mg.err;
+            return false;
+        }
+        T r;
+        while (mg.next(r))
+            if (!fn(r)) return false;
+        if (mg.failed) {
+            err = mg.err;
+            return false;
         }
         return true;
     }
-    bool write_piece(const RunVec& runs, std::string& err) {
+    bool write_piece(const Vec& recs, std::string& err) {
         const std::string name = fresh_name();
         FILE* f = fopen(name.c_str(), "wb");
         if (!f) {
@@ -802,19 +829,19 @@ struct RunSpill {
             return false;
         }
         files.push_back(name);
-        const size_t put = fwrite(runs.data(), sizeof(Run), runs.size(), f);
-        if (fclose(f) != 0 || put != runs.size()) {
+        const size_t put = fwrite((const void*)recs.data(), sizeof(T), recs.size(), f);
+        if (fclose(f) != 0 || put != recs.size()) {
             err = "short write on the temporary file " + name;
             return false;
         }
         return true;
     }
     // sort the buffered records and write them as one more piece; the buffer comes back empty
-    bool flush(RunVec& runs, int threads, uint32_t key_bits, size_t buf_records, std::string& err) {
-        if (runs.empty()) return true;
-        parallel_sort_by_key(runs, threads, key_bits, [](const Run& r) { return r.mm; });
-        if (!write_piece(runs, err)) return false;
-        runs.clear();
+    bool flush(Vec& recs, int threads, uint32_t key_bits, size_t buf_records, std::string& err, bool sorted_already = false) {
+        if (recs.empty()) return true;
+        if (!sorted_already) parallel_sort_by_key(recs, threads, key_bits, [](const T& r) { return Key()(r); });
+        if (!write_piece(recs, err)) return false;
+        recs.clear();
         if (files.size() < kMaxPieces) return true;
         // too many pieces: merge them all into one
         const std::string name = fresh_name();
@@ -823,18 +850,18 @@ struct RunSpill {
             err = "cannot create the temporary file " + name;
             return false;
         }
-        RunVec out;
+        Vec out;
         out.reserve(buf_records);
         bool wrote = true;
-        const bool ok = merge(files, buf_records, err, [&](const Run& r) {
+        const bool ok = merge(files, buf_records, err, [&](const T& r) {
             out.push_back(r);
             if (out.size() == buf_records) {
-                wrote = fwrite(out.data(), sizeof(Run), out.size(), f) == out.size();
+                wrote = fwrite((const void*)out.data(), sizeof(T), out.size(), f) == out.size();
                 out.clear();
             }
             return wrote;
         });
-        if (ok && !out.empty()) wrote = fwrite(out.data(), sizeof(Run), out.size(), f) == out.size();
+        if (ok && !out.empty()) wrote = fwrite((const void*)out.data(), sizeof(T), out.size(), f) == out.size();
         const bool closed = fclose(f) == 0;
         for (const std::string& p : files) ::remove(p.c_str());
         files.assign(1, name);
@@ -842,6 +869,66 @@ struct RunSpill {
             if (err.empty()) err = "short write on the temporary file " + name;
             return false;
         }
+        return true;
+    }
+};
+struct RunKey {
+    uint64_t operator()(const Run& r) const { return r.mm; }
+};
+typedef Spill<Run, RunVec, RunKey> RunSpill;
+
+// A sequential file of records (written once, read front to back any number of times): the per-minimizer vectors of a build with a memory limit.
+template <typename T>
+struct RecordFile {
+    std::string path;
+    FILE* f = nullptr;
+    std::vector<T> buf;
+    size_t at = 0, n = 0;
+    uint64_t count = 0;
+    bool failed = false, writing = false;
+    ~RecordFile() {
+        if (f) fclose(f);
+        if (!path.empty()) ::remove(path.c_str());
+    }
+    bool create(const std::string& p, size_t buf_records) {
+        path = p;
+        buf.reserve(std::max<size_t>(1, buf_records));
+        writing = true;
+        return (f = fopen(p.c_str(), "wb")) != nullptr;
+    }
+    bool put(const T& r) {
+        buf.push_back(r);
+        ++count;
+        if (buf.size() == buf.capacity()) return spill();
+        return true;
+    }
+    bool spill() {
+        const bool ok = fwrite((const void*)buf.data(), sizeof(T), buf.size(), f) == buf.size();
+        buf.clear();
+        return ok;
+    }
+    bool rewind_for_reading() {  // (also after a read pass)
+        bool ok = true;
+        if (writing) {
+            ok = spill();
+            writing = false;
+        }
+        if (f) ok = (fclose(f) == 0) && ok;
+        f = fopen(path.c_str(), "rb");
+        buf.resize(buf.capacity());
+        at = n = 0;
+        return ok && f;
+    }
+    bool next(T& r) {
+        if (at == n) {
+            n = fread((void*)buf.data(), sizeof(T), buf.size(), f);
+            at = 0;
+            if (n == 0) {
+                failed = ferror(f) != 0;
+                return false;
+            }
+        }
+        r = buf[at++];
         return true;
     }
 };
