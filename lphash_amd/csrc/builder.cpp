@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <queue>
 #include <string>
 #include <thread>
@@ -176,6 +177,37 @@ void ef_encode(EliasFano& e, uint64_t n, uint64_t u, bool leading_zero, Get get,
             }
         });
     }
+    d1_build(e.d1, e.high);
+}
+
+// The same encoding when the values are cheaper to produce a chunk at a time than one by one (running sums): produce(c, emit) calls
+// emit(i, value) for every i of chunk c = [c * chunk, min(n, (c + 1) * chunk)); chunks run in parallel.
+template <typename Produce>
+void ef_encode_chunked(EliasFano& e, uint64_t n, uint64_t u, bool leading_zero, uint64_t chunk, int threads, Produce produce) {
+    e = EliasFano();
+    if (n == 0) return;
+    const uint64_t nn = n + (leading_zero ? 1 : 0);
+    const uint64_t l = (nn && u / nn) ? msb64(u / nn) : 0;
+    bv_init(e.high, nn + (u >> l) + 1);
+    cv_init(e.low, nn, l);
+    const uint64_t low_mask = (1ULL << l) - 1;
+    uint64_t at = 0;
+    if (leading_zero) {
+        bv_set(e.high, 0);
+        at = 1;
+    }
+    uint64_t* high = e.high.bits.data();
+    uint64_t* low = e.low.bits.data();
+    const std::function<void(uint64_t, uint64_t)> emit = [&](uint64_t i, uint64_t v) {  // neighbours share words, hence the atomic ORs
+        if (l) {
+            const uint64_t pos = (i + at) * l, blk = pos >> 6, sh = pos & 63, x = v & low_mask;
+            __atomic_fetch_or(&low[blk], x << sh, __ATOMIC_RELAXED);
+            if (sh + l > 64) __atomic_fetch_or(&low[blk + 1], x >> (64 - sh), __ATOMIC_RELAXED);
+        }
+        const uint64_t hp = (v >> l) + i + at;
+        __atomic_fetch_or(&high[hp >> 6], 1ULL << (hp & 63), __ATOMIC_RELAXED);
+    };
+    parallel_for((size_t)((n + chunk - 1) / chunk), threads, [&](size_t c) { produce(c, emit); });
     d1_build(e.d1, e.high);
 }
 
@@ -933,6 +965,243 @@ struct RecordFile {
     }
 };
 
+// the per-minimizer vectors of a build with a memory limit (external_memory_vector<mm_triplet_t> and <uint64_t>, src/partitioned_mphf.cpp:88-130)
+struct UniqRec {  // one distinct minimizer, in minimizer order: p1 = size = 0 for a repeated one
+    uint64_t mm;
+    uint8_t p1, size;
+};
+struct OrderRec {  // the same, keyed by its value under the minimizer MPHF
+    uint64_t order;
+    uint8_t p1, size;
+};
+struct OrderKey {
+    uint64_t operator()(const OrderRec& r) const { return r.order; }
+};
+typedef std::vector<OrderRec, DefaultInitAllocator<OrderRec>> OrderVec;
+struct CollRec {  // (first window, size) of a super-k-mer of a repeated minimizer
+    uint64_t first;
+    uint32_t size, pad;
+};
+struct CollKey {
+    uint64_t operator()(const CollRec& r) const { return r.first; }
+};
+typedef std::vector<CollRec, DefaultInitAllocator<CollRec>> CollVec;
+
+// ---------------------------------------------------------------------------------------------
+// PTHash construction with a memory limit (single_phf::build_in_external_memory, what src/partitioned_mphf.cpp:143-160 calls):
+// the (bucket, hash) pairs are sorted in pieces on disk; their merge writes every bucket into the file of its size; the search
+// reads those files from the largest size down -- the order of the in-memory search (non-increasing size, then increasing id) --
+// a piece at a time, with the table of taken positions carried from piece to piece.  In memory: the pilots (8 B per bucket), the
+// table's bitmap, one piece.  Same function, bit for bit, as phf_build.
+// ---------------------------------------------------------------------------------------------
+struct BucketRec {
+    uint64_t hash;
+    uint32_t bucket, pad;
+};
+struct BucketKey {
+    uint64_t operator()(const BucketRec& r) const { return r.bucket; }
+};
+typedef std::vector<BucketRec, DefaultInitAllocator<BucketRec>> BucketVec;
+
+class PhfExternalBuilder {
+  public:
+    static constexpr uint64_t kBig = 256;  // buckets of at least this many keys (unheard of for hashed keys) share one file, sorted in memory
+    bool begin(SinglePhf& f, uint64_t n, uint64_t seed, double c, double alpha, const std::string& dir, uint64_t budget_bytes, int threads, int device,
+               std::string& err) {
+        f_ = &f;
+        threads_ = threads;
+        device_ = device;
+        dir_ = dir;
+        if (!phf_setup(f, n, seed, c, alpha, num_buckets_, err)) return false;
+        spill_.dir = dir;
+        spill_.kind = "buckets";
+        cap_ = std::max<size_t>(4096, (size_t)(budget_bytes / 4 / sizeof(BucketRec)));
+        merge_buf_ = std::max<size_t>(256, std::min<size_t>(1 << 16, cap_ / (2 * Spill<BucketRec, BucketVec, BucketKey>::kMaxPieces)));
+        piece_keys_ = std::max<size_t>(4096, (size_t)(budget_bytes / 4 / 8));
+        buf_.reserve(std::min<uint64_t>(cap_, n));
+        pushed_ = 0;
+        return true;
+    }
+    bool push(uint64_t hash, std::string& err) {
+        if (buf_.size() >= cap_ && !spill_.flush(buf_, threads_, 32, merge_buf_, err)) return false;
+        buf_.push_back(BucketRec{hash, (uint32_t)bucket_of(*f_, hash), 0});
+        ++pushed_;
+        return true;
+    }
+    bool finish(std::string& err) {
+        SinglePhf& f = *f_;
+        const uint64_t n = f.num_keys;
+        if (pushed_ != n) {
+            err = "pthash build: internal error (keys announced != keys given)";
+            return false;
+        }
+        if (n == 0) return true;
+        // 1. buckets, one after the other by id, into the file of their size
+        std::vector<std::unique_ptr<RecordFile<uint64_t>>> by_size(kBig + 1);  // [s] for s < kBig: (id, s hashes)...; [kBig]: (size, id, hashes)...
+        uint64_t max_size = 0;
+        {
+            std::vector<uint64_t> keys;
+            uint32_t cur = 0;
+            bool have = false, ok = true;
+            auto close_bucket = [&]() {
+                if (!have) return;
+                std::sort(keys.begin(), keys.end());
+                for (size_t i = 1; i < keys.size(); ++i)
+                    if (keys[i] == keys[i - 1]) {
+                        err = "pthash seed failure: duplicate 64-bit hash inside a bucket (duplicate key in the input?)";
+                        ok = false;
+                        return;
+                    }
+                const uint64_t s = keys.size(), slot = std::min<uint64_t>(s, kBig);
+                max_size = std::max(max_size, s);
+                if (!by_size[slot]) {
+                    by_size[slot].reset(new RecordFile<uint64_t>());
+                    if (!by_size[slot]->create(dir_ + "/lphash.tmp." + std::to_string((long)getpid()) + "." + std::to_string(file_serial()) + ".size" + std::to_string(slot), 1 << 12)) {
+                        err = "cannot create the temporary file " + by_size[slot]->path;
+                        ok = false;
+                        return;
+                    }
+                }
+                RecordFile<uint64_t>& out = *by_size[slot];
+                bool w = true;
+                if (slot == kBig) w = out.put(s);
+                w = w && out.put(cur);
+                for (uint64_t h : keys) w = w && out.put(h);
+                if (!w) {
+                    err = "short write on the temporary file " + out.path;
+                    ok = false;
+                }
+                keys.clear();
+                have = false;
+            };
+            auto feed = [&](const BucketRec& r) {
+                if (have && r.bucket != cur) close_bucket();
+                if (!ok) return false;
+                cur = r.bucket;
+                have = true;
+                keys.push_back(r.hash);
+                return true;
+            };
+            if (spill_.files.empty()) {  // everything still in memory: one sort, no file of pairs
+                parallel_sort_by_key(buf_, threads_, 32, [](const BucketRec& r) { return (uint64_t)r.bucket; });
+                for (const BucketRec& r : buf_)
+                    if (!feed(r)) return false;
+            } else {
+                if (!spill_.flush(buf_, threads_, 32, merge_buf_, err)) return false;
+                if (!Spill<BucketRec, BucketVec, BucketKey>::merge(spill_.files, merge_buf_, err, feed)) return false;
+            }
+            close_bucket();
+            if (!ok) return false;
+            BucketVec().swap(buf_);
+            spill_.drop();
+        }
+        // 2. the search, a piece of the order at a time
+        std::vector<uint64_t> pilots(num_buckets_, 0);
+        std::vector<uint64_t> taken(words_for(f.table_size) + 1, 0);
+        std::vector<uint64_t> hs, bstart(1, 0);
+        std::vector<uint32_t> ids;
+        CpuPilotSearch cpu;
+        uint64_t placed = 0;
+        auto search_piece = [&]() -> bool {
+            if (ids.empty()) return true;
+            const uint64_t nb = ids.size();
+            std::vector<uint32_t> order(nb);
+            for (uint64_t i = 0; i < nb; ++i) order[i] = (uint32_t)i;
+            std::vector<uint64_t> local(nb, 0);
+            bool searched = false;
+            if (device_ >= 0 && hs.size() >= 4096) {
+                std::vector<uint64_t> t = taken;  // (left as it was if the device fails half-way)
+                std::string gerr;
+                searched = gpu_pilot_search(device_, hs, bstart, order, nb, f.table_size, f.seed, local, t, gerr);
+                if (searched) taken.swap(t);
+                else {
+                    fprintf(stderr, "[lphq_build] WARNING: GPU pilot search failed (%s); falling back to the sequential CPU search\n", gerr.c_str());
+                    std::fill(local.begin(), local.end(), 0);
+                }
+            }
+            if (!searched) {
+                cpu.prepare(f.seed, threads_);
+                if (!cpu.run(f, hs.data(), bstart.data(), order.data(), nb, taken, local.data(), err)) return false;
+            }
+            for (uint64_t i = 0; i < nb; ++i) pilots[ids[i]] = local[i];
+            placed += hs.size();
+            hs.clear();
+            bstart.assign(1, 0);
+            ids.clear();
+            return true;
+        };
+        auto add_bucket = [&](uint32_t id, const uint64_t* keys, uint64_t s) -> bool {
+            if (!hs.empty() && hs.size() + s > piece_keys_ && !search_piece()) return false;
+            ids.push_back(id);
+            hs.insert(hs.end(), keys, keys + s);
+            bstart.push_back(hs.size());
+            return true;
+        };
+        if (by_size[kBig]) {  // (size, id, hashes) records: all in memory, by non-increasing size then id
+            RecordFile<uint64_t>& in = *by_size[kBig];
+            if (!in.rewind_for_reading()) return io_error(in, err);
+            struct Big {
+                uint64_t size, id;
+                std::vector<uint64_t> keys;
+            };
+            std::vector<Big> big;
+            uint64_t s = 0, id = 0, h = 0;
+            while (in.next(s)) {
+                if (!in.next(id)) return io_error(in, err);
+                big.push_back(Big{s, id, {}});
+                big.back().keys.reserve(s);
+                for (uint64_t j = 0; j < s; ++j) {
+                    if (!in.next(h)) return io_error(in, err);
+                    big.back().keys.push_back(h);
+                }
+            }
+            if (in.failed) return io_error(in, err);
+            std::sort(big.begin(), big.end(), [](const Big& a, const Big& b) { return a.size != b.size ? a.size > b.size : a.id < b.id; });
+            for (const Big& b : big)
+                if (!add_bucket((uint32_t)b.id, b.keys.data(), b.size)) return false;
+            by_size[kBig].reset();
+        }
+        std::vector<uint64_t> keys;
+        for (uint64_t s = std::min<uint64_t>(max_size, kBig - 1); s >= 1; --s) {
+            if (!by_size[s]) continue;
+            RecordFile<uint64_t>& in = *by_size[s];
+            if (!in.rewind_for_reading()) return io_error(in, err);
+            keys.resize(s);
+            uint64_t id = 0;
+            while (in.next(id)) {
+                for (uint64_t j = 0; j < s; ++j)
+                    if (!in.next(keys[j])) return io_error(in, err);
+                if (!add_bucket((uint32_t)id, keys.data(), s)) return false;
+            }
+            if (in.failed) return io_error(in, err);
+            by_size[s].reset();
+        }
+        if (!search_piece()) return false;
+        if (placed != n) {
+            err = "pthash build: internal error (keys searched != keys given)";
+            return false;
+        }
+        return phf_finalize(f, num_buckets_, pilots, taken, err);
+    }
+
+  private:
+    static uint64_t file_serial() {
+        static std::atomic<uint64_t> serial{0};
+        return serial.fetch_add(1);
+    }
+    static bool io_error(const RecordFile<uint64_t>& f, std::string& err) {
+        err = "read error on the temporary file " + f.path;
+        return false;
+    }
+    SinglePhf* f_ = nullptr;
+    uint64_t num_buckets_ = 0, pushed_ = 0;
+    int threads_ = 1, device_ = -1;
+    std::string dir_;
+    Spill<BucketRec, BucketVec, BucketKey> spill_;
+    BucketVec buf_;
+    size_t cap_ = 0, merge_buf_ = 0, piece_keys_ = 0;
+};
+
 }  // namespace
 }  // namespace lphq
 
@@ -1082,6 +1351,17 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
     TripletVec uniq;
     WordVec uniq_mm;
     std::vector<std::pair<uint64_t, uint32_t>> colliding;  // (first window, size) of every super-k-mer of a repeated minimizer
+    // ... and their homes when there is a memory limit
+    const bool external = max_memory_bytes != 0;
+    const size_t ext_cap = std::max<size_t>(4096, (size_t)(max_memory_bytes / 4 / 16));  // records of 16 bytes per sorted piece
+    const size_t ext_merge_buf = std::max<size_t>(256, std::min<size_t>(1 << 16, ext_cap / (2 * RunSpill::kMaxPieces)));
+    const uint32_t coord_bits = msb64(base | 1) + 1;  // input coordinates
+    RecordFile<UniqRec> uniq_file;
+    Spill<CollRec, CollVec, CollKey> coll_spill;
+    coll_spill.dir = spill.dir;
+    coll_spill.kind = "repeated";
+    CollVec coll_buf;
+    uint64_t n_colliding = 0, n_colliding_kmers = 0;
     {
         // records arrive ascending by minimizer; a minimizer seen once keeps (offset, size), one seen more often sends all its super-k-mers
         // to the fallback
@@ -1126,7 +1406,7 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
                 for (size_t i = t * 65536, e = std::min(nc, i + 65536); i < e; ++i) colliding[i] = {on_device.colliding_first[i], on_device.colliding_size[i]};
             });
             on_device = ClassifiedMinimizers();
-        } else if (spill.files.empty()) {
+        } else if (!external) {
             if (!runs_sorted) parallel_sort_by_key(runs, threads, 2 * m, [](const Run& r) { return r.mm; });
             lap("part 2: sort runs by minimizer");
             // pieces that begin at the first record of a minimizer, one classifier each, joined in order
@@ -1161,26 +1441,43 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
                 std::copy(part[t].colliding.begin(), part[t].colliding.end(), colliding.begin() + co[t]);
                 Classifier().uniq.swap(part[t].uniq);
             });
-        } else {
-            if (!spill.flush(runs, threads, 2 * m, merge_buf, err)) return fail(LPHQ_ERR_IO, err);
+        } else {  // with a memory limit: the distinct minimizers go to a file as the merge delivers them, the repeated ones' super-k-mers to sorted pieces
+            if (!spill.flush(runs, threads, 2 * m, merge_buf, err, runs_sorted)) return fail(LPHQ_ERR_IO, err);
             RunVec().swap(runs);
             if (verbose) fprintf(stderr, "[lphq_build] %zu sorted pieces of super-k-mer records in %s\n", spill.files.size(), spill.dir.c_str());
+            if (!uniq_file.create(spill.dir + "/lphash.tmp." + std::to_string((long)getpid()) + ".minimizers", 1 << 14))
+                return fail(LPHQ_ERR_IO, "cannot create the temporary file " + uniq_file.path);
             Classifier c;
+            bool wrote = true;
+            auto drain = [&]() {
+                for (size_t i = 0; i < c.uniq.size(); ++i) wrote = uniq_file.put(UniqRec{c.uniq_mm[i], c.uniq[i].p1, c.uniq[i].size}) && wrote;
+                c.uniq.clear();
+                c.uniq_mm.clear();
+                for (const auto& cw : c.colliding) {
+                    if (coll_buf.size() >= ext_cap && !coll_spill.flush(coll_buf, threads, coord_bits, ext_merge_buf, err)) return false;
+                    coll_buf.push_back(CollRec{cw.first, cw.second, 0});
+                    n_colliding_kmers += cw.second;
+                    ++n_colliding;
+                }
+                c.colliding.clear();
+                return wrote;
+            };
             if (!RunSpill::merge(spill.files, merge_buf, err, [&](const Run& r) {
                     c.feed(r);
-                    return true;
+                    return c.uniq.size() < 4096 || drain();
                 }))
-                return fail(LPHQ_ERR_IO, err);
+                return fail(LPHQ_ERR_IO, err.empty() ? "short write on the temporary file " + uniq_file.path : err);
             c.close_group();
-            uniq.swap(c.uniq);
-            uniq_mm.swap(c.uniq_mm);
-            colliding.swap(c.colliding);
-            for (const std::string& f : spill.files) ::remove(f.c_str());
-            spill.files.clear();
+            if (!drain()) return fail(LPHQ_ERR_IO, err.empty() ? "short write on the temporary file " + uniq_file.path : err);
+            spill.drop();
         }
     }
     RunVec().swap(runs);
-    const uint64_t D = uniq.size();
+    if (!external) {
+        n_colliding = colliding.size();
+        for (const auto& cw : colliding) n_colliding_kmers += cw.second;
+    }
+    const uint64_t D = external ? uniq_file.count : uniq.size();
     lap("part 2: classify");
 
     LphFile x;
@@ -1191,21 +1488,111 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
     x.mm_seed = mm_seed;
     x.nkmers = nkmers;
     x.distinct_minimizers = D;
-    {
+    if (!external) {
         std::vector<uint64_t> hashes(D);
         parallel_for((D + 65535) / 65536, threads, [&](size_t t) {
             for (size_t i = t * 65536, e = std::min<size_t>(D, i + 65536); i < e; ++i) hashes[i] = murmur64a_u64(uniq_mm[i], pthash_seed);
         });
         if (!phf_build(x.minimizer_order, hashes, pthash_seed, c, alpha, threads, device, err)) return fail(LPHQ_ERR_FORMAT, err);
+    } else {  // build_minimizers_mphf -> build_in_external_memory (src/partitioned_mphf.cpp:143-150)
+        PhfExternalBuilder pb;
+        if (!pb.begin(x.minimizer_order, D, pthash_seed, c, alpha, spill.dir, max_memory_bytes, threads, device, err)) return fail(LPHQ_ERR_FORMAT, err);
+        if (!uniq_file.rewind_for_reading()) return fail(LPHQ_ERR_IO, "cannot reopen the temporary file " + uniq_file.path);
+        UniqRec u;
+        while (uniq_file.next(u))
+            if (!pb.push(murmur64a_u64(u.mm, pthash_seed), err)) return fail(LPHQ_ERR_IO, err);
+        if (uniq_file.failed) return fail(LPHQ_ERR_IO, "read error on the temporary file " + uniq_file.path);
+        if (!pb.finish(err)) return fail(err.find("temporary file") != std::string::npos ? LPHQ_ERR_IO : LPHQ_ERR_FORMAT, err);
     }
     lap("part 2: PTHash over minimizers");
 
-    // ---- Part 3: order by the minimizer MPHF (a bijection onto [0, D): direct placement) ---------------
-    TripletVec by_order(D);  // zeroed below by all threads (itself == 0: not filled yet)
-    parallel_for((D + 65535) / 65536, threads, [&](size_t t) { memset((void*)(by_order.data() + t * 65536), 0, (std::min<size_t>(D, (t + 1) * 65536) - t * 65536) * sizeof(Triplet)); });
-    {
-        std::vector<uint64_t> free_table;
-        if (!x.minimizer_order.free_slots.decode(free_table, err)) return fail(LPHQ_ERR_FORMAT, err);
+    // ---- Part 3: order by the minimizer MPHF (a bijection onto [0, D)), then the inverted index over that order ----------------
+    // The index is written from stretches of the order: the whole of it at once (direct placement in memory), or -- with a memory limit --
+    // what a merge of sorted pieces delivers, a stretch at a time (external_memory_vector<mm_triplet_t> mm_sorted_by_mphf,
+    // src/partitioned_mphf.cpp:92-104).  A stretch begins at a multiple of 64 (its pieces own whole words of the root bit vector).
+    std::vector<uint8_t> lr, mn, left_positions, right_or_collision_sizes, none_sizes, none_positions;  // build_inverted_index, src/partitioned_mphf.cpp:163-268
+    std::vector<uint8_t> u_pos, u_size;                                                                  // build_pos_index / build_size_index, src/unpartitioned_mphf.cpp:156-176
+    uint64_t universe = 0;
+    if (kind == LPHQ_PARTITIONED) bv_init(x.root.bv, D);
+    auto index_stretch = [&](uint64_t first, const Triplet* tr, uint64_t count) {
+        if (kind != LPHQ_PARTITIONED) {
+            const size_t old = u_pos.size();
+            u_pos.resize(old + count);
+            u_size.resize(old + count);
+            parallel_for((size_t)((count + 65535) / 65536), threads, [&](size_t t) {
+                for (uint64_t i = t * 65536, e = std::min<uint64_t>(count, i + 65536); i < e; ++i) {
+                    u_pos[old + i] = tr[i].p1;
+                    u_size[old + i] = tr[i].size;
+                }
+            });
+            return;
+        }
+        // pieces of a multiple of 64 minimizers, one set of output arrays each, joined in order
+        struct Piece {
+            std::vector<uint8_t> lr, mn, left_positions, right_or_collision_sizes, none_sizes, none_positions;
+            uint64_t universe = 0, n_maximal = 0;
+        };
+        const uint64_t per = std::max<uint64_t>(1u << 16, ((count + (uint64_t)threads - 1) / (uint64_t)threads + 63) & ~63ull);
+        const size_t pieces = (size_t)((count + per - 1) / per);
+        std::vector<Piece> part(pieces);
+        parallel_for(pieces, threads, [&](size_t pi) {
+            Piece& o = part[pi];
+            const uint64_t lo = pi * per, hi = std::min<uint64_t>(count, lo + per);
+            o.lr.reserve(hi - lo);
+            o.mn.reserve(hi - lo);
+            for (uint64_t i = lo; i < hi; ++i) {
+                const Triplet& t = tr[i];
+                if (t.size == 0) {  // RIGHT_OR_COLLISION, size 0 marks a repeated minimizer
+                    o.lr.push_back(1);
+                    o.right_or_collision_sizes.push_back(0);
+                } else if (t.p1 == k - m) {
+                    if (t.size == W) {  // MAXIMAL
+                        bv_set(x.root.bv, first + i);
+                        o.mn.push_back(0);
+                        ++o.n_maximal;
+                    } else {  // RIGHT
+                        o.lr.push_back(1);
+                        o.right_or_collision_sizes.push_back(t.size);
+                        o.universe += t.size;
+                    }
+                } else if (t.p1 == t.size - 1) {  // LEFT: stores p1 + 1
+                    o.lr.push_back(0);
+                    o.left_positions.push_back((uint8_t)(t.p1 + 1));
+                    o.universe += (uint64_t)t.p1 + 1;
+                } else {  // NONE
+                    bv_set(x.root.bv, first + i);
+                    o.mn.push_back(1);
+                    o.none_positions.push_back(t.p1);
+                    o.none_sizes.push_back(t.size);
+                    o.universe += (uint64_t)t.p1 + t.size;
+                }
+            }
+        });
+        auto join = [&](std::vector<uint8_t>& out, std::vector<uint8_t> Piece::*field) {
+            std::vector<size_t> at(pieces + 1, out.size());
+            for (size_t pi = 0; pi < pieces; ++pi) at[pi + 1] = at[pi] + (part[pi].*field).size();
+            out.resize(at[pieces]);
+            parallel_for(pieces, threads, [&](size_t pi) {
+                std::copy((part[pi].*field).begin(), (part[pi].*field).end(), out.begin() + at[pi]);
+                std::vector<uint8_t>().swap(part[pi].*field);
+            });
+        };
+        join(lr, &Piece::lr);
+        join(mn, &Piece::mn);
+        join(left_positions, &Piece::left_positions);
+        join(right_or_collision_sizes, &Piece::right_or_collision_sizes);
+        join(none_sizes, &Piece::none_sizes);
+        join(none_positions, &Piece::none_positions);
+        for (const Piece& o : part) {
+            universe += o.universe;
+            x.n_maximal += o.n_maximal;
+        }
+    };
+    std::vector<uint64_t> free_table;
+    if (!x.minimizer_order.free_slots.decode(free_table, err)) return fail(LPHQ_ERR_FORMAT, err);
+    if (!external) {
+        TripletVec by_order(D);  // zeroed below by all threads (itself == 0: not filled yet)
+        parallel_for((D + 65535) / 65536, threads, [&](size_t t) { memset((void*)(by_order.data() + t * 65536), 0, (std::min<size_t>(D, (t + 1) * 65536) - t * 65536) * sizeof(Triplet)); });
         std::atomic<bool> bad{false};
         parallel_for((D + 65535) / 65536, threads, [&](size_t t) {
             for (size_t i = t * 65536, e = std::min<size_t>(D, i + 65536); i < e; ++i) {
@@ -1225,79 +1612,78 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
                 if (by_order[i].itself != 1) hole.store(true);
         });
         if (hole.load()) return fail(LPHQ_ERR_FORMAT, "internal: minimizer MPHF is not a bijection");
-    }
-    TripletVec().swap(uniq);
-    WordVec().swap(uniq_mm);
-    lap("part 3: order by minimizer MPHF");
-
-    if (kind == LPHQ_PARTITIONED) {  // build_inverted_index, src/partitioned_mphf.cpp:163-268
-        bv_init(x.root.bv, D);
-        std::vector<uint8_t> lr, mn;
-        std::vector<uint8_t> left_positions, right_or_collision_sizes, none_sizes, none_positions;
-        uint64_t universe = 0;
+        TripletVec().swap(uniq);
+        WordVec().swap(uniq_mm);
+        lap("part 3: order by minimizer MPHF");
+        index_stretch(0, by_order.data(), D);
+    } else {
+        Spill<OrderRec, OrderVec, OrderKey> order_spill;
+        order_spill.dir = spill.dir;
+        order_spill.kind = "order";
+        const uint32_t order_bits = msb64(D | 1) + 1;
         {
-            // pieces of a multiple of 64 minimizers (a piece owns its words of the root bit vector), one set of output arrays each, joined in order
-            struct Piece {
-                std::vector<uint8_t> lr, mn, left_positions, right_or_collision_sizes, none_sizes, none_positions;
-                uint64_t universe = 0, n_maximal = 0;
-            };
-            const uint64_t per = std::max<uint64_t>(1u << 16, ((D + (uint64_t)threads - 1) / (uint64_t)threads + 63) & ~63ull);
-            const size_t pieces = (size_t)((D + per - 1) / per);
-            std::vector<Piece> part(pieces);
-            parallel_for(pieces, threads, [&](size_t pi) {
-                Piece& o = part[pi];
-                const uint64_t lo = pi * per, hi = std::min<uint64_t>(D, lo + per);
-                o.lr.reserve(hi - lo);
-                o.mn.reserve(hi - lo);
-                for (uint64_t i = lo; i < hi; ++i) {
-                    const Triplet& t = by_order[i];
-                    if (t.size == 0) {  // RIGHT_OR_COLLISION, size 0 marks a repeated minimizer
-                        o.lr.push_back(1);
-                        o.right_or_collision_sizes.push_back(0);
-                    } else if (t.p1 == k - m) {
-                        if (t.size == W) {  // MAXIMAL
-                            bv_set(x.root.bv, i);
-                            o.mn.push_back(0);
-                            ++o.n_maximal;
-                        } else {  // RIGHT
-                            o.lr.push_back(1);
-                            o.right_or_collision_sizes.push_back(t.size);
-                            o.universe += t.size;
-                        }
-                    } else if (t.p1 == t.size - 1) {  // LEFT: stores p1 + 1
-                        o.lr.push_back(0);
-                        o.left_positions.push_back((uint8_t)(t.p1 + 1));
-                        o.universe += (uint64_t)t.p1 + 1;
-                    } else {  // NONE
-                        bv_set(x.root.bv, i);
-                        o.mn.push_back(1);
-                        o.none_positions.push_back(t.p1);
-                        o.none_sizes.push_back(t.size);
-                        o.universe += (uint64_t)t.p1 + t.size;
+            if (!uniq_file.rewind_for_reading()) return fail(LPHQ_ERR_IO, "cannot reopen the temporary file " + uniq_file.path);
+            OrderVec piece;
+            piece.reserve(std::min<uint64_t>(ext_cap, D));
+            std::atomic<bool> bad{false};
+            bool more = true;
+            while (more) {
+                UniqRec u;
+                while (piece.size() < ext_cap && (more = uniq_file.next(u))) piece.push_back(OrderRec{u.mm, u.p1, u.size});
+                parallel_for((piece.size() + 4095) / 4096, threads, [&](size_t t) {
+                    for (size_t i = t * 4096, e = std::min(piece.size(), i + 4096); i < e; ++i) {
+                        piece[i].order = phf_eval(x.minimizer_order, murmur64a_u64(piece[i].order, pthash_seed), &free_table);
+                        if (piece[i].order >= D) bad.store(true);
                     }
-                }
-            });
-            auto join = [&](std::vector<uint8_t>& out, std::vector<uint8_t> Piece::*field) {
-                std::vector<size_t> at(pieces + 1, 0);
-                for (size_t pi = 0; pi < pieces; ++pi) at[pi + 1] = at[pi] + (part[pi].*field).size();
-                out.resize(at[pieces]);
-                parallel_for(pieces, threads, [&](size_t pi) {
-                    std::copy((part[pi].*field).begin(), (part[pi].*field).end(), out.begin() + at[pi]);
-                    std::vector<uint8_t>().swap(part[pi].*field);
                 });
-            };
-            join(lr, &Piece::lr);
-            join(mn, &Piece::mn);
-            join(left_positions, &Piece::left_positions);
-            join(right_or_collision_sizes, &Piece::right_or_collision_sizes);
-            join(none_sizes, &Piece::none_sizes);
-            join(none_positions, &Piece::none_positions);
-            for (const Piece& o : part) {
-                universe += o.universe;
-                x.n_maximal += o.n_maximal;
+                if (bad.load()) return fail(LPHQ_ERR_FORMAT, "internal: minimizer MPHF out of range");
+                if (!order_spill.flush(piece, threads, order_bits, ext_merge_buf, err)) return fail(LPHQ_ERR_IO, err);
+            }
+            if (uniq_file.failed) return fail(LPHQ_ERR_IO, "read error on the temporary file " + uniq_file.path);
+        }
+        lap("part 3: order by minimizer MPHF (sorted pieces)");
+        const uint64_t stretch_cap = std::max<uint64_t>(1u << 16, (uint64_t)(ext_cap & ~(size_t)65535));
+        TripletVec stretch;
+        stretch.reserve(std::min<uint64_t>(stretch_cap, D));
+        uint64_t first = 0, seen = 0;
+        Spill<OrderRec, OrderVec, OrderKey>::Merger mg;
+        if (!mg.open(order_spill.files, ext_merge_buf)) return fail(LPHQ_ERR_IO, mg.err);
+        OrderRec r;
+        while (mg.next(r)) {
+            if (r.order != seen) return fail(LPHQ_ERR_FORMAT, "internal: minimizer MPHF is not a bijection");
+            ++seen;
+            stretch.push_back(Triplet{1, r.p1, r.size});
+            if (stretch.size() == stretch_cap) {
+                index_stretch(first, stretch.data(), stretch.size());
+                first += stretch.size();
+                stretch.clear();
             }
         }
-        lap("  inverted index: classify by type");
+        if (mg.failed) return fail(LPHQ_ERR_IO, mg.err);
+        if (seen != D) return fail(LPHQ_ERR_FORMAT, "internal: minimizer MPHF is not a bijection");
+        index_stretch(first, stretch.data(), stretch.size());
+    }
+    std::vector<uint64_t>().swap(free_table);
+    lap("  inverted index: classify by type");
+
+    // Elias-Fano over the prefix sums of n bytes, value(i) each (append_iterator + cumulative_iterator, src/partitioned_mphf.cpp:246-262): the
+    // sums are never stored -- per-chunk totals, a scan over the chunks, then every chunk on its own.
+    auto ef_encode_prefix_sums = [&](EliasFano& e, uint64_t n, uint64_t total, const std::function<uint8_t(uint64_t)>& value) {
+        const uint64_t chunk = 1u << 16;
+        const size_t nch = (size_t)((n + chunk - 1) / chunk);
+        std::vector<uint64_t> csum(nch + 1, 0);
+        parallel_for(nch, threads, [&](size_t c) {
+            uint64_t t = 0;
+            for (uint64_t i = c * chunk, e2 = std::min(n, i + chunk); i < e2; ++i) t += value(i);
+            csum[c + 1] = t;
+        });
+        for (size_t c = 0; c < nch; ++c) csum[c + 1] += csum[c];
+        ef_encode_chunked(e, n, total, true, chunk, threads, [&](size_t c, const std::function<void(uint64_t, uint64_t)>& emit) {
+            uint64_t t = csum[c];
+            for (uint64_t i = c * chunk, e2 = std::min(n, i + chunk); i < e2; ++i) emit(i, t += value(i));
+        });
+    };
+    if (kind == LPHQ_PARTITIONED) {
         auto pack_bits = [&](BitVector& bv, const std::vector<uint8_t>& bytes) {  // one 64-bit word per step: words are independent
             bv_init(bv, bytes.size());
             const size_t nw = bv.bits.size(), wchunk = 1 << 12;
@@ -1311,6 +1697,8 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
         };
         pack_bits(x.left_right.bv, lr);
         pack_bits(x.max_none.bv, mn);
+        std::vector<uint8_t>().swap(lr);
+        std::vector<uint8_t>().swap(mn);
         rs_build(x.root, threads);
         rs_build(x.left_right, threads);
         rs_build(x.max_none, threads);
@@ -1318,84 +1706,101 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
         x.right_coll_sizes_start = left_positions.size();
         x.none_sizes_start = x.right_coll_sizes_start + right_or_collision_sizes.size();
         x.none_pos_start = x.none_sizes_start + none_sizes.size();
-        // append_iterator + cumulative_iterator over the four arrays: a prefix sum over their concatenation (per-piece sums, a scan over the pieces,
-        // then every piece on its own)
         const std::vector<uint8_t>* arrays[4] = {&left_positions, &right_or_collision_sizes, &none_sizes, &none_positions};
         const uint64_t starts[5] = {0, x.right_coll_sizes_start, x.none_sizes_start, x.none_pos_start, x.none_pos_start + none_positions.size()};
-        const uint64_t n_cum = starts[4];
-        auto value_at = [&](uint64_t i) -> uint8_t {
+        ef_encode_prefix_sums(x.sizes_and_positions, starts[4], universe, [&](uint64_t i) -> uint8_t {
             const int a = i < starts[2] ? (i < starts[1] ? 0 : 1) : (i < starts[3] ? 2 : 3);
             return (*arrays[a])[i - starts[a]];
-        };
-        std::vector<uint64_t, DefaultInitAllocator<uint64_t>> cum(n_cum);
+        });
+        lap("  inverted index: Elias-Fano over the cumulative sums");
+    } else {
+        uint64_t pos_sum = 0, size_sum = 0;
         {
             const uint64_t chunk = 1u << 16;
-            const size_t nch = (size_t)((n_cum + chunk - 1) / chunk);
-            std::vector<uint64_t> csum(nch + 1, 0);
+            const size_t nch = (size_t)((D + chunk - 1) / chunk);
+            std::vector<uint64_t> ps(nch, 0), ss(nch, 0);
             parallel_for(nch, threads, [&](size_t c) {
-                uint64_t t = 0;
-                for (uint64_t i = c * chunk, e = std::min(n_cum, i + chunk); i < e; ++i) t += value_at(i);
-                csum[c + 1] = t;
+                for (uint64_t i = c * chunk, e = std::min(D, i + chunk); i < e; ++i) {
+                    ps[c] += u_pos[i];
+                    ss[c] += u_size[i];
+                }
             });
-            for (size_t c = 0; c < nch; ++c) csum[c + 1] += csum[c];
-            parallel_for(nch, threads, [&](size_t c) {
-                uint64_t t = csum[c];
-                for (uint64_t i = c * chunk, e = std::min(n_cum, i + chunk); i < e; ++i) cum[i] = t += value_at(i);
-            });
+            for (size_t c = 0; c < nch; ++c) {
+                pos_sum += ps[c];
+                size_sum += ss[c];
+            }
         }
-        lap("  inverted index: cumulative sums");
-        ef_encode(x.sizes_and_positions, n_cum, universe, true, [&](uint64_t i) { return cum[i]; }, threads);
-        lap("  inverted index: Elias-Fano");
-    } else {  // build_pos_index / build_size_index, src/unpartitioned_mphf.cpp:156-176
-        uint64_t pos_sum = 0, size_sum = 0;
-        std::vector<uint64_t> cp(D), cs(D);
-        for (uint64_t i = 0; i < D; ++i) {
-            cp[i] = pos_sum += by_order[i].p1;
-            cs[i] = size_sum += by_order[i].size;
-        }
-        ef_encode(x.positions, D, pos_sum, true, [&](uint64_t i) { return cp[i]; }, threads);
-        ef_encode(x.sizes, D, size_sum, true, [&](uint64_t i) { return cs[i]; }, threads);
+        ef_encode_prefix_sums(x.positions, D, pos_sum, [&](uint64_t i) { return u_pos[i]; });
+        ef_encode_prefix_sums(x.sizes, D, size_sum, [&](uint64_t i) { return u_size[i]; });
         x.num_kmers_in_main_index = size_sum;
     }
-    TripletVec().swap(by_order);
     lap("part 3: inverted index (wavelet tree, EF)");
 
     // ---- Part 4: fallback PTHash over the k-mers of repeated minimizers, in input order ----------------
     {
-        // second pass over the input (partitioned_mphf.cpp:110-130)
-        std::sort(colliding.begin(), colliding.end());
+        // second pass over the input (partitioned_mphf.cpp:110-130); the super-k-mers of repeated minimizers by position: sorted in memory,
+        // or the merge of the sorted pieces
         std::vector<uint64_t> fh;
-        const u128 km_mask = (((u128)1) << (2 * k)) - 1;
+        PhfExternalBuilder pb;
+        Spill<CollRec, CollVec, CollKey>::Merger mg;
         size_t ci = 0;
+        CollRec cw{0, 0, 0};
+        bool have = false;
+        if (!external) {
+            std::sort(colliding.begin(), colliding.end());
+            fh.reserve(n_colliding_kmers);
+        } else {
+            if (!coll_spill.flush(coll_buf, threads, coord_bits, ext_merge_buf, err)) return fail(LPHQ_ERR_IO, err);
+            CollVec().swap(coll_buf);
+            if (!mg.open(coll_spill.files, ext_merge_buf)) return fail(LPHQ_ERR_IO, mg.err);
+            if (!pb.begin(x.fallback_kmer_order, n_colliding_kmers, pthash_seed, c, alpha, spill.dir, max_memory_bytes, threads, device, err)) return fail(LPHQ_ERR_FORMAT, err);
+        }
+        auto advance = [&]() {  // the next super-k-mer into cw
+            if (!external) {
+                have = ci < colliding.size();
+                if (have) cw = CollRec{colliding[ci].first, colliding[ci].second, 0};
+                ++ci;
+            } else {
+                have = mg.next(cw);
+            }
+        };
+        advance();
+        const u128 km_mask = (((u128)1) << (2 * k)) - 1;
         uint64_t at = 0;  // global coordinate of the current record's first base
         const char* const* records = nullptr;
         const size_t* lengths = nullptr;
         size_t nb = 0;
         int rc = 0;
-        while (ci < colliding.size() && (rc = src.next(1, records, lengths, nb)) > 0) {
-            for (size_t r = 0; r < nb && ci < colliding.size(); ++r) {
+        while (have && (rc = src.next(1, records, lengths, nb)) > 0) {
+            for (size_t r = 0; r < nb && have; ++r) {
                 const uint64_t end = at + lengths[r];
-                for (; ci < colliding.size() && colliding[ci].first < end; ++ci) {
-                    const auto& cw = colliding[ci];
-                    if (cw.first < at || cw.first + cw.second + k - 1 > end) return fail(LPHQ_ERR_IO, "the second pass over the input does not match the first");
+                for (; have && cw.first < end; advance()) {
+                    if (cw.first < at || cw.first + cw.size + k - 1 > end) return fail(LPHQ_ERR_IO, "the second pass over the input does not match the first");
                     const char* s = records[r] + (cw.first - at);
                     u128 km = 0;
                     for (uint32_t j = 0; j < k - 1; ++j) km = (km << 2) | (u128)(nt4((uint8_t)s[j]) & 3);
-                    for (uint32_t w = 0; w < cw.second; ++w) {
+                    for (uint32_t w = 0; w < cw.size; ++w) {
                         km = ((km << 2) | (u128)(nt4((uint8_t)s[w + k - 1]) & 3)) & km_mask;
                         // fallback_hasher, include/constants.hpp:56-70
                         uint64_t h;
                         if (kmer_bits == 64) h = murmur64a_u64((uint64_t)km, pthash_seed);
                         else h = murmur64a_u64((uint64_t)km, pthash_seed) ^ murmur64a_u64((uint64_t)(km >> 64), ~pthash_seed);
-                        fh.push_back(h);
+                        if (!external) fh.push_back(h);
+                        else if (!pb.push(h, err)) return fail(LPHQ_ERR_IO, err);
                     }
                 }
                 at = end;
             }
         }
         if (rc < 0) return fail(LPHQ_ERR_IO, "the record source failed during the second pass");
-        if (ci != colliding.size()) return fail(LPHQ_ERR_IO, "the second pass over the input is shorter than the first");
-        if (!phf_build(x.fallback_kmer_order, fh, pthash_seed, c, alpha, threads, device, err)) return fail(LPHQ_ERR_FORMAT, err);
+        if (external && mg.failed) return fail(LPHQ_ERR_IO, mg.err);
+        if (have) return fail(LPHQ_ERR_IO, "the second pass over the input is shorter than the first");
+        if (!external) {
+            if (!phf_build(x.fallback_kmer_order, fh, pthash_seed, c, alpha, threads, device, err)) return fail(LPHQ_ERR_FORMAT, err);
+        } else {
+            if (!pb.finish(err)) return fail(err.find("temporary file") != std::string::npos ? LPHQ_ERR_IO : LPHQ_ERR_FORMAT, err);
+            coll_spill.drop();
+        }
     }
 
     lap("part 4: fallback MPHF");
@@ -1435,7 +1840,7 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
         stats->num_records = n_records;
         stats->num_super_kmers = n_super_kmers;
         stats->distinct_minimizers = D;
-        stats->colliding_super_kmers = colliding.size();
+        stats->colliding_super_kmers = n_colliding;
         stats->fallback_kmers = x.fallback_kmer_order.num_keys;
         stats->file_bytes = w.buf.size();
     }

@@ -50,6 +50,7 @@ bool gpu_pilot_search(int device, const std::vector<uint64_t>& hs, const std::ve
     uint8_t* d_ready = nullptr;
     const size_t nb = bstart.size() - 1;
     const size_t taken_u32 = (table_size + 63) / 64 * 2 + 2;
+    uint64_t ones_before = 0;
     std::vector<uint32_t> bstart32(bstart.begin(), bstart.end());
     std::vector<uint64_t> pilot_by_order(n_nonempty ? n_nonempty : 1, 0);
     if (table_size == 0 || table_size > 0xFFFFFFFFull || hs.size() > 0xFFFFFFFFull) {
@@ -76,7 +77,14 @@ bool gpu_pilot_search(int device, const std::vector<uint64_t>& hs, const std::ve
     HIP_OK(hipMemcpy(d_hs, hs.data(), hs.size() * 8, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_bstart, bstart32.data(), bstart32.size() * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice));
-    HIP_OK(hipMemset(d_taken, 0, taken_u32 * 4));
+    if (taken_words.empty()) {
+        HIP_OK(hipMemset(d_taken, 0, taken_u32 * 4));
+    } else {  // the table an earlier piece of this search left
+        std::vector<uint32_t> t32(taken_u32, 0);
+        for (size_t i = 0; i < taken_u32 && i / 2 < taken_words.size(); ++i) t32[i] = (uint32_t)(taken_words[i / 2] >> (32 * (i & 1)));
+        for (uint64_t w : taken_words) ones_before += (uint64_t)__builtin_popcountll(w);
+        HIP_OK(hipMemcpy(d_taken, t32.data(), taken_u32 * 4, hipMemcpyHostToDevice));
+    }
     HIP_OK(hipMemset(d_owner, 0xFF, table_size * 4));
     HIP_OK(hipMemset(d_pilot, 0, pilot_by_order.size() * 8));
     HIP_OK(hipMemset(d_ready, 0, pilot_by_order.size()));
@@ -120,7 +128,7 @@ bool gpu_pilot_search(int device, const std::vector<uint64_t>& hs, const std::ve
     {
         uint64_t ones = 0;
         for (uint64_t w : taken_words) ones += (uint64_t)__builtin_popcountll(w);
-        if (ones != hs.size()) {
+        if (ones != ones_before + hs.size()) {
             err = "gpu pilot search: internal error (occupied slots != keys)";
             goto done;
         }

@@ -336,11 +336,13 @@ def test_cli_build_from_long_records_with_threads(tmp_path):
     assert out.read_bytes() == ref.read_bytes()
 
 
-@pytest.mark.parametrize("k,m,bits,kind", [(31, 20, 64, 0), (31, 15, 64, 1), (63, 20, 128, 0)])
+@pytest.mark.parametrize("k,m,bits,kind", [(31, 20, 64, 0), (31, 15, 64, 1), (63, 20, 128, 0), (21, 8, 64, 0), (33, 7, 128, 1)])
 def test_streamed_build_with_a_memory_limit_writes_the_same_file(tmp_path, k, m, bits, kind):
     """lphq_build_stream (the reference's two passes over the input + external_memory_vector, src/partitioned_mphf.cpp:58-130): whatever the batch
     boundaries and the memory limit -- no spill, a few sorted pieces, more than 64 pieces (merged on the way) -- the bytes are those of the in-memory
-    build (itself byte-identical to the oracle's builder), the statistics too, and the temporary files are gone."""
+    build (itself byte-identical to the oracle's builder), the statistics too, and the temporary files are gone.  With a limit every per-minimizer
+    vector lives in files too (distinct minimizers, their order under the MPHF, the super-k-mers of repeated minimizers -- most of them at m = 7, 8)
+    and both PTHash functions are built from sorted pieces of (bucket, hash) pairs, searched a piece at a time."""
     recs = dedup_records(random_records(99 + k, 60, max(k - 2, 1), 110_000), k)
     recs = recs[:7] + [b"", b"ACGT"] + recs[7:]  # empty and too-short records inside a batch and at batch boundaries
     want_path, got_path, spill = str(tmp_path / "mem.lph"), str(tmp_path / "str.lph"), tmp_path / "spill"
@@ -362,6 +364,8 @@ def test_streamed_build_with_a_memory_limit_writes_the_same_file(tmp_path, k, m,
     # > 64 pieces at the smallest limit: 32-byte records, pieces of max(4096, limit / 4 / 32) records
     if (k, m) == (31, 20):
         assert want_stats["num_super_kmers"] > 64 * max(4096, (1 << 18) // 4 // 32)
+    if m == 8:  # repeated minimizers: more of their super-k-mers than 64 pieces of 4096, more fallback k-mers than 64 pieces of (bucket, hash) pairs
+        assert want_stats["colliding_super_kmers"] > 64 * 4096 and want_stats["fallback_kmers"] > 64 * 4096
 
 
 def test_streamed_build_errors(tmp_path):
