@@ -226,11 +226,15 @@ int lphq_build_device(const char* const* records, const size_t* lengths, size_t 
  * sorted runs spilled to temporary files, merged by a heap).  `next` is called until it returns 0; every call that returns 1 hands over
  * one batch of WHOLE records (pointers valid until the following call).  The input is read twice: next(ctx, 0, ...) serves the first
  * pass, next(ctx, 1, ...) the second (the first call with pass = 1 restarts the input from its beginning).  < 0 from `next` aborts with
- * LPHQ_ERR_IO.  The sequence is never held whole: a batch at a time.  The super-k-mer records (32 B each, ~2 / (k - m + 2) per k-mer) are
- * sorted in pieces of at most max_memory_bytes / 4 and spilled to `tmp_dir` (created if absent; files lphash.tmp.<pid>.<n>.runs, removed
- * before returning); max_memory_bytes = 0: no limit, nothing is spilled.  What stays in memory regardless: 24 B per DISTINCT minimizer and the
- * PTHash construction over them (the reference keeps those in external memory as well; here they are bounded by the number of minimizers, not by
- * the input).  The bytes written are those of lphq_build on the same records, whatever the batch boundaries and the memory limit. */
+ * LPHQ_ERR_IO.  The sequence is never held whole: a batch at a time.  With max_memory_bytes != 0 everything whose size follows the input lives
+ * in `tmp_dir` (created if absent; files lphash.tmp.<pid>.*, removed before returning), as in the reference (src/partitioned_mphf.cpp:58-130):
+ * the super-k-mer records (32 B each, ~2 / (k - m + 2) per k-mer; sorted pieces of at most max_memory_bytes / 4, merged by a heap), the distinct
+ * minimizers, their order under the minimizer MPHF (sorted pieces again), the super-k-mers of repeated minimizers, and the (bucket, hash) pairs of
+ * both PTHash constructions (single_phf::build_in_external_memory: the merge of the sorted pieces files every bucket under its size, the pilot
+ * search -- on `device` or on the CPU -- reads those files from the largest size down, a piece at a time, with the table of taken positions carried
+ * over).  What stays in memory: one piece, the index under construction (its bit vectors, <= 2 B per distinct minimizer of sizes and positions),
+ * 8 B of pilot per PTHash bucket and the bitmaps of the two tables.  max_memory_bytes = 0: no limit, nothing touches the disk.  The bytes written
+ * are those of lphq_build on the same records, whatever the batch boundaries and the memory limit. */
 typedef int (*lphq_record_source)(void* ctx, int pass, const char* const** records, const size_t** lengths, size_t* n_records);
 int lphq_build_stream(lphq_record_source next, void* ctx, int k, int m, uint64_t mm_seed, double c, int kind, int kmer_bits, int threads,
                       int device /* < 0: CPU pilot search */, const char* tmp_dir /* NULL: "." */, uint64_t max_memory_bytes,

@@ -61,6 +61,20 @@ void parallel_for(size_t n_tasks, int threads, const std::function<void(size_t)>
     for (auto& th : pool) th.join();
 }
 
+inline double resident_mb(bool anonymous_only = true) {  // (verbose builds only: where the memory goes; a memory-mapped input counts as file pages)
+    double anon_kb = 0, file_kb = 0;
+    FILE* f = fopen("/proc/self/status", "r");
+    if (f) {
+        char line[256];
+        while (fgets(line, sizeof line, f)) {
+            if (!strncmp(line, "RssAnon:", 8)) anon_kb = atof(line + 8);
+            if (!strncmp(line, "RssFile:", 8)) file_kb = atof(line + 8);
+        }
+        fclose(f);
+    }
+    return (anonymous_only ? anon_kb : anon_kb + file_kb) / 1024.0;
+}
+
 inline uint64_t words_for(uint64_t bits) { return (bits + 63) / 64; }
 inline unsigned msb64(uint64_t x) { return 63u - (unsigned)__builtin_clzll(x); }
 
@@ -1228,7 +1242,7 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
     auto tprev = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         auto now = std::chrono::steady_clock::now();
-        if (verbose) fprintf(stderr, "[lphq_build] %-44s %8.3f s\n", what, std::chrono::duration<double>(now - tprev).count());
+        if (verbose) fprintf(stderr, "[lphq_build] %-44s %8.3f s   rss %6.0f MB anonymous, %6.0f MB with file pages\n", what, std::chrono::duration<double>(now - tprev).count(), resident_mb(), resident_mb(false));
         tprev = now;
     };
     const double alpha = 0.94;       // partitioned_mphf.cpp:48

@@ -732,7 +732,8 @@ int build_main(int kind, int argc, char** argv) {
         return 3;
     }
     // src/parser_build.cpp:74-86: -d creates the directory, --max-memory is capped at 255 (GB).  With a limit the input is streamed in
-    // batches and the super-k-mer records are sorted in pieces spilled to -d (lphq_build_stream, the reference's external_memory_vector);
+    // batches and every vector of the construction lives in sorted pieces under -d (lphq_build_stream: the reference's external_memory_vector
+    // and build_in_external_memory);
     // without one (the reference would assume 8 GB) the input is read whole and nothing touches the disk.  --max-memory-mb: the same in MB.
     const std::string tmp_dir = a.get("-d") ? *a.get("-d") : ".";  // constants::default_tmp_dirname
     if (a.get("-d")) (void)::mkdir(tmp_dir.c_str(), 0777);         // essentials::create_directory

@@ -1,7 +1,9 @@
 """One-off robustness run of index construction on the GPU (not part of the test suite): random (k, m, width, kind), random ragged record sets with
 empty / short records and non-ACGT bases, random batch splits and memory limits -- the files written with the super-k-mer extraction + sort (+ classification, for the
 in-memory call) and the pilot search on the GPU (lphq_build_stream and lphq_build_device, device 0) must equal, byte for byte, the one the host-only builder writes (itself byte-identical to the oracle's
-builder, tests/test_host_cpu.py).   gpurun --timeout 1200 -- python tests/gpu_build_fuzz.py [seconds]"""
+builder, tests/test_host_cpu.py).   gpurun --timeout 1200 -- python tests/gpu_build_fuzz.py [seconds]
+LPHQ_FUZZ_DEVICE=-1 runs the streamed half without a GPU (batch splits and memory limits -- every vector of the construction in sorted pieces on disk,
+both PTHash searches in pieces -- against the in-memory build on the host)."""
 import os
 import sys
 import tempfile
@@ -16,6 +18,7 @@ import lphash_amd as L  # noqa: E402
 from util import dedup_records, random_records  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+dev = int(os.environ.get("LPHQ_FUZZ_DEVICE", "0"))
 rng = np.random.default_rng(20261003)
 tmp = tempfile.mkdtemp()
 t_end = time.time() + budget
@@ -54,17 +57,19 @@ while time.time() < t_end:
         n_skipped += 1
         continue
     per_batch = int(rng.integers(1, len(recs) + 1))
-    limit = int(rng.choice([0, 0, 1 << 17, 1 << 20]))
+    limit = int(rng.choice([0, 0, 1 << 17, 1 << 20] if dev >= 0 else [1 << 12, 1 << 15, 1 << 17, 1 << 20]))
 
     def batches():
         for i in range(0, len(recs), per_batch):
             yield recs[i:i + per_batch]
 
-    sg = L.build_stream(batches, k, m, gpu, kind=kind, kmer_bits=bits, threads=8, device=0, tmp_dir=os.path.join(tmp, "spill"), max_memory_bytes=limit)
+    sg = L.build_stream(batches, k, m, gpu, kind=kind, kmer_bits=bits, threads=8, device=dev, tmp_dir=os.path.join(tmp, "spill"), max_memory_bytes=limit)
     assert sg == sh, (k, m, bits, kind, seed, shape, per_batch, limit, sg, sh)
     assert open(gpu, "rb").read() == open(host, "rb").read(), (k, m, bits, kind, seed, shape, per_batch, limit)
-    sm = L.build(recs, k, m, gpu, kind=kind, kmer_bits=bits, threads=8, device=0)  # one batch: classified on the device as well
-    assert sm == sh and open(gpu, "rb").read() == open(host, "rb").read(), ("in-memory", k, m, bits, kind, seed, shape)
+    assert os.listdir(os.path.join(tmp, "spill")) == [] if limit else True
+    if dev >= 0:
+        sm = L.build(recs, k, m, gpu, kind=kind, kmer_bits=bits, threads=8, device=dev)  # one batch: classified on the device as well
+        assert sm == sh and open(gpu, "rb").read() == open(host, "rb").read(), ("in-memory", k, m, bits, kind, seed, shape)
     n_cfg += 1
     n_kmers += sh["num_kmers"]
-print(f"gpu build fuzz ok: {n_cfg} random configurations ({n_skipped} skipped: unbuildable key sets), {n_kmers} k-mers, files identical to the host builder's, in {budget:.0f} s")
+print(f"{'gpu' if dev >= 0 else 'host (memory limits)'} build fuzz ok: {n_cfg} random configurations ({n_skipped} skipped: unbuildable key sets), {n_kmers} k-mers, files identical to the host builder's, in {budget:.0f} s")

@@ -538,7 +538,7 @@ def test_host_sources_under_sanitizers(tmp_path):
             for j in range(0, len(r), 70):
                 f.write(r[j:j + 70] + b"\n")
     env = dict(os.environ, UBSAN_OPTIONS="print_stacktrace=1", ASAN_OPTIONS="detect_leaks=1")
-    for k, m, kind, bits in ((31, 20, 0, 64), (63, 20, 0, 128), (31, 20, 1, 64)):
+    for k, m, kind, bits in ((31, 20, 0, 64), (63, 20, 0, 128), (31, 20, 1, 64), (21, 8, 0, 64)):  # (m = 8: most minimizers repeat)
         out = tmp_path / f"o_{k}_{kind}.lph"
         for threads in (1, 8):
             r = subprocess.run([exe, "build", str(fa), str(k), str(m), str(kind), str(bits), str(threads), str(out)], capture_output=True, text=True, env=env)
@@ -546,7 +546,7 @@ def test_host_sources_under_sanitizers(tmp_path):
         ref = tmp_path / "ref.lph"
         L.build(recs, k, m, str(ref), kind=kind, kmer_bits=bits, threads=2)
         assert out.read_bytes() == ref.read_bytes()
-        # the streamed builder: small batches, sorted pieces spilled and merged
+        # the streamed builder: small batches, every vector of the construction in sorted pieces, spilled and merged; both PTHash searches in pieces
         r = subprocess.run([exe, "build_stream", str(fa), str(k), str(m), str(kind), str(bits), "4", str(out), str(1 << 12), str(tmp_path / "spill")],
                            capture_output=True, text=True, env=env)
         assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
