@@ -768,6 +768,11 @@ struct CallbackSource : RecordSource {  // lphq_build_stream
 // (include/external_memory_vector.hpp:43-109: push_back -> sort_and_flush, const_iterator = heap over the files)
 // T = a trivially copyable record, Vec = the vector type the caller fills, Key()(record) = the 64-bit sort key
 // ---------------------------------------------------------------------------------------------
+inline std::string tmp_name(const std::string& dir, const std::string& kind) {  // unique within the process (several builds may share a directory)
+    static std::atomic<uint64_t> serial{0};
+    return dir + "/lphash.tmp." + std::to_string((long)getpid()) + "." + std::to_string(serial.fetch_add(1)) + "." + kind;
+}
+
 template <typename T, typename Vec, typename Key>
 struct Spill {
     std::string dir;
@@ -779,10 +784,7 @@ struct Spill {
         for (const std::string& f : files) ::remove(f.c_str());
         files.clear();
     }
-    std::string fresh_name() {
-        static std::atomic<uint64_t> serial{0};
-        return dir + "/lphash.tmp." + std::to_string((long)getpid()) + "." + std::to_string(serial.fetch_add(1)) + "." + kind;
-    }
+    std::string fresh_name() { return tmp_name(dir, kind); }
     struct Reader {
         FILE* f = nullptr;
         Vec buf;
@@ -1050,6 +1052,14 @@ class PhfExternalBuilder {
             return false;
         }
         if (n == 0) return true;
+        const bool verbose = getenv("LPHQ_BUILD_VERBOSE") != nullptr;
+        auto tprev = std::chrono::steady_clock::now();
+        auto lap = [&](const std::string& what) {
+            auto now = std::chrono::steady_clock::now();
+            if (verbose) fprintf(stderr, "[lphq_build]   pthash: %-50s %8.3f s\n", what.c_str(), std::chrono::duration<double>(now - tprev).count());
+            tprev = now;
+        };
+        const size_t n_pair_pieces = spill_.files.size() + (spill_.files.empty() ? 0 : 1);
         // 1. buckets, one after the other by id, into the file of their size
         std::vector<std::unique_ptr<RecordFile<uint64_t>>> by_size(kBig + 1);  // [s] for s < kBig: (id, s hashes)...; [kBig]: (size, id, hashes)...
         uint64_t max_size = 0;
@@ -1070,7 +1080,7 @@ class PhfExternalBuilder {
                 max_size = std::max(max_size, s);
                 if (!by_size[slot]) {
                     by_size[slot].reset(new RecordFile<uint64_t>());
-                    if (!by_size[slot]->create(dir_ + "/lphash.tmp." + std::to_string((long)getpid()) + "." + std::to_string(file_serial()) + ".size" + std::to_string(slot), 1 << 12)) {
+                    if (!by_size[slot]->create(tmp_name(dir_, "size" + std::to_string(slot)), 1 << 12)) {
                         err = "cannot create the temporary file " + by_size[slot]->path;
                         ok = false;
                         return;
@@ -1109,7 +1119,9 @@ class PhfExternalBuilder {
             BucketVec().swap(buf_);
             spill_.drop();
         }
+        lap(std::to_string(n_pair_pieces) + " sorted pieces of (bucket, hash) -> files by size");
         // 2. the search, a piece of the order at a time
+        uint64_t n_search_pieces = 0, n_on_gpu = 0;
         std::vector<uint64_t> pilots(num_buckets_, 0);
         std::vector<uint64_t> taken(words_for(f.table_size) + 1, 0);
         std::vector<uint64_t> hs, bstart(1, 0);
@@ -1127,8 +1139,10 @@ class PhfExternalBuilder {
                 std::vector<uint64_t> t = taken;  // (left as it was if the device fails half-way)
                 std::string gerr;
                 searched = gpu_pilot_search(device_, hs, bstart, order, nb, f.table_size, f.seed, local, t, gerr);
-                if (searched) taken.swap(t);
-                else {
+                if (searched) {
+                    taken.swap(t);
+                    ++n_on_gpu;
+                } else {
                     fprintf(stderr, "[lphq_build] WARNING: GPU pilot search failed (%s); falling back to the sequential CPU search\n", gerr.c_str());
                     std::fill(local.begin(), local.end(), 0);
                 }
@@ -1138,6 +1152,7 @@ class PhfExternalBuilder {
                 if (!cpu.run(f, hs.data(), bstart.data(), order.data(), nb, taken, local.data(), err)) return false;
             }
             for (uint64_t i = 0; i < nb; ++i) pilots[ids[i]] = local[i];
+            ++n_search_pieces;
             placed += hs.size();
             hs.clear();
             bstart.assign(1, 0);
@@ -1195,14 +1210,13 @@ class PhfExternalBuilder {
             err = "pthash build: internal error (keys searched != keys given)";
             return false;
         }
-        return phf_finalize(f, num_buckets_, pilots, taken, err);
+        lap("pilot search in " + std::to_string(n_search_pieces) + " pieces (" + std::to_string(n_on_gpu) + " on the GPU)");
+        const bool ok = phf_finalize(f, num_buckets_, pilots, taken, err);
+        lap("dictionary encode, free slots");
+        return ok;
     }
 
   private:
-    static uint64_t file_serial() {
-        static std::atomic<uint64_t> serial{0};
-        return serial.fetch_add(1);
-    }
     static bool io_error(const RecordFile<uint64_t>& f, std::string& err) {
         err = "read error on the temporary file " + f.path;
         return false;
@@ -1459,7 +1473,7 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
             if (!spill.flush(runs, threads, 2 * m, merge_buf, err, runs_sorted)) return fail(LPHQ_ERR_IO, err);
             RunVec().swap(runs);
             if (verbose) fprintf(stderr, "[lphq_build] %zu sorted pieces of super-k-mer records in %s\n", spill.files.size(), spill.dir.c_str());
-            if (!uniq_file.create(spill.dir + "/lphash.tmp." + std::to_string((long)getpid()) + ".minimizers", 1 << 14))
+            if (!uniq_file.create(tmp_name(spill.dir, "minimizers"), 1 << 14))
                 return fail(LPHQ_ERR_IO, "cannot create the temporary file " + uniq_file.path);
             Classifier c;
             bool wrote = true;
