@@ -715,8 +715,8 @@ void parallel_sort_by_key(Vec& v, int threads, uint32_t key_bits, KeyFn key) {
     v.swap(tmp);
 }
 
-struct Triplet {  // mm_triplet_t, include/constants.hpp:37-43 (itself is replaced by the minimizer order)
-    uint64_t itself;
+struct Triplet {  // what is left of mm_triplet_t (include/constants.hpp:37-43) once the minimizer itself has become a position: (p1, size), 0 / 0 for a
+                  // repeated minimizer; both at most k - m + 1 <= 63, so 0xFF / 0xFF marks a slot nothing was placed in yet
     uint8_t p1, size;
 };
 
@@ -1402,8 +1402,8 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
             void close_group() {
                 if (!have) return;
                 uniq_mm.push_back(prev.mm);
-                if (repeated) uniq.push_back({0, 0, 0});
-                else uniq.push_back({0, (uint8_t)(prev.q - prev.first), (uint8_t)prev.size});
+                if (repeated) uniq.push_back({0, 0});
+                else uniq.push_back({(uint8_t)(prev.q - prev.first), (uint8_t)prev.size});
                 have = false;
             }
             void feed(const Run& r) {
@@ -1427,7 +1427,7 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
             parallel_for((nu + 65535) / 65536, threads, [&](size_t t) {
                 for (size_t i = t * 65536, e = std::min(nu, i + 65536); i < e; ++i) {
                     const uint16_t ps = on_device.offset_size[i];
-                    uniq[i] = Triplet{0, (uint8_t)(ps & 0xFF), (uint8_t)(ps >> 8)};
+                    uniq[i] = Triplet{(uint8_t)(ps & 0xFF), (uint8_t)(ps >> 8)};
                 }
             });
             parallel_for((nc + 65535) / 65536, threads, [&](size_t t) {
@@ -1619,8 +1619,8 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
     std::vector<uint64_t> free_table;
     if (!x.minimizer_order.free_slots.decode(free_table, err)) return fail(LPHQ_ERR_FORMAT, err);
     if (!external) {
-        TripletVec by_order(D);  // zeroed below by all threads (itself == 0: not filled yet)
-        parallel_for((D + 65535) / 65536, threads, [&](size_t t) { memset((void*)(by_order.data() + t * 65536), 0, (std::min<size_t>(D, (t + 1) * 65536) - t * 65536) * sizeof(Triplet)); });
+        TripletVec by_order(D);  // 0xFF below by all threads: not filled yet
+        parallel_for((D + 65535) / 65536, threads, [&](size_t t) { memset((void*)(by_order.data() + t * 65536), 0xFF, (std::min<size_t>(D, (t + 1) * 65536) - t * 65536) * sizeof(Triplet)); });
         std::atomic<bool> bad{false};
         parallel_for((D + 65535) / 65536, threads, [&](size_t t) {
             for (size_t i = t * 65536, e = std::min<size_t>(D, i + 65536); i < e; ++i) {
@@ -1630,14 +1630,13 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
                     continue;
                 }
                 by_order[o] = uniq[i];
-                by_order[o].itself = 1;  // mark filled
             }
         });
         if (bad.load()) return fail(LPHQ_ERR_FORMAT, "internal: minimizer MPHF out of range");
         std::atomic<bool> hole{false};
         parallel_for((D + 65535) / 65536, threads, [&](size_t t) {
             for (size_t i = t * 65536, e = std::min<size_t>(D, i + 65536); i < e; ++i)
-                if (by_order[i].itself != 1) hole.store(true);
+                if (by_order[i].size == 0xFF) hole.store(true);
         });
         if (hole.load()) return fail(LPHQ_ERR_FORMAT, "internal: minimizer MPHF is not a bijection");
         TripletVec().swap(uniq);
@@ -1680,7 +1679,7 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
         while (mg.next(r)) {
             if (r.order != seen) return fail(LPHQ_ERR_FORMAT, "internal: minimizer MPHF is not a bijection");
             ++seen;
-            stretch.push_back(Triplet{1, r.p1, r.size});
+            stretch.push_back(Triplet{r.p1, r.size});
             if (stretch.size() == stretch_cap) {
                 index_stretch(first, stretch.data(), stretch.size());
                 first += stretch.size();

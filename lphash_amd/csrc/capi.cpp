@@ -36,6 +36,7 @@ struct Scratch {
     uint64_t* d_out = nullptr;
     size_t d_out_cap = 0;
     uint64_t* d_offs = nullptr;  // 4 record offsets + 1 counter
+    uint64_t* h_pin = nullptr;   // pinned: the five words above on their way to the device, then the counter on its way back ([5])
 };
 struct lphq_index {
     lphq_image_header hdr;
@@ -221,6 +222,7 @@ static void scratch_destroy(Scratch* s) {
     if (s->d_seq) (void)hipFree(s->d_seq);
     if (s->d_out) (void)hipFree(s->d_out);
     if (s->d_offs) (void)hipFree(s->d_offs);
+    if (s->h_pin) (void)hipHostFree(s->h_pin);
     delete s;
 }
 
@@ -268,6 +270,7 @@ static Scratch* scratch_acquire(lphq_index* idx, int device) {
     s->device = device;
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_offs, 8 * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_pin, 8 * sizeof(uint64_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         (void)fail_hip(e, "scratch slot");
         scratch_destroy(s);
@@ -659,17 +662,22 @@ extern "C" int lphq_query_contig(const lphq_index* cidx, const char* contig, siz
         HIP_TRY(hipMalloc((void**)&sc->d_out, want * 8));
         sc->d_out_cap = want;
     }
-    // the slot's own stream: callers on other threads run concurrently (the copies from / to pageable memory are staged by the
-    // runtime; pinned caller buffers make them truly asynchronous)
-    const uint64_t offs[4] = {0, (uint64_t)length, 0, (uint64_t)nwin};
+    // The slot's own stream: callers on other threads run concurrently (the copies from / to pageable memory are staged by the
+    // runtime; pinned caller buffers make them truly asynchronous).  One wait per call: the offsets travel from the slot's pinned
+    // words, and whether the record holds a non-ACGT base at all is counted on the device behind the lookup kernel.
+    uint64_t* hp = sc->h_pin;
+    hp[0] = 0, hp[1] = (uint64_t)length, hp[2] = 0, hp[3] = (uint64_t)nwin, hp[4] = 0, hp[5] = 0;
     HIP_TRY(hipMemcpyAsync(sc->d_seq, contig, length, hipMemcpyHostToDevice, sc->stream));
-    HIP_TRY(hipMemcpyAsync(sc->d_offs, offs, sizeof offs, hipMemcpyHostToDevice, sc->stream));
-    HIP_TRY(hipStreamSynchronize(sc->stream));  // `offs` lives on this stack frame
+    HIP_TRY(hipMemcpyAsync(sc->d_offs, hp, 5 * sizeof(uint64_t), hipMemcpyHostToDevice, sc->stream));
     HIP_TRY(launch_query_records(idx->hdr, r->d_image, sc->d_seq, length, sc->d_offs, sc->d_offs + 2, 1, sc->d_out, streaming, sc->stream));
+    if (streaming) {
+        HIP_TRY(launch_count_bad_bases(sc->d_seq, length, (unsigned long long*)(sc->d_offs + 4), sc->stream));
+        HIP_TRY(hipMemcpyAsync(hp + 5, sc->d_offs + 4, sizeof(uint64_t), hipMemcpyDeviceToHost, sc->stream));
+    }
     HIP_TRY(hipMemcpyAsync(out, sc->d_out, nwin * 8, hipMemcpyDeviceToHost, sc->stream));
     HIP_TRY(hipStreamSynchronize(sc->stream));
     size_t n = nwin;
-    if (streaming) {
+    if (streaming && hp[5] != 0) {
         // Drop windows holding a non-ACGT base (the reference emits nothing for them).  Validity is taken from the input, not
         // from the LPHQ_INVALID sentinel: a non-member k-mer's wrapped arithmetic may legitimately produce 2^64-1.
         auto valid_base = [](unsigned char ch) {
@@ -679,16 +687,12 @@ extern "C" int lphq_query_contig(const lphq_index* cidx, const char* contig, siz
             }
         };
         size_t last_bad = (size_t)-1;  // position of the last invalid base seen
-        bool any_bad = false;
-        for (size_t i = 0; i < length && !any_bad; ++i) any_bad = !valid_base((unsigned char)contig[i]);
-        if (any_bad) {
-            n = 0;
-            for (size_t i = 0; i < length; ++i) {
-                if (!valid_base((unsigned char)contig[i])) last_bad = i;
-                if (i + 1 >= k) {  // window ending at base i starts at i + 1 - k
-                    const size_t w = i + 1 - k;
-                    if (last_bad == (size_t)-1 || last_bad < w) out[n++] = out[w];
-                }
+        n = 0;
+        for (size_t i = 0; i < length; ++i) {
+            if (!valid_base((unsigned char)contig[i])) last_bad = i;
+            if (i + 1 >= k) {  // window ending at base i starts at i + 1 - k
+                const size_t w = i + 1 - k;
+                if (last_bad == (size_t)-1 || last_bad < w) out[n++] = out[w];
             }
         }
     }

@@ -368,6 +368,38 @@ def test_streamed_build_with_a_memory_limit_writes_the_same_file(tmp_path, k, m,
         assert want_stats["colliding_super_kmers"] > 64 * 4096 and want_stats["fallback_kmers"] > 64 * 4096
 
 
+def test_concurrent_builds_share_a_temporary_directory(tmp_path):
+    """Several builds with a memory limit at once in one process and one temporary directory (the names of the temporary files carry a process-wide serial):
+    each writes the file of the in-memory build, and the directory is empty afterwards."""
+    import threading
+
+    jobs = [(31, 20, 64, 0, 11), (21, 8, 64, 0, 12), (31, 15, 64, 1, 13), (31, 20, 64, 0, 14)]
+    inputs = {j: dedup_records(random_records(j[4], 25, j[0], 60_000), j[0]) for j in jobs}
+    want = {}
+    for j in jobs:
+        k, m, bits, kind, _ = j
+        L.build(inputs[j], k, m, str(tmp_path / "want.lph"), kind=kind, kmer_bits=bits, threads=2)
+        want[j] = (tmp_path / "want.lph").read_bytes()
+    spill, errors = tmp_path / "shared", []
+
+    def work(j, i):
+        k, m, bits, kind, _ = j
+        try:
+            out = str(tmp_path / f"got{i}.lph")
+            L.build_stream(lambda: iter([inputs[j][:9], inputs[j][9:]]), k, m, out, kind=kind, kmer_bits=bits, threads=2, tmp_dir=str(spill), max_memory_bytes=1 << 16)
+            if open(out, "rb").read() != want[j]:
+                errors.append((j, "different file"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((j, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(j, i)) for i, j in enumerate(jobs)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert errors == [] and os.listdir(spill) == []
+
+
 def test_streamed_build_errors(tmp_path):
     recs = dedup_records(random_records(5, 12, 200, 4000), 31)
     out = str(tmp_path / "x.lph")
