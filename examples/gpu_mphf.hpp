@@ -7,7 +7,7 @@
 // and, in query<MPHF>() (src/query.cpp:37), essentials::load(hf, name) -> hf.load(name).  examples/query_main.cpp is that driver,
 // restated, so that the binding is built and run by this repository's tests (tests/test_zz_gpu_next.py::test_integration_stub_*).
 //
-// Two ways to ask: operator()(contig, length, streaming) is the reference's call, one record at a time (two copies and two waits per record:
+// Two ways to ask: operator()(contig, length, streaming) is the reference's call, one record at a time (copies in and out and a wait per record:
 // faithful, and ~200x below what the device does); submit() / collect() take MANY records per call and keep batches in flight
 // (lphq_session_*): that is the one a driver should loop over -- examples/query_main.cpp does, and keeps the literal loop as --per-record.
 //

@@ -165,7 +165,7 @@ int lphq_query_contig(const lphq_index* idx, const char* contig, size_t length, 
                       uint64_t* out, size_t cap, size_t* n_out);
 
 /* ---- batched host-buffer queries: MPHF::operator() over MANY records per call, pipelined (ABI 3) ----
- * lphq_query_contig pays two synchronous copies and two stream synchronisations per record; a driver that loops over records like
+ * lphq_query_contig pays its copies and one stream synchronisation per record; a driver that loops over records like
  * src/query.cpp:48-59 gets 0.5-1 G k-mers/s from it.  A session keeps `depth` batches in flight on one stream of one device: submit copies the
  * records of a batch to the device (one asynchronous copy per run of records that are adjacent in memory -- a batch parsed into one arena is one
  * copy), runs the kernel and copies the codes into pinned host memory owned by the session, all without waiting; collect waits for the OLDEST
