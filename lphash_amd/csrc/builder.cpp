@@ -749,7 +749,8 @@ typedef std::vector<BucketRec, DefaultInitAllocator<BucketRec>> BucketVec;
 
 class PhfExternalBuilder {
   public:
-    static constexpr uint64_t kBig = 256;  // buckets of at least this many keys (unheard of for hashed keys) share one file, sorted in memory
+    uint64_t kBig = 256;  // buckets of at least this many keys (unheard of for hashed keys) share one file, sorted in memory
+                          // (LPHQ_EXT_BIG_BUCKET lowers the threshold: a test hook, the result does not depend on it)
     bool begin(SinglePhf& f, uint64_t n, uint64_t seed, double c, double alpha, const std::string& dir, uint64_t budget_bytes, int threads, int device,
                std::string& err) {
         f_ = &f;
@@ -759,6 +760,7 @@ class PhfExternalBuilder {
         if (!phf_setup(f, n, seed, c, alpha, num_buckets_, err)) return false;
         spill_.dir = dir;
         spill_.kind = "buckets";
+        if (const char* e = getenv("LPHQ_EXT_BIG_BUCKET")) kBig = std::max<uint64_t>(2, std::min<uint64_t>(256, strtoull(e, nullptr, 10)));
         cap_ = std::max<size_t>(4096, (size_t)(budget_bytes / 4 / sizeof(BucketRec)));
         merge_buf_ = std::max<size_t>(256, std::min<size_t>(1 << 16, cap_ / (2 * Spill<BucketRec, BucketVec, BucketKey>::kMaxPieces)));
         piece_keys_ = std::max<size_t>(4096, (size_t)(budget_bytes / 4 / 8));

@@ -364,6 +364,13 @@ def test_streamed_build_with_a_memory_limit_writes_the_same_file(tmp_path, k, m,
     # > 64 pieces at the smallest limit: 32-byte records, pieces of max(4096, limit / 4 / 32) records
     if (k, m) == (31, 20):
         assert want_stats["num_super_kmers"] > 64 * max(4096, (1 << 18) // 4 // 32)
+    if (k, m) in ((31, 20), (21, 8)):  # buckets of "unheard-of" size share one file and are ordered in memory: the threshold lowered to 3 keys puts most buckets there
+        os.environ["LPHQ_EXT_BIG_BUCKET"] = "3"
+        try:
+            stats = L.build_stream(lambda: iter([recs]), k, m, got_path, kind=kind, kmer_bits=bits, threads=4, tmp_dir=str(spill), max_memory_bytes=1 << 19)
+        finally:
+            del os.environ["LPHQ_EXT_BIG_BUCKET"]
+        assert open(got_path, "rb").read() == want and stats == want_stats and os.listdir(spill) == []
     if m == 8:  # repeated minimizers: more of their super-k-mers than 64 pieces of 4096, more fallback k-mers than 64 pieces of (bucket, hash) pairs
         assert want_stats["colliding_super_kmers"] > 64 * 4096 and want_stats["fallback_kmers"] > 64 * 4096
 
