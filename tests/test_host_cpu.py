@@ -407,6 +407,41 @@ def test_concurrent_builds_share_a_temporary_directory(tmp_path):
     assert errors == [] and os.listdir(spill) == []
 
 
+def test_build_with_a_memory_limit_when_the_disk_refuses_writes(tmp_path):
+    """A full disk in the middle of a construction in external memory (RLIMIT_FSIZE in a child process: every write past the limit fails): whichever
+    temporary file is hit first -- sorted pieces of super-k-mer records, the file of distinct minimizers, the (bucket, hash) pairs, the files by
+    bucket size, the order pieces -- the CLI reports the file and exits non-zero, nothing is left in the temporary directory; with room enough the
+    file is the in-memory one."""
+    import resource
+    import signal
+
+    exe = os.path.join(ROOT, "lphash_amd", "lphash")
+    recs = dedup_records(random_records(777, 30, 50_000, 120_000), 31)
+    fa = tmp_path / "in.fa"
+    with open(fa, "wb") as f:
+        for i, r in enumerate(recs):
+            f.write(b">c%d\n" % i + r + b"\n")
+    want = tmp_path / "want.lph"
+    r0 = subprocess.run([exe, "build-p", "-i", str(fa), "-k", "31", "-m", "20", "-o", str(want), "--cpu", "-t", "4"], capture_output=True, text=True)
+    assert r0.returncode == 0, r0.stderr
+    failed = set()
+    for limit_kb in (64, 200, 700, 1500, 3000, 6000, 1 << 20):
+        def pre():
+            signal.signal(signal.SIGXFSZ, signal.SIG_IGN)
+            resource.setrlimit(resource.RLIMIT_FSIZE, (limit_kb << 10, limit_kb << 10))
+
+        d, out = tmp_path / f"ext{limit_kb}", tmp_path / f"got{limit_kb}.lph"
+        r = subprocess.run([exe, "build-p", "-i", str(fa), "-k", "31", "-m", "20", "-o", str(out), "--cpu", "-t", "4", "-d", str(d), "--max-memory-mb", "2"],
+                           capture_output=True, text=True, preexec_fn=pre)
+        assert os.listdir(d) == [], (limit_kb, os.listdir(d))
+        if r.returncode == 0:
+            assert out.read_bytes() == want.read_bytes(), limit_kb
+        else:
+            assert "temporary file" in r.stderr or "short write" in r.stderr or "cannot write" in r.stderr, (limit_kb, r.stderr[-500:])
+            failed.add(r.stderr.strip().rsplit(".", 1)[-1] if "temporary file" in r.stderr else "output")
+    assert len(failed) >= 2 and r.returncode == 0, failed  # more than one kind of file was the first to be refused; the last run had room
+
+
 def test_streamed_build_errors(tmp_path):
     recs = dedup_records(random_records(5, 12, 200, 4000), 31)
     out = str(tmp_path / "x.lph")
