@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -239,13 +240,24 @@ extern "C" void lphq_close(lphq_index* idx) {
 }
 
 // the replica queries of the calling thread run on: its current HIP device if the index is attached there, else the primary
+// LPHQ_TEST_SELF_PEER (a test hook for boxes with one GPU): a device may be attached twice -- the second replica is made by the peer-copy path of
+// lphq_attach_devices, from the first, on the same device -- and queries use the LAST replica of the current device, i.e. the copy.
+static bool self_peer_hook() {
+    static const bool on = getenv("LPHQ_TEST_SELF_PEER") != nullptr;
+    return on;
+}
 static const Replica* pick_replica(const lphq_index* idx) {
     if (idx->reps.empty()) return nullptr;
     if (idx->reps.size() > 1) {
         int cur = -1;
-        if (hipGetDevice(&cur) == hipSuccess)
+        if (hipGetDevice(&cur) == hipSuccess) {
+            if (self_peer_hook()) {
+                for (size_t i = idx->reps.size(); i-- > 0;)
+                    if (idx->reps[i].device == cur) return &idx->reps[i];
+            }
             for (const Replica& r : idx->reps)
                 if (r.device == cur) return &r;
+        }
     }
     return &idx->reps[0];
 }
@@ -404,8 +416,9 @@ static int check_device(int device) {
 // the primary replica (xGMI between GPUs of one node; the runtime stages through the host when peer access is unavailable).
 // With `stream` the peer copy is only queued there (lphq_attach_devices runs the copies to all devices concurrently and waits once).
 static int add_replica(lphq_index* idx, int device, hipStream_t* queued_on = nullptr) {
-    for (const Replica& r : idx->reps)
-        if (r.device == device) return LPHQ_OK;
+    if (!(self_peer_hook() && queued_on && idx->reps.size() == 1))
+        for (const Replica& r : idx->reps)
+            if (r.device == device) return LPHQ_OK;
     if (idx->reps.empty() && idx->image.empty()) return fail(LPHQ_ERR_STATE, "no host image to upload");
     int rc = check_device(device);
     if (rc) return rc;

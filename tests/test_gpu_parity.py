@@ -388,6 +388,54 @@ def test_cli_many_batches_keep_record_order(tmp_path):
         assert np.array_equal(np.fromfile(sink, dtype=np.uint64), want)
 
 
+def test_peer_copied_replica_answers_like_the_uploaded_one(tmp_path):
+    """The replica path of lphq_attach_devices on a box with ONE GPU (LPHQ_TEST_SELF_PEER, read once per process: hence the child): the device is
+    attached twice, the second replica is a peer copy of the first (hipMemcpyPeerAsync on a stream of the destination, waited for at the end of the
+    call) and every query of the process is answered from that copy -- records, packed k-mers, one-record calls and a session, against the oracle."""
+    import subprocess
+    import sys
+
+    torch_dev()
+    script = r"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import lphash_amd as L, orc
+from util import random_records, dedup_records, pack_kmers
+k, m = 31, 20
+recs = dedup_records(random_records(4711, 20, 500, 20000), k)
+path = os.path.join(sys.argv[2], "t.lph")
+L.build(recs, k, m, path, kmer_bits=64, threads=4)
+h = L.Mphf.load(path, kmer_bits=64)
+h.attach_devices([0, 0])
+info = h.replica_info()
+assert [d for d, _ in info] == [0, 0] and info[0][1] == 0 and info[1][1] in (1, 2), info
+o = orc.Index(path, 0, 64)
+dev = torch.device("cuda:0")
+want = [np.asarray(o(r, True), dtype=np.uint64) for r in recs]
+for r, w in zip(recs[:6], want):
+    assert np.array_equal(np.asarray(h(r, streaming=True), dtype=np.uint64), w) and np.array_equal(np.asarray(h(r, streaming=False), dtype=np.uint64), w)
+flat = np.frombuffer(b"".join(recs), dtype=np.uint8)
+lens = np.array([len(r) for r in recs], dtype=np.int64)
+so, oo = np.concatenate([[0], np.cumsum(lens)]), np.concatenate([[0], np.cumsum(lens - k + 1)])
+d_seq, d_so, d_oo = torch.from_numpy(flat.copy()).to(dev), torch.from_numpy(so).to(dev), torch.from_numpy(oo).to(dev)
+for streaming in (True, False):
+    d_out = torch.zeros(int(oo[-1]), dtype=torch.int64, device=dev)
+    h.query_records(d_seq.data_ptr(), len(flat), d_so.data_ptr(), len(recs), d_out.data_ptr(), d_oo.data_ptr(), streaming)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint64), np.concatenate(want)), streaming
+s = h.session(depth=2)
+s.submit(recs, streaming=True)
+got = s.collect()
+s.close()
+assert len(got) == len(want) and all(np.array_equal(np.asarray(g, dtype=np.uint64), w) for g, w in zip(got, want))
+print("replica ok", info)
+"""
+    env = dict(os.environ, LPHQ_TEST_SELF_PEER="1")
+    r = subprocess.run([sys.executable, "-c", script, ROOT, str(tmp_path)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "replica ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
 def test_cli_eight_workers_ragged_and_idle_shards(tmp_path):
     """`--devices 0,0,0,0,0,0,0,0`: the sharding `lphash query-* --gpus 8` does on an 8-GPU node, with eight workers on the one GPU here.  Ragged
     records (many shorter than k, so some shards hold bases but no k-mer) and files with fewer records than workers (idle shards): codes and
