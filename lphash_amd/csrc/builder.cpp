@@ -749,7 +749,7 @@ typedef std::vector<BucketRec, DefaultInitAllocator<BucketRec>> BucketVec;
 
 class PhfExternalBuilder {
   public:
-    uint64_t kBig = 256;  // buckets of at least this many keys (unheard of for hashed keys) share one file, sorted in memory
+    uint64_t big_bucket_ = 256;  // buckets of at least this many keys (unheard of for hashed keys) share one file, sorted in memory
                           // (LPHQ_EXT_BIG_BUCKET lowers the threshold: a test hook, the result does not depend on it)
     bool begin(SinglePhf& f, uint64_t n, uint64_t seed, double c, double alpha, const std::string& dir, uint64_t budget_bytes, int threads, int device,
                std::string& err) {
@@ -760,7 +760,7 @@ class PhfExternalBuilder {
         if (!phf_setup(f, n, seed, c, alpha, num_buckets_, err)) return false;
         spill_.dir = dir;
         spill_.kind = "buckets";
-        if (const char* e = getenv("LPHQ_EXT_BIG_BUCKET")) kBig = std::max<uint64_t>(2, std::min<uint64_t>(256, strtoull(e, nullptr, 10)));
+        if (const char* e = getenv("LPHQ_EXT_BIG_BUCKET")) big_bucket_ = std::max<uint64_t>(2, std::min<uint64_t>(256, strtoull(e, nullptr, 10)));
         cap_ = std::max<size_t>(4096, (size_t)(budget_bytes / 4 / sizeof(BucketRec)));
         merge_buf_ = std::max<size_t>(256, std::min<size_t>(1 << 16, cap_ / (2 * Spill<BucketRec, BucketVec, BucketKey>::kMaxPieces)));
         piece_keys_ = std::max<size_t>(4096, (size_t)(budget_bytes / 4 / 8));
@@ -792,7 +792,7 @@ class PhfExternalBuilder {
         };
         const size_t n_pair_pieces = spill_.files.size() + (spill_.files.empty() ? 0 : 1);
         // 1. buckets, one after the other by id, into the file of their size
-        std::vector<std::unique_ptr<RecordFile<uint64_t>>> by_size(kBig + 1);  // [s] for s < kBig: (id, s hashes)...; [kBig]: (size, id, hashes)...
+        std::vector<std::unique_ptr<RecordFile<uint64_t>>> by_size(big_bucket_ + 1);  // [s] for s < big_bucket_: (id, s hashes)...; [big_bucket_]: (size, id, hashes)...
         uint64_t max_size = 0;
         {
             std::vector<uint64_t> keys;
@@ -807,7 +807,7 @@ class PhfExternalBuilder {
                         ok = false;
                         return;
                     }
-                const uint64_t s = keys.size(), slot = std::min<uint64_t>(s, kBig);
+                const uint64_t s = keys.size(), slot = std::min<uint64_t>(s, big_bucket_);
                 max_size = std::max(max_size, s);
                 if (!by_size[slot]) {
                     by_size[slot].reset(new RecordFile<uint64_t>());
@@ -819,7 +819,7 @@ class PhfExternalBuilder {
                 }
                 RecordFile<uint64_t>& out = *by_size[slot];
                 bool w = true;
-                if (slot == kBig) w = out.put(s);
+                if (slot == big_bucket_) w = out.put(s);
                 w = w && out.put(cur);
                 for (uint64_t h : keys) w = w && out.put(h);
                 if (!w) {
@@ -897,8 +897,8 @@ class PhfExternalBuilder {
             bstart.push_back(hs.size());
             return true;
         };
-        if (by_size[kBig]) {  // (size, id, hashes) records: all in memory, by non-increasing size then id
-            RecordFile<uint64_t>& in = *by_size[kBig];
+        if (by_size[big_bucket_]) {  // (size, id, hashes) records: all in memory, by non-increasing size then id
+            RecordFile<uint64_t>& in = *by_size[big_bucket_];
             if (!in.rewind_for_reading()) return io_error(in, err);
             struct Big {
                 uint64_t size, id;
@@ -919,10 +919,10 @@ class PhfExternalBuilder {
             std::sort(big.begin(), big.end(), [](const Big& a, const Big& b) { return a.size != b.size ? a.size > b.size : a.id < b.id; });
             for (const Big& b : big)
                 if (!add_bucket((uint32_t)b.id, b.keys.data(), b.size)) return false;
-            by_size[kBig].reset();
+            by_size[big_bucket_].reset();
         }
         std::vector<uint64_t> keys;
-        for (uint64_t s = std::min<uint64_t>(max_size, kBig - 1); s >= 1; --s) {
+        for (uint64_t s = std::min<uint64_t>(max_size, big_bucket_ - 1); s >= 1; --s) {
             if (!by_size[s]) continue;
             RecordFile<uint64_t>& in = *by_size[s];
             if (!in.rewind_for_reading()) return io_error(in, err);
