@@ -298,6 +298,13 @@ class Session:
             lib.lphq_session_close(self._s)
             self._s = C.c_void_p()
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def __del__(self):
         try:
             self.close()

@@ -590,5 +590,8 @@ def test_session_batches_match_oracle(name):
                 s.submit(batches[nxt], streaming)
         assert done == len(batches)
         s.close()
+    with h.session(depth=1) as s:  # (a context manager too)
+        s.submit(batches[0], True)
+        assert len(s.collect()) == len(batches[0])
     assert h.replica_info() == [(0, 0)]
     h.close()
