@@ -246,11 +246,22 @@ void rs_build(RsBitVector& r, int threads = 1) {
 // ---------------------------------------------------------------------------------------------
 // essentials::saver
 // ---------------------------------------------------------------------------------------------
-struct Writer {
-    std::vector<uint8_t> buf;
+struct Writer {  // straight to the file: no second copy of the index in memory
+    FILE* f = nullptr;
+    uint64_t bytes = 0;
+    bool ok = true;
+    ~Writer() {
+        if (f) fclose(f);
+    }
+    bool open(const char* path) { return (f = fopen(path, "wb")) != nullptr; }
+    bool close() {  // true: every byte went out
+        if (f && fclose(f) != 0) ok = false;
+        f = nullptr;
+        return ok;
+    }
     void raw(const void* p, size_t n) {
-        const uint8_t* b = (const uint8_t*)p;
-        buf.insert(buf.end(), b, b + n);
+        if (n && fwrite(p, 1, n, f) != n) ok = false;
+        bytes += n;
     }
     void u64(uint64_t v) { raw(&v, 8); }
     template <typename T>
@@ -1565,6 +1576,7 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
     lap("part 4: fallback MPHF");
     // ---- essentials::save ----------------------------------------------------------------------------
     Writer w;
+    if (!w.open(out_path)) return fail(LPHQ_ERR_IO, std::string("cannot write ") + out_path);
     w.raw(&x.k, 1);
     w.raw(&x.m, 1);
     w.u64(x.mm_seed);
@@ -1588,11 +1600,10 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
         w.put(x.sizes);
         w.put(x.fallback_kmer_order);
     }
-    FILE* fo = fopen(out_path, "wb");
-    if (!fo) return fail(LPHQ_ERR_IO, std::string("cannot write ") + out_path);
-    size_t put = fwrite(w.buf.data(), 1, w.buf.size(), fo);
-    fclose(fo);
-    if (put != w.buf.size()) return fail(LPHQ_ERR_IO, std::string("short write on ") + out_path);
+    if (!w.close()) {
+        ::remove(out_path);  // (not a file a loader should ever meet)
+        return fail(LPHQ_ERR_IO, std::string("short write on ") + out_path);
+    }
     lap("save");
     if (stats) {
         stats->num_kmers = nkmers;
@@ -1601,7 +1612,7 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
         stats->distinct_minimizers = D;
         stats->colliding_super_kmers = n_colliding;
         stats->fallback_kmers = x.fallback_kmer_order.num_keys;
-        stats->file_bytes = w.buf.size();
+        stats->file_bytes = w.bytes;
     }
     return LPHQ_OK;
 }
@@ -1678,17 +1689,17 @@ extern "C" int lphq_build_pthash(const char* const* records, const size_t* lengt
     std::string err;
     if (!phf_build(f, seconds, seed, c, 0.94, threads, device, err, &firsts)) return fail(LPHQ_ERR_FORMAT, err);
     Writer w;
+    if (!w.open(out_path)) return fail(LPHQ_ERR_IO, std::string("cannot write ") + out_path);
     w.put(f);
-    FILE* fo = fopen(out_path, "wb");
-    if (!fo) return fail(LPHQ_ERR_IO, std::string("cannot write ") + out_path);
-    const size_t put = fwrite(w.buf.data(), 1, w.buf.size(), fo);
-    fclose(fo);
-    if (put != w.buf.size()) return fail(LPHQ_ERR_IO, std::string("short write on ") + out_path);
+    if (!w.close()) {
+        ::remove(out_path);  // (not a file a loader should ever meet)
+        return fail(LPHQ_ERR_IO, std::string("short write on ") + out_path);
+    }
     if (stats) {
         memset(stats, 0, sizeof *stats);
         stats->num_kmers = n;
         stats->num_records = n_records;
-        stats->file_bytes = w.buf.size();
+        stats->file_bytes = w.bytes;
     }
     return LPHQ_OK;
 }
