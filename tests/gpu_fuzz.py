@@ -1,6 +1,6 @@
 """One-off robustness run on the GPU (not part of the test suite: minutes of oracle time): random (k, m, width, kind) configurations, random record
-batches with ragged lengths, empty records, non-ACGT bases and every pointer alignment, through lphq_query_records (streaming and random), lphq_query_packed
-and lphq_query_contig -- every code compared with the CPU oracle.   gpurun --timeout 1500 -- python tests/gpu_fuzz.py [seconds]"""
+batches with ragged lengths, empty records, non-ACGT bases and every pointer alignment, through lphq_query_records (streaming and random), lphq_query_packed,
+lphq_query_contig and lphq_session_* -- every code compared with the CPU oracle.   gpurun --timeout 1500 -- python tests/gpu_fuzz.py [seconds]"""
 import os
 import sys
 import tempfile
@@ -81,10 +81,26 @@ while time.time() < t_end:
             elif streaming:
                 exp = o(r, False)  # random-mode codes of the windows; streaming emits them for fully valid windows only
                 assert np.array_equal(got[valid], exp[valid]) and (got[~valid] == np.uint64(2**64 - 1)).all(), (k, m, bits, kind, streaming, i)
-                assert np.array_equal(h(r, streaming=True), o(r, True)[: valid.sum()]) or bad.any()
+                assert np.array_equal(h(r, streaming=True), exp[valid]), (k, m, bits, kind, "contig", i)  # one-record call: codes of the fully valid windows
             else:
                 assert np.array_equal(got, o(r, False)), (k, m, bits, kind, streaming, i)
             n_codes += len(got)
+    if kind != 2:  # the same batch through a session (ABI 3), two halves in flight: per record what the one-record call returns
+        half = len(batch) // 2
+        for streaming in (True, False):
+            with h.session(depth=2) as ses:
+                ses.submit(batch[:half], streaming)
+                ses.submit(batch[half:], streaming)
+                got = ses.collect() + ses.collect()
+            assert len(got) == len(batch)
+            for i, r in enumerate(batch):
+                exp = o(r, False) if len(r) >= k else np.zeros(0, dtype=np.uint64)
+                if streaming and len(r) >= k:
+                    bad = np.array([c not in b"ACGTUacgtu" for c in r])
+                    cs = np.concatenate([[0], np.cumsum(bad)])
+                    exp = exp[(cs[k:] - cs[:-k]) == 0]
+                assert np.array_equal(got[i], exp), (k, m, bits, kind, "session", streaming, i)
+                n_codes += len(exp)
     seq = b"".join(recs)[:5000]
     if len(seq) >= k:
         pos = np.arange(0, len(seq) - k + 1, dtype=np.int64)
