@@ -444,6 +444,23 @@ def test_build_with_a_memory_limit_when_the_disk_refuses_writes(tmp_path):
     assert len(failed) >= 2 and r.returncode == 0, failed  # more than one kind of file was the first to be refused; the last run had room
 
 
+def test_every_environment_hook_is_documented():
+    """Every LPHQ_* variable the product reads (getenv in lphash_amd/csrc, os.environ in the Python mirror) has its line in INTEGRATION.md section 5."""
+    import re
+
+    names = set()
+    csrc = os.path.join(ROOT, "lphash_amd", "csrc")
+    for root, _, files in os.walk(csrc):
+        for f in files:
+            if f.endswith((".cpp", ".hpp", ".hip", ".cuh", ".h")):
+                names |= set(re.findall(r'getenv\("(LPHQ_[A-Z0-9_]+)"\)', open(os.path.join(root, f), errors="replace").read()))
+    for f in os.listdir(os.path.join(ROOT, "lphash_amd")):
+        if f.endswith(".py"):
+            names |= set(re.findall(r'environ(?:\.get)?[\[(]"(LPHQ_[A-Z0-9_]+)"', open(os.path.join(ROOT, "lphash_amd", f)).read()))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert len(names) >= 15 and [n for n in sorted(names) if f"`{n}`" not in doc] == []
+
+
 def test_streamed_build_errors(tmp_path):
     recs = dedup_records(random_records(5, 12, 200, 4000), 31)
     out = str(tmp_path / "x.lph")
