@@ -232,7 +232,7 @@ int lphq_build_device(const char* const* records, const size_t* lengths, size_t 
  * minimizers, their order under the minimizer MPHF (sorted pieces again), the super-k-mers of repeated minimizers, and the (bucket, hash) pairs of
  * both PTHash constructions (single_phf::build_in_external_memory: the merge of the sorted pieces files every bucket under its size, the pilot
  * search -- on `device` or on the CPU -- reads those files from the largest size down, a piece at a time, with the table of taken positions carried
- * over).  What stays in memory: one piece, the index under construction (its bit vectors, <= 2 B per distinct minimizer of sizes and positions),
+ * over).  What stays in memory: one piece, the index under construction (its bit vectors and, until they are encoded, <= 3 B per distinct minimizer: type, size, position),
  * 8 B of pilot per PTHash bucket and the bitmaps of the two tables.  max_memory_bytes = 0: no limit, nothing touches the disk.  The bytes written
  * are those of lphq_build on the same records, whatever the batch boundaries and the memory limit. */
 typedef int (*lphq_record_source)(void* ctx, int pass, const char* const** records, const size_t** lengths, size_t* n_records);
