@@ -617,10 +617,15 @@ def test_host_sources_under_sanitizers(tmp_path):
         pytest.skip("g++ not available")
     csrc = os.path.join(ROOT, "lphash_amd", "csrc")
     exe = str(tmp_path / "san_host")
+    texe = str(tmp_path / "tsan_host")  # (the ThreadSanitizer build of the last part compiles meanwhile)
+    tsan_cc = subprocess.Popen([gxx, "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-I" + csrc, os.path.join(ROOT, "tests", "san", "san_host.cpp"),
+                                os.path.join(csrc, "builder.cpp"), os.path.join(csrc, "lph_format.cpp"), os.path.join(csrc, "image.cpp"), "-o", texe, "-lz", "-lpthread"],
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     cc = subprocess.run([gxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I" + csrc,
                          os.path.join(ROOT, "tests", "san", "san_host.cpp"), os.path.join(csrc, "builder.cpp"), os.path.join(csrc, "lph_format.cpp"),
                          os.path.join(csrc, "image.cpp"), "-o", exe, "-lz", "-lpthread"], capture_output=True, text=True)
     if cc.returncode != 0 and "sanitize" in cc.stderr:
+        tsan_cc.wait()
         pytest.skip("this g++ has no sanitizer runtime")
     assert cc.returncode == 0, cc.stderr[-2000:]
     recs = random_records(808, 30, 300, 6000) + random_records(809, 2, 90_000, 120_000)
@@ -678,11 +683,7 @@ def test_host_sources_under_sanitizers(tmp_path):
     r = subprocess.run([exe, "inflate_par_fuzz", str(small), "120", "11", "4", "12000", str(tmp_path / "bad.gz")], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
     # ... and under ThreadSanitizer: the pool, the chain and the emits of the parallel decoder race-free
-    texe = str(tmp_path / "tsan_host")
-    cc = subprocess.run([gxx, "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-I" + csrc, os.path.join(ROOT, "tests", "san", "san_host.cpp"),
-                         os.path.join(csrc, "builder.cpp"), os.path.join(csrc, "lph_format.cpp"), os.path.join(csrc, "image.cpp"), "-o", texe, "-lz", "-lpthread"],
-                        capture_output=True, text=True)
-    if cc.returncode == 0:  # (a g++ without the TSan runtime: the ASan run above stands alone)
+    if tsan_cc.wait() == 0:  # (a g++ without the TSan runtime: the ASan run above stands alone)
         for threads, span in ((4, 40_000), (6, 9_000)):
             r = subprocess.run([texe, "inflate_par", str(gz), str(threads), str(span)], capture_output=True, text=True, timeout=900)
             assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
