@@ -69,7 +69,7 @@ bool run_rounds(Dev& dev, SearchArgs a, uint64_t n_nonempty, uint32_t look_ahead
     // (builder.cpp) finishes with the sequential CPU search.
     const uint64_t round_cap = n_nonempty + (uint64_t)c[kMaxIdle] + 64u;
     double max_seconds = 120.0;
-    if (const char* e = getenv("LPHQ_SEARCH_MAX_SECONDS")) max_seconds = std::min(3600.0, std::max(1.0, atof(e)));
+    if (const char* e = getenv("LPHQ_SEARCH_MAX_SECONDS")) max_seconds = std::min(3600.0, std::max(1e-3, atof(e)));  // (milliseconds: the tests of the fall-back to the CPU search)
     const auto t_start = std::chrono::steady_clock::now();
     uint64_t enqueued = 0;
     for (;;) {

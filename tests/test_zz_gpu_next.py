@@ -79,6 +79,32 @@ def test_gpu_super_kmer_extraction_build_is_byte_identical(tmp_path, k, m, bits,
         assert ss == sc and open(pg, "rb").read() == want, (per_batch, limit)
 
 
+def test_gpu_pilot_search_giving_up_falls_back_to_the_cpu_search(tmp_path, capfd):
+    """A GPU pilot search that runs out of its wall-clock limit (here: a millisecond, checked after every round) hands the buckets to the sequential CPU
+    search -- loudly, and with the same file: in memory (the whole search again) and with a memory limit (piece by piece, from the table of taken positions
+    the pieces before left)."""
+    from util import random_records
+
+    torch_dev()
+    recs = dedup_records(random_records(2024, 40, 2000, 60_000), 31)
+    want_path, got = str(tmp_path / "cpu.lph"), str(tmp_path / "got.lph")
+    want_stats = L.build(recs, 31, 20, want_path, kmer_bits=64, threads=8)
+    want = open(want_path, "rb").read()
+    os.environ["LPHQ_SEARCH_MAX_SECONDS"] = "0.001"
+    os.environ["LPHQ_SEARCH_ROUNDS_PER_SYNC"] = "1"
+    try:
+        capfd.readouterr()
+        s1 = L.build(recs, 31, 20, got, kmer_bits=64, threads=8, device=0)
+        err1 = capfd.readouterr().err
+        assert s1 == want_stats and open(got, "rb").read() == want
+        s2 = L.build_stream(lambda: iter([recs[:11], recs[11:]]), 31, 20, got, kmer_bits=64, threads=8, device=0, tmp_dir=str(tmp_path / "spill"), max_memory_bytes=1 << 20)
+        err2 = capfd.readouterr().err
+        assert s2 == want_stats and open(got, "rb").read() == want
+    finally:
+        del os.environ["LPHQ_SEARCH_MAX_SECONDS"], os.environ["LPHQ_SEARCH_ROUNDS_PER_SYNC"]
+    assert "falling back to the sequential CPU search" in err1 and err2.count("falling back to the sequential CPU search") >= 2, (err1[-300:], err2[-600:])
+
+
 @pytest.mark.parametrize("k,bits", [(31, 64), (31, 128), (63, 128)])
 def test_pthash_competitor_harness(tmp_path, k, bits):
     """the PTHash half of the reference's ptbb_build / ptbb_query on the GPU.  Codes == the oracle's restatement of
