@@ -282,6 +282,15 @@ class RecordSet:
         return acc
 
 
+class BenchFailure(SystemExit):
+    """job.fail: ends the process with `code` like sys.exit, and carries the reason (exit code 3 = GPU results differ from the oracle; 2 = set-up,
+    e.g. a missing shared file in --cache-dir)."""
+
+    def __init__(self, code, msg):
+        super().__init__(code)
+        self.msg = msg
+
+
 class Job:
     """What the workloads of one bench process share."""
 
@@ -333,7 +342,7 @@ class Job:
                 self.dist.destroy_process_group()
             except Exception:
                 pass
-        sys.exit(code)
+        raise BenchFailure(code, msg)
 
 
 def load_oracle(job, wl, path):
@@ -886,8 +895,14 @@ def main():
             # a parity failure (every rank reaches job.fail together: the verdict is a collective) ends the job with that code -- but the headline was
             # measured and checked before: rank 0 still prints it, with the failed workload named in secondary_errors
             exit_code = ex.code if isinstance(ex.code, int) and ex.code else 3
-            errors.append({"name": wl["name"], "error": "GPU results differ from the oracle (see stderr)", "parity_vs_oracle": False})
-            dist = None  # (job.fail has torn the process group down)
+            why = getattr(ex, "msg", None) or f"exit code {exit_code}"
+            err = {"name": wl["name"], "error": why[:300], "exit_code": exit_code}
+            if exit_code == 3:  # the only code that is a verdict on the results; anything else is named for what it is
+                err["parity_vs_oracle"] = False
+            errors.append(err)
+            if job.dist is not None:
+                job.dist = None  # (job.fail has torn the process group down)
+            dist = None
             break
         except Exception as ex:  # noqa: BLE001 -- the headline must survive e.g. a host without the memory for the 2 B-k-mer set
             if dist is not None:

@@ -103,7 +103,10 @@ int lphq_open_device_image(const void* d_image, size_t nbytes, int device, lphq_
 int lphq_attach(lphq_index* idx, int device);
 /* lphq_attach for devices[0..n): the single-process form of "index replicated on every GPU, query batches sharded"
  * (one process per GPU uses lphq_open_device_image after an RCCL broadcast instead).  The reference object a
- * binding replaces is one immutable `MPHF hf` shared by all callers (include/partitioned_mphf.hpp:21-23). */
+ * binding replaces is one immutable `MPHF hf` shared by all callers (include/partitioned_mphf.hpp:21-23).
+ * On failure the replicas whose copy did not complete are NOT attached (a retry makes them again); those that completed stay --
+ * lphq_attached_devices says what is there.  Attach rule: lphq_attach / lphq_attach_devices may run while sessions are open (a session holds its
+ * replica's device and image by value) but not concurrently with the other query entry points of the same handle, which read the replica list. */
 int lphq_attach_devices(lphq_index* idx, const int* devices, int n);
 /* Attached devices in attach order (primary first): writes min(*n, cap) ordinals, *n = number attached. */
 int lphq_attached_devices(const lphq_index* idx, int* devices, int cap, int* n);
@@ -173,9 +176,12 @@ int lphq_query_contig(const lphq_index* idx, const char* contig, size_t length, 
  *
  * A session belongs to one thread at a time; any number of sessions (and other calls) may use one index concurrently.  The device is the calling
  * thread's current HIP device at lphq_session_open if the index has a replica there, otherwise the primary one.
+ * Lifetime: close sessions before the index.  If lphq_close comes first the handle is dead for every other call, but the index's device memory
+ * is only released by the lphq_session_close of its last session -- a session never reads freed memory, whatever order a garbage collector picks.
  *
  * submit: the records' memory must stay valid and unchanged until the batch is collected (pinned memory -- lphq_host_alloc -- makes the copies
  *   truly asynchronous; pageable memory works, the runtime stages it).  LPHQ_ERR_STATE when `depth` batches are already in flight.
+ *   When submit fails nothing of the batch is in flight any more (the stream is drained before the call returns): the records may be freed.
  * collect: *codes holds the batch's codes record after record, record r at [(*offsets)[r], (*offsets)[r + 1]) -- (*offsets)[r + 1] - (*offsets)[r]
  *   is what the reference's vector.size() would be: max(0, len_r - k + 1) windows, minus (streaming only) the windows that hold a non-ACGT base,
  *   decided from the input bases as in lphq_query_contig.  The pointers are valid until the next lphq_session_submit on this session.

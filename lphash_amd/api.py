@@ -270,6 +270,7 @@ class Session:
 
     def __init__(self, mphf, depth=2):
         self._s = C.c_void_p()
+        self._mphf = mphf  # the session uses the index's device image: keep the index alive as long as the session (lphq.h: close sessions first)
         self._keep = []  # the records of the batches in flight (their memory must outlive the copies)
         check(lib.lphq_session_open(mphf._h, depth, C.byref(self._s)))
 

@@ -1235,7 +1235,9 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
             };
             if (!RunSpill::merge(spill.files, merge_buf, err, [&](const Run& r) {
                     c.feed(r);
-                    return c.uniq.size() < 4096 || drain();
+                    // (both lists are bounded: one heavily repeated minimizer -- millions of super-k-mers on a low-complexity genome -- grows `colliding`
+                    //  alone; draining in the middle of a group is fine, the group's state lives in prev / have / repeated)
+                    return (c.uniq.size() < 4096 && c.colliding.size() < 4096) || drain();
                 }))
                 return fail(LPHQ_ERR_IO, err.empty() ? "short write on the temporary file " + uniq_file.path : err);
             c.close_group();

@@ -2,6 +2,8 @@
 // No CPU query path exists here: every query entry point launches HIP kernels or fails.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -48,6 +50,8 @@ struct lphq_index {
     std::vector<Replica> reps;   // reps[0] = primary device
     std::mutex pool_mu;          // guards pool only (pop / push of a slot), never held across device work
     std::vector<Scratch*> pool;
+    std::atomic<int> open_sessions{0};  // lphq_session handles that still use this index
+    std::atomic<bool> closing{false};   // lphq_close was called while sessions were open: the last lphq_session_close frees the index
 };
 
 static thread_local std::string g_err;
@@ -67,6 +71,17 @@ static int fail_hip(hipError_t e, const char* what) {
     do {                                                \
         hipError_t e_ = (call);                         \
         if (e_ != hipSuccess) return fail_hip(e_, #call); \
+    } while (0)
+
+// For calls made AFTER work was queued on `stream` that reads or writes caller memory (or a slot that goes back to its pool on return): on
+// failure nothing may still be in flight when the caller learns that the call did not happen.
+#define HIP_TRY_DRAIN(call, stream)                        \
+    do {                                                   \
+        hipError_t e_ = (call);                            \
+        if (e_ != hipSuccess) {                            \
+            (void)hipStreamSynchronize(stream);            \
+            return fail_hip(e_, #call);                    \
+        }                                                  \
     } while (0)
 
 static bool header_is_consistent(const lphq_image_header& h, size_t nbytes, std::string& why);
@@ -227,8 +242,7 @@ static void scratch_destroy(Scratch* s) {
     delete s;
 }
 
-extern "C" void lphq_close(lphq_index* idx) {
-    if (!idx) return;
+static void destroy_index(lphq_index* idx) {
     for (Scratch* s : idx->pool) scratch_destroy(s);
     for (const Replica& r : idx->reps) {
         if (r.owns && r.d_image) {
@@ -239,12 +253,26 @@ extern "C" void lphq_close(lphq_index* idx) {
     delete idx;
 }
 
+// A session keeps using the replica's device memory until it is closed: closing the index first only marks it; the free happens when the last
+// session goes (include/lphq.h).  The handle itself is dead for the caller from here on in either case.
+extern "C" void lphq_close(lphq_index* idx) {
+    if (!idx) return;
+    idx->closing.store(true);
+    if (idx->open_sessions.load() > 0) return;
+    destroy_index(idx);
+}
+
 // the replica queries of the calling thread run on: its current HIP device if the index is attached there, else the primary
 // LPHQ_TEST_SELF_PEER (a test hook for boxes with one GPU): a device may be attached twice -- the second replica is made by the peer-copy path of
 // lphq_attach_devices, from the first, on the same device -- and queries use the LAST replica of the current device, i.e. the copy.
 static bool self_peer_hook() {
     static const bool on = getenv("LPHQ_TEST_SELF_PEER") != nullptr;
     return on;
+}
+// LPHQ_TEST_FAIL_PEER_COPY=N (test hook): the first N peer copies of lphq_attach_devices are reported as failed after their wait
+static bool test_fail_peer_copy() {
+    static std::atomic<int> left{getenv("LPHQ_TEST_FAIL_PEER_COPY") ? atoi(getenv("LPHQ_TEST_FAIL_PEER_COPY")) : 0};
+    return left.load() > 0 && left.fetch_sub(1) > 0;
 }
 static const Replica* pick_replica(const lphq_index* idx) {
     if (idx->reps.empty()) return nullptr;
@@ -473,19 +501,42 @@ extern "C" int lphq_attach(lphq_index* idx, int device) {
 extern "C" int lphq_attach_devices(lphq_index* idx, const int* devices, int n) {
     if (!idx || (n > 0 && !devices)) return fail(LPHQ_ERR_ARG, "null argument");
     if (n <= 0) return fail(LPHQ_ERR_ARG, "no device given");
-    std::vector<std::pair<int, hipStream_t>> pending;
+    struct Pending {
+        int device;
+        hipStream_t stream;
+        size_t rep;  // index into idx->reps of the replica the copy fills
+    };
+    std::vector<Pending> pending;
     int rc = LPHQ_OK;
     for (int i = 0; i < n && rc == LPHQ_OK; ++i) {
         hipStream_t st = nullptr;
         rc = add_replica(idx, devices[i], &st);
-        if (st) pending.push_back({devices[i], st});
+        if (st) pending.push_back({devices[i], st, idx->reps.size() - 1});
     }
-    for (auto& p : pending) {  // (also after a failure: nothing may still be writing into a replica when the caller closes the index)
-        DeviceGuard g(p.first);
-        const hipError_t e = hipStreamSynchronize(p.second);
-        (void)hipStreamDestroy(p.second);
-        if (e != hipSuccess && rc == LPHQ_OK) rc = fail_hip(e, "hipMemcpyPeerAsync(image)");
+    std::string first_error = rc == LPHQ_OK ? std::string() : g_err;
+    std::vector<size_t> failed;
+    for (Pending& p : pending) {  // (also after a failure: nothing may still be writing into a replica when the caller closes the index)
+        DeviceGuard g(p.device);
+        hipError_t e = hipStreamSynchronize(p.stream);
+        (void)hipStreamDestroy(p.stream);
+        if (e == hipSuccess && test_fail_peer_copy()) e = hipErrorUnknown;
+        if (e != hipSuccess) {
+            failed.push_back(p.rep);
+            if (rc == LPHQ_OK) {
+                rc = fail_hip(e, "hipMemcpyPeerAsync(image)");
+                first_error = g_err;
+            }
+        }
     }
+    // A replica whose copy did not complete must not stay attached: a retry would find its device "already attached" and queries there would read
+    // a partial image.  (Replicas whose copies completed stay: the call is not all-or-nothing, lphq_attached_devices says what is there.)
+    for (size_t j = failed.size(); j-- > 0;) {
+        Replica& r = idx->reps[failed[j]];
+        DeviceGuard g(r.device);
+        (void)hipFree(r.d_image);
+        idx->reps.erase(idx->reps.begin() + (std::ptrdiff_t)failed[j]);
+    }
+    if (rc != LPHQ_OK) g_err = first_error;
     return rc;
 }
 
@@ -681,14 +732,14 @@ extern "C" int lphq_query_contig(const lphq_index* cidx, const char* contig, siz
     uint64_t* hp = sc->h_pin;
     hp[0] = 0, hp[1] = (uint64_t)length, hp[2] = 0, hp[3] = (uint64_t)nwin, hp[4] = 0, hp[5] = 0;
     HIP_TRY(hipMemcpyAsync(sc->d_seq, contig, length, hipMemcpyHostToDevice, sc->stream));
-    HIP_TRY(hipMemcpyAsync(sc->d_offs, hp, 5 * sizeof(uint64_t), hipMemcpyHostToDevice, sc->stream));
-    HIP_TRY(launch_query_records(idx->hdr, r->d_image, sc->d_seq, length, sc->d_offs, sc->d_offs + 2, 1, sc->d_out, streaming, sc->stream));
+    HIP_TRY_DRAIN(hipMemcpyAsync(sc->d_offs, hp, 5 * sizeof(uint64_t), hipMemcpyHostToDevice, sc->stream), sc->stream);
+    HIP_TRY_DRAIN(launch_query_records(idx->hdr, r->d_image, sc->d_seq, length, sc->d_offs, sc->d_offs + 2, 1, sc->d_out, streaming, sc->stream), sc->stream);
     if (streaming) {
-        HIP_TRY(launch_count_bad_bases(sc->d_seq, length, (unsigned long long*)(sc->d_offs + 4), sc->stream));
-        HIP_TRY(hipMemcpyAsync(hp + 5, sc->d_offs + 4, sizeof(uint64_t), hipMemcpyDeviceToHost, sc->stream));
+        HIP_TRY_DRAIN(launch_count_bad_bases(sc->d_seq, length, (unsigned long long*)(sc->d_offs + 4), sc->stream), sc->stream);
+        HIP_TRY_DRAIN(hipMemcpyAsync(hp + 5, sc->d_offs + 4, sizeof(uint64_t), hipMemcpyDeviceToHost, sc->stream), sc->stream);
     }
-    HIP_TRY(hipMemcpyAsync(out, sc->d_out, nwin * 8, hipMemcpyDeviceToHost, sc->stream));
-    HIP_TRY(hipStreamSynchronize(sc->stream));
+    HIP_TRY_DRAIN(hipMemcpyAsync(out, sc->d_out, nwin * 8, hipMemcpyDeviceToHost, sc->stream), sc->stream);
+    HIP_TRY_DRAIN(hipStreamSynchronize(sc->stream), sc->stream);
     size_t n = nwin;
     if (streaming && hp[5] != 0) {
         // Drop windows holding a non-ACGT base (the reference emits nothing for them).  Validity is taken from the input, not
@@ -736,7 +787,8 @@ struct SessionSlot {
 };
 struct lphq_session {
     lphq_index* idx = nullptr;
-    const Replica* rep = nullptr;
+    int device = -1;                    // of the replica picked at open; by value: lphq_attach* may grow (and move) idx->reps afterwards
+    const uint8_t* d_image = nullptr;
     hipStream_t stream = nullptr;
     int depth = 2;
     uint64_t submitted = 0, collected = 0;
@@ -761,12 +813,16 @@ extern "C" int lphq_session_open(const lphq_index* cidx, int depth, lphq_session
     if (!out) return fail(LPHQ_ERR_ARG, "null argument");
     *out = nullptr;
     if (depth < 1 || depth > 4) return fail(LPHQ_ERR_ARG, "depth must be 1..4");
+    if (idx->closing.load()) return fail(LPHQ_ERR_STATE, "the index was closed");
     lphq_session* s = new (std::nothrow) lphq_session();
     if (!s) return fail(LPHQ_ERR_ARG, "out of memory");
     s->idx = idx;
-    s->rep = pick_replica(idx);
+    const Replica* rep = pick_replica(idx);
+    s->device = rep->device;
+    s->d_image = rep->d_image;
     s->depth = depth;
-    DeviceGuard g(s->rep->device);
+    idx->open_sessions.fetch_add(1);
+    DeviceGuard g(s->device);
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     for (int i = 0; i < depth && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&s->slot[i].done, hipEventDisableTiming);
     if (e != hipSuccess) {
@@ -779,7 +835,7 @@ extern "C" int lphq_session_open(const lphq_index* cidx, int depth, lphq_session
 
 extern "C" void lphq_session_close(lphq_session* s) {
     if (!s) return;
-    DeviceGuard g(s->rep->device);
+    DeviceGuard g(s->device);
     if (s->stream) {
         (void)hipStreamSynchronize(s->stream);
         (void)hipStreamDestroy(s->stream);
@@ -792,7 +848,9 @@ extern "C" void lphq_session_close(lphq_session* s) {
         if (sl.h_offs) (void)hipHostFree(sl.h_offs);
         if (sl.h_out) (void)hipHostFree(sl.h_out);
     }
+    lphq_index* idx = s->idx;
     delete s;
+    if (idx && idx->open_sessions.fetch_sub(1) == 1 && idx->closing.load()) destroy_index(idx);  // lphq_close came first: this was the last user
 }
 
 template <typename T>
@@ -821,7 +879,7 @@ static hipError_t grow_pinned(T*& p, size_t& cap, size_t want) {
 extern "C" int lphq_session_reserve(lphq_session* s, size_t total_bases, size_t n_records) {
     if (!s) return fail(LPHQ_ERR_ARG, "null argument");
     if (s->submitted != s->collected) return fail(LPHQ_ERR_STATE, "batches in flight: collect them first");
-    DeviceGuard g(s->rep->device);
+    DeviceGuard g(s->device);
     for (int i = 0; i < s->depth; ++i) {
         SessionSlot& sl = s->slot[i];
         HIP_TRY(grow_device(sl.d_seq, sl.d_seq_cap, total_bases + 64));
@@ -841,7 +899,7 @@ extern "C" int lphq_session_submit(lphq_session* s, const char* const* records, 
     const uint32_t k = idx->hdr.k;
     if (idx->hdr.kind >= LPHQ_PTHASH) streaming = 1;  // (as lphq_query_contig: the competitor functions yield nothing for windows holding a non-ACGT base)
     SessionSlot& sl = s->slot[s->submitted % (uint64_t)s->depth];
-    DeviceGuard g(s->rep->device);
+    DeviceGuard g(s->device);
     uint64_t so = 0, oo = 0;
     for (size_t i = 0; i < n; ++i) {
         if (lengths[i] && !records[i]) return fail(LPHQ_ERR_ARG, "null record");
@@ -875,20 +933,20 @@ extern "C" int lphq_session_submit(lphq_session* s, const char* const* records, 
         const char* run = records[i];
         size_t len = lengths[i], j = i + 1;
         while (j < n && (lengths[j] == 0 || records[j] == run + len)) len += lengths[j++];
-        if (len) HIP_TRY(hipMemcpyAsync(sl.d_seq + at, run, len, hipMemcpyHostToDevice, s->stream));
+        if (len) HIP_TRY_DRAIN(hipMemcpyAsync(sl.d_seq + at, run, len, hipMemcpyHostToDevice, s->stream), s->stream);
         at += len;
         i = j;
     }
-    HIP_TRY(hipMemcpyAsync(sl.d_offs, sl.h_offs, (2 * (n + 1) + 1) * 8, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY_DRAIN(hipMemcpyAsync(sl.d_offs, sl.h_offs, (2 * (n + 1) + 1) * 8, hipMemcpyHostToDevice, s->stream), s->stream);
     if (oo) {
-        HIP_TRY(launch_query_records(idx->hdr, s->rep->d_image, sl.d_seq, so, sl.d_offs, sl.d_offs + n + 1, n, sl.d_out, streaming, s->stream));
+        HIP_TRY_DRAIN(launch_query_records(idx->hdr, s->d_image, sl.d_seq, so, sl.d_offs, sl.d_offs + n + 1, n, sl.d_out, streaming, s->stream), s->stream);
         if (streaming) {
-            HIP_TRY(launch_count_bad_bases(sl.d_seq, (size_t)so, (unsigned long long*)(sl.d_offs + 2 * n + 2), s->stream));
-            HIP_TRY(hipMemcpyAsync(sl.h_offs + 2 * n + 2, sl.d_offs + 2 * n + 2, 8, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY_DRAIN(launch_count_bad_bases(sl.d_seq, (size_t)so, (unsigned long long*)(sl.d_offs + 2 * n + 2), s->stream), s->stream);
+            HIP_TRY_DRAIN(hipMemcpyAsync(sl.h_offs + 2 * n + 2, sl.d_offs + 2 * n + 2, 8, hipMemcpyDeviceToHost, s->stream), s->stream);
         }
-        HIP_TRY(hipMemcpyAsync(sl.h_out, sl.d_out, (size_t)oo * 8, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY_DRAIN(hipMemcpyAsync(sl.h_out, sl.d_out, (size_t)oo * 8, hipMemcpyDeviceToHost, s->stream), s->stream);
     }
-    HIP_TRY(hipEventRecord(sl.done, s->stream));
+    HIP_TRY_DRAIN(hipEventRecord(sl.done, s->stream), s->stream);
     sl.in_flight = true;
     ++s->submitted;
     return LPHQ_OK;
@@ -898,7 +956,7 @@ extern "C" int lphq_session_collect(lphq_session* s, const uint64_t** codes, con
     if (!s || !codes || !offsets || !n_records) return fail(LPHQ_ERR_ARG, "null argument");
     if (s->submitted == s->collected) return fail(LPHQ_ERR_STATE, "no batch in flight");
     SessionSlot& sl = s->slot[s->collected % (uint64_t)s->depth];
-    DeviceGuard g(s->rep->device);
+    DeviceGuard g(s->device);
     HIP_TRY(hipEventSynchronize(sl.done));
     sl.in_flight = false;
     ++s->collected;

@@ -10,6 +10,7 @@
 //   san_host inflate_par_fuzz <file.gz> <n> <seed> <threads> <span> <tmp>      n corrupted / truncated copies (written to <tmp>) through ParallelGzReader
 //   san_host load  <file.lph> <kind> <kmer_bits>                             parse + cross-check + flat image
 //   san_host fuzz  <file.lph> <kind> <kmer_bits> <n> <seed>                  n corrupted copies through the loader
+//   san_host limits <file.lph> <kind> <kmer_bits>                            the parsed file with each count of the device layout's 32-bit limits forged past it
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -67,6 +68,42 @@ static int load(const std::vector<uint8_t>& buf, int kind, int bits, bool verbos
     return 0;
 }
 
+// The device layout is narrower than the format: < 2^32 keys / table positions, buckets, distinct minimizers.  A file that large cannot be
+// forged byte by byte (its vectors would have to be that long to pass the loader's cross-checks), so the PARSED file is forged: each limit must be refused by
+// build_image with the text lphq_open maps to LPHQ_ERR_UNSUPPORTED (capi.cpp: "beyond the device layout"), never hashed with truncated 32-bit arithmetic.
+static int limits(const std::vector<uint8_t>& buf, int kind, int bits) {
+    lphq::LphFile good;
+    std::string err;
+    if (!lphq::parse_lph(buf.data(), buf.size(), kind, bits, good, err)) return 1;
+    const uint64_t big = 1ull << 32;
+    struct Case {
+        const char* name;
+        void (*forge)(lphq::LphFile&, uint64_t);
+    } cases[] = {
+        {"num_keys", [](lphq::LphFile& x, uint64_t b) { x.minimizer_order.num_keys = b; }},
+        {"table_size", [](lphq::LphFile& x, uint64_t b) { x.minimizer_order.table_size = b + 7; }},
+        {"num_dense", [](lphq::LphFile& x, uint64_t b) { x.minimizer_order.num_dense = b; }},
+        {"num_sparse", [](lphq::LphFile& x, uint64_t b) { x.minimizer_order.num_sparse = b; }},
+        {"buckets", [](lphq::LphFile& x, uint64_t b) { x.minimizer_order.num_dense = b / 2, x.minimizer_order.num_sparse = b / 2; }},
+        {"distinct_minimizers", [](lphq::LphFile& x, uint64_t b) { x.distinct_minimizers = b; }},
+        {"fallback_keys", [](lphq::LphFile& x, uint64_t b) { x.fallback_kmer_order.num_keys = b; }},
+    };
+    int bad = 0;
+    for (const Case& c : cases) {
+        lphq::LphFile x = good;
+        c.forge(x, big);
+        std::vector<uint8_t> image;
+        err.clear();
+        const bool ok = lphq::build_image(x, image, err);
+        const bool refused = !ok && err.find("beyond the device layout") != std::string::npos;
+        printf("%s: %s (%s)\n", c.name, refused ? "refused" : "NOT REFUSED", err.c_str());
+        bad += !refused;
+    }
+    std::vector<uint8_t> image;
+    if (!lphq::build_image(good, image, err)) return 3;  // (the unforged file still builds)
+    return bad ? 2 : 0;
+}
+
 struct Source {  // lphq_record_source over a file: batches of ~20,000 bases, the file reopened for the second pass
     const char* path;
     int threads, pass = -1;
@@ -103,6 +140,7 @@ struct Source {  // lphq_record_source over a file: batches of ~20,000 bases, th
 int main(int argc, char** argv) {
     if (argc < 2) return 64;
     const std::string cmd = argv[1];
+    if (cmd == "limits" && argc == 5) return limits(slurp(argv[2]), atoi(argv[3]), atoi(argv[4]));
     if (cmd == "build_stream" && argc == 11) {
         Source src;
         src.path = argv[2];

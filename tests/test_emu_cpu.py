@@ -185,6 +185,75 @@ def test_tile_kernels_non_acgt_on_the_emulator(emuk, tmp_path):
         assert emuk.emu_kernel_count_valid(gs.ctypes.data, len(gs), C.byref(cnt)) == 0 and cnt.value == int(valid.sum())
 
 
+@pytest.mark.parametrize("k,m,bits,kind", [(31, 20, 64, 0), (63, 20, 128, 0), (31, 20, 64, 1), (47, 20, 128, 1), (31, 15, 64, 0)])
+def test_low_complexity_ties_on_the_emulator(emuk, tmp_path, k, m, bits, kind):
+    """Equal m-mers inside a window at the BASELINE (k, m) pairs (on uniform bases a tie there has probability ~1e-10 per window): homopolymers, tandem
+    repeats of period < k - m + 1, N runs of k bases and more, in the index and in the queries, through every tile-kernel variant == the oracle
+    (leftmost minimum: mphf_utils.hpp:118-137, partitioned_mphf.hpp:119-160).  The same inputs run on the GPU in tests/test_gpu_real.py."""
+    from real_fixture import valid_windows
+    from util import low_complexity_index_records, low_complexity_queries
+
+    recs = low_complexity_index_records(k, 900 + k + m)
+    assert sum(1 for r in recs if len(set(r)) == 1) >= 3
+    path, po = str(tmp_path / "t.lph"), str(tmp_path / "o.lph")
+    L.build(recs, k, m, path, kind=kind, kmer_bits=bits, threads=4)
+    orc.build(recs, k, m, po, kind=kind, kmer_bits=bits)
+    assert open(path, "rb").read() == open(po, "rb").read()  # the product's position-parallel builder on tied minimizers == the reference's state machine
+    o = orc.Index(path, kind, bits)
+    h = (L.Mphf if kind == 0 else L.MphfAlt).load(path, kmer_bits=bits)
+    qs = low_complexity_queries(recs, k, 5 + k)
+    exp = [o(q, False) if len(q) >= k else np.zeros(0, dtype=np.uint64) for q in qs]
+    val = [valid_windows(q, k) for q in qs]
+    for q, e, v in zip(qs, exp, val):
+        if v.size and v.all():
+            assert np.array_equal(o(q, True), e)  # clean records: the reference's streaming branch breaks ties like its random branch
+    BLK, RAW, S8 = 0x10000, 0x20000, 0x40000
+    for streaming, mis, block in [(True, 0, 256), (True, 5, 256 | BLK), (True, 3, 128 | RAW), (False, 0, 256), (True, 0, 128 | S8), (True, 9, 256 | S8)]:
+        got = emu_records(emuk, h, qs, k, streaming, mis, block)
+        for g, e, v in zip(got, exp, val):
+            if streaming:
+                assert np.array_equal(g[v], e[v]) and np.all(g[~v] == np.uint64(L.INVALID)), (streaming, mis, block)
+            else:
+                assert np.array_equal(g, e)
+
+
+@pytest.mark.parametrize("name", ["se_k31_m20_b64_p", "se_k63_m20_b128_p", "se_k47_m20_b128_u"])
+def test_real_data_on_the_emulator(emuk, tmp_path, name):
+    """The device sources on real genomic input (tests/golden/real/: the reference's bundled unitigs and query files): slices of the unitigs (members),
+    of the Salmonella genome, of the E. coli genome with its runs of N and reads with N, against the committed codes and the oracle."""
+    import json
+
+    from real_fixture import CASES, OUT, load_inputs, query_sets, unitig_records, valid_windows
+
+    kind, k, m, bits, ust = CASES[name]
+    z = load_inputs()
+    recs = unitig_records(z, ust)
+    path = os.path.join(OUT, name + ".lph")
+    if not os.path.exists(path):
+        path = str(tmp_path / "x.lph")
+        L.build(recs, k, m, path, kind=kind, kmer_bits=bits, threads=8)
+    e = json.load(open(os.path.join(OUT, "expected.json")))["cases"][name]
+    o = orc.Index(path, kind, bits)
+    h = (L.Mphf if kind == 0 else L.MphfAlt).load(path, kmer_bits=bits)
+    assert h.get_kmer_count() == e["nkmers"]
+    qs = query_sets(z)
+    heads = np.load(os.path.join(OUT, f"codes_{name}.npz"))
+    batch = [qs["salmonella"][0][:6000], qs["ecoli"][0][9000:15_000], qs["ecoli"][1][5000:9000]] + qs["fastq"][:30] + qs["fastq"][-30:]
+    batch += sorted(recs, key=len)[:40] + [r[:5000] for r in sorted(recs, key=len)[-3:]]
+    exp = [o(q, False) if len(q) >= k else np.zeros(0, dtype=np.uint64) for q in batch]
+    assert np.array_equal(exp[0], heads["salmonella"][:len(exp[0])])  # what the build container's oracle said
+    val = [valid_windows(q, k) for q in batch]
+    assert any((~v).any() for v in val)
+    S8 = 0x40000
+    for streaming, mis, block in [(True, 0, 256), (False, 0, 256), (True, 7, 128 | S8)]:
+        got = emu_records(emuk, h, batch, k, streaming, mis, block)
+        for g, x, v in zip(got, exp, val):
+            if streaming:
+                assert np.array_equal(g[v], x[v]) and np.all(g[~v] == np.uint64(L.INVALID))
+            else:
+                assert np.array_equal(g, x)
+
+
 @pytest.mark.parametrize("k,m,bits,kind", [(31, 20, 64, 0), (63, 20, 128, 0), (21, 8, 64, 1)])
 def test_packed_and_pack_kernels_on_the_emulator(emuk, tmp_path, k, m, bits, kind):
     recs = dedup_records(random_records(k + 3 * m, 8, 200, 1500), k)

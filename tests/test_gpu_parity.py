@@ -407,7 +407,14 @@ recs = dedup_records(random_records(4711, 20, 500, 20000), k)
 path = os.path.join(sys.argv[2], "t.lph")
 L.build(recs, k, m, path, kmer_bits=64, threads=4)
 h = L.Mphf.load(path, kmer_bits=64)
-h.attach_devices([0, 0])
+try:  # LPHQ_TEST_FAIL_PEER_COPY=1: the first peer copy "fails" after its wait -- the half-made replica must not stay attached (ADVICE r04)
+    h.attach_devices([0, 0])
+    raise SystemExit("the injected copy failure was not reported")
+except L.LphqError:
+    pass
+assert h.replica_info() == [(0, 0)], h.replica_info()
+assert np.array_equal(np.asarray(h(recs[0], streaming=True)), np.asarray(orc.Index(path, 0, 64)(recs[0], True)))  # the uploaded replica still answers
+h.attach_devices([0, 0])  # the retry makes the copy (it used to return at once: "device already attached")
 info = h.replica_info()
 assert [d for d, _ in info] == [0, 0] and info[0][1] == 0 and info[1][1] in (1, 2), info
 o = orc.Index(path, 0, 64)
@@ -431,7 +438,7 @@ s.close()
 assert len(got) == len(want) and all(np.array_equal(np.asarray(g, dtype=np.uint64), w) for g, w in zip(got, want))
 print("replica ok", info)
 """
-    env = dict(os.environ, LPHQ_TEST_SELF_PEER="1")
+    env = dict(os.environ, LPHQ_TEST_SELF_PEER="1", LPHQ_TEST_FAIL_PEER_COPY="1")
     r = subprocess.run([sys.executable, "-c", script, ROOT, str(tmp_path)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "replica ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
 

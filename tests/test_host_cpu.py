@@ -26,6 +26,9 @@ def test_abi_exports_every_declared_symbol():
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r"\b(lphq_[a-z_]+)\b", nm))
     assert declared <= exported, declared - exported
+    # ... and nothing else: a drop-in C ABI exports its header (csrc/lphq.map), not kernel stubs or the C++ internals
+    names = {ln.split()[-1].split("@")[0] for ln in nm.splitlines() if ln.strip()}
+    assert names - {"LPHQ_3"} == declared, sorted(names ^ declared)[:20]
 
 
 def test_no_torch_types_and_no_oracle_in_the_product():
@@ -659,6 +662,9 @@ def test_host_sources_under_sanitizers(tmp_path):
         for cmd in ((["load", str(out), str(kind), str(bits)], ["fuzz", str(out), str(kind), str(bits), "150", str(k)]) if m > 8 else ()):
             r = subprocess.run([exe] + cmd, capture_output=True, text=True, env=env)
             assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+        if m > 8:  # the device layout's 32-bit limits, each forged into the parsed file: refused with LPHQ_ERR_UNSUPPORTED's text, never mis-hashed
+            r = subprocess.run([exe, "limits", str(out), str(kind), str(bits)], capture_output=True, text=True, env=env)
+            assert r.returncode == 0 and r.stdout.count(": refused") == 7 and "NOT REFUSED" not in r.stdout, (r.stdout, r.stderr[-2000:])
 
     # the .gz decoder of the serial input path: a file through the threaded source (odd read sizes), then corrupted copies through the decoder
     import gzip

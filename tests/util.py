@@ -35,3 +35,38 @@ def dedup_records(recs, k):
             seen |= set(ks)
             keep.append(r)
     return keep
+
+
+def low_complexity_index_records(k, seed):
+    """Index records whose windows hold EQUAL m-mers (ties of the minimizer hash -> the leftmost-minimum rule decides): homopolymers, tandem repeats of
+    period p as long as they may be without repeating a k-mer (k + p - 1 bases), short repeats inside random flanks, beside ordinary random records."""
+    rng = np.random.default_rng(seed)
+    recs = [bytes([c]) * k for c in b"ACGT"]  # one k-mer each: every m-mer of the window is the same
+    for unit in (b"AC", b"AG", b"CT", b"ACG", b"AAT", b"ACGT", b"AACCG", b"AAAAAC", b"ACGTTGC", b"ACCGGTTA", b"AAAAAAAAAAG"):
+        p = len(unit)
+        recs.append((unit * (k // p + 3))[:k + p - 1])  # p distinct k-mers, every one a rotation of the other
+    for unit in (b"A", b"T", b"CA", b"GT", b"TTG", b"ACAG"):
+        for _ in range(3):
+            p = len(unit)
+            rep = (unit * k)[:int(rng.integers(k // 2, k + p - 1))]
+            left, right = random_records(int(rng.integers(1 << 30)), 2, k, 3 * k)
+            recs.append(left + rep + right)
+    recs += random_records(seed + 1, 12, 300, 4000)
+    return dedup_records(recs, k)
+
+
+def low_complexity_queries(recs, k, seed):
+    rng = np.random.default_rng(seed)
+    big = b"".join(recs)
+    qs = list(recs)
+    qs += [b"A" * 700, b"C" * (k + 1), b"T" * 2048, (b"AC" * 600), (b"ACG" * 500)[:1400], (b"AAAAAAAAAAG" * 200), (b"ACGTTGC" * 300)]  # repeats far longer than a window (non-members)
+    for _ in range(6):  # members interrupted by runs of N of k bases and more, and by single N
+        a = int(rng.integers(0, len(big) - 3000))
+        q = bytearray(big[a:a + 3000])
+        s = int(rng.integers(100, 2000))
+        run = k + int(rng.integers(0, 40))
+        q[s:s + run] = b"N" * run
+        q[int(rng.integers(0, 3000 - 1))] = ord("N")
+        qs.append(bytes(q[:3000]))
+    qs += [b"N" * (2 * k), b"A" * (k - 1) + b"N" + b"A" * k, (b"A" * k + b"N") * 20, b"G" * 300 + b"NN" + b"G" * 300]
+    return qs
