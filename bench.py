@@ -21,7 +21,10 @@ Multi-GPU: the index is built once on rank 0, its flat device image is broadcast
 (torch.distributed backend "nccl"), and every rank processes its own batch -- no data-path collective
  => weak scaling; value = lookups of all ranks / max-over-ranks time.  Every rank checks a
 slice of ITS OWN timed batch against the oracle, the verdicts are all-reduced, and a failure on any rank ends the
-whole job with exit code 3.  Rank 0 prints ONE JSON line.
+whole job with exit code 3.  Rank 0 prints ONE JSON line.  The headline stays the weak line (N = 1 equals the
+single-GPU bench); at N > 1 every workload also carries a `strong` entry: a FIXED job (2^31 probes of one seeded set;
+all windows of the index records) sharded over the ranks by lphash_amd/dist.py's shard_range / shard_records, value =
+total units / max-over-ranks time -- "query batches sharded across the GPUs" as BASELINE.json's C4 words it.
 
 `--plan-only` (no GPU needed; gloo when WORLD_SIZE > 1) stops before the first GPU call: it resolves the workloads
 and cache paths, checks that every rank resolved the same plan and prints it -- what tests/test_dist_cpu.py runs.
@@ -55,6 +58,43 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 # VALU issue peak in lane-instructions/s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (one wave64 instruction = 4 cycles of a SIMD)
 VALU_PEAK_LANE_INSTR = 256 * 4 * 16 * 2.4e9
 RECORD_KMERS = 100_000  # k-mers per synthetic record
+# Line requests per second the fabric behind the L2s sustains for scattered 128-B gathers (measured: profiles/r01_microbench2.txt 55-68 G lines/s beyond L2;
+# the k=31 random kernel sits at 57.9 G lines/s, profiles/r04_pmc_c2_raw.txt x r04_c2_kernel_stats.txt): the ceiling of a kernel whose index is on chip
+FABRIC_LINE_PEAK = 57.9e9
+STRONG_CHUNK_LOG2 = 24  # the fixed probe set of the strong-scaling line is drawn in chunks of 2^24 probes, chunk c from seed 5000 + c: any rank can draw any part of it
+
+
+def sha256_file(path):
+    hsh = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            hsh.update(blk)
+    return hsh.hexdigest()
+
+
+def pinned_index_digest(wl):
+    """The SHA-256 the ORACLE builder's file has for this synthetic set (tests/golden/full_size_digests.json, made by tools/full_size_digests.py in the
+    build container: C2 / C5 at 100 M, C4 at 2 B k-mers), or None when the set is not one of those."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "tests", "golden", "full_size_digests.json")))
+    except (OSError, ValueError):
+        return None
+    if wl["kind"] not in ("p", "u"):
+        return None
+    return table.get(f"{wl['kind']}_k{wl['k']}_m{wl['m']}_b{wl['kmer_bits']}_seed1_{wl['n_records']}x{wl['rec_len']}")
+
+
+def strong_plan(wl, world, strong_total_log2):
+    """What every rank does in the STRONG-scaling pass of a workload (fixed total work, split without overlap): random mode = a fixed set of
+    2^strong_total_log2 probes cut by shard_range; streaming = the index records cut by shard_records (contiguous, by base count).  Pure function of
+    the plan: [(begin, end)] per rank, in units of probes / records."""
+    from lphash_amd.dist import shard_range, shard_records
+
+    if wl["mode"] == "random":
+        total = 1 << strong_total_log2
+        return {"unit": "probes", "total": total, "shards": [list(shard_range(total, r, world)) for r in range(world)]}
+    lens = [wl["rec_len"]] * wl["n_records"]
+    return {"unit": "records", "total": wl["n_records"], "shards": [list(shard_records(lens, r, world)) for r in range(world)]}
 
 
 def log(*a):
@@ -110,13 +150,24 @@ def secondary_workloads(args, head):
     return [make_workload("C3", "stream", "p", 31, 20, 100_000_000, 0, st, wu, 22, args.gpu_build),
             make_workload("C5", "random", "u", 31, 20, 100_000_000, 28, st, wu, 22, args.gpu_build),
             make_workload("C4-random", "random", "p", 63, 20, c4, 28, st, wu, 21, True),
-            make_workload("C4-stream", "stream", "p", 63, 20, c4, 0, st, wu, 21, True)]
+            make_workload("C4-stream", "stream", "p", 63, 20, c4, 0, st, wu, 21, True),
+            # BASELINE.md section 3's secondary inputs: half the probes uniformly random non-members; the index records in shuffled order
+            make_workload("C2-nonmember50", "random", "p", 31, 20, 100_000_000, 28, st, wu, 22, args.gpu_build, nonmember_frac=0.5),
+            make_workload("C3-shuffled", "stream", "p", 31, 20, 100_000_000, 0, st, wu, 22, args.gpu_build, shuffle_records=True)]
 
 
 def plan_of(args):
     head = headline_workload(args)
     wls = [head] + secondary_workloads(args, head)
-    return {"gpus": args.gpus, "cache_dir": args.cache_dir, "workloads": wls, "index_paths": [index_path(args.cache_dir, w) for w in wls]}
+    plan = {"gpus": args.gpus, "cache_dir": args.cache_dir, "workloads": wls, "index_paths": [index_path(args.cache_dir, w) for w in wls]}
+    if args.gpus > 1 or args.dist_single or args.strong:
+        plan["strong"] = [strong_plan(w, args.gpus, strong_total_log2_of(args, w)) for w in wls]
+    return plan
+
+
+def strong_total_log2_of(args, wl):
+    """log2 of the fixed probe set of the strong-scaling pass: what 8 GPUs answer in one step of the weak line (2^31 for the BASELINE workloads)"""
+    return args.strong_total_log2 if args.strong_total_log2 > 0 else wl["batch_log2"] + 3
 
 
 def algorithmic_bytes_per_lookup(h, mode, k, W, partitioned):
@@ -354,6 +405,116 @@ def load_oracle(job, wl, path):
     return orc.Index(path, orc.PARTITIONED if wl["kind"] == "p" else orc.UNPARTITIONED, wl["kmer_bits"])
 
 
+def strong_pass(job, wl, h, recs, d_seq, o, stream, rec_order):
+    """The STRONG-scaling line of one workload (north_star: "query batches sharded across 8 x MI355X"): a FIXED job -- 2^strong_total_log2 probes of one
+    common, seeded set (random mode) or every window of the index records (streaming) -- split over the ranks without overlap (lphash_amd/dist.py:
+    shard_range / shard_records), each rank's shard resident in its HBM before the timed region, no data-path collective.  value = total units x steps /
+    max-over-ranks time.  Checked on every rank: the first 2^18 codes of its shard against the oracle; streaming: the codes of ALL shards together are a
+    permutation of [0, n) by two all-reduced checksums (sum and sum of squares, wrapping 64-bit, against their closed forms)."""
+    args, rank, world, dev, dist, torch, np = job.args, job.rank, job.world, job.dev, job.dist, job.torch, job.np
+    k, mode, kmer_bits = wl["k"], wl["mode"], wl["kmer_bits"]
+    rec_len, n_records, nk = wl["rec_len"], wl["n_records"], wl["kmers"]
+    steps, warmup = wl["steps"], wl["warmup"]
+    sp = strong_plan(wl, world, strong_total_log2_of(args, wl))
+    lo, hi = sp["shards"][rank]
+    tag = f"[bench r{rank} {wl['name']} strong]"
+    wpk = kmer_bits // 64
+    if mode == "random":
+        mine = hi - lo
+        total_units = sp["total"]
+        d_k = torch.empty(max(mine, 1) * wpk, dtype=torch.int64, device=dev)
+        C = 1 << STRONG_CHUNK_LOG2
+        for c in range(lo // C, (hi + C - 1) // C if mine else 0):  # chunk c of the common set: the same numbers on whichever rank draws it
+            g = torch.Generator(device=dev)
+            g.manual_seed(5000 + c)
+            win = torch.randint(0, nk, (C,), generator=g, device=dev, dtype=torch.int64)
+            a, b = max(lo, c * C), min(hi, (c + 1) * C)
+            win = win[a - c * C:b - c * C]
+            pos = (win // RECORD_KMERS) * rec_len + win % RECORD_KMERS
+            h.pack_kmers(d_seq.data_ptr(), pos.data_ptr(), b - a, d_k.data_ptr() + (a - lo) * wpk * 8, stream)
+            torch.cuda.synchronize()
+            del win, pos
+        d_o = torch.empty(max(mine, 1), dtype=torch.int64, device=dev)
+
+        def step():
+            if mine:
+                h.query_packed(d_k.data_ptr(), mine, d_o.data_ptr(), stream)
+    else:
+        n_mine = hi - lo
+        wpr = rec_len - k + 1
+        mine = n_mine * wpr
+        total_units = n_records * wpr
+        seq_off = torch.arange(0, n_mine + 1, dtype=torch.int64, device=dev) * rec_len
+        out_off = torch.arange(0, n_mine + 1, dtype=torch.int64, device=dev) * wpr
+        d_o = torch.empty(max(mine, 1), dtype=torch.int64, device=dev)
+        base = d_seq.data_ptr() + lo * rec_len
+
+        def step():
+            if n_mine:
+                h.query_records(base, n_mine * rec_len, seq_off.data_ptr(), n_mine, d_o.data_ptr(), out_off.data_ptr(), True, stream)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    job.barrier()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        step()
+        b.record()
+    torch.cuda.synchronize()
+    job.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    per_rank = [kernel_ms]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        me = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(me) for _ in range(world)]
+        dist.all_gather(every, me)
+        per_rank = [float(e.item()) for e in every]
+    # parity: this rank's shard against the oracle (a sample), all shards together against the closed forms
+    ok = True
+    if o is not None and mine:
+        S = min(mine, 1 << 18)
+        if mode == "random":
+            exp = o.query_packed(d_k[:S * wpk].cpu().numpy().view(np.uint64))
+        else:
+            nr = max(1, min(hi - lo, S // (rec_len - k + 1)))
+            exp = np.concatenate([o(recs[(lo + i) if rec_order is None else int(rec_order[lo + i])], True) for i in range(nr)])
+            S = len(exp)
+        ok = bool(np.array_equal(d_o[:S].cpu().numpy().view(np.uint64), exp))
+    sums_ok = None
+    if mode == "stream" or wl["nonmember_frac"] == 0.0:
+        v = d_o[:mine]
+        inside = bool(mine == 0 or (int(v.min()) >= 0 and int(v.max()) < nk))
+        ok = ok and inside
+        if mode == "stream":  # every window of the set exactly once over all ranks: the codes are 0 .. n-1 in some order
+            t = torch.stack([v.sum(), (v * v).sum()]) if mine else torch.zeros(2, dtype=torch.int64, device=dev)
+            if dist is not None:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)  # (wrapping int64 addition)
+            n = total_units
+            want = [(n * (n - 1) // 2) % (1 << 64), ((n - 1) * n * (2 * n - 1) // 6) % (1 << 64)]
+            got = [int(x) % (1 << 64) for x in t.tolist()]
+            sums_ok = got == want
+            ok = ok and sums_ok
+    if not all_ranks_ok(dist, torch, dev, ok):
+        job.fail(3, f"{wl['name']} strong-scaling pass: GPU results differ from the oracle, leave [0, n) or do not cover it (this rank: {ok}, checksums: {sums_ok})")
+    log(f"{tag} shard [{lo}, {hi}) of {sp['total']} {sp['unit']}: {mine} units, kernel {kernel_ms:.3f} ms; all ranks == oracle on their samples"
+        + ("" if sums_ok is None else "; codes of all shards = a permutation of [0, n) by sum and sum of squares"))
+    del d_o
+    if rank != 0:
+        return None
+    return {"scaling": "strong", "value": total_units * steps / elapsed, "unit": "k-mer lookups/s", "n_gpus": world, "total_units_per_step": total_units,
+            "split": f"{sp['unit']} by " + ("shard_range" if mode == "random" else "shard_records") + " (lphash_amd/dist.py), contiguous, no overlap",
+            "shards": sp["shards"], "ms_per_step": elapsed / steps * 1e3, "kernel_ms_per_rank": per_rank, "kernel_ms_max": max(per_rank),
+            "parity_vs_oracle": True if o is not None else None, "all_shards_cover_0_n": sums_ok,
+            "note": "fixed job: the same total work at every N (the weak line above fixes the work PER GPU); at N = 1 this is one GPU doing all of it"}
+
+
 def run_workload(job, wl):
     """One workload on every rank: index (rank 0 builds / loads, RCCL broadcast of the image), per-rank batch resident in HBM, warmup, timed
     steps between barriers, parity of the timed output against the oracle on every rank, CPU baseline on rank 0.  Returns the result
@@ -377,6 +538,7 @@ def run_workload(job, wl):
     path = index_path(args.cache_dir, wl)
     build_s = None
     h = None
+    index_sha = digest_ok = None
     if rank == 0:
         if not os.path.exists(path):
             t0 = time.time()
@@ -391,6 +553,11 @@ def run_workload(job, wl):
             os.replace(tmp, path)
             build_s = time.time() - t0
             log(f"{tag} built index over {nk} k-mers in {build_s:.1f}s -> {path} ({os.path.getsize(path)} bytes)")
+        index_sha = sha256_file(path)
+        want_sha = pinned_index_digest(wl)
+        digest_ok = None if want_sha is None else (want_sha["sha256"] == index_sha and want_sha["bytes"] == os.path.getsize(path))
+        log(f"{tag} index file {path}: {os.path.getsize(path)} bytes, sha256 {index_sha}"
+            + ("" if want_sha is None else f" -- the oracle builder's file (tests/golden/full_size_digests.json): {'SAME' if digest_ok else 'DIFFERENT: ' + want_sha['sha256']}"))
         t0 = time.time()
         h = load(path, local_rank)
         log(f"{tag} loaded + attached in {time.time() - t0:.1f}s: {h.get_kmer_count()} k-mers, {h.get_minimizer_L0()} minimizers, "
@@ -534,8 +701,14 @@ def run_workload(job, wl):
                        "cpu_quota_cores": quota,
                        "sample": f"first {S3} probes of the timed batch, {nthreads} POSIX threads over contiguous slices (= the CPUs visible, capped at twice the "
                                  f"container's CPU-time quota: the fastest setting on the box, tools/host_probe.py)"}
+    if digest_ok is False:  # the index the GPU just answered from is not the file the oracle builder writes for this set: no parity claim stands on it
+        parity = False
     if not all_ranks_ok(dist, torch, dev, parity is not False):
-        job.fail(3, f"{wl['name']}: GPU results differ from the oracle on at least one rank (this rank: {parity})")
+        job.fail(3, f"{wl['name']}: GPU results differ from the oracle on at least one rank (this rank: {parity}; index digest pinned: {digest_ok})")
+
+    strong = None
+    if dist is not None or args.strong:
+        strong = strong_pass(job, wl, h, recs, d_seq, o, stream, rec_order)
 
     if rank == 0 and o is not None and wl["headline"] and args.b1_records > 0 and not competitor:
         # BASELINE.md B1, "the number the reference tool would print": the oracle's restatement of src/query.cpp:24-88 over a
@@ -602,28 +775,32 @@ def run_workload(job, wl):
     # ---- N > 1: every replica (rank 0 parsed the file, the others received the image over RCCL) must answer alike ----
     replicas_agree = None
     if dist is not None:
-        if mode == "random":  # a probe set common to all ranks (the timed batches differ per rank)
-            gc = torch.Generator(device=dev)
-            gc.manual_seed(777)
-            Qc = 1 << 20
-            win = torch.randint(0, nk, (Qc,), generator=gc, device=dev, dtype=torch.int64)
-            posc = (win // RECORD_KMERS) * rec_len + win % RECORD_KMERS
-            d_kc = torch.empty(Qc * (kmer_bits // 64), dtype=torch.int64, device=dev)
-            h.pack_kmers(d_seq.data_ptr(), posc.data_ptr(), Qc, d_kc.data_ptr(), stream)
-            d_chk = torch.empty(Qc, dtype=torch.int64, device=dev)
-            h.query_packed(d_kc.data_ptr(), Qc, d_chk.data_ptr(), stream)
-            torch.cuda.synchronize()
-        else:  # every rank streamed the same records
-            d_chk = d_out
+        # a probe set common to all ranks, in both modes (random: the timed batches differ per rank; streaming: the weak line streams the same records
+        # on every rank -- their checksum rides along -- but the strong line's shards differ): packed k-mers of seeded windows through the random kernel
+        gc = torch.Generator(device=dev)
+        gc.manual_seed(777)
+        Qc = 1 << 20
+        win = torch.randint(0, nk, (Qc,), generator=gc, device=dev, dtype=torch.int64)
+        posc = (win // RECORD_KMERS) * rec_len + win % RECORD_KMERS
+        d_kc = torch.empty(Qc * (kmer_bits // 64), dtype=torch.int64, device=dev)
+        h.pack_kmers(d_seq.data_ptr(), posc.data_ptr(), Qc, d_kc.data_ptr(), stream)
+        d_chk = torch.empty(Qc, dtype=torch.int64, device=dev)
+        h.query_packed(d_kc.data_ptr(), Qc, d_chk.data_ptr(), stream)
+        torch.cuda.synchronize()
         weights = torch.arange(d_chk.numel(), dtype=torch.int64, device=dev) * 2 + 1  # order-dependent checksum, wrapping int64 arithmetic
-        t = torch.stack([d_chk.sum(), (d_chk * weights).sum(), d_chk.max()])
+        parts = [d_chk.sum(), (d_chk * weights).sum(), d_chk.max()]
         del weights
+        if mode == "stream":  # every rank streamed the same records in the weak line
+            weights = torch.arange(d_out.numel(), dtype=torch.int64, device=dev) * 2 + 1
+            parts += [d_out.sum(), (d_out * weights).sum()]
+            del weights
+        t = torch.stack(parts)
         tmin, tmax = t.clone(), t.clone()
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         replicas_agree = bool(torch.equal(tmin, tmax)) and (competitor or int(t[2].item()) < nk)
         common_ok = True
-        if rank == 0 and mode == "random" and o is not None:  # the common probes against the oracle (checker only)
+        if rank == 0 and o is not None:  # the common probes against the oracle (checker only)
             common_ok = bool(np.array_equal(o.query_packed(d_kc.cpu().numpy().view(np.uint64)), d_chk.cpu().numpy().view(np.uint64)))
             log(f"{tag} {Qc} probes common to all ranks: GPU == oracle: {common_ok}")
             parity = parity and common_ok
@@ -679,7 +856,7 @@ def run_workload(job, wl):
             "rccl_ranks": int(dist.get_world_size()) if dist is not None else 1,
             "replicas_agree": replicas_agree,
         }
-        traffic = valu = traffic_stale = traffic_src = None
+        traffic = valu = traffic_stale = traffic_src = l2_miss = rocprof_us = None
         try:  # HBM bytes and VALU instructions per unit from the committed PMC passes of this exact workload (never measured inside this run)
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             key = f"{mode}|{wl['kind']}|k{k}|m{m}|n{nk}|b{wl['batch_log2'] if mode == 'random' else 0}"
@@ -691,6 +868,9 @@ def run_workload(job, wl):
                     traffic = tj[key]["bytes_per_unit"] * units
                     traffic_src = tj[key].get("source")
                     valu = tj[key].get("valu_lane_instr_per_unit"), tj[key].get("valu_source")
+                    l2_miss = tj[key].get("l2_misses_per_unit")
+                    if tj[key].get("kernel_us_rocprof"):
+                        rocprof_us = tj[key]["kernel_us_rocprof"], tj[key].get("kernel_stats_source")
                 else:
                     traffic_stale = {"counters_taken_on_tree": tj[key].get("tree"), "this_tree": device_source_sha(), "source": tj[key].get("source"),
                                      "note": "the committed counter passes predate a change of the device sources: traffic / instr_per_unit withheld"}
@@ -707,17 +887,41 @@ def run_workload(job, wl):
             kernel_name = "k_query_packed"
         else:
             kernel_name = "k_query_tiles_stream8" if W >= 8 else "k_query_tiles_stream"  # (kStream8MinW, lphash_amd/csrc/stream8_device.cuh)
-        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        # What binds the kernel, from the evidence in this line -- the HBM `frac` stays the figure north_star asks for:
+        #   valu_issue            the committed SQ_INSTS_VALU pass x this run's rate is >= 0.9 of the VALU issue peak
+        #   fabric_line_requests  the image is Infinity-Cache resident: the index lines never reach HBM; the L2 misses of the committed TCC pass x this run's
+        #                         rate against the line-request rate the fabric sustains for scattered gathers (FABRIC_LINE_PEAK)
+        #   hbm                   otherwise (the image exceeds the Infinity Cache, or no counters for this tree / variant)
+        residency = "infinity_cache" if image_bytes < (256 << 20) else "hbm"
+        valu_frac = (valu[0] * units / kernel_s / VALU_PEAK_LANE_INSTR) if (valu is not None and valu[0]) else None
+        line_rate = (l2_miss * units / kernel_s) if l2_miss else None
+        if valu_frac is not None and valu_frac >= 0.9:
+            bound, why = "valu_issue", f"roofline_valu.frac {valu_frac:.2f} >= 0.9"
+        elif residency == "infinity_cache":
+            bound = "fabric_line_requests"
+            why = (f"index on chip; {l2_miss} L2 misses per unit x rate = {line_rate / 1e9:.1f} G lines/s of {FABRIC_LINE_PEAK / 1e9:.1f} G lines/s" if line_rate else
+                   "index on chip (no counter pass for this tree / variant: the line rate is not stated)")
+        else:
+            bound, why = "hbm", "index beyond the Infinity Cache: its lines come from HBM" + ("" if valu_frac is None else f"; roofline_valu.frac {valu_frac:.2f}")
+        wall_s = elapsed / steps  # the time base the driver's clock bounds (barrier to barrier, launch overheads included)
+        out["roofline"] = {"bound": bound, "bound_evidence": why, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "time_base": "HIP events around each launch on the launch stream, mean over the timed steps (max over ranks at N > 1)",
+                           "frac_from_ms_per_step": bpl * units / wall_s / 1e9 / HBM_PEAK_GBS,
+                           "kernel_us_rocprof": rocprof_us[0] if rocprof_us else None, "kernel_stats_source": rocprof_us[1] if rocprof_us else None,
+                           "frac_from_rocprof": (bpl * units / (rocprof_us[0] * 1e-6) / 1e9 / HBM_PEAK_GBS) if rocprof_us else None,
                            "peak_measured": peak_read, "peak_measured_copy": peak_copy,
                            "frac_of_measured": (achieved / peak_read) if peak_read else None,
                            "traffic": traffic, "traffic_source": traffic_src, "bytes_per_lookup": bpl, "kernel": kernel_name,
                            "compulsory_bytes_per_lookup": compulsory, "achieved_compulsory": compulsory * units / kernel_s / 1e9,
                            "frac_compulsory": compulsory * units / kernel_s / 1e9 / HBM_PEAK_GBS,
-                           "index_residency": ("infinity_cache" if image_bytes < (256 << 20) else "hbm"),
+                           "index_residency": residency,
                            "index_residency_note": (f"the {image_bytes / 1e6:.1f}-MB image is smaller than the 256-MiB Infinity Cache: its lines are re-read from on-chip "
                                                     "memory, `traffic` counts fabric requests, and the HBM proper carries the compulsory stream only"
                                                     if image_bytes < (256 << 20) else
                                                     f"the {image_bytes / 1e6:.1f}-MB image exceeds the 256-MiB Infinity Cache: index lines come from HBM")}
+        if line_rate:
+            out["roofline"].update({"l2_misses_per_unit": l2_miss, "line_requests_per_s": line_rate, "line_requests_peak": FABRIC_LINE_PEAK,
+                                    "frac_line_requests": line_rate / FABRIC_LINE_PEAK})
         if traffic_stale is not None:
             out["roofline"]["traffic_stale"] = traffic_stale
         if valu is not None and valu[0]:
@@ -742,6 +946,10 @@ def run_workload(job, wl):
             out["cli_end_to_end"] = cli_b1
         if binding_b1 is not None:
             out["binding_end_to_end"] = binding_b1
+        out["index_sha256"] = index_sha
+        out["index_digest_pinned"] = digest_ok
+        if strong is not None:
+            out["strong"] = strong
         if build_s is not None:
             out["index_build_s"] = build_s
         if bcast_s is not None:
@@ -754,7 +962,8 @@ def run_workload(job, wl):
 
 def secondary_entry(out, wl):
     keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "kernel_ms", "kernel_ms_min", "kernel_ms_max", "parity_vs_oracle",
-            "parity_ranks_checked", "replicas_agree", "roofline", "roofline_valu", "cpu_baseline", "index_build_s", "image_broadcast_ms")
+            "parity_ranks_checked", "replicas_agree", "roofline", "roofline_valu", "cpu_baseline", "index_build_s", "image_broadcast_ms", "scaling", "strong",
+            "index_sha256", "index_digest_pinned")
     e = {"name": wl["name"], "workload": out["config"]["workload"], "units_per_step_per_gpu": out["config"]["units_per_step_per_gpu"],
          "index_image_bytes": out["config"]["index_image_bytes"]}
     e.update({k_: out[k_] for k_ in keep if k_ in out})
@@ -791,6 +1000,9 @@ def main():
                     help="records of the index set the reference-faithful driver baseline (B1: gz + parse inside the timer) reads; 0 = skip")
     ap.add_argument("--no-secondary", action="store_true", help="headline only: skip the C3 / C5 / C4 measurements that follow a default (C2) run")
     ap.add_argument("--secondary-c4-kmers", type=int, default=2_000_000_000, help="k-mers of the C4 secondary workloads (BASELINE.json: 2 B)")
+    ap.add_argument("--strong", action="store_true", help="also run the strong-scaling pass (fixed total work, sharded) with one rank and no process group")
+    ap.add_argument("--strong-total-log2", type=int, default=0,
+                    help="random mode: log2 of the fixed probe set of the strong-scaling pass (default: batch-log2 + 3 = what 8 GPUs answer per step of the weak line)")
     ap.add_argument("--plan-records", action="store_true",
                     help="with --plan-only: also run the record-set logic of the first workload (rank 0 generates and shares through --cache-dir, the other "
                          "ranks stream the file) and report source, CRC-32 and peak RSS per rank")
@@ -847,10 +1059,21 @@ def main():
                 records_report = gathered
             else:
                 records_report = [mine]
+        strong_report = None
+        if "strong" in plan:  # what THIS rank would take of every workload's fixed job, as it works it out from its own RANK (gathered: the test checks the partition)
+            mine = {"rank": rank, "shards": [strong_plan(w, world, strong_total_log2_of(args, w))["shards"][rank] for w in plan["workloads"]]}
+            if dist is not None:
+                gathered = [None] * world
+                dist.all_gather_object(gathered, mine)
+                strong_report = gathered
+            else:
+                strong_report = [mine]
         if dist is not None:
             dist.destroy_process_group()
         if rank == 0:
             line = {"plan": plan, "ranks": world, "ranks_agree": True}
+            if strong_report is not None:
+                line["strong_shards_by_rank"] = strong_report
             if records_report is not None:
                 line["records"] = records_report
             result_out.write(json.dumps(line) + "\n")

@@ -22,7 +22,8 @@ def shard_records(lengths, rank, world):
         return 0, 0
     cum = np.cumsum(lengths)
     total = int(cum[-1])
-    bounds = [int(np.searchsorted(cum, (total * r) // world, side="left")) for r in range(world)] + [len(lengths)]
+    # shard r starts after the records that END at or before r / world of the bases (equal-length records split evenly: 1000 records, 2 ranks -> 500 + 500)
+    bounds = [int(np.searchsorted(cum, (total * r) // world, side="right")) for r in range(world)] + [len(lengths)]
     bounds[0] = 0
     for i in range(1, len(bounds)):
         bounds[i] = max(bounds[i], bounds[i - 1])

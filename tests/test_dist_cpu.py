@@ -118,7 +118,9 @@ def test_bench_plan_names_every_baseline_configuration():
     assert r.returncode == 0, r.stderr[-2000:]
     plan = json.loads(r.stdout.strip().splitlines()[-1])["plan"]
     names = [w["name"] for w in plan["workloads"]]
-    assert names == ["C2", "C3", "C5", "C4-random", "C4-stream"]
+    assert names == ["C2", "C3", "C5", "C4-random", "C4-stream", "C2-nonmember50", "C3-shuffled"]  # the last two: BASELINE.md section 3's secondary inputs
+    assert plan["workloads"][5]["nonmember_frac"] == 0.5 and plan["workloads"][6]["shuffle_records"] is True
+    assert plan["index_paths"][5] == plan["index_paths"][0] == plan["index_paths"][6] and "strong" not in plan  # (one rank, no --strong: the weak line only)
     c4 = plan["workloads"][3]
     assert (c4["k"], c4["m"], c4["kmers"], c4["kmer_bits"], c4["batch_log2"], c4["steps"], c4["warmup"]) == (63, 20, 2_000_000_000, 128, 28, 20, 5)
     assert plan["workloads"][1]["mode"] == "stream" and plan["workloads"][2]["kind"] == "u" and plan["workloads"][4]["mode"] == "stream"
@@ -144,14 +146,53 @@ def test_bench_rank_logic_gloo_world2(tmp_path):
     line = json.loads(lines[0])
     assert line["ranks"] == 2 and line["ranks_agree"] is True
     assert line["plan"]["gpus"] == 2 and line["plan"]["cache_dir"] == str(tmp_path / "cache")
-    assert all(w["steps"] == 7 and w["warmup"] == 3 for w in line["plan"]["workloads"]) and len(line["plan"]["workloads"]) == 5
+    assert all(w["steps"] == 7 and w["warmup"] == 3 for w in line["plan"]["workloads"]) and len(line["plan"]["workloads"]) == 7
     assert all(p.startswith(str(tmp_path / "cache")) for p in line["plan"]["index_paths"])
+    _check_strong_partition(line, 2)
     r = _run_bench(args, {"LPHQ_BENCH_TEST_FAIL_RANK": "1"})
     assert r.returncode != 0 and '"plan"' not in r.stdout
     assert "a rank failed" in r.stderr
     # WORLD_SIZE that contradicts --gpus: refused before anything else happens
     r = _run_bench(["--gpus", "1", "--plan-only"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode == 2 and "WORLD_SIZE=2 but --gpus 1" in r.stderr
+
+
+def _check_strong_partition(line, world):
+    """The strong-scaling plan (fixed total work): per workload the ranks' shards -- as EACH RANK worked its own out -- are the plan's, contiguous, without
+    overlap, and cover the fixed job: 2^31 probes (random; = 8 GPUs x the weak line's 2^28) or all records (streaming)."""
+    plan, by_rank = line["plan"], sorted(line["strong_shards_by_rank"], key=lambda e: e["rank"])
+    assert [e["rank"] for e in by_rank] == list(range(world)) and len(plan["strong"]) == len(plan["workloads"])
+    for wi, (wl, sp) in enumerate(zip(plan["workloads"], plan["strong"])):
+        shards = [e["shards"][wi] for e in by_rank]
+        assert shards == sp["shards"] and len(shards) == world
+        assert shards[0][0] == 0 and shards[-1][1] == sp["total"] and all(a[1] == b[0] for a, b in zip(shards, shards[1:])) and all(a <= b for a, b in shards)
+        if wl["mode"] == "random":
+            assert sp["unit"] == "probes" and sp["total"] == 1 << (wl["batch_log2"] + 3)
+        else:
+            assert sp["unit"] == "records" and sp["total"] == wl["n_records"]
+        sizes = [b - a for a, b in shards]
+        assert max(sizes) - min(sizes) <= 1  # equal-length records / probes: the shards differ by at most one unit
+
+
+def test_bench_strong_plan_partitions_the_fixed_job_gloo_world8(tmp_path):
+    """`--gpus 8 --plan-only`: eight ranks over gloo each take their shard of every workload's fixed job (C4: 2^31 probes -> 2^28 per GPU; 20,000 records ->
+    2,500 per GPU), and the shards partition it; ragged cases of the two sharding functions beside it."""
+    import json
+
+    from lphash_amd.dist import shard_range, shard_records
+
+    r = _run_bench(["--gpus", "8", "--plan-only", "--cache-dir", str(tmp_path / "cache")], timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    _check_strong_partition(line, 8)
+    c4r, c4s = line["plan"]["strong"][3], line["plan"]["strong"][4]
+    assert c4r["shards"][3] == [3 << 28, 4 << 28] and c4s["shards"][7] == [17_500, 20_000]
+    for n, w in ((10, 3), (7, 8), (0, 4), (1 << 31, 6)):
+        cuts = [shard_range(n, r_, w) for r_ in range(w)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+    lens = [5, 0, 100, 3, 3, 3, 50, 1]
+    cuts = [shard_records(lens, r_, 3) for r_ in range(3)]
+    assert cuts[0][0] == 0 and cuts[-1][1] == len(lens) and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
 
 
 def test_bench_record_set_is_shared_not_regenerated_gloo_world8(tmp_path):
