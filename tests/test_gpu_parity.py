@@ -272,6 +272,28 @@ def test_large_index_properties(tmp_path, kind, k, m, bits, n_rec):
     path = str(tmp_path / "big.lph")
     # sequential CPU pilot search (the query path is what is under test) except at 2 B k-mers, where it would take minutes
     L.build(recs, k, m, path, kind=kind, kmer_bits=bits, threads=0, device=0 if n_rec > 1000 else None)
+    # the file just built against the ORACLE builder's on the same set (tests/golden/full_size_digests.json, tools/full_size_digests.py: 20 minutes of one
+    # core at 2 B k-mers, so it is derived once in the build container): CPU pilot search at 100 M, GPU extraction + pilot search at 2 B -- same bytes
+    import hashlib
+    import json
+
+    def sha256_file(p_):
+        hs = hashlib.sha256()
+        with open(p_, "rb") as f_:
+            for blk in iter(lambda: f_.read(1 << 24), b""):
+                hs.update(blk)
+        return hs.hexdigest()
+
+    pinned = json.load(open(os.path.join(ROOT, "tests", "golden", "full_size_digests.json"))).get(f"{'pu'[kind]}_k{k}_m{m}_b{bits}_seed1_{n_rec}x{L_rec}")
+    assert (pinned is not None) == (n_rec >= 1000)
+    if pinned is not None:
+        assert os.path.getsize(path) == pinned["bytes"] and sha256_file(path) == pinned["sha256"], "full-size build differs from the oracle builder's file"
+    if n_rec > 1000:  # ... and with a memory limit of 1 GB (sorted pieces on disk, the pilot search piece by piece on the device): the same file
+        p2 = str(tmp_path / "ext.lph")
+        L.build_stream(lambda: (recs[i:i + 250] for i in range(0, n_rec, 250)), k, m, p2, kind=kind, kmer_bits=bits, threads=0, device=0,
+                       tmp_dir=str(tmp_path / "spill"), max_memory_bytes=1 << 30)
+        assert sha256_file(p2) == pinned["sha256"]
+        os.remove(p2)
     h = (L.Mphf if kind == 0 else L.MphfAlt).load(path, kmer_bits=bits, device=0)
     n = n_rec * 100_000
     assert h.get_kmer_count() == n

@@ -149,3 +149,23 @@ def test_kernels_fit_their_register_and_lds_budget(src):
              "k_extract_runs": "extract.hip", "k_assemble_runs": "extract.hip", "k_group_flags": "extract.hip", "k_group_scatter": "extract.hip"}
     expected = {k for k in BUDGET if where.get(k, "kernels.hip") == src}
     assert seen == expected, (seen, expected)
+
+
+def test_the_committed_isa_listing_is_of_this_tree():
+    """profiles/isa_rest.json (tools/isa_rest_listing.py --json: the VALU instructions of k_query_packed by step, what bench.py's floor_instr_per_unit cites) was
+    taken on the device sources in this tree -- it is regenerated offline (hipcc, no GPU), so there is no reason for it to lag -- and adds up: the listed total is
+    within 1 % of the counter pass of the same tree where profiles/pmc_traffic.json has one."""
+    import json
+    import sys
+
+    sys.path.insert(0, ROOT)
+    from bench import device_source_sha
+
+    ij = json.load(open(os.path.join(ROOT, "profiles", "isa_rest.json")))
+    assert ij["tree"] == device_source_sha(), "device sources changed: run `python tools/isa_rest_listing.py --json > profiles/isa_rest.json` (and refresh profiles/r05_isa_rest.txt)"
+    tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    for tkey, pkey in (("0,false,4", "random|p|k31|m20|n100000000|b28"), ("1,false,4", "random|u|k31|m20|n100000000|b28"), ("0,true,6", "random|p|k63|m20|n2000000000|b28")):
+        e = ij[tkey]
+        assert e["scan_instr_per_unit"] == 29 * e["W"] and abs(e["listed_instr_per_unit"] - e["scan_instr_per_unit"] - e["rest_instr_per_unit_listed"]) < 0.2
+        if tj.get(pkey, {}).get("tree") == ij["tree"]:
+            assert abs(e["listed_instr_per_unit"] / tj[pkey]["valu_lane_instr_per_unit"] - 1.0) < 0.01, (tkey, e["listed_instr_per_unit"], tj[pkey]["valu_lane_instr_per_unit"])

@@ -246,6 +246,16 @@ def test_bench_collective_path_with_one_rank(tmp_path, mode):
     # compared their own timed batch with the oracle, and the CPU baseline of rank 0 at any N
     assert len(line["kernel_ms_per_rank"]) == 1 and line["kernel_ms_min"] == line["kernel_ms_max"] == line["kernel_ms_per_rank"][0] > 0
     assert line["parity_ranks_checked"] == 1 and line["cpu_baseline"]["value"] > 0 and "secondary" not in line
+    # the strong-scaling pass (a fixed job sharded over the ranks) with the one rank: its shard is the whole job -- 2^(20+3) probes of the common seeded set,
+    # or every window of the 20 records; checked against the oracle, streaming also as a permutation of [0, n) by the all-reduced checksums
+    st = line["strong"]
+    assert line["scaling"] == "weak" and st["scaling"] == "strong" and st["n_gpus"] == 1 and st["parity_vs_oracle"] is True and st["value"] > 0
+    if mode == "random":
+        assert st["total_units_per_step"] == 1 << 23 and st["shards"] == [[0, 1 << 23]] and st["all_shards_cover_0_n"] is None
+    else:
+        assert st["total_units_per_step"] == 2_000_000 and st["shards"] == [[0, 20]] and st["all_shards_cover_0_n"] is True
+    assert line["roofline"]["bound"] in ("fabric_line_requests", "hbm", "valu_issue") and line["roofline"]["frac_from_ms_per_step"] > 0
+    assert line["index_sha256"] and line["index_digest_pinned"] is None  # (2 M k-mers: not one of the pinned full-size sets)
 
 
 @pytest.mark.parametrize("name", ["p_k31_m20_b64", "u_k31_m20_b64", "p_k63_m20_b128", "p_k21_m8_b64_fallback"])

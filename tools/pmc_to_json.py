@@ -42,5 +42,14 @@ for suf, (key, units, frag) in WL.items():
         e["valu_source"] = f"profiles/{tag}_pmc_{suf}_raw.txt (SQ_INSTS_VALU)"
     if "TCC_MISS_sum" in c:
         e["l2_misses_per_unit"] = round(c["TCC_MISS_sum"] / units, 3)
+    stats = os.path.join(d, f"{tag}_{suf}_kernel_stats.txt")  # rocprofv3 --kernel-trace --stats of the same command (tools/pmc_passes.sh): average duration of the kernel
+    if os.path.exists(stats):
+        for line in open(stats):
+            f = line.split()
+            if len(f) > 12 and frag in line and f[0].isdigit():
+                e["kernel_us_rocprof"] = float(f[2])
+                e["kernel_us_rocprof_calls"] = int(f[0])
+                e["kernel_stats_source"] = f"profiles/{tag}_{suf}_kernel_stats.txt"
+                break
     out[key] = e
 print(json.dumps(out, indent=1))
