@@ -81,3 +81,31 @@ def test_product_cpu_builder_writes_the_oracle_file_on_real_unitigs(tmp_path, na
         assert np.array_equal(flat[:HEAD], heads[qname]) and sha(flat) == e["queries"][qname]["random_sha256"]
         st_codes = np.concatenate([r[valid_windows(q, k)] for q, r in zip(qrecs, rnd)])
         assert st_codes.size == e["queries"][qname]["valid_windows"] and sha(st_codes) == e["queries"][qname]["streaming_sha256"]
+
+
+@pytest.mark.parametrize("k,m,bits,kind,ust,n_rec", [(31, 20, 64, 0, "ust_k31", 120), (63, 17, 128, 0, "ust_k63", 40), (47, 20, 128, 1, "ust_k31", 80), (31, 15, 64, 1, "ust_k31", 80)])
+def test_python_model_equals_the_oracle_on_real_unitigs(tmp_path, k, m, bits, kind, ust, n_rec):
+    """The third restatement (tests/golden/pymodel.py: pure Python, no code shared with the C oracle or the product) on a slice of the REAL unitigs -- 
+    medium-sized records of the set, real minimizer skew and colliding minimizers -- and on low-complexity records (homopolymers, tandem repeats: tied minimizer
+    hashes): its serialized bytes == the oracle builder's == the product builder's, its codes == the oracle's."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT)))
+    import pymodel
+    from util import low_complexity_index_records
+
+    z = load_inputs()
+    real = [r for r in unitig_records(z, ust) if 300 <= len(r) <= 12_000][:n_rec]  # (pure Python: ~10^5 k-mers)
+    assert sum(map(len, real)) > 40_000
+    for recs in (real, [r for r in low_complexity_index_records(k, 77) if len(r) < 600][:40]):
+        po, pp = str(tmp_path / "o.lph"), str(tmp_path / "p.lph")
+        orc.build(recs, k, m, po, kind=kind, kmer_bits=bits)
+        L.build(recs, k, m, pp, kind=kind, kmer_bits=bits, threads=4)
+        mdl = pymodel.Model(recs, k, m, kind, bits)
+        want = open(po, "rb").read()
+        assert mdl.serialize() == want and open(pp, "rb").read() == want
+        ix = orc.Index(po, kind, bits)
+        assert (mdl.nkmers, mdl.D, len(mdl.fallback_keys)) == (ix.nkmers, ix.distinct_minimizers, ix.fallback_keys)
+        for q in recs[:3] + [query_sets(z)["ecoli"][0][9_900:10_400], b"A" * (k + 30), (b"AC" * k)]:
+            clean = bytes(c if c in b"ACGT" else ord("A") for c in q)  # the model takes valid bases only; the random branch reads anything else as A (mphf_utils.hpp:108)
+            assert np.array_equal(np.array(mdl.query(clean), dtype=np.uint64), ix(q, False))
