@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import lphash_amd as L  # noqa: E402
-from util import dedup_records, random_records  # noqa: E402
+from util import dedup_records, genomic_like_records, random_records  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 dev = int(os.environ.get("LPHQ_FUZZ_DEVICE", "0"))
@@ -29,14 +29,16 @@ while time.time() < t_end:
     m = int(rng.integers(max(1, k - 61), min(k, 32) + 1))
     kind = int(rng.integers(0, 2))
     seed = int(rng.integers(1, 1 << 30))
-    shape = int(rng.integers(0, 3))
-    if shape == 0:  # a few long records
+    shape = int(rng.integers(0, 5))
+    if shape >= 3 and k >= 8:  # round 5: sets with the shape of genomes -- repeats, diverged copies: most super-k-mers under repeated minimizers (the external
+        recs = genomic_like_records(seed, int(rng.integers(5, 120)), k, int(rng.choice([400, 4000, 30_000])))  # classifier's `colliding` list, the fallback PTHash in pieces)
+    elif shape == 0:  # a few long records
         recs = random_records(seed, int(rng.integers(1, 6)), 5_000, 120_000)
     elif shape == 1:  # many short ones (tens of records per tile), some shorter than k, some empty
         recs = random_records(seed, int(rng.integers(50, 2000)), 0, 4 * k + 10)
     else:
         recs = random_records(seed, int(rng.integers(3, 40)), 0, 6_000) + random_records(seed + 1, 2, 20_000, 60_000)
-    recs = dedup_records(recs, k)
+    recs = dedup_records(recs, k) if shape < 3 or k < 8 else recs
     if not recs:
         continue
     if rng.integers(0, 2):  # non-ACGT bases, lower case

@@ -14,13 +14,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import lphash_amd as L  # noqa: E402
 import orc  # noqa: E402
-from util import dedup_records, pack_kmers, random_records  # noqa: E402
+from util import dedup_records, genomic_like_records, pack_kmers, random_records  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(20261002)
 t_end = time.time() + budget
-n_cfg = n_codes = 0
+n_cfg = n_codes = n_genomic = n_fallback = 0
 tmp = tempfile.mkdtemp()
 while time.time() < t_end:
     bits = int(rng.choice([64, 128]))
@@ -28,7 +28,14 @@ while time.time() < t_end:
     m = int(rng.integers(max(1, k - 61), min(k, 32) + 1))
     kind = int(rng.integers(0, 3))  # 2 = bare PTHash over k-mers
     nrec = int(rng.integers(3, 40))
-    recs = random_records(int(rng.integers(1 << 30)), nrec, k, int(rng.choice([k + 5, 300, 3000, 12000])))
+    genomic = k >= 14 and rng.random() < 0.4  # round 5: not only i.i.d. uniform bases -- GC skew, tandem repeats, diverged copies (shared minimizers: fallback path)
+    if genomic:
+        recs = genomic_like_records(int(rng.integers(1 << 30)), nrec, k, int(rng.choice([300, 3000, 12000])))
+        n_genomic += 1
+        if not recs:
+            continue
+    else:
+        recs = random_records(int(rng.integers(1 << 30)), nrec, k, int(rng.choice([k + 5, 300, 3000, 12000])))
     if k < 14:
         recs = dedup_records(recs, k)[:6]
         if not recs:
@@ -42,12 +49,16 @@ while time.time() < t_end:
             L.build(recs, k, m, path, kind=kind, kmer_bits=bits, threads=8)
             o = orc.Index(path, kind, bits)
             h = (L.Mphf if kind == 0 else L.MphfAlt).load(path, kmer_bits=bits, device=0)
+            n_fallback += int(o.fallback_keys)
     except L.LphqError as e:  # duplicate k-mers in random short records / unplaceable tiny sets: not what is under test
         if "duplicate" in str(e) or "no pilot" in str(e):
             continue
         raise
     # batch: members, non-members, short, empty, records with invalid bases
     batch = list(recs) + random_records(int(rng.integers(1 << 30)), 5, 0, 2000) + [b"", recs[0][: k - 1]]
+    if genomic:  # queries of that shape too: repeats far longer than a window, runs of N of k bases and more
+        unit = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(rng.integers(1, 6)))])
+        batch += [unit * (3000 // len(unit)), recs[0][: len(recs[0]) // 2] + b"N" * (k + int(rng.integers(0, 9))) + recs[0][len(recs[0]) // 2:], b"A" * 500 + recs[-1]]
     for i in range(0, len(batch), 3):
         q = bytearray(batch[i])
         for p in rng.integers(0, max(len(q), 1), 3):
@@ -112,4 +123,5 @@ while time.time() < t_end:
         assert np.array_equal(d_o.cpu().numpy().view(np.uint64), o.query_packed(pk)), (k, m, bits, kind, "packed")
     h.close()
     n_cfg += 1
-print(f"gpu fuzz ok: {n_cfg} random configurations, {n_codes} codes compared with the oracle in {budget:.0f} s")
+print(f"gpu fuzz ok: {n_cfg} random configurations ({n_genomic} drawn with genomic-like records; {n_fallback} k-mers in fallback functions in total), "
+      f"{n_codes} codes compared with the oracle in {budget:.0f} s")

@@ -217,6 +217,36 @@ def test_low_complexity_ties_on_the_emulator(emuk, tmp_path, k, m, bits, kind):
                 assert np.array_equal(g, e)
 
 
+@pytest.mark.parametrize("k,m,bits,kind", [(31, 20, 64, 0), (63, 20, 128, 0), (21, 8, 64, 1), (47, 17, 128, 0)])
+def test_genomic_like_sets_on_the_emulator(emuk, tmp_path, k, m, bits, kind):
+    """Index sets with the shape of genomes (tests/util.py: GC skew, tandem repeats, diverged copies of earlier segments -> 5-70 % of the k-mers sit behind
+    colliding minimizers, where uniform bases put 0.01 %): the product builder's file == the oracle builder's, and the tile kernels == the oracle with the
+    fallback function on the common path."""
+    from real_fixture import valid_windows
+    from util import genomic_like_records
+
+    recs = genomic_like_records(1000 + k + m, 30, k, 5000)
+    path, po = str(tmp_path / "t.lph"), str(tmp_path / "o.lph")
+    L.build(recs, k, m, path, kind=kind, kmer_bits=bits, threads=4)
+    orc.build(recs, k, m, po, kind=kind, kmer_bits=bits)
+    assert open(path, "rb").read() == open(po, "rb").read()
+    o = orc.Index(path, kind, bits)
+    assert o.fallback_keys > 0.03 * o.nkmers
+    h = (L.Mphf if kind == 0 else L.MphfAlt).load(path, kmer_bits=bits)
+    noisy = bytearray(recs[1])
+    noisy[len(noisy) // 3:len(noisy) // 3 + k + 4] = b"N" * (k + 4)
+    batch = recs[:12] + [bytes(noisy), recs[0][::-1], b"AC" * 400, recs[2][:k], b""]
+    exp = [o(q, False) if len(q) >= k else np.zeros(0, dtype=np.uint64) for q in batch]
+    val = [valid_windows(q, k) for q in batch]
+    for q, e, v in zip(batch, exp, val):
+        if v.size and v.all():
+            assert np.array_equal(o(q, True), e)
+    for streaming, mis, block in [(True, 0, 256), (False, 2, 256), (True, 5, 128 | 0x40000)]:
+        got = emu_records(emuk, h, batch, k, streaming, mis, block)
+        for g, e, v in zip(got, exp, val):
+            assert np.array_equal(g[v], e[v]) if streaming else np.array_equal(g, e)
+
+
 @pytest.mark.parametrize("name", ["se_k31_m20_b64_p", "se_k63_m20_b128_p", "se_k47_m20_b128_u"])
 def test_real_data_on_the_emulator(emuk, tmp_path, name):
     """The device sources on real genomic input (tests/golden/real/: the reference's bundled unitigs and query files): slices of the unitigs (members),

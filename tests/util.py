@@ -70,3 +70,35 @@ def low_complexity_queries(recs, k, seed):
         qs.append(bytes(q[:3000]))
     qs += [b"N" * (2 * k), b"A" * (k - 1) + b"N" + b"A" * k, (b"A" * k + b"N") * 20, b"G" * 300 + b"NN" + b"G" * 300]
     return qs
+
+
+def genomic_like_records(seed, n, k, max_len):
+    """Records with the SHAPE of genomic sequence instead of i.i.d. uniform bases: a GC content drawn per set, tandem repeats and homopolymer runs as long as they
+    may be without repeating a k-mer, and diverged copies of earlier segments (one substitution in every window of k - 1 bases: no k-mer is repeated, but most
+    minimizers are -- the colliding-minimizer / fallback path of src/partitioned_mphf.cpp:163-268 gets real work).  De-duplicated like every index set."""
+    rng = np.random.default_rng(seed)
+    gc = rng.uniform(0.3, 0.7)
+    probs = np.array([(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2])
+    recs = []
+    for _ in range(n):
+        ln = int(rng.integers(k, max(k + 1, max_len)))
+        r = bytearray(ACGT[rng.choice(4, size=ln, p=probs)].tobytes())
+        style = rng.integers(0, 4)
+        if style == 1 and ln > 3 * k:  # a tandem repeat / homopolymer inside
+            p = int(rng.integers(1, 7))
+            unit = bytes(ACGT[rng.integers(0, 4, p)])
+            rep = (unit * (k // p + 3))[:int(rng.integers(max(2, k // 2), k + p - 1))]
+            at = int(rng.integers(0, ln - len(rep)))
+            r[at:at + len(rep)] = rep
+        elif style == 2 and recs:  # a diverged copy of a segment of an earlier record
+            src = recs[int(rng.integers(0, len(recs)))]
+            seg_len = min(len(src), ln)
+            a = int(rng.integers(0, len(src) - seg_len + 1))
+            seg = bytearray(src[a:a + seg_len])
+            step = max(1, k - 1)
+            for pos in range(int(rng.integers(0, step)), seg_len, step):
+                seg[pos] = b"ACGT"[(b"ACGT".index(seg[pos]) + 1 + int(rng.integers(0, 3))) % 4]
+            at = int(rng.integers(0, ln - seg_len + 1))
+            r[at:at + seg_len] = seg
+        recs.append(bytes(r))
+    return dedup_records(recs, k)
