@@ -79,7 +79,7 @@ def pinned_index_digest(wl):
         table = json.load(open(os.path.join(ROOT, "tests", "golden", "full_size_digests.json")))
     except (OSError, ValueError):
         return None
-    if wl["kind"] not in ("p", "u"):
+    if wl["kind"] not in ("p", "u") or wl["index_set"] != "uniform":
         return None
     return table.get(f"{wl['kind']}_k{wl['k']}_m{wl['m']}_b{wl['kmer_bits']}_seed1_{wl['n_records']}x{wl['rec_len']}")
 
@@ -105,12 +105,12 @@ def log(*a):
 # the plan: pure functions of the arguments (no GPU, no torch) -- every rank must resolve the same one
 # ----------------------------------------------------------------------------------------------------------
 def make_workload(name, mode, kind, k, m, kmers, batch_log2, steps, warmup, cpu_sample_log2, gpu_build, nonmember_frac=0.0,
-                  shuffle_records=False, bbhash_gamma=1.0, headline=False):
+                  shuffle_records=False, bbhash_gamma=1.0, headline=False, index_set="uniform"):
     n_records = max(1, kmers // RECORD_KMERS)
     return {"name": name, "mode": mode, "kind": kind, "k": k, "m": m, "kmers": n_records * RECORD_KMERS, "n_records": n_records,
             "rec_len": RECORD_KMERS + k - 1, "kmer_bits": 64 if k <= 31 else 128, "batch_log2": batch_log2, "steps": steps, "warmup": warmup,
             "cpu_sample_log2": cpu_sample_log2, "gpu_build": bool(gpu_build), "nonmember_frac": nonmember_frac,
-            "shuffle_records": bool(shuffle_records), "bbhash_gamma": bbhash_gamma, "headline": headline}
+            "shuffle_records": bool(shuffle_records), "bbhash_gamma": bbhash_gamma, "headline": headline, "index_set": index_set}
 
 
 def config_name(wl):
@@ -125,18 +125,19 @@ def config_name(wl):
 
 def index_path(cache_dir, wl):
     g = wl["bbhash_gamma"] if wl["kind"] == "bbhash" else ""
-    return os.path.join(cache_dir, f"synth_seed1_{wl['kind']}{g}_k{wl['k']}_m{wl['m']}_n{wl['kmers']}_b{wl['kmer_bits']}.lph")
+    d = "" if wl["index_set"] == "uniform" else "_" + wl["index_set"]
+    return os.path.join(cache_dir, f"synth_seed1{d}_{wl['kind']}{g}_k{wl['k']}_m{wl['m']}_n{wl['kmers']}_b{wl['kmer_bits']}.lph")
 
 
 def headline_workload(args):
     wl = make_workload("headline", args.mode, args.kind, args.k, args.m, args.kmers, args.batch_log2, args.steps, args.warmup, args.cpu_sample_log2,
-                       args.gpu_build, args.nonmember_frac, args.shuffle_records, args.bbhash_gamma, headline=True)
+                       args.gpu_build, args.nonmember_frac, args.shuffle_records, args.bbhash_gamma, headline=True, index_set=args.index_set)
     wl["name"] = config_name(wl)
     return wl
 
 
 def is_default_headline(wl):
-    return (wl["mode"], wl["kind"], wl["k"], wl["m"], wl["kmers"], wl["batch_log2"], wl["nonmember_frac"]) == ("random", "p", 31, 20, 100_000_000, 28, 0.0)
+    return (wl["mode"], wl["kind"], wl["k"], wl["m"], wl["kmers"], wl["batch_log2"], wl["nonmember_frac"], wl["index_set"]) == ("random", "p", 31, 20, 100_000_000, 28, 0.0, "uniform")
 
 
 def secondary_workloads(args, head):
@@ -353,17 +354,20 @@ class Job:
         self.valu = {}
 
     def records(self, wl):
-        from lphash_amd.synth import synthetic_records
+        from lphash_amd.synth import diverged_copy_records, synthetic_records
 
-        key = (wl["n_records"], wl["rec_len"])
+        key = (wl["n_records"], wl["rec_len"], wl["index_set"])
         if key not in self._records:
             self._records.clear()  # one set at a time (C4's is 2 GB)
             t0 = time.time()
-            n, ln = key
-            path = os.path.join(self.args.cache_dir, f"records_seed1_{n}x{ln}.u8") if self.world > 1 else None
+            n, ln, which = key
+            path = os.path.join(self.args.cache_dir, f"records_seed1_{n}x{ln}" + ("" if which == "uniform" else "_" + which) + ".u8") if self.world > 1 else None
             rs = None
             if self.rank == 0:
-                flat, _ = synthetic_records(seed=1, n_records=n, length=ln, views=False)
+                if which == "uniform":
+                    flat, _ = synthetic_records(seed=1, n_records=n, length=ln, views=False)
+                else:  # a set with the repeat structure of a genome (lphash_amd/synth.py): tens of per cent of the k-mers behind colliding minimizers
+                    flat, _ = diverged_copy_records(seed=1, n_records=n, length=ln, k=wl["k"], views=False)
                 rs = RecordSet(n, ln, flat=flat, source="generated")
                 log(f"[bench r{self.rank}] generated {n} records x {ln} bases in {time.time() - t0:.1f}s")
                 if path is not None and not (os.path.exists(path) and os.path.getsize(path) == n * ln):
@@ -839,7 +843,8 @@ def run_workload(job, wl):
             "data": "synthetic",
             "config": {
                 "workload": cfg_name + (f": boomphf::mphf over the k-mers, gamma {wl['bbhash_gamma']}," if kind == L.BBHASH else ": pthash::single_phf over the k-mers," if kind == L.PTHASH else (": partitioned LP-MPHF" if kind == L.PARTITIONED else ": unpartitioned LP-MPHF"))
-                + f" k={k} m={m}, {nk} k-mers (SplitMix64 seed 1, {n_records} records x {rec_len} bases); "
+                + f" k={k} m={m}, {nk} k-mers (SplitMix64 seed 1, {n_records} records x {rec_len} bases"
+                + ("" if wl["index_set"] == "uniform" else f"; the second half of the records = diverged copies of the first half: {h.info.fallback_kmers / nk:.1%} of the k-mers in the fallback function") + "); "
                 + ((f"2^{wl['batch_log2']} random positive packed k-mer lookups per GPU per step" if wl["nonmember_frac"] == 0.0 else
                     f"2^{wl['batch_log2']} random packed k-mer lookups per GPU per step, {wl['nonmember_frac']:.0%} of them uniformly random non-members")
                    if mode == "random"
@@ -860,7 +865,7 @@ def run_workload(job, wl):
         try:  # HBM bytes and VALU instructions per unit from the committed PMC passes of this exact workload (never measured inside this run)
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             key = f"{mode}|{wl['kind']}|k{k}|m{m}|n{nk}|b{wl['batch_log2'] if mode == 'random' else 0}"
-            variant = wl["nonmember_frac"] != 0.0 or rec_order is not None
+            variant = wl["nonmember_frac"] != 0.0 or rec_order is not None or wl["index_set"] != "uniform"
             if key in tj and not variant:  # (counter passes exist for the default kernels on the primary workloads only)
                 # the passes are evidence for the kernels they were taken on: an entry whose device sources are not the ones in this tree is reported
                 # as stale and contributes no number
@@ -1010,6 +1015,9 @@ def main():
     ap.add_argument("--nonmember-frac", type=float, default=0.0,
                     help="random mode: this fraction of the probes are uniformly random k-mers (non-members; SURVEY 8(d) secondary run)")
     ap.add_argument("--shuffle-records", action="store_true", help="stream mode: the index records in a random order (SURVEY 8(d) variant)")
+    ap.add_argument("--index-set", choices=["uniform", "diverged"], default="uniform",
+                    help="uniform: i.i.d. bases (BASELINE's synthetic sets); diverged: half the records are diverged copies of the other half -- the repeat structure of a "
+                         "genome: 30 % (k=31) to 60 % (k=63) of the k-mers behind colliding minimizers, answered by the fallback function (not a BASELINE configuration)")
     ap.add_argument("--cache-dir", default=os.environ.get("LPHQ_BENCH_CACHE", "/tmp/lphq_bench_cache"))
     ap.add_argument("--no-hbm-probe", action="store_true", help="skip the in-run measurement of the HBM copy ceiling (roofline.peak_measured)")
     ap.add_argument("--dist-single", action="store_true",

@@ -224,3 +224,58 @@ def test_low_complexity_ties_match_oracle(tmp_path, k, m, bits, kind):
     torch.cuda.synchronize()
     assert np.array_equal(d_o.cpu().numpy().view(np.uint64), o.query_packed(pk))
     h.close()
+
+
+@pytest.mark.parametrize("kind,k,m,bits,n_rec", [(0, 31, 20, 64, 600), (0, 63, 20, 128, 400), (1, 31, 20, 64, 300)])
+def test_large_repeat_rich_index_properties(tmp_path, kind, k, m, bits, n_rec):
+    """The fallback path at scale.  Uniform bases put 0.01-0.14 % of the k-mers behind colliding minimizers; a genome has repeats.  lphash_amd/synth.py's
+    diverged-copy set (half the records are copies of the other half with one substitution per k - 1 bases: no repeated k-mer, most minimizers repeated) at
+    30-60 M k-mers puts 30 % (k=31) / 63 % (k=63) of them there -- fallback functions of 10-25 M keys.  The index built with the GPU stages is byte for byte the
+    host builder's; streaming and random passes over all records are bijections onto [0, n) and agree; sampled records and a packed batch equal the oracle."""
+    from lphash_amd.synth import diverged_copy_records
+
+    torch, dev = torch_dev()
+    L_rec = 100_000 + k - 1
+    flat, recs = diverged_copy_records(seed=5, n_records=n_rec, length=L_rec, k=k)
+    pg, pc = str(tmp_path / "gpu.lph"), str(tmp_path / "cpu.lph")
+    sg = L.build(recs, k, m, pg, kind=kind, kmer_bits=bits, threads=0, device=0)
+    n = n_rec * 100_000
+    assert sg["num_kmers"] == n and sg["fallback_kmers"] > 0.25 * n, sg
+    if n_rec <= 400:  # (the sequential host search over tens of millions of keys takes its time: the two smaller sets)
+        sc = L.build(recs, k, m, pc, kind=kind, kmer_bits=bits, threads=0)
+        assert sc == sg and hashlib.sha256(open(pc, "rb").read()).hexdigest() == hashlib.sha256(open(pg, "rb").read()).hexdigest()
+    h = (L.Mphf if kind == 0 else L.MphfAlt).load(pg, kmer_bits=bits, device=0)
+    assert h.get_kmer_count() == n and h.info.fallback_kmers == sg["fallback_kmers"]
+    d_seq = torch.from_numpy(flat).to(dev)
+    seq_off = torch.arange(0, n_rec + 1, dtype=torch.int64, device=dev) * L_rec
+    out_off = torch.arange(0, n_rec + 1, dtype=torch.int64, device=dev) * 100_000
+    outs = []
+    for streaming in (True, False):
+        d_out = torch.empty(n, dtype=torch.int64, device=dev)
+        h.query_records(d_seq.data_ptr(), int(d_seq.numel()), seq_off.data_ptr(), n_rec, d_out.data_ptr(), out_off.data_ptr(), streaming)
+        torch.cuda.synchronize()
+        assert int(d_out.min()) == 0 and int(d_out.max()) == n - 1
+        seen = torch.zeros(n, dtype=torch.uint8, device=dev)
+        seen[d_out] = 1
+        assert int(seen.sum(dtype=torch.int64)) == n
+        del seen
+        outs.append(d_out)
+    assert torch.equal(outs[0], outs[1])
+    o = orc.Index(pg, kind, bits)
+    assert o.fallback_keys == sg["fallback_kmers"]
+    for i in sorted({0, 1, n_rec // 2 - 1, n_rec // 2, n_rec // 2 + 1, n_rec - 1}):  # originals and their diverged copies
+        assert np.array_equal(outs[0][i * 100_000:(i + 1) * 100_000].cpu().numpy().view(np.uint64), o(recs[i], True))
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    Q = 1 << 20
+    win = torch.randint(0, n, (Q,), generator=g, device=dev, dtype=torch.int64)
+    pos = (win // 100_000) * L_rec + win % 100_000
+    d_k = torch.empty(Q * (bits // 64), dtype=torch.int64, device=dev)
+    h.pack_kmers(d_seq.data_ptr(), pos.data_ptr(), Q, d_k.data_ptr())
+    d_o = torch.empty(Q, dtype=torch.int64, device=dev)
+    h.query_packed(d_k.data_ptr(), Q, d_o.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(d_o, outs[0][win])
+    S = 1 << 18
+    assert np.array_equal(d_o[:S].cpu().numpy().view(np.uint64), o.query_packed(d_k[: S * (bits // 64)].cpu().numpy().view(np.uint64)))
+    h.close()
