@@ -623,4 +623,15 @@ def test_session_batches_match_oracle(name):
         s.submit(batches[0], True)
         assert len(s.collect()) == len(batches[0])
     assert h.replica_info() == [(0, 0)]
+    # lifetime: the index closed BEFORE its session -- lphq_close only marks it, the session keeps answering from the replica it holds by value and
+    # the last lphq_session_close releases the device memory; a second attach while a session is open does not move anything under it
+    s = h.session(depth=2)
+    h.attach(0)
+    s.submit(batches[0], True)
     h.close()
+    with pytest.raises(L.LphqError):
+        h(batches[0][0], streaming=True)  # the handle is dead for every other call (the Python mirror holds NULL now)
+    s.submit(batches[4], False)
+    got0, got4 = s.collect(), s.collect()
+    assert all(np.array_equal(g, want(r, True)) for g, r in zip(got0, batches[0])) and all(np.array_equal(g, want(r, False)) for g, r in zip(got4, batches[4]))
+    s.close()

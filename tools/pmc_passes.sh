@@ -21,9 +21,8 @@ run write WRITE_SIZE
 run l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 run sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
 run sq2 SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_INSTS_LDS
-# (round 5) the L2 -> fabric side by request size and target: what rocprofv3 --list-avail offers for "DRAM vs on-die" -- _DRAM names the TARGET (local memory, as
-# opposed to GMI / IO), it does not say whether the Infinity Cache served the request
-run ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_64B_sum
+# (round 5: a pass over the TCC_EA0_RDREQ_* / _DRAM_* counters aborted rocprofv3 with signal 6 on this pool -- not collected; those counters name the TARGET of a
+#  request (local memory vs GMI / IO), not whether the Infinity Cache served it, profiles/r05_nt_stream.txt)
 # kernel trace of the same command (durations for the rates)
 d=$R/gpurun_out/trace_${TAG}
 timeout 900 rocprofv3 --kernel-trace --stats -d $d -o t -- python3 $R/bench.py "${BENCH_ARGS[@]}" --steps 10 --warmup 2 --no-cpu-baseline --no-hbm-probe --gpu-build > /dev/null 2> $R/gpurun_out/trace_${TAG}.err
