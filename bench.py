@@ -41,14 +41,17 @@ sys.path.insert(0, ROOT)
 
 
 def device_source_sha():
-    """sha256 (first 16 hex digits) over the device sources of the query kernels: what a counter pass in profiles/pmc_traffic.json is evidence for."""
+    """sha256 (first 16 hex digits) over the device sources of the QUERY kernels: what a counter pass in profiles/pmc_traffic.json (and the ISA listing in
+    profiles/isa_rest.json) is evidence for.  The construction kernels (extract_device.cuh, search_device.cuh; extract.hip, search.hip) are not part of it: a
+    change there cannot move a query kernel's counters.  (Until round 5 the two construction headers were hashed along: the sha of the same query sources
+    was 2767c5d441027723 then.)"""
     import glob
     import hashlib
 
     hsh = hashlib.sha256()
     csrc = os.path.join(ROOT, "lphash_amd", "csrc")
-    for pth in sorted(glob.glob(os.path.join(csrc, "*.cuh")) + glob.glob(os.path.join(csrc, "gfx950", "*.cuh")) +
-                      [os.path.join(csrc, "kernels.hip"), os.path.join(csrc, "stream8.hip"), os.path.join(csrc, "image_layout.h")]):
+    for pth in sorted([os.path.join(csrc, f) for f in ("kernels_device.cuh", "device_query.cuh", "stream8_device.cuh", "kernels.hip", "stream8.hip", "image_layout.h")] +
+                      glob.glob(os.path.join(csrc, "gfx950", "*.cuh"))):
         hsh.update(os.path.basename(pth).encode())
         hsh.update(open(pth, "rb").read())
     return hsh.hexdigest()[:16]

@@ -604,9 +604,17 @@ uint64_t phf_eval(const SinglePhf& f, uint64_t hash, const std::vector<uint64_t>
 typedef SuperKmerRun Run;  // extract.hpp: {mm, first, q, size, pad}, batch coordinates are global
 typedef SuperKmerRuns RunVec;  // (a vector whose resize() does not touch the new elements)
 
-// Windows [wa, wb) of one record (record base pointer s, window w covers bases [w, w+k)).
+// Windows [wa, wb) of one record of rec_len bases (record base pointer s, window w covers bases [w, w+k)).
 // Windows holding a non-ACGT base are skipped and cut runs (the reference resets there, minimizer.hpp:150-164).
-void extract_runs(const char* s, uint64_t rec_off, uint64_t wa, uint64_t wb, uint32_t k, uint32_t m, uint64_t seed, RunVec& out) {
+// One window is valid and still in no run, because the reference leaves it out: the only window of a stretch of EXACTLY k valid bases that a non-ACGT base
+// closes inside the record.  from_string looks for the minimum of a stretch's first window when base k + 1 arrives (minimizer.hpp:61-66); a break after base k
+// comes first, finds min_pos still unset and pushes nothing (minimizer.hpp:139-152; get_colliding_kmers, :287-301, alike) -- while the k-mer was counted
+// (:60).  Such a window adds to `lost` (it is part of nkmers) and to no super-k-mer, so the file is the reference's byte for byte on such input too.  (A stretch
+// of k bases that ends WITH the record is kept: minimizer.hpp:154-163.)
+inline bool lost_window(const char* s, uint64_t rec_len, uint64_t w, uint32_t k) {
+    return (w == 0 || nt4((uint8_t)s[w - 1]) > 3) && w + k < rec_len && nt4((uint8_t)s[w + k]) > 3;
+}
+void extract_runs(const char* s, uint64_t rec_len, uint64_t rec_off, uint64_t wa, uint64_t wb, uint32_t k, uint32_t m, uint64_t seed, RunVec& out, uint64_t& lost) {
     if (wa >= wb) return;
     const uint32_t W = k - m + 1;
     const uint64_t mask = m >= 32 ? ~0ULL : ((1ULL << (2 * m)) - 1);
@@ -640,6 +648,10 @@ void extract_runs(const char* s, uint64_t rec_off, uint64_t wa, uint64_t wb, uin
         if (valid_run < k) continue;
         const uint64_t w = i + 1 - k;  // window ending at base i
         if (w < wa) continue;
+        if (valid_run == k && lost_window(s, rec_len, w, k)) {  // (valid_run == k: the first whole window since the last break, or since the chunk began)
+            ++lost;
+            continue;  // the base after it is the break: the state is reset there
+        }
         // leftmost minimum over m-mer positions [w, w+W-1] (pq == w+W-1)
         if (cur_q == ~0ULL || cur_q < w || valid_run == k) {
             // (re)scan the whole window
@@ -1030,6 +1042,7 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
         struct Chunk { size_t rec; uint64_t wa, wb; };
         std::vector<Chunk> chunks;
         std::vector<RunVec> chunk_runs;
+        std::vector<uint64_t> chunk_lost;
         while ((rc = src.next(0, records, lengths, nb)) > 0) {
             rec_off.assign(nb + 1, base);
             for (size_t r = 0; r < nb; ++r) rec_off[r + 1] = rec_off[r] + lengths[r];
@@ -1057,7 +1070,9 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
             if (extract_device >= 0) {  // super-k-mers of the batch from the GPU, already sorted by minimizer
                 std::string gerr;
                 const bool was_empty = runs.empty() && spill.files.empty();
-                if (gpu_extract_sorted_runs(extract_device, records, lengths, nb, base, k, m, mm_seed, threads, verbose, runs, gerr)) {
+                uint64_t lost = 0;
+                if (gpu_extract_sorted_runs(extract_device, records, lengths, nb, base, k, m, mm_seed, threads, verbose, runs, lost, gerr)) {
+                    nkmers += lost;  // (counted like the reference counts them, in no super-k-mer: extract_runs)
                     runs_sorted = was_empty;  // still sorted as a whole if this is all there is
                     if (runs.size() >= run_cap) {  // over the memory limit: one more sorted piece
                         for (const Run& x : runs) nkmers += x.size;
@@ -1075,11 +1090,13 @@ static int build_impl(RecordSource& src, int k_, int m_, uint64_t mm_seed, doubl
             }
             runs_sorted = false;
             chunk_runs.assign(chunks.size(), RunVec());
+            chunk_lost.assign(chunks.size(), 0);
             parallel_for(chunks.size(), threads, [&](size_t ci) {
                 const Chunk& ch = chunks[ci];
                 chunk_runs[ci].reserve((ch.wb - ch.wa) * 2 / (W + 1) + 16);
-                extract_runs(records[ch.rec], rec_off[ch.rec], ch.wa, ch.wb, k, m, mm_seed, chunk_runs[ci]);
+                extract_runs(records[ch.rec], lengths[ch.rec], rec_off[ch.rec], ch.wa, ch.wb, k, m, mm_seed, chunk_runs[ci], chunk_lost[ci]);
             });
+            for (uint64_t x : chunk_lost) nkmers += x;
             size_t total = runs.size();
             for (auto& v : chunk_runs) total += v.size();
             if (runs.capacity() < total) runs.reserve(std::min(run_cap, std::max(total, runs.capacity() * 2)));

@@ -80,6 +80,7 @@ struct Extractor {
     hipStream_t stream = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
     unsigned long long produced = 0;  // super-k-mers of the batch; sorted by minimizer in d_mm[1] / d_val[1] after extract_and_sort()
+    unsigned long long lost = 0;      // valid windows in no super-k-mer (the reference leaves them out, builder.cpp: lost_window); part of the k-mer count
     std::chrono::steady_clock::time_point tprev = std::chrono::steady_clock::now();
 
     Extractor(std::string& e, bool v, int t) : err(e), verbose(v), threads(t) { (void)hipGetDevice(&prev); }
@@ -140,7 +141,7 @@ struct Extractor {
         STEP(hipStreamCreate(&stream));
         STEP(hipMalloc((void**)&d_seq, (size_t)total + 2 * kFront + 16));
         STEP(hipMalloc((void**)&d_off, (n_records + 1) * sizeof(uint64_t)));
-        STEP(hipMalloc((void**)&d_cursor, 2 * sizeof(unsigned long long)));
+        STEP(hipMalloc((void**)&d_cursor, 3 * sizeof(unsigned long long)));  // [0] runs produced, [1] k-mers of the runs (classification), [2] lost windows (extract_device.cuh)
         STEP(hipMemsetAsync(d_seq, 0, kFront, stream));
         STEP(hipMemsetAsync(d_seq + kFront + total, 0, kFront + 16, stream));
         STEP(hipMemcpyAsync(d_off, off.data(), (n_records + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
@@ -181,19 +182,20 @@ struct Extractor {
                 STEP(hipMalloc((void**)&d_mm[i], (size_t)cap * sizeof(uint64_t)));
                 STEP(hipMalloc((void**)&d_val[i], (size_t)cap * sizeof(RunVal)));
             }
-            STEP(hipMemsetAsync(d_cursor, 0, 2 * sizeof(unsigned long long), stream));
+            STEP(hipMemsetAsync(d_cursor, 0, 3 * sizeof(unsigned long long), stream));
             const uint64_t kMaxTiles = (1u << 24) - 1;
             for (uint64_t tb = 0; tb < tiles; tb += kMaxTiles) {
                 const unsigned grid = (unsigned)std::min<uint64_t>(kMaxTiles, tiles - tb);
                 if (W >= kBlockMinW)
                     k_extract_runs<kStreamBlockDefault, true><<<grid, kStreamBlockDefault, 0, stream>>>(seq_al, shift, total, d_off, (uint32_t)n_records, k, m, mm_seed,
-                                                                                                         first_base, d_mm[0], d_val[0], d_cursor, cap, tb);
+                                                                                                         first_base, d_mm[0], d_val[0], d_cursor, cap, tb, d_cursor + 2);
                 else
                     k_extract_runs<kStreamBlockDefault, false><<<grid, kStreamBlockDefault, 0, stream>>>(seq_al, shift, total, d_off, (uint32_t)n_records, k, m, mm_seed,
-                                                                                                          first_base, d_mm[0], d_val[0], d_cursor, cap, tb);
+                                                                                                          first_base, d_mm[0], d_val[0], d_cursor, cap, tb, d_cursor + 2);
                 STEP(hipGetLastError());
             }
             STEP(hipMemcpyAsync(&produced, d_cursor, sizeof produced, hipMemcpyDeviceToHost, stream));
+            STEP(hipMemcpyAsync(&lost, d_cursor + 2, sizeof lost, hipMemcpyDeviceToHost, stream));
             STEP(hipStreamSynchronize(stream));
             if (produced <= cap) break;
             if (attempt == 1) {
@@ -250,11 +252,13 @@ struct Extractor {
 }  // namespace
 
 bool gpu_extract_sorted_runs(int device, const char* const* records, const size_t* lengths, size_t n_records, uint64_t first_base, uint32_t k, uint32_t m,
-                             uint64_t mm_seed, int threads, bool verbose, SuperKmerRuns& out, std::string& err) {
+                             uint64_t mm_seed, int threads, bool verbose, SuperKmerRuns& out, uint64_t& lost_windows, std::string& err) {
     const size_t out_before = out.size();
+    lost_windows = 0;
     Extractor x(err, verbose, threads);
     auto body = [&]() -> bool {
         if (!x.extract_and_sort(device, records, lengths, n_records, first_base, k, m, mm_seed)) return false;
+        lost_windows = x.lost;
         if (!x.produced) return true;
         SuperKmerRun* d_runs = nullptr;
         if (!x.step(hipMalloc((void**)&d_runs, (size_t)x.produced * sizeof(SuperKmerRun)), "hipMalloc(records)")) return false;
@@ -279,6 +283,7 @@ bool gpu_extract_classified(int device, const char* const* records, const size_t
         if (!x.extract_and_sort(device, records, lengths, n_records, 0, k, m, mm_seed)) return false;
         const size_t n = (size_t)x.produced;
         out.num_super_kmers = n;
+        out.num_kmers = x.lost;  // (+ the k-mers of the super-k-mers, below)
         if (!n) return true;
         // flags: low word 1 = first record of its minimizer, high word 1 = record of a minimizer that has several; an exclusive scan of the
         // packed pair gives every record its slot among the distinct minimizers and among the colliding records
@@ -305,7 +310,7 @@ bool gpu_extract_classified(int device, const char* const* records, const size_t
                 break;
             const uint64_t sum = last_flag + last_slot;
             const size_t n_uniq = (size_t)(sum & 0xFFFFFFFFull), n_coll = (size_t)(sum >> 32);
-            out.num_kmers = totals[1];
+            out.num_kmers = totals[1] + x.lost;  // the reference's count: every window of k valid bases, also the ones it leaves out of every super-k-mer
             if (!S(hipMalloc((void**)&d_umm, std::max<size_t>(n_uniq, 1) * 8), "hipMalloc") || !S(hipMalloc((void**)&d_ups, std::max<size_t>(n_uniq, 1) * 2), "hipMalloc") ||
                 !S(hipMalloc((void**)&d_cfirst, std::max<size_t>(n_coll, 1) * 8), "hipMalloc") || !S(hipMalloc((void**)&d_csize, std::max<size_t>(n_coll, 1) * 4), "hipMalloc"))
                 break;

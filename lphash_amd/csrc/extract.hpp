@@ -58,7 +58,8 @@ bool gpu_extract_classified(int device, const char* const* records, const size_t
 
 // Every super-k-mer of the batch (whole records; first_base = global coordinate of the batch's first base) APPENDED to `out`, ascending by
 // minimizer (ties in no particular order).  false + err when the device path is unavailable or fails (out is then as it was) -- the caller
-// runs the host extraction instead, loudly.
+// runs the host extraction instead, loudly.  lost_windows: valid windows that belong to no super-k-mer because the reference leaves them out (the one window
+// of a stretch of exactly k valid bases closed by a non-ACGT base inside its record, builder.cpp: lost_window) -- they count as k-mers.
 bool gpu_extract_sorted_runs(int device, const char* const* records, const size_t* lengths, size_t n_records, uint64_t first_base, uint32_t k, uint32_t m,
-                             uint64_t mm_seed, int threads, bool verbose, SuperKmerRuns& out, std::string& err);
+                             uint64_t mm_seed, int threads, bool verbose, SuperKmerRuns& out, uint64_t& lost_windows, std::string& err);
 }  // namespace lphq

@@ -29,7 +29,8 @@ __global__ __launch_bounds__(BLOCK) void k_extract_runs(const uint8_t* __restric
                                                           uint32_t n_records, uint32_t k, uint32_t m, uint64_t mm_seed,
                                                           uint64_t first_base /* global coordinate of the batch's first base */, uint64_t* __restrict__ out_mm,
                                                           RunVal* __restrict__ out_val, unsigned long long* __restrict__ cursor, uint64_t cap,
-                                                          uint64_t tile_base /* first tile of this launch */) {
+                                                          uint64_t tile_base /* first tile of this launch */,
+                                                          unsigned long long* __restrict__ lost_windows /* += valid windows the reference leaves out of every run */) {
     constexpr int kPos = 4 * BLOCK, NW = tile_words(kPos);
     constexpr int NBADW = (NW + 8) / 2 + 2;
     constexpr int NDW = (NW + 1) * 4;
@@ -199,6 +200,24 @@ __global__ __launch_bounds__(BLOCK) void k_extract_runs(const uint8_t* __restric
         if (nib) atomicOr(&sm_bound[a >> 5], nib << (a & 31u));
 #pragma unroll
         for (uint32_t jw = 0; jw < 4; ++jw) lead[jw] = lead[jw] && a + jw >= 1u && a + jw <= S;  // the starts this tile owns
+        // The reference's lost window (builder.cpp: lost_window): a stretch of EXACTLY k valid bases that a non-ACGT base closes inside its record has one
+        // window; from_string never pushes it (minimizer.hpp:61-66,139-152) but counts its k-mer.  Here: a valid window whose left neighbour is no window
+        // (record start, or the bad base is the one before the stretch) and whose right neighbour is a window of the same record that holds a bad base (it
+        // can only be base w + k).  It starts no run -- it stays a boundary -- and is counted once, by the tile that owns it.
+        if (sm_anybad != 0u) {
+            uint32_t nlost = 0;
+#pragma unroll
+            for (uint32_t jw = 0; jw < 4; ++jw) {
+                if (!lead[jw]) continue;
+                const uint32_t lc = jw ? code[jw - 1] : left;
+                const uint32_t rc = jw < 3 ? code[jw + 1] : (uint32_t)sm_code[a + 4u];
+                if (lc >= 0xFFFEu && rc == 0xFFFFu) {
+                    lead[jw] = false;
+                    ++nlost;
+                }
+            }
+            if (nlost) atomicAdd(lost_windows, (unsigned long long)nlost);
+        }
     }
     uint32_t slot[4];
     {

@@ -114,7 +114,7 @@ extern "C" int emu_kernel_gather_payload(const uint64_t* codes, size_t n, const 
 // produced (it may exceed cap: then only cap of them were written), or -1.
 extern "C" long long emu_kernel_extract_runs(const char* seq, uint64_t total, const uint64_t* seq_off, uint32_t n_records, uint32_t k, uint32_t m, uint64_t mm_seed,
                                              uint64_t first_base, uint64_t* out_mm, uint64_t* out_val /* 2 words per run: first, p1 | size << 32 */, uint64_t cap,
-                                             int force_form /* 0: as the launcher picks, 1: block minima, 2: direct */) {
+                                             int force_form /* 0: as the launcher picks, 1: block minima, 2: direct */, unsigned long long* lost_windows) {
     if (((uintptr_t)seq & 15u) || total < k || n_records == 0) return -1;
     static_assert(sizeof(RunVal) == 16, "two words per run");
     const uint64_t shift = 16;
@@ -123,15 +123,16 @@ extern "C" long long emu_kernel_extract_runs(const char* seq, uint64_t total, co
     const uint32_t S = extract_tile_stride(W, 4 * kStreamBlockDefault);
     const unsigned tiles = (unsigned)((shift + total - k) / S + 1);
     unsigned long long cursor = 0;
+    *lost_windows = 0;
     const bool blk = force_form ? force_form == 1 : W >= kBlockMinW;
     if (blk && W < 4) return -1;
     if (blk)
         emu::launch(tiles, kStreamBlockDefault, [&] {
-            k_extract_runs<kStreamBlockDefault, true>(seq_al, shift, total, seq_off, n_records, k, m, mm_seed, first_base, out_mm, (RunVal*)out_val, &cursor, cap, 0);
+            k_extract_runs<kStreamBlockDefault, true>(seq_al, shift, total, seq_off, n_records, k, m, mm_seed, first_base, out_mm, (RunVal*)out_val, &cursor, cap, 0, lost_windows);
         });
     else
         emu::launch(tiles, kStreamBlockDefault, [&] {
-            k_extract_runs<kStreamBlockDefault, false>(seq_al, shift, total, seq_off, n_records, k, m, mm_seed, first_base, out_mm, (RunVal*)out_val, &cursor, cap, 0);
+            k_extract_runs<kStreamBlockDefault, false>(seq_al, shift, total, seq_off, n_records, k, m, mm_seed, first_base, out_mm, (RunVal*)out_val, &cursor, cap, 0, lost_windows);
         });
     return (long long)cursor;
 }

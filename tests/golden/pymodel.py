@@ -265,17 +265,17 @@ LEFT, RIGHT, MAXIMAL, NONE = 0, 1, 2, 3
 
 
 def segments(record):
-    """maximal runs of valid bases of a record, as lists of 2-bit codes"""
+    """maximal runs of valid bases of a record, as (list of 2-bit codes, closed): closed = a non-ACGT byte ends the run (False: the record's end does)"""
     cur = []
     for ch in record:
         if ch in NT:
             cur.append(NT[ch])
         else:
             if cur:
-                yield cur
+                yield cur, True
             cur = []
     if cur:
-        yield cur
+        yield cur, False
 
 
 def windows_of(codes, k, m, mm_seed):
@@ -303,8 +303,15 @@ class Model:
         supers = []  # (minimizer, p1 of the first k-mer, [k-mers]) in input order
         self.nkmers = 0
         for rec in records:
-            for codes in segments(rec):
+            for codes, closed in segments(rec):
                 if len(codes) < k:
+                    continue
+                if len(codes) == k and closed:
+                    # A run of EXACTLY k valid bases that a non-ACGT byte closes: minimizer::from_string counts its k-mer (include/minimizer.hpp:60) but looks
+                    # for the window's minimum only when base k + 1 arrives (:61-66); the break comes first and pushes nothing (:139-152), and
+                    # get_colliding_kmers (:287-301) skips it the same way.  The k-mer is in nkmers and in no super-k-mer.  (A run of k bases that ends WITH the
+                    # record is kept: :154-163.)
+                    self.nkmers += 1
                     continue
                 prev = None
                 for kv, mm, off, where in windows_of(codes, k, m, mm_seed):

@@ -36,7 +36,7 @@ bool gpu_pilot_search(int, const std::vector<uint64_t>&, const std::vector<uint6
     err = "no GPU in the sanitizer harness";
     return false;
 }
-bool gpu_extract_sorted_runs(int, const char* const*, const size_t*, size_t, uint64_t, uint32_t, uint32_t, uint64_t, int, bool, SuperKmerRuns&,
+bool gpu_extract_sorted_runs(int, const char* const*, const size_t*, size_t, uint64_t, uint32_t, uint32_t, uint64_t, int, bool, SuperKmerRuns&, uint64_t&,
                              std::string& err) {
     err = "no GPU in the sanitizer harness";
     return false;

@@ -526,13 +526,14 @@ def test_bbhash_competitor_against_the_real_boophf(emuk, tmp_path, name):
 # ------------------------------------------------------------------------------------------------------------------
 # index construction, part 1 on the GPU: k_extract_runs (extract_device.cuh)
 # ------------------------------------------------------------------------------------------------------------------
-def expected_runs(recs, k, m, seed, first_base=0):
+def expected_runs(recs, k, m, seed, first_base=0, lost=None):
     """Super-k-mers by the independent Python model (tests/golden/pymodel.py): maximal runs of consecutive k-mers of a stretch of valid
     bases whose leftmost-minimum m-mer sits at the same position -> (minimizer, first window (global), offset, size)."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import pymodel
 
     runs, at = [], first_base
+    lost = [0] if lost is None else lost  # lost[0] += the windows the reference leaves out of every run
     for rec in recs:
         pos = 0
         text = bytes(rec)  # (iterating bytes yields the ints pymodel.NT is keyed by)
@@ -544,7 +545,9 @@ def expected_runs(recs, k, m, seed, first_base=0):
             while end < len(text) and text[end] in pymodel.NT:
                 end += 1
             codes = [pymodel.NT[c] for c in text[pos:end]]
-            if len(codes) >= k:
+            if len(codes) == k and end < len(text):  # exactly k valid bases closed by a non-ACGT byte: the reference counts the k-mer and pushes no record
+                lost[0] += 1                         # (include/minimizer.hpp:60-66,139-152)
+            elif len(codes) >= k:
                 prev = None
                 for w, (_kv, mm, p, best) in enumerate(pymodel.windows_of(codes, k, m, seed)):
                     if best == prev:
@@ -563,7 +566,7 @@ def test_extract_runs_kernel_on_the_emulator(emu, k, m, form):
     several tiles): the set of super-k-mer records equals the independent Python model's; a too-small output buffer is reported through the counter."""
     emu.emu_kernel_extract_runs.restype = C.c_longlong
     emu.emu_kernel_extract_runs.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,
-                                            C.c_uint64, C.c_int]
+                                            C.c_uint64, C.c_int, C.POINTER(C.c_ulonglong)]
     rng = np.random.default_rng(k * 100 + m)
     recs = random_records(k + m, 5, 900, 2600) + [b"", b"ACGT"[: min(4, k - 1)]] + random_records(k, 40, 0, 2 * k) + random_records(m, 3, 3000, 5000)
     noisy = bytearray(recs[1])
@@ -571,8 +574,19 @@ def test_extract_runs_kernel_on_the_emulator(emu, k, m, form):
         noisy[p] = ord("N")
     recs[1] = bytes(noisy)
     recs[2] = recs[2].lower()
+    # stretches of exactly k valid bases: closed by a non-ACGT byte (the reference leaves their window out of every run), closed by the record's end (kept), at a
+    # record's start, two in a row, k + 1 bases (kept), beside tile borders (the long record)
+    kk = [random_records(1000 + i, 1, k, k)[0] for i in range(8)]
+    recs += [kk[0] + b"N" + random_records(77, 1, 300, 300)[0] + b"N" + kk[1] + b"NN" + kk[2] + b"N" + kk[3], kk[4] + b"N", b"N" + kk[5], kk[6] + b"A" + b"N" + kk[7][:k - 1] + b"N"]
+    big = bytearray(recs[-5])
+    for at in range(500, len(big) - 2 * k, 509):
+        big[at] = ord("N")
+        big[at + k + 1] = ord("N")
+    recs[-5] = bytes(big)
     seed, first_base = 42, 1_000_000_007
-    want = expected_runs(recs, k, m, seed, first_base)
+    lost_want = [0]
+    want = expected_runs(recs, k, m, seed, first_base, lost_want)
+    assert lost_want[0] >= 8
     flat = np.frombuffer(b"".join(recs), dtype=np.uint8)
     raw = np.full(len(flat) + 256, ord("#"), dtype=np.uint8)
     base = (-raw.ctypes.data) % 16 + 64
@@ -581,16 +595,19 @@ def test_extract_runs_kernel_on_the_emulator(emu, k, m, form):
     cap = len(want) + 7
     mm = np.zeros(cap, dtype=np.uint64)
     val = np.zeros(2 * cap, dtype=np.uint64)
-    n = emu.emu_kernel_extract_runs(raw.ctypes.data + base, len(flat), seq_off.ctypes.data, len(recs), k, m, seed, first_base, mm.ctypes.data, val.ctypes.data, cap, form)
-    assert n == len(want)
+    lost = C.c_ulonglong()
+    n = emu.emu_kernel_extract_runs(raw.ctypes.data + base, len(flat), seq_off.ctypes.data, len(recs), k, m, seed, first_base, mm.ctypes.data, val.ctypes.data, cap, form,
+                                    C.byref(lost))
+    assert n == len(want) and lost.value == lost_want[0]
     got = sorted((int(mm[i]), int(val[2 * i]), int(val[2 * i + 1]) & 0xFFFFFFFF, int(val[2 * i + 1]) >> 32) for i in range(n))
     assert got == want
     # not enough room: the counter still says how many there are, nothing is written beyond the buffer
     small = max(1, len(want) // 3)
     mm2 = np.full(small + 1, 0xDEAD, dtype=np.uint64)
     val2 = np.full(2 * small + 2, 0xDEAD, dtype=np.uint64)
-    n2 = emu.emu_kernel_extract_runs(raw.ctypes.data + base, len(flat), seq_off.ctypes.data, len(recs), k, m, seed, first_base, mm2.ctypes.data, val2.ctypes.data, small, form)
-    assert n2 == len(want) and mm2[small] == 0xDEAD and val2[2 * small] == 0xDEAD
+    n2 = emu.emu_kernel_extract_runs(raw.ctypes.data + base, len(flat), seq_off.ctypes.data, len(recs), k, m, seed, first_base, mm2.ctypes.data, val2.ctypes.data, small, form,
+                                     C.byref(lost))
+    assert n2 == len(want) and lost.value == lost_want[0] and mm2[small] == 0xDEAD and val2[2 * small] == 0xDEAD
 
 
 def test_classify_kernels_on_the_emulator(emu):

@@ -79,6 +79,38 @@ def test_gpu_super_kmer_extraction_build_is_byte_identical(tmp_path, k, m, bits,
         assert ss == sc and open(pg, "rb").read() == want, (per_batch, limit)
 
 
+def test_gpu_extraction_follows_the_reference_on_dirty_index_input(tmp_path):
+    """k_extract_runs on index sets made of stretches of k - 1, k, k + 1, m, ... valid bases between non-ACGT bytes: a stretch of EXACTLY k bases closed by such a
+    byte is counted as a k-mer and pushed into no super-k-mer by the reference (include/minimizer.hpp:60-66,139-152); the GPU stages -- one batch (classified on
+    the device), several batches, pieces under a memory limit -- write the oracle's file, k-mer count included."""
+    from util import dirty_index_records, random_records
+
+    torch_dev()
+    n = 0
+    for seed in range(60):
+        k = [15, 21, 31, 47, 63][seed % 5]
+        m = [7, 20, 13, 17, 5][seed % 5] if k > 21 else [7, 11, 5][seed % 3]
+        bits = 64 if k <= 31 else 128
+        recs = dirty_index_records(1000 + seed, k, m, n_records=9)
+        if recs is None:
+            continue
+        recs = recs + random_records(seed, 2, 3000, 9000)  # (several tiles)
+        po, pg = str(tmp_path / "o.lph"), str(tmp_path / "g.lph")
+        try:
+            orc.build(recs, k, m, po, kind=seed % 2, kmer_bits=bits)
+        except RuntimeError:
+            continue
+        want = open(po, "rb").read()
+        st = L.build(recs, k, m, pg, kind=seed % 2, kmer_bits=bits, threads=4, device=0)
+        assert open(pg, "rb").read() == want, (seed, k, m)
+        assert st["num_kmers"] == orc.Index(po, seed % 2, bits).nkmers
+        L.build_stream(lambda: iter([recs[:3], recs[3:7], recs[7:]]), k, m, pg, kind=seed % 2, kmer_bits=bits, threads=4, device=0, tmp_dir=str(tmp_path / "spill"),
+                       max_memory_bytes=(1 << 14) if seed % 2 else 0)
+        assert open(pg, "rb").read() == want, (seed, k, m, "streamed")
+        n += 1
+    assert n > 40
+
+
 def test_gpu_pilot_search_giving_up_falls_back_to_the_cpu_search(tmp_path, capfd):
     """A GPU pilot search that runs out of its wall-clock limit (here: a millisecond, checked after every round) hands the buckets to the sequential CPU
     search -- loudly, and with the same file: in memory (the whole search again) and with a memory limit (piece by piece, from the table of taken positions

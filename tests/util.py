@@ -102,3 +102,32 @@ def genomic_like_records(seed, n, k, max_len):
             r[at:at + seg_len] = seg
         recs.append(bytes(r))
     return dedup_records(recs, k)
+
+
+def dirty_index_records(seed, k, m, n_records=6):
+    """Index records full of non-ACGT breaks at the distances that matter: stretches of k - 1, k, k + 1, m - 1, m, m + 1, 2k, ... valid bases, closed by one to three
+    N, at the start, in the middle and at the end of records.  A stretch of EXACTLY k bases closed by an N is the case the reference treats specially (its k-mer is
+    counted but pushed into no super-k-mer, include/minimizer.hpp:60-66,139-152).  No k-mer is repeated among the valid windows (else None)."""
+    rng = np.random.default_rng(seed)
+    recs = []
+    for _ in range(n_records):
+        parts = []
+        for _ in range(int(rng.integers(1, 7))):
+            ln = int(rng.choice([k - 1, k, k, k + 1, k + 2, max(1, m - 1), m, m + 1, 2 * k, 5 * k, int(rng.integers(1, 300))]))
+            parts.append(random_records(int(rng.integers(1 << 30)), 1, ln, ln)[0])
+        rec = b"".join(p + b"N" * int(rng.integers(1, 4)) for p in parts)
+        if rng.random() < 0.5:
+            rec = rec.rstrip(b"N")
+        if rng.random() < 0.3:
+            rec = b"N" + rec
+        recs.append(rec)
+    seen = set()
+    for r in recs:
+        for i in range(len(r) - k + 1):
+            w = r[i:i + k]
+            if b"N" in w:
+                continue
+            if w in seen:
+                return None
+            seen.add(w)
+    return recs if seen else None
