@@ -279,3 +279,53 @@ def test_large_repeat_rich_index_properties(tmp_path, kind, k, m, bits, n_rec):
     S = 1 << 18
     assert np.array_equal(d_o[:S].cpu().numpy().view(np.uint64), o.query_packed(d_k[: S * (bits // 64)].cpu().numpy().view(np.uint64)))
     h.close()
+
+
+def test_chromosome_sized_record_through_every_path(tmp_path):
+    """ONE record of 30 M bases (a chromosome arm; every other test cuts its input into records of <= 100 kbases): index built from it with the GPU stages, then the
+    record through lphq_query_records (one record = 29,297 streaming tiles), a session, and the CLI with 1-MB batches (FASTA with 80-column lines: the record is far
+    larger than a batch) and with three workers: a bijection onto [0, n), streaming == random, == the oracle on a 2 M-window slice, the CLI's count and codes."""
+    from lphash_amd.synth import random_bases
+
+    torch, dev = torch_dev()
+    k, m, n_bases = 31, 20, int(os.environ.get("LPHQ_TEST_CHR_BASES", "30000000"))  # (a multiple of 80; 320,000,000 = larger than human chromosome 1: one-off runs)
+    flat = random_bases(99, n_bases)
+    rec = flat.tobytes()
+    n = n_bases - k + 1
+    path = str(tmp_path / "chr.lph")
+    st = L.build([rec], k, m, path, kmer_bits=64, threads=0, device=0)
+    assert st["num_kmers"] == n and st["num_records"] == 1
+    h = L.Mphf.load(path, kmer_bits=64, device=0)
+    d_seq = torch.from_numpy(flat).to(dev)
+    so = torch.tensor([0, n_bases], dtype=torch.int64, device=dev)
+    oo = torch.tensor([0, n], dtype=torch.int64, device=dev)
+    outs = []
+    for streaming in (True, False):
+        d_out = torch.empty(n, dtype=torch.int64, device=dev)
+        h.query_records(d_seq.data_ptr(), n_bases, so.data_ptr(), 1, d_out.data_ptr(), oo.data_ptr(), streaming)
+        torch.cuda.synchronize()
+        seen = torch.zeros(n, dtype=torch.uint8, device=dev)
+        seen[d_out] = 1
+        assert int(d_out.min()) == 0 and int(d_out.max()) == n - 1 and int(seen.sum(dtype=torch.int64)) == n
+        outs.append(d_out)
+    assert torch.equal(outs[0], outs[1])
+    codes = outs[0].cpu().numpy().view(np.uint64)
+    o = orc.Index(path, 0, 64)
+    a = 13_000_003
+    assert np.array_equal(o(rec[a:a + 2_000_000 + k - 1], True), codes[a:a + 2_000_000])
+    with h.session(depth=2) as s:
+        s.submit([rec], True)
+        got = s.collect()
+        assert len(got) == 1 and np.array_equal(got[0], codes)
+    h.close()
+    fa = tmp_path / "chr.fa"
+    with open(fa, "wb") as f:
+        f.write(b">chr_synthetic one record\n")
+        f.write(np.concatenate([flat.reshape(-1, 80), np.full((n_bases // 80, 1), 10, dtype=np.uint8)], axis=1).tobytes())
+    exe = os.path.join(ROOT, "lphash_amd", "lphash")
+    for extra in (["--batch-mb", "1"], ["--devices", "0,0,0"], []):
+        sink = tmp_path / "codes.u64"
+        r = subprocess.run([exe, "query-p", "-i", path, "-q", str(fa), "--kmer-bits", "64", "--output", str(sink)] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert int(r.stdout.split(",")[2]) == n
+        assert np.array_equal(np.fromfile(sink, dtype=np.uint64), codes), extra
