@@ -797,7 +797,8 @@ struct lphq_session {
 
 extern "C" void* lphq_host_alloc(size_t bytes) {
     void* p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    // (portable: a caller's record buffers may feed sessions on several devices)
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }

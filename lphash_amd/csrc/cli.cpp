@@ -181,7 +181,8 @@ struct ArenaCache {
         }
         void* p = nullptr;
         if (pinned) {
-            if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) p = nullptr;
+            // (portable: one parse arena feeds the copies to EVERY device of --gpus N, whichever device was current when it was allocated)
+            if (hipHostMalloc(&p, n, hipHostMallocPortable) != hipSuccess) p = nullptr;
         } else
             p = malloc(n);
         if (p) blocks.push_back({p, n, true});
