@@ -255,10 +255,16 @@ def hbm_ceiling_gbs(torch, dev):
     return n * 8 / t_read / 1e9, 2 * n * 8 / t_copy / 1e9
 
 
+def gather_device(dist, torch, dev):
+    """where the small tensors of an all_gather live: the GPU under RCCL; the host under gloo (its all_gather has no CUDA form -- the LPHQ_BENCH_SHARE_DEVICE0 test mode
+    and --plan-only)"""
+    return torch.device("cpu") if dist.get_backend() == "gloo" else dev
+
+
 def plans_agree(dist, torch, dev, plan):
     """Every rank resolved the same plan (arguments, workloads, cache paths)?  all-gather of a digest; collective, same verdict on every rank."""
     digest = hashlib.sha256(json.dumps(plan, sort_keys=True).encode()).digest()
-    mine = torch.tensor(list(digest[:16]), dtype=torch.int64, device=dev)
+    mine = torch.tensor(list(digest[:16]), dtype=torch.int64, device=gather_device(dist, torch, dev))
     every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(every, mine)
     return all(bool(torch.equal(e, mine)) for e in every)
@@ -479,7 +485,7 @@ def strong_pass(job, wl, h, recs, d_seq, o, stream, rec_order):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        me = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+        me = torch.tensor([kernel_ms], dtype=torch.float64, device=gather_device(dist, torch, dev))
         every = [torch.zeros_like(me) for _ in range(world)]
         dist.all_gather(every, me)
         per_rank = [float(e.item()) for e in every]
@@ -656,7 +662,7 @@ def run_workload(job, wl):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        mine = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+        mine = torch.tensor([kernel_ms], dtype=torch.float64, device=gather_device(dist, torch, dev))
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)  # a straggler shows here, not only in the max
         kernel_ms_per_rank = [float(e.item()) for e in every]
@@ -862,6 +868,7 @@ def run_workload(job, wl):
             "parity_vs_oracle": parity,
             "parity_ranks_checked": world if parity is not None else 0,
             "rccl_ranks": int(dist.get_world_size()) if dist is not None else 1,
+            "collective_backend": (dist.get_backend() if dist is not None else None),
             "replicas_agree": replicas_agree,
         }
         traffic = valu = traffic_stale = traffic_src = l2_miss = rocprof_us = None
@@ -1112,6 +1119,12 @@ def main():
     import lphash_amd as L
 
     assert torch.cuda.is_available(), "bench.py needs a GPU: the query path has no CPU fallback"
+    # LPHQ_BENCH_SHARE_DEVICE0=1 (test hook for boxes with ONE GPU): every rank works on cuda:0 and the process group runs over gloo (RCCL refuses two ranks
+    # on one device) -- everything but the transport of the collectives is then the N > 1 run: N processes, the records shared through the cache directory, the
+    # image broadcast into another process's memory, per-rank batches and oracle checks, the sharded strong-scaling pass, the verdict collectives.
+    share0 = os.environ.get("LPHQ_BENCH_SHARE_DEVICE0") == "1"
+    if share0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -1122,7 +1135,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:
             os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share0:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     job = Job(args, rank, local_rank, world, dev, dist, torch, np, L)
     if dist is not None and not all_ranks_ok(dist, torch, dev, plans_agree(dist, torch, dev, plan)):
         job.fail(2, "the ranks resolved different plans (arguments / cache paths differ between ranks)")

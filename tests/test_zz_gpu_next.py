@@ -290,6 +290,39 @@ def test_bench_collective_path_with_one_rank(tmp_path, mode):
     assert line["index_sha256"] and line["index_digest_pinned"] is None  # (2 M k-mers: not one of the pinned full-size sets)
 
 
+@pytest.mark.parametrize("mode", ["random", "stream"])
+def test_bench_two_ranks_on_one_gpu(tmp_path, mode):
+    """`bench.py --gpus 2` as TWO PROCESSES on the one GPU of the box (LPHQ_BENCH_SHARE_DEVICE0: both ranks on cuda:0, collectives over gloo because RCCL refuses two
+    ranks on one device): everything of the N > 1 run but the transport -- bench.py launches its own ranks, rank 0 generates the records and shares them through the
+    cache directory, rank 1 reads that file and receives the image by broadcast into ITS process, each rank times its own batch and checks it against the oracle, the
+    verdicts are all-reduced, the strong-scaling pass cuts the fixed job in two different shards (and, streaming, proves by the all-reduced checksums that the two
+    halves together are a permutation of [0, n)), rank 0 prints one line."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mode", mode, "--kmers", "3000000", "--batch-log2", "20", "--steps", "3", "--warmup", "1",
+           "--no-hbm-probe", "--b1-records", "0", "--cache-dir", str(tmp_path)]
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["LPHQ_BENCH_SHARE_DEVICE0"] = "1"
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["collective_backend"] == "gloo" and line["scaling"] == "weak"
+    assert line["parity_vs_oracle"] is True and line["parity_ranks_checked"] == 2 and line["replicas_agree"] is True
+    assert len(line["kernel_ms_per_rank"]) == 2 and all(x > 0 for x in line["kernel_ms_per_rank"]) and line["image_broadcast_ms"] > 0
+    units = line["config"]["units_per_step_per_gpu"]
+    assert abs(line["value"] - 2 * units * line["steps"] / (line["ms_per_step"] * line["steps"] * 1e-3)) / line["value"] < 1e-6  # whole-job value = both ranks' units / max time
+    st = line["strong"]
+    assert st["scaling"] == "strong" and st["n_gpus"] == 2 and st["parity_vs_oracle"] is True and len(st["kernel_ms_per_rank"]) == 2
+    if mode == "random":
+        assert st["total_units_per_step"] == 1 << 23 and st["shards"] == [[0, 1 << 22], [1 << 22, 1 << 23]]
+    else:
+        assert st["total_units_per_step"] == 3_000_000 and st["shards"] == [[0, 15], [15, 30]] and st["all_shards_cover_0_n"] is True
+    assert "shared_file" in r.stderr or "records_seed1_30x" in r.stderr or os.path.exists(os.path.join(str(tmp_path), "records_seed1_30x100030.u8"))
+
+
 @pytest.mark.parametrize("name", ["p_k31_m20_b64", "u_k31_m20_b64", "p_k63_m20_b128", "p_k21_m8_b64_fallback"])
 def test_integration_stub_query_driver(tmp_path, name):
     """The reference-side binding of INTEGRATION.md as compiled code: examples/query_example (gpu_mphf<> over include/lphq.h under the reference's
