@@ -506,7 +506,10 @@ def strong_pass(job, wl, h, recs, d_seq, o, stream, rec_order):
         inside = bool(mine == 0 or (int(v.min()) >= 0 and int(v.max()) < nk))
         ok = ok and inside
         if mode == "stream":  # every window of the set exactly once over all ranks: the codes are 0 .. n-1 in some order
-            t = torch.stack([v.sum(), (v * v).sum()]) if mine else torch.zeros(2, dtype=torch.int64, device=dev)
+            t = torch.zeros(2, dtype=torch.int64, device=dev)
+            for a_ in range(0, mine, 1 << 26):  # (a chunk at a time: v * v of a 2 G-code shard is 16 GB)
+                c_ = v[a_:a_ + (1 << 26)]
+                t += torch.stack([c_.sum(), (c_ * c_).sum()])
             if dist is not None:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)  # (wrapping int64 addition)
             n = total_units
@@ -800,13 +803,18 @@ def run_workload(job, wl):
         d_chk = torch.empty(Qc, dtype=torch.int64, device=dev)
         h.query_packed(d_kc.data_ptr(), Qc, d_chk.data_ptr(), stream)
         torch.cuda.synchronize()
-        weights = torch.arange(d_chk.numel(), dtype=torch.int64, device=dev) * 2 + 1  # order-dependent checksum, wrapping int64 arithmetic
-        parts = [d_chk.sum(), (d_chk * weights).sum(), d_chk.max()]
-        del weights
+        def ordered_checksum(v):  # (sum, order-dependent weighted sum) in wrapping int64 arithmetic, a chunk at a time: C4's 2 G codes would need 32 GB of temporaries at once
+            tot = torch.zeros(2, dtype=torch.int64, device=dev)
+            step_ = 1 << 26
+            for a_ in range(0, int(v.numel()), step_):
+                c_ = v[a_:a_ + step_]
+                w_ = torch.arange(a_, a_ + int(c_.numel()), dtype=torch.int64, device=dev) * 2 + 1
+                tot += torch.stack([c_.sum(), (c_ * w_).sum()])
+            return [tot[0], tot[1]]
+
+        parts = ordered_checksum(d_chk) + [d_chk.max()]
         if mode == "stream":  # every rank streamed the same records in the weak line
-            weights = torch.arange(d_out.numel(), dtype=torch.int64, device=dev) * 2 + 1
-            parts += [d_out.sum(), (d_out * weights).sum()]
-            del weights
+            parts += ordered_checksum(d_out)
         t = torch.stack(parts)
         tmin, tmax = t.clone(), t.clone()
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
