@@ -1305,7 +1305,11 @@ static void ptbb_hash(u128 kmer, int kmer_bits, uint64_t seed, uint64_t* first, 
     }
 }
 
-/* the k-mers ptbb_file_itr yields for one record (ptbb.hpp:108-131): every window of k valid bases, forward strand */
+/* the k-mers ptbb_file_itr yields for one record (ptbb.hpp:108-131): every window of k valid bases, forward strand.
+ * Defined divergence: when a record's LAST stretch of valid bases is shorter than k and follows a non-ACGT byte, the reference's operator++ runs
+ * into the record's end with nbases_since_last_break < k, returns with has_next() still true, and the caller consumes *itr once more -- a chimeric k-mer (the km
+ * register is not reset at a break: the last bases before the break + the tail).  Neither this restatement nor the product yields that key; ACGT-only input, and
+ * any input whose records end in a stretch of >= k valid bases, is unaffected. */
 typedef void (*kmer_fn)(u128 kmer, void* ctx);
 static uint64_t ptbb_each_kmer(const char* s, size_t len, uint32_t k, kmer_fn fn, void* ctx) {
     const u128 km_mask = (((u128)1) << (2 * k)) - 1;
