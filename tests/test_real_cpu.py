@@ -83,7 +83,7 @@ def test_product_cpu_builder_writes_the_oracle_file_on_real_unitigs(tmp_path, na
         assert st_codes.size == e["queries"][qname]["valid_windows"] and sha(st_codes) == e["queries"][qname]["streaming_sha256"]
 
 
-@pytest.mark.parametrize("k,m,bits,kind,ust,n_rec", [(31, 20, 64, 0, "ust_k31", 120), (63, 17, 128, 0, "ust_k63", 40), (47, 20, 128, 1, "ust_k31", 80), (31, 15, 64, 1, "ust_k31", 80)])
+@pytest.mark.parametrize("k,m,bits,kind,ust,n_rec", [(31, 20, 64, 0, "ust_k31", 70), (63, 17, 128, 0, "ust_k63", 40), (47, 20, 128, 1, "ust_k31", 80), (31, 15, 64, 1, "ust_k31", 80)])
 def test_python_model_equals_the_oracle_on_real_unitigs(tmp_path, k, m, bits, kind, ust, n_rec):
     """The third restatement (tests/golden/pymodel.py: pure Python, no code shared with the C oracle or the product) on a slice of the REAL unitigs -- 
     medium-sized records of the set, real minimizer skew and colliding minimizers -- and on low-complexity records (homopolymers, tandem repeats: tied minimizer
