@@ -46,8 +46,7 @@ bool gpu_pilot_search(int device, const std::vector<uint64_t>& hs, const std::ve
     int prev = -1;
     uint64_t* d_hs = nullptr;
     uint32_t *d_bstart = nullptr, *d_order = nullptr, *d_taken = nullptr, *d_owner = nullptr, *d_ctl = nullptr;
-    uint64_t *d_pilot = nullptr, *d_cur = nullptr, *d_fixed = nullptr;
-    uint32_t* d_list = nullptr;
+    uint64_t* d_pilot = nullptr;
     uint8_t* d_ready = nullptr;
     const size_t nb = bstart.size() - 1;
     const size_t taken_u32 = (table_size + 63) / 64 * 2 + 2;
@@ -75,9 +74,6 @@ bool gpu_pilot_search(int device, const std::vector<uint64_t>& hs, const std::ve
     HIP_OK(hipMalloc((void**)&d_pilot, pilot_by_order.size() * 8));
     HIP_OK(hipMalloc((void**)&d_ctl, kCtlWords * 4));
     HIP_OK(hipMalloc((void**)&d_ready, pilot_by_order.size()));
-    HIP_OK(hipMalloc((void**)&d_cur, pilot_by_order.size() * 8));
-    HIP_OK(hipMalloc((void**)&d_fixed, kRepairListCap * 8));
-    HIP_OK(hipMalloc((void**)&d_list, kRepairListCap * 4));
     HIP_OK(hipMemcpy(d_hs, hs.data(), hs.size() * 8, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_bstart, bstart32.data(), bstart32.size() * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice));
@@ -102,9 +98,6 @@ bool gpu_pilot_search(int device, const std::vector<uint64_t>& hs, const std::ve
         a.owner = d_owner;
         a.pilot = d_pilot;
         a.ready = d_ready;
-        a.cur = d_cur;
-        a.list = d_list;
-        a.fixed = d_fixed;
         a.ctl = d_ctl;
         a.seedx = seed ^ (8ull * LPHQ_MURMUR_M);
         a.div = divisor_u32(table_size);
@@ -113,13 +106,9 @@ bool gpu_pilot_search(int device, const std::vector<uint64_t>& hs, const std::ve
             bool set_ctl(const uint32_t (&c)[kCtlWords]) { return hipMemcpy(d_ctl, c, sizeof c, hipMemcpyHostToDevice) == hipSuccess; }
             bool get_ctl(uint32_t (&c)[kCtlWords]) { return hipMemcpy(c, d_ctl, sizeof c, hipMemcpyDeviceToHost) == hipSuccess && hipGetLastError() == hipSuccess; }
             void launch_search(const SearchArgs& x, int g) { k_search<<<g, 256>>>(x); }
-            void launch_repair_begin(const SearchArgs& x, int g) { k_repair_begin<<<g, 256>>>(x); }
-            void launch_repair_claim(const SearchArgs& x, int g) { k_repair_claim<<<g, 256>>>(x); }
-            void launch_repair_list(const SearchArgs& x, int g) { k_repair_list<<<g, 256>>>(x); }
-            void launch_repair_fix(const SearchArgs& x, int g) { k_repair_fix<<<g, 256>>>(x); }
-            void launch_repair_release(const SearchArgs& x, int g) { k_repair_release<<<g, 256>>>(x); }
-            void launch_repair_apply(const SearchArgs& x) { k_repair_apply<<<1, 256>>>(x); }
-            void launch_repair_commit(const SearchArgs& x, int g) { k_repair_commit<<<g, 256>>>(x); }
+            void launch_claim(const SearchArgs& x, int g) { k_claim<<<g, 256>>>(x); }
+            void launch_validate(const SearchArgs& x, int g) { k_validate<<<g, 256>>>(x); }
+            void launch_commit(const SearchArgs& x, int g) { k_commit<<<g, 256>>>(x); }
             void launch_advance(const SearchArgs& x) { k_advance<<<1, 64>>>(x); }
         } dev{d_ctl};
         const uint32_t steps = getenv("LPHQ_SEARCH_STEPS") ? (uint32_t)std::max(1, atoi(getenv("LPHQ_SEARCH_STEPS"))) : 16u;                    // tuning aids (16 steps x 256 pilots measured best)
@@ -156,9 +145,6 @@ done:
     if (d_pilot) (void)hipFree(d_pilot);
     if (d_ctl) (void)hipFree(d_ctl);
     if (d_ready) (void)hipFree(d_ready);
-    if (d_cur) (void)hipFree(d_cur);
-    if (d_fixed) (void)hipFree(d_fixed);
-    if (d_list) (void)hipFree(d_list);
     if (prev >= 0) (void)hipSetDevice(prev);
     return ok;
 }

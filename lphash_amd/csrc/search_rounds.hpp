@@ -1,12 +1,12 @@
 // search_rounds.hpp -- host side of the rounds of the GPU pilot search, written against a small device backend so that the
 // product (HIP: search.hip) and the CPU emulator of the tests (tests/emu/emu_search.cpp) run the very same control logic.
-// A round is k_search, k_repair_begin, a fixed number of repair passes (k_repair_claim, _list, _fix, _release, _apply), k_repair_commit, k_advance; its windows live in device memory (search_device.cuh), so the
+// A round is k_search, k_claim, k_validate, k_commit, k_advance; its windows live in device memory (search_device.cuh), so the
 // host enqueues `rounds_per_sync` rounds back to back and looks at the control words once per batch instead of once per
 // round (C2: ~9 K rounds; the per-round read-back was about half of the search's wall time).
 //
 // Backend Dev provides:
 //   bool set_ctl(const uint32_t (&c)[kCtlWords]);  bool get_ctl(uint32_t (&c)[kCtlWords]);   // get_ctl synchronises
-//   void launch_search(const search::SearchArgs&, int workgroups);  launch_repair_begin / _claim / _list / _fix / _release / _commit likewise;  launch_repair_apply(args);
+//   void launch_search(const search::SearchArgs&, int workgroups);  launch_claim / launch_validate / launch_commit likewise;
 //   void launch_advance(const search::SearchArgs&);
 #pragma once
 #include <algorithm>
@@ -63,10 +63,6 @@ bool run_rounds(Dev& dev, SearchArgs a, uint64_t n_nonempty, uint32_t look_ahead
     // one wave per bucket of the largest commit window
     const int search_grid = (int)std::min<uint64_t>(look_ahead, n_nonempty);
     const int commit_grid = (int)((std::min<uint64_t>(8192u, n_nonempty) * (uint64_t)kWave + 255) / 256);
-    const int begin_grid = (int)((std::min<uint64_t>(8192u, n_nonempty) + 255) / 256);
-    const int fix_grid = (int)std::min<uint64_t>(1024u, n_nonempty);
-    uint32_t repair_passes = 6;  // (tuning aid LPHQ_SEARCH_REPAIR_PASSES, 1..32; the result does not depend on it)
-    if (const char* e = getenv("LPHQ_SEARCH_REPAIR_PASSES")) repair_passes = (uint32_t)std::min(32, std::max(1, atoi(e)));
     // Host-side bounds, independent of the control words the device writes: every round either commits >= 1 bucket or
     // counts towards kMaxIdle, so a correct search needs at most n_nonempty + kMaxIdle rounds (C2: ~9 K for 1.9 M buckets);
     // and a wall-clock limit (LPHQ_SEARCH_MAX_SECONDS, default 120 s; C4-scale searches take < 20 s).  On either the caller
@@ -79,17 +75,9 @@ bool run_rounds(Dev& dev, SearchArgs a, uint64_t n_nonempty, uint32_t look_ahead
     for (;;) {
         for (uint32_t r = 0; r < rounds_per_sync; ++r) {
             dev.launch_search(a, search_grid);
-            // repair passes (search_device.cuh): the commit window is iterated to the sequential answer instead of being cut at its first conflict; a pass that
-            // changes nothing turns the remaining ones into empty launches
-            dev.launch_repair_begin(a, begin_grid);
-            for (uint32_t p = 0; p < repair_passes; ++p) {
-                dev.launch_repair_claim(a, commit_grid);
-                dev.launch_repair_list(a, commit_grid);
-                dev.launch_repair_fix(a, fix_grid);
-                dev.launch_repair_release(a, commit_grid);
-                dev.launch_repair_apply(a);
-            }
-            dev.launch_repair_commit(a, commit_grid);
+            dev.launch_claim(a, commit_grid);
+            dev.launch_validate(a, commit_grid);
+            dev.launch_commit(a, commit_grid);
             dev.launch_advance(a);
         }
         if (!dev.get_ctl(c)) {

@@ -22,16 +22,11 @@ struct EmuDev {  // "device" memory is host memory, a launch is an emulated grid
         const bool over = (ctl[kDone] | ctl[kFailed] | ctl[kStuck]) != 0;
         return (unsigned)std::min<uint64_t>((uint64_t)g, over ? 1u : (uint64_t)need + 1u);
     }
-    unsigned commit_wgs() const { return ctl[kConverged] ? 0u : (unsigned)(((uint64_t)ctl[kNCommit] * kWave + 255) / 256); }  // (a settled round: one workgroup runs the early exit)
-    unsigned commit_wgs_always() const { return (unsigned)(((uint64_t)ctl[kNCommit] * kWave + 255) / 256); }
+    unsigned commit_wgs() const { return (unsigned)(((uint64_t)ctl[kNCommit] * kWave + 255) / 256); }
     void launch_search(const SearchArgs& x, int g) { emu::launch(cut(g, ctl[kNSearch]), 256, [&] { k_search(x); }); }
-    void launch_repair_begin(const SearchArgs& x, int g) { emu::launch(cut(g, (ctl[kNCommit] + 255) / 256), 256, [&] { k_repair_begin(x); }); }
-    void launch_repair_claim(const SearchArgs& x, int g) { emu::launch(cut(g, commit_wgs()), 256, [&] { k_repair_claim(x); }); }
-    void launch_repair_list(const SearchArgs& x, int g) { emu::launch(cut(g, commit_wgs()), 256, [&] { k_repair_list(x); }); }
-    void launch_repair_fix(const SearchArgs& x, int g) { emu::launch(ctl[kConverged] ? 1u : (unsigned)std::min<uint64_t>((uint64_t)g, (uint64_t)ctl[kListCount] + 1u), 256, [&] { k_repair_fix(x); }); }
-    void launch_repair_release(const SearchArgs& x, int g) { emu::launch(cut(g, commit_wgs()), 256, [&] { k_repair_release(x); }); }
-    void launch_repair_apply(const SearchArgs& x) { emu::launch(1, 256, [&] { k_repair_apply(x); }); }
-    void launch_repair_commit(const SearchArgs& x, int g) { emu::launch(cut(g, commit_wgs_always()), 256, [&] { k_repair_commit(x); }); }
+    void launch_claim(const SearchArgs& x, int g) { emu::launch(cut(g, commit_wgs()), 256, [&] { k_claim(x); }); }
+    void launch_validate(const SearchArgs& x, int g) { emu::launch(cut(g, commit_wgs()), 256, [&] { k_validate(x); }); }
+    void launch_commit(const SearchArgs& x, int g) { emu::launch(cut(g, commit_wgs()), 256, [&] { k_commit(x); }); }
     void launch_advance(const SearchArgs& x) { emu::launch(1, 64, [&] { k_advance(x); }); }
 };
 uint64_t murmur_u64(uint64_t v, uint64_t seed) { return murmur8(v, seed ^ (8ull * LPHQ_MURMUR_M)); }
@@ -42,8 +37,6 @@ extern "C" int emu_pilot_search(const uint64_t* hs, const uint32_t* bstart, cons
                                 uint32_t look_ahead, uint32_t steps, uint32_t rounds_per_sync, uint64_t* pilot_by_order, uint32_t* taken, uint64_t* rounds) {
     std::vector<uint32_t> owner(table_size, kNoOwner);
     std::vector<uint8_t> ready(n_nonempty ? n_nonempty : 1, 0);
-    std::vector<uint64_t> cur(n_nonempty ? n_nonempty : 1, 0), fixed(kRepairListCap, 0);
-    std::vector<uint32_t> list(kRepairListCap, 0);
     uint32_t ctl[kCtlWords];
     memset(ctl, 0, sizeof ctl);
     memset(taken, 0, ((table_size + 63) / 64 * 2 + 2) * 4);
@@ -57,9 +50,6 @@ extern "C" int emu_pilot_search(const uint64_t* hs, const uint32_t* bstart, cons
     a.owner = owner.data();
     a.pilot = pilot_by_order;
     a.ready = ready.data();
-    a.cur = cur.data();
-    a.list = list.data();
-    a.fixed = fixed.data();
     a.ctl = ctl;
     a.seedx = seed ^ (8ull * LPHQ_MURMUR_M);
     a.div = divisor_u32(table_size);

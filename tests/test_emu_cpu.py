@@ -307,20 +307,10 @@ def test_packed_and_pack_kernels_on_the_emulator(emuk, tmp_path, k, m, bits, kin
 # ------------------------------------------------------------------------------------------------------------------
 # GPU pilot search of the index builder (search_device.cuh kernels + search_rounds.hpp round loop) on the emulator
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n_keys,look_ahead,steps,seed,passes", [(3000, 16384, 32, 1, 0), (2000, 16384, 4, 2, 0), (2500, 8192, 1, 3, 0), (800, 100, 1000000, 4, 0), (4000, 16384, 32, 5, 0),
-                                                                 (3500, 16384, 32, 6, 1), (3500, 16384, 32, 6, 2), (3000, 16384, 2, 7, 3), (3000, 16384, 1, 9, 32)])
-def test_gpu_pilot_search_on_the_emulator(emuk, n_keys, look_ahead, steps, seed, passes, monkeypatch):
-    _pilot_search_case(emuk, n_keys, look_ahead, steps, seed, passes, monkeypatch.setenv)
-
-
-def _pilot_search_case(emuk, n_keys, look_ahead, steps, seed, passes, setenv):
-    """Speculative window + repair passes (round 5: the window iterated to the fixed point, search_device.cuh) must give exactly the sequential first-fit
-    pilots and bitmap, for any step budget, for (clamped) out-of-range look-ahead values -- the configuration that once committed unsearched buckets --
-    and for ANY number of passes per round: with one or two passes most rounds end unsettled and commit only the prefix before the first bucket that
-    changed in the last pass; with a step budget of one a repair often runs out of budget and cuts the window."""
-    if passes:
-        setenv("LPHQ_SEARCH_REPAIR_PASSES", str(passes))
-    setenv("LPHQ_SEARCH_MAX_SECONDS", "3000")  # (the wall-clock limit of the round loop is meant for a GPU; an emulated launch costs milliseconds)
+@pytest.mark.parametrize("n_keys,look_ahead,steps,seed", [(3000, 16384, 32, 1), (2000, 16384, 4, 2), (2500, 8192, 1, 3), (800, 100, 1000000, 4), (4000, 16384, 32, 5)])
+def test_gpu_pilot_search_on_the_emulator(emuk, n_keys, look_ahead, steps, seed):
+    """Speculative window + claim/validate/commit must give exactly the sequential first-fit pilots and bitmap, for any step
+    budget and for (clamped) out-of-range look-ahead values -- the configuration that once committed unsearched buckets."""
     lib = emuk
     lib.emu_pilot_search.restype = C.c_int
     lib.emu_pilot_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
@@ -374,11 +364,9 @@ def test_kernels_under_other_thread_schedules(emuk, tmp_path, mode, seed):
         test_tile_kernels_on_the_emulator(emuk, tmp_path, 47, 17, 128, 1)  # unpartitioned, 128-bit k-mers
         test_tile_kernels_non_acgt_on_the_emulator(emuk, tmp_path)
         test_packed_and_pack_kernels_on_the_emulator(emuk, tmp_path, 31, 20, 64, 0)
-        _pilot_search_case(emuk, 1500, 16384, 8, 3, 3, os.environ.__setitem__)  # (the repair passes too: list appends, the fix workgroups' barriers, the one-workgroup apply)
+        test_gpu_pilot_search_on_the_emulator(emuk, 1500, 16384, 8, 3)
     finally:
         emuk.emu_set_schedule(0, 0)
-        os.environ.pop("LPHQ_SEARCH_REPAIR_PASSES", None)
-        os.environ.pop("LPHQ_SEARCH_MAX_SECONDS", None)
 
 
 REF_NT4 = "/root/reference/src/constants.cpp"

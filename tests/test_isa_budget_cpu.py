@@ -31,13 +31,9 @@ BUDGET = {
     "k_group_flags": (64, 0),
     "k_group_scatter": (64, 0),
     "k_search": (64, 1024),
-    "k_repair_begin": (64, 0),
-    "k_repair_claim": (64, 0),
-    "k_repair_list": (64, 0),
-    "k_repair_fix": (64, 1024),
-    "k_repair_release": (64, 0),
-    "k_repair_apply": (64, 0),
-    "k_repair_commit": (64, 0),
+    "k_claim": (64, 0),
+    "k_validate": (64, 0),
+    "k_commit": (64, 0),
     "k_advance": (64, 0),
 }
 # SGPR spills go to VGPR lanes, not to memory.  k_query_packed takes the 1.2-KB header by value (measured 2 % faster than reading the header from the
@@ -149,8 +145,7 @@ def test_kernels_fit_their_register_and_lds_budget(src):
         assert u.get("SGPRs Spill", 0) <= SGPR_SPILLS.get(key, 0), (name, u)
         assert u["VGPRs"] + u.get("AGPRs", 0) <= vg, (name, u)
         assert u.get("LDS Size", 0) <= lds, (name, u)
-    where = {"k_query_tiles_stream8": "stream8.hip", "k_search": "search.hip", "k_repair_begin": "search.hip", "k_repair_claim": "search.hip", "k_repair_list": "search.hip", "k_repair_fix": "search.hip", "k_repair_release": "search.hip",
-             "k_repair_apply": "search.hip", "k_repair_commit": "search.hip", "k_advance": "search.hip",
+    where = {"k_query_tiles_stream8": "stream8.hip", "k_search": "search.hip", "k_claim": "search.hip", "k_validate": "search.hip", "k_commit": "search.hip", "k_advance": "search.hip",
              "k_extract_runs": "extract.hip", "k_assemble_runs": "extract.hip", "k_group_flags": "extract.hip", "k_group_scatter": "extract.hip"}
     expected = {k for k in BUDGET if where.get(k, "kernels.hip") == src}
     assert seen == expected, (seen, expected)
