@@ -26,9 +26,11 @@ extern "C" {
 #endif
 
 /* Version of this interface.  An entry point never changes its signature: new behaviour gets a new name and the number goes up
- * (2: lphq_count_valid_on_stream, lphq_abi_version; 3: lphq_session_*, lphq_host_alloc / lphq_host_free, lphq_replica_info).  A caller compiled
- * against version N works with any library reporting >= N. */
-#define LPHQ_ABI_VERSION 3
+ * (2: lphq_count_valid_on_stream, lphq_abi_version; 3: lphq_session_*, lphq_host_alloc / lphq_host_free, lphq_replica_info; 4: the run-encoded
+ * streaming result -- lphq_query_records_runs, lphq_expand_runs, lphq_session_submit_runs / lphq_session_collect_runs --, the fused lookup -> payload
+ * pass lphq_query_records_gather, and sessions over several replicas, lphq_session_open_devices).  A caller compiled against version N works with
+ * any library reporting >= N. */
+#define LPHQ_ABI_VERSION 4
 int lphq_abi_version(void);
 
 /* ---- status codes ---- */
@@ -157,6 +159,65 @@ int lphq_count_valid_async(const lphq_index* idx, const uint64_t* d_codes, size_
  * whose code happens to be < num_kmers; that is the nature of the structure, not of this call.) */
 int lphq_gather_payload(const lphq_index* idx, const uint64_t* d_codes, size_t n, const void* d_table, uint32_t elem_bytes, uint64_t missing,
                         void* d_out, void* stream);
+
+/* ---- the streaming result as the reference COMPUTES it: runs (ABI 4) ----
+ * The reference's streaming branch asks the function once per super-k-mer and then counts: the k-mers that follow under the same minimizer get the
+ * previous code + 1 or - 1 (include/partitioned_mphf.hpp:131-145, case 0: `++mm_ctx.local_rank` for RIGHT / NONE minimizers, `--` for LEFT / MAXIMAL;
+ * include/unpartitioned_mphf.hpp:130-137: `++hval`), and only k-mers under a colliding minimizer are looked up one by one in the fallback function
+ * (:133-135).  A streaming pass therefore IS a list of affine runs -- (k - m + 2) / 2 windows each on random sequence: 6.5 at k = 31 / m = 20, 22.5
+ * at k = 63 -- which src/query.cpp:52-54 expands into a vector and throws away.  lphq_query_records_runs hands out the runs themselves: 16 bytes per
+ * run instead of 8 per k-mer leave the kernel (and, through a session, cross PCIe).
+ *
+ * One lphq_run = a run of windows of ONE record whose codes are affine (or explicit):
+ *   code    kind UP / DOWN: the code of the run's first window; window first + i has code + i (UP) or code - i (DOWN), wrapping like the reference's
+ *           uint64_t arithmetic.  kind EXPLICIT (colliding minimizer): index of the run's first code in the explicit-code array of the run's arena;
+ *           window first + i has d_codes[arena * arena_codes + code + i]
+ *   where   LPHQ_RUN_FIRST: index of the run's first window in the code space lphq_query_records writes (d_out_offsets[r] + window within record r);
+ *           LPHQ_RUN_LENGTH: windows in the run (>= 1); LPHQ_RUN_KIND
+ * Windows that hold a non-ACGT base belong to no run (the reference emits nothing for them).  Every other window of the batch belongs to exactly
+ * one run.  Runs are cut where the kernel's tiles and waves end (every 512 window starts at most), so a long super-k-mer may arrive as two or three
+ * adjacent runs of the same kind; nothing else splits it.
+ *
+ * Layout: LPHQ_RUN_ARENAS arenas.  A workgroup appends the runs of its tile to arena (tile % LPHQ_RUN_ARENAS) with ONE atomic add per tile; one
+ * counter for the whole batch would serialise -- measured 83 M atomics/s on one address, 4.2 G/s over 64 (tools/gather_ceiling.hip,
+ * profiles/r06_gather_ceiling.txt) -- where a 2 G-window batch has 2.1 M tiles in 7 ms.  Arena a holds d_counts[a].runs runs at
+ * d_runs[a * arena_runs ...] (in no particular order: each run says where it goes) and d_counts[a].codes explicit codes at d_codes[a * arena_codes ...],
+ * arena_runs = cap_runs / LPHQ_RUN_ARENAS, arena_codes = cap_codes / LPHQ_RUN_ARENAS (both capacities: multiples of LPHQ_RUN_ARENAS).  A counter may
+ * END ABOVE its arena's capacity: the entries beyond were not written and the result is incomplete -- check after the stream has finished, or let
+ * lphq_expand_runs report it.  Sizing: a batch of n windows yields about 2 n / (k - m + 2) + n / 500 runs on random sequence, at most n. */
+typedef struct lphq_run {
+    uint64_t code;
+    uint64_t where;
+} lphq_run;
+enum { LPHQ_RUN_UP = 0, LPHQ_RUN_DOWN = 1, LPHQ_RUN_EXPLICIT = 2 };
+#define LPHQ_RUN_FIRST(r) ((r).where & 0xFFFFFFFFFFULL)                     /* < 2^40: batches of up to 2^40 windows */
+#define LPHQ_RUN_LENGTH(r) ((uint32_t)(((r).where >> 40) & 0x3FFFFFu))
+#define LPHQ_RUN_KIND(r) ((uint32_t)((r).where >> 62))
+#define LPHQ_RUN_ARENAS 32
+typedef struct lphq_run_counts { /* one per arena, a cache line of its own (the arenas' atomics must not meet on a line) */
+    uint64_t runs, codes, reserved[14];
+} lphq_run_counts;
+/* The streaming pass of lphq_query_records (same arguments, same tiles, same lookups) with the run-encoded result.  d_counts: LPHQ_RUN_ARENAS
+ * entries, zeroed by the call on `stream`.  LPHQ_ERR_ARG for competitor handles (kind >= LPHQ_PTHASH: their codes are not affine) and for batches
+ * of 2^40 windows or more. */
+int lphq_query_records_runs(const lphq_index* idx, const char* d_seq, size_t total_bases, const uint64_t* d_seq_offsets, size_t n_records,
+                            const uint64_t* d_out_offsets, lphq_run* d_runs, size_t cap_runs, uint64_t* d_codes, size_t cap_codes,
+                            lphq_run_counts* d_counts, void* stream);
+/* d_out[0..n_out) from the runs: what lphq_query_records(streaming = 1) writes for the same batch, LPHQ_INVALID included (d_out is filled with it
+ * first).  Asynchronous; *d_status (8 bytes of device memory, may be NULL) is set to 0, or to 1 when an arena had overflowed or a run points
+ * outside [0, n_out) -- such runs are skipped. */
+int lphq_expand_runs(const lphq_index* idx, const lphq_run* d_runs, size_t cap_runs, const uint64_t* d_codes, size_t cap_codes,
+                     const lphq_run_counts* d_counts, uint64_t* d_out, size_t n_out, uint64_t* d_status, void* stream);
+
+/* ---- streaming lookup fused with its consumer (ABI 4) ----
+ * d_payload_out[d_out_offsets[r] + i] = d_table[code of window i of record r], elements of elem_bytes = 1, 2, 4 or 8 bytes: lphq_query_records
+ * (streaming) followed by lphq_gather_payload, in one kernel -- the codes never reach memory.  The k-mers of a super-k-mer have consecutive codes,
+ * so their payload is contiguous in d_table: the reads this pass adds are what "locality-preserving" buys.  Windows that hold a non-ACGT base and
+ * codes that are not slots of the function (>= num_kmers: a non-member k-mer's wrapped arithmetic) yield the low elem_bytes bytes of `missing`,
+ * as in lphq_gather_payload.  LPHQ_ERR_ARG for competitor handles. */
+int lphq_query_records_gather(const lphq_index* idx, const char* d_seq, size_t total_bases, const uint64_t* d_seq_offsets, size_t n_records,
+                              const uint64_t* d_out_offsets, const void* d_table, uint32_t elem_bytes, uint64_t missing, void* d_payload_out,
+                              void* stream);
 
 /* ---- host-buffer convenience: mirrors MPHF::operator()(contig, length, streaming) ----
  * Copies the record to the device, runs the GPU path, copies the codes back and (streaming

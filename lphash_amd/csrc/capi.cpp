@@ -50,8 +50,11 @@ struct lphq_index {
     std::vector<Replica> reps;   // reps[0] = primary device
     std::mutex pool_mu;          // guards pool only (pop / push of a slot), never held across device work
     std::vector<Scratch*> pool;
-    std::atomic<int> open_sessions{0};  // lphq_session handles that still use this index
-    std::atomic<bool> closing{false};   // lphq_close was called while sessions were open: the last lphq_session_close frees the index
+    // ONE count of the users of this object: the caller's handle holds one reference (dropped by lphq_close), every open session one (dropped by
+    // lphq_session_close).  Whoever takes it from 1 to 0 destroys the index -- exactly once, whatever the interleaving of a closing main thread and a
+    // worker closing the last session (two flags checked in two orders could both see "I am last": a double free).
+    std::atomic<int> refs{1};
+    std::atomic<bool> closing{false};   // lphq_close was called: the handle is dead for new sessions (the memory lives until the last reference goes)
 };
 
 static thread_local std::string g_err;
@@ -255,11 +258,13 @@ static void destroy_index(lphq_index* idx) {
 
 // A session keeps using the replica's device memory until it is closed: closing the index first only marks it; the free happens when the last
 // session goes (include/lphq.h).  The handle itself is dead for the caller from here on in either case.
+static void index_unref(lphq_index* idx) {
+    if (idx->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) destroy_index(idx);
+}
 extern "C" void lphq_close(lphq_index* idx) {
     if (!idx) return;
     idx->closing.store(true);
-    if (idx->open_sessions.load() > 0) return;
-    destroy_index(idx);
+    index_unref(idx);  // the handle's own reference
 }
 
 // the replica queries of the calling thread run on: its current HIP device if the index is attached there, else the primary
@@ -635,6 +640,62 @@ extern "C" int lphq_query_records(const lphq_index* idx, const char* d_seq, size
     return LPHQ_OK;
 }
 
+// the capacity arguments of the run-encoded result: whole arenas
+static int check_run_caps(size_t cap_runs, size_t cap_codes) {
+    if (cap_runs == 0 || cap_runs % LPHQ_RUN_ARENAS || cap_codes % LPHQ_RUN_ARENAS) return fail(LPHQ_ERR_ARG, "cap_runs / cap_codes must be multiples of LPHQ_RUN_ARENAS (cap_runs > 0)");
+    return LPHQ_OK;
+}
+
+extern "C" int lphq_query_records_runs(const lphq_index* idx, const char* d_seq, size_t total_bases, const uint64_t* d_seq_offsets, size_t n_records,
+                                       const uint64_t* d_out_offsets, lphq_run* d_runs, size_t cap_runs, uint64_t* d_codes, size_t cap_codes,
+                                       lphq_run_counts* d_counts, void* stream) {
+    REQUIRE_ATTACHED(idx);
+    if (idx->hdr.kind >= LPHQ_PTHASH) return fail(LPHQ_ERR_ARG, "run-encoded results exist for LP-MPHF handles only (a competitor's codes are not affine)");
+    if (!d_runs || !d_counts || (cap_codes && !d_codes)) return fail(LPHQ_ERR_ARG, "null buffer");
+    if (n_records && (!d_seq_offsets || !d_out_offsets)) return fail(LPHQ_ERR_ARG, "null buffer");
+    if (n_records > 0xFFFFFFFFull) return fail(LPHQ_ERR_ARG, "more than 2^32-1 records in one batch");
+    if (total_bases && !d_seq) return fail(LPHQ_ERR_ARG, "null buffer");
+    if ((uint64_t)total_bases >= (1ull << 40)) return fail(LPHQ_ERR_ARG, "a run addresses its first window in 40 bits: batches of up to 2^40 - 1 bases");
+    const int rc = check_run_caps(cap_runs, cap_codes);
+    if (rc) return rc;
+    const Replica* r = pick_replica(idx);
+    DeviceGuard g(r->device);
+    const S8RunsArgs sink{d_runs, d_codes, d_counts, (uint64_t)cap_runs / LPHQ_RUN_ARENAS, (uint64_t)cap_codes / LPHQ_RUN_ARENAS};
+    HIP_TRY(launch_query_records_runs(idx->hdr, r->d_image, d_seq, total_bases, d_seq_offsets, d_out_offsets, n_records, sink, (hipStream_t)stream));
+    return LPHQ_OK;
+}
+
+extern "C" int lphq_expand_runs(const lphq_index* idx, const lphq_run* d_runs, size_t cap_runs, const uint64_t* d_codes, size_t cap_codes,
+                                const lphq_run_counts* d_counts, uint64_t* d_out, size_t n_out, uint64_t* d_status, void* stream) {
+    REQUIRE_ATTACHED(idx);
+    if (!d_runs || !d_counts || (cap_codes && !d_codes) || (n_out && !d_out)) return fail(LPHQ_ERR_ARG, "null buffer");
+    const int rc = check_run_caps(cap_runs, cap_codes);
+    if (rc) return rc;
+    const Replica* r = pick_replica(idx);
+    DeviceGuard g(r->device);
+    HIP_TRY(launch_expand_runs(d_runs, (uint64_t)cap_runs / LPHQ_RUN_ARENAS, d_codes, (uint64_t)cap_codes / LPHQ_RUN_ARENAS, d_counts, d_out, n_out,
+                               (unsigned long long*)d_status, (hipStream_t)stream));
+    return LPHQ_OK;
+}
+
+extern "C" int lphq_query_records_gather(const lphq_index* idx, const char* d_seq, size_t total_bases, const uint64_t* d_seq_offsets, size_t n_records,
+                                         const uint64_t* d_out_offsets, const void* d_table, uint32_t elem_bytes, uint64_t missing, void* d_payload_out,
+                                         void* stream) {
+    REQUIRE_ATTACHED(idx);
+    if (idx->hdr.kind >= LPHQ_PTHASH) return fail(LPHQ_ERR_ARG, "the fused lookup -> payload pass exists for LP-MPHF handles only (competitors: lphq_query_records + lphq_gather_payload)");
+    if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8) return fail(LPHQ_ERR_ARG, "elem_bytes must be 1, 2, 4 or 8");
+    if (n_records && (!d_seq_offsets || !d_out_offsets || !d_table || !d_payload_out)) return fail(LPHQ_ERR_ARG, "null buffer");
+    if (n_records > 0xFFFFFFFFull) return fail(LPHQ_ERR_ARG, "more than 2^32-1 records in one batch");
+    if (total_bases && !d_seq) return fail(LPHQ_ERR_ARG, "null buffer");
+    const Replica* r = pick_replica(idx);
+    DeviceGuard g(r->device);
+    const uint32_t el = elem_bytes == 1 ? 0u : elem_bytes == 2 ? 1u : elem_bytes == 4 ? 2u : 3u;
+    const uint64_t miss = el == 3u ? missing : (missing & ((1ull << (8u * elem_bytes)) - 1ull));
+    const S8GatherArgs sink{(const uint8_t*)d_table, (uint8_t*)d_payload_out, idx->hdr.nkmers, miss, el};
+    HIP_TRY(launch_query_records_gather(idx->hdr, r->d_image, d_seq, total_bases, d_seq_offsets, d_out_offsets, n_records, sink, (hipStream_t)stream));
+    return LPHQ_OK;
+}
+
 extern "C" int lphq_pack_kmers(const lphq_index* idx, const char* d_seq, const uint64_t* d_pos, size_t n, void* d_kmers, void* stream) {
     REQUIRE_ATTACHED(idx);
     if (n && (!d_seq || !d_pos || !d_kmers)) return fail(LPHQ_ERR_ARG, "null buffer");
@@ -814,15 +875,22 @@ extern "C" int lphq_session_open(const lphq_index* cidx, int depth, lphq_session
     if (!out) return fail(LPHQ_ERR_ARG, "null argument");
     *out = nullptr;
     if (depth < 1 || depth > 4) return fail(LPHQ_ERR_ARG, "depth must be 1..4");
-    if (idx->closing.load()) return fail(LPHQ_ERR_STATE, "the index was closed");
+    // the reference first, then the check: a lphq_close that slips in between finds the count >= 2 and cannot free the index under this call
+    idx->refs.fetch_add(1, std::memory_order_acq_rel);
+    if (idx->closing.load()) {
+        index_unref(idx);
+        return fail(LPHQ_ERR_STATE, "the index was closed");
+    }
     lphq_session* s = new (std::nothrow) lphq_session();
-    if (!s) return fail(LPHQ_ERR_ARG, "out of memory");
+    if (!s) {
+        index_unref(idx);
+        return fail(LPHQ_ERR_ARG, "out of memory");
+    }
     s->idx = idx;
     const Replica* rep = pick_replica(idx);
     s->device = rep->device;
     s->d_image = rep->d_image;
     s->depth = depth;
-    idx->open_sessions.fetch_add(1);
     DeviceGuard g(s->device);
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     for (int i = 0; i < depth && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&s->slot[i].done, hipEventDisableTiming);
@@ -851,7 +919,7 @@ extern "C" void lphq_session_close(lphq_session* s) {
     }
     lphq_index* idx = s->idx;
     delete s;
-    if (idx && idx->open_sessions.fetch_sub(1) == 1 && idx->closing.load()) destroy_index(idx);  // lphq_close came first: this was the last user
+    if (idx) index_unref(idx);  // (lphq_close came first and this was the last session: the index goes now)
 }
 
 template <typename T>

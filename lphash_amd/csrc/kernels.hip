@@ -142,4 +142,56 @@ hipError_t launch_query_records(const lphq_image_header& H, const uint8_t* d_img
     return hipSuccess;
 }
 
+// The streaming pass into another sink: the tiles of launch_query_records(streaming), every W (the eight-per-lane kernel takes narrow windows through its
+// raw-hash form; they are rare -- k - m + 1 < 8 -- and the sinks exist once)
+template <typename SinkArgs, typename LaunchP, typename LaunchU>
+static hipError_t launch_stream_sink(const lphq_image_header& H, const uint8_t* d_img, const char* d_seq, uint64_t total_bases, const uint64_t* d_seq_off,
+                                     const uint64_t* d_out_off, size_t n_records, const SinkArgs& sink, hipStream_t stream, LaunchP lp, LaunchU lu) {
+    if (H.kind >= 2 || n_records > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    if (n_records == 0 || total_bases < H.k) return hipSuccess;
+    const uint64_t shift = (uint64_t)((uintptr_t)d_seq & 15u);
+    const uint8_t* seq_al = (const uint8_t*)d_seq - shift;
+    const uint64_t tw = stream_tile_windows(H.W, 8 * 128), tiles = (shift + total_bases + tw - 1) / tw;
+    const uint64_t kMaxTiles = (1u << 24) - 1;
+    for (uint64_t tile_base = 0; tile_base < tiles; tile_base += kMaxTiles) {
+        const int grid = (int)std::min<uint64_t>(kMaxTiles, tiles - tile_base);
+        const hipError_t e = H.kind == 0 ? lp(H, d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, sink, tile_base, grid, stream)
+                                         : lu(H, d_img, seq_al, shift, total_bases, d_seq_off, d_out_off, (uint32_t)n_records, sink, tile_base, grid, stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_query_records_runs(const lphq_image_header& H, const uint8_t* d_img, const char* d_seq, uint64_t total_bases, const uint64_t* d_seq_off,
+                                     const uint64_t* d_out_off, size_t n_records, const S8RunsArgs& sink, hipStream_t stream) {
+    const hipError_t e = hipMemsetAsync(sink.counts, 0, sizeof(lphq_run_counts) * LPHQ_RUN_ARENAS, stream);
+    if (e != hipSuccess) return e;
+    return launch_stream_sink(H, d_img, d_seq, total_bases, d_seq_off, d_out_off, n_records, sink, stream, launch_stream8_runs_p, launch_stream8_runs_u);
+}
+
+hipError_t launch_query_records_gather(const lphq_image_header& H, const uint8_t* d_img, const char* d_seq, uint64_t total_bases, const uint64_t* d_seq_off,
+                                       const uint64_t* d_out_off, size_t n_records, const S8GatherArgs& sink, hipStream_t stream) {
+    return launch_stream_sink(H, d_img, d_seq, total_bases, d_seq_off, d_out_off, n_records, sink, stream, launch_stream8_gather_p, launch_stream8_gather_u);
+}
+
+hipError_t launch_expand_runs(const lphq_run* d_runs, uint64_t arena_runs, const uint64_t* d_codes, uint64_t arena_codes, const lphq_run_counts* d_counts, uint64_t* d_out,
+                              uint64_t n_out, unsigned long long* d_status, hipStream_t stream) {
+    hipError_t e = n_out ? hipMemsetAsync(d_out, 0xFF, n_out * sizeof(uint64_t), stream) : hipSuccess;  // LPHQ_INVALID: windows that belong to no run
+    if (e == hipSuccess && d_status) e = hipMemsetAsync(d_status, 0, sizeof(uint64_t), stream);
+    if (e != hipSuccess) return e;
+    // (the grid is sized for full arenas: the counts live on the device; a workgroup whose slice of its arena is empty returns at once)
+    const int gx = grid_for((size_t)std::min<uint64_t>(arena_runs, (uint64_t)1 << 31), kBlock, 1024);
+    k_expand_runs<><<<dim3((unsigned)gx, LPHQ_RUN_ARENAS), kBlock, 0, stream>>>(d_runs, arena_runs, d_codes, arena_codes, d_counts, d_out, n_out, d_status);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact_runs(const lphq_run* d_runs, uint64_t arena_runs, const uint64_t* d_codes, uint64_t arena_codes, const lphq_run_counts* d_counts,
+                               lphq_run* d_dense_runs, uint64_t cap_dense_runs, uint64_t* d_dense_codes, uint64_t cap_dense_codes, unsigned long long* d_totals,
+                               hipStream_t stream) {
+    const int gx = grid_for((size_t)std::min<uint64_t>(std::max(arena_runs, arena_codes), (uint64_t)1 << 31), kBlock * 4, 256);
+    k_compact_runs<><<<dim3((unsigned)gx, LPHQ_RUN_ARENAS), kBlock, 0, stream>>>(d_runs, arena_runs, d_codes, arena_codes, d_counts, d_dense_runs, cap_dense_runs, d_dense_codes,
+                                                                             cap_dense_codes, d_totals);
+    return hipGetLastError();
+}
+
 }  // namespace lphq

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_query.cuh"
+#include "stream_sinks.h"
 
 namespace lphq {
 
@@ -862,6 +863,108 @@ __global__ __launch_bounds__(kBlock) void k_gather_payload(const uint64_t* __res
         const uint64_t c = __builtin_nontemporal_load(codes + i);
         __builtin_nontemporal_store(c < n_slots ? table[c] : missing, out + i);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// the run-encoded streaming result (include/lphq.h: lphq_run; produced by k_query_tiles_stream8<.., kSinkRuns>)
+// ------------------------------------------------------------------------------------------
+// lphq_expand_runs: out[first + i] = code +- i (or the explicit code) for every run of every arena.  A workgroup takes 256 runs of one arena at a time:
+// their lengths are summed in LDS (inclusive scan), and the windows of the 256 runs are then dealt out to the lanes one each per step, found by a binary
+// search over the scan -- dense lanes whatever the mix of run lengths (1 .. 512).  `out` was filled with LPHQ_INVALID by the launcher.  status: set to 1 when an
+// arena had overflowed or a run points outside [0, n_out).
+template <int BLOCK = kBlock>
+__global__ __launch_bounds__(kBlock) void k_expand_runs(const lphq_run* __restrict__ runs, uint64_t arena_runs, const uint64_t* __restrict__ codes, uint64_t arena_codes,
+                                                        const lphq_run_counts* __restrict__ counts, uint64_t* __restrict__ out, uint64_t n_out,
+                                                        unsigned long long* __restrict__ status) {
+    __shared__ uint64_t sm_code[kBlock], sm_where[kBlock];
+    __shared__ uint32_t sm_incl[kBlock], sm_wsum[kBlock / 64];
+    const uint32_t tid = threadIdx.x, arena = blockIdx.y;
+    const uint64_t have = counts[arena].runs, n = have < arena_runs ? have : arena_runs;
+    bool bad = have > arena_runs || counts[arena].codes > arena_codes;
+    const lphq_run* const src = runs + (uint64_t)arena * arena_runs;
+    const uint64_t* const xsrc = codes + (uint64_t)arena * arena_codes;
+    for (uint64_t c0 = (uint64_t)blockIdx.x * kBlock; c0 < n; c0 += (uint64_t)gridDim.x * kBlock) {
+        lphq_run r{0, 0};
+        if (c0 + tid < n) r = src[c0 + tid];
+        uint32_t len = LPHQ_RUN_LENGTH(r);
+        const uint64_t first = LPHQ_RUN_FIRST(r);
+        if (first + len > n_out || (LPHQ_RUN_KIND(r) == LPHQ_RUN_EXPLICIT && r.code + len > arena_codes) || LPHQ_RUN_KIND(r) == 3u) {  // not a run of this batch: skipped
+            bad = bad || len != 0u;
+            len = 0;
+        }
+        // inclusive scan of the lengths over the workgroup: shuffles inside a wave, the waves' sums through LDS
+        uint32_t incl = len;
+        for (uint32_t o = 1; o < 64u; o <<= 1) {
+            const uint32_t up = __shfl(incl, (int)((tid & 63u) >= o ? (tid & 63u) - o : 0u), 64);
+            if ((tid & 63u) >= o) incl += up;
+        }
+        if ((tid & 63u) == 63u) sm_wsum[tid >> 6] = incl;
+        __syncthreads();
+        for (uint32_t w = 0; w < (tid >> 6); ++w) incl += sm_wsum[w];
+        sm_code[tid] = r.code;
+        sm_where[tid] = (r.where & ~(0x3FFFFFull << 40)) | ((uint64_t)len << 40);
+        sm_incl[tid] = incl;
+        __syncthreads();
+        const uint32_t total = sm_incl[kBlock - 1];
+        for (uint32_t e = tid; e < total; e += kBlock) {
+            uint32_t lo = 0, hi = kBlock - 1;  // first run whose inclusive sum exceeds e
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) / 2u;
+                if (sm_incl[mid] > e) hi = mid;
+                else lo = mid + 1u;
+            }
+            const uint64_t w = sm_where[lo], code = sm_code[lo];
+            const uint32_t i = e - (sm_incl[lo] - (uint32_t)((w >> 40) & 0x3FFFFFu)), kind = (uint32_t)(w >> 62);
+            const uint64_t v = kind == (uint32_t)LPHQ_RUN_EXPLICIT ? xsrc[code + i] : (kind == (uint32_t)LPHQ_RUN_UP ? code + i : code - i);
+            out[(w & 0xFFFFFFFFFFull) + i] = v;
+        }
+        __syncthreads();
+    }
+    if (bad && status) *status = 1ull;
+}
+
+// Sessions move a batch's runs over PCIe as ONE dense array: arena after arena, explicit-code indices rebased to the dense code array.  totals[0] = runs,
+// totals[1] = explicit codes, totals[2] = 1 if an arena had overflowed (the batch must be answered some other way).  Every workgroup works the 32 prefix sums
+// out for itself (a few hundred instructions; no second launch, no scan library).
+template <int BLOCK = kBlock>
+__global__ __launch_bounds__(kBlock) void k_compact_runs(const lphq_run* __restrict__ runs, uint64_t arena_runs, const uint64_t* __restrict__ codes, uint64_t arena_codes,
+                                                         const lphq_run_counts* __restrict__ counts, lphq_run* __restrict__ dense_runs, uint64_t cap_dense_runs,
+                                                         uint64_t* __restrict__ dense_codes, uint64_t cap_dense_codes, unsigned long long* __restrict__ totals) {
+    __shared__ uint64_t sm_rbase[LPHQ_RUN_ARENAS + 1], sm_xbase[LPHQ_RUN_ARENAS + 1];
+    __shared__ uint32_t sm_over;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) {
+        uint64_t r = 0, x = 0;
+        uint32_t over = 0;
+        for (uint32_t a = 0; a < (uint32_t)LPHQ_RUN_ARENAS; ++a) {
+            sm_rbase[a] = r;
+            sm_xbase[a] = x;
+            const uint64_t nr = counts[a].runs, nx = counts[a].codes;
+            over |= (nr > arena_runs || nx > arena_codes) ? 1u : 0u;
+            r += nr < arena_runs ? nr : arena_runs;
+            x += nx < arena_codes ? nx : arena_codes;
+        }
+        sm_rbase[LPHQ_RUN_ARENAS] = r;
+        sm_xbase[LPHQ_RUN_ARENAS] = x;
+        sm_over = over | (r > cap_dense_runs || x > cap_dense_codes ? 1u : 0u);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        totals[0] = sm_rbase[LPHQ_RUN_ARENAS];
+        totals[1] = sm_xbase[LPHQ_RUN_ARENAS];
+        totals[2] = sm_over;
+    }
+    if (sm_over) return;
+    const uint32_t a = blockIdx.y;
+    const uint64_t nr = sm_rbase[a + 1] - sm_rbase[a], nx = sm_xbase[a + 1] - sm_xbase[a];
+    const lphq_run* const src = runs + (uint64_t)a * arena_runs;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + tid; i < nr; i += (uint64_t)gridDim.x * kBlock) {
+        lphq_run r = src[i];
+        if (LPHQ_RUN_KIND(r) == (uint32_t)LPHQ_RUN_EXPLICIT) r.code += sm_xbase[a];
+        dense_runs[sm_rbase[a] + i] = r;
+    }
+    const uint64_t* const xsrc = codes + (uint64_t)a * arena_codes;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + tid; i < nx; i += (uint64_t)gridDim.x * kBlock) dense_codes[sm_xbase[a] + i] = xsrc[i];
 }
 
 }  // namespace lphq

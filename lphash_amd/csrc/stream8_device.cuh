@@ -18,8 +18,22 @@
 #include <gfx950/wave_scan.cuh>
 
 #include "kernels_device.cuh"
+#include "stream_sinks.h"
 
 namespace lphq {
+
+template <int SINK>
+struct S8SinkArgs {
+    typedef S8NoArgs type;
+};
+template <>
+struct S8SinkArgs<kSinkRuns> {
+    typedef S8RunsArgs type;
+};
+template <>
+struct S8SinkArgs<kSinkGather> {
+    typedef S8GatherArgs type;
+};
 
 constexpr int kS8Block = 128;                          // threads per workgroup; 8 * BLOCK m-mer positions per tile (256 threads / 2048 positions: measured equal at W = 8, 12,
                                                        // profiles/r03_stream8.txt (9); the template parameter stays for the emulator's coverage)
@@ -156,12 +170,13 @@ __device__ __forceinline__ void window_argmin8_raw(const uint64_t* __restrict__ 
 }
 
 // DIRECT: window minima from the raw hashes (narrow windows) instead of block prefix minima
-template <int KIND, bool K128, int P, int BLOCK = kS8Block, bool DIRECT = (P == 4), int W8 = -1>
+template <int KIND, bool K128, int P, int BLOCK = kS8Block, bool DIRECT = (P == 4), int W8 = -1, int SINK = kSinkCodes>
 // (second launch bound = waves per SIMD the register allocation must leave room for: 8 = 64 VGPRs for the wide-window variant, whose LDS now allows the
 // 16 workgroups per CU that takes; the narrow-window variant stays at its 71)
 __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(const uint8_t* __restrict__ img, const uint8_t* __restrict__ seq_al, uint64_t shift, uint64_t total,
                                                                   const uint64_t* __restrict__ seq_off, const uint64_t* __restrict__ out_off, uint32_t n_records,
-                                                                  uint64_t* __restrict__ out, uint64_t tile_base /* first tile of this launch */) {
+                                                                  uint64_t* __restrict__ out, uint64_t tile_base /* first tile of this launch */,
+                                                                  const typename S8SinkArgs<SINK>::type sink) {
     const lphq_image_header& H = *(const lphq_image_header*)img;
     constexpr int kS8Pos = 8 * BLOCK, NW = tile_words(kS8Pos);
     constexpr uint32_t kS8Row = s8_row<BLOCK>();
@@ -182,6 +197,8 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
     __shared__ uint32_t sm_rec[2], sm_count, sm_slot_count;  // (a counter of its own for the slot-by-slot path: lanes may still be reading sm_count)
     __shared__ uint64_t sm_roff[3];                   // seq_off[rlo], seq_off[rlo+1], out_off[rlo]
     __shared__ uint64_t sm_rtab[2 * kS8RecCap + 1];   // multi-record tiles: the tile's slice of seq_off / out_off
+    __shared__ uint32_t sm_wlead[BLOCK / 64];         // kSinkRuns: leaders per wave (a run's slot = the tile's reservation + the leaders of the waves before + its rank in its wave)
+    __shared__ uint64_t sm_tile_at;                   // kSinkRuns: first entry of the tile's reservation in its arena
     const uint32_t tid = threadIdx.x;
     const uint32_t k = H.k, m = H.m, W = H.W;
     const uint32_t TW = stream_tile_windows(W, kS8Pos);
@@ -378,6 +395,7 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
         const uint32_t wave_leaders = __shfl(incl, 63, 64);
         uint32_t b = 0;
         if (lane == 0 && wave_leaders) b = atomicAdd(&sm_count, wave_leaders);
+        if (SINK == kSinkRuns && lane == 0) sm_wlead[tid >> 6] = wave_leaders;
         uint32_t at = __shfl(b, 0, 64) + incl - mine;  // queue entry of the lane's first leader
         if (at < QCAP) {  // (a lane writes at most 8 entries from there: the queue has 8 entries of slack; a tile with more than QCAP leaders is redone below)
 #pragma unroll
@@ -391,6 +409,11 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
 
     // ---- E: one lookup per super-k-mer, dense lanes; a round = up to BLOCK leaders, one per lane ----
     const uint32_t nlead = sm_count;
+    if constexpr (SINK == kSinkRuns) {
+        // one reservation per tile, asked for here and used in phase F: the atomic's round trip hides behind the lookups.  (One counter per arena, not one
+        // for the batch: atomics on one address serialise at ~80 M/s on this chip, tools/gather_ceiling.hip.)
+        if (tid == 0) sm_tile_at = nlead ? atomicAdd((unsigned long long*)&sink.counts[(tile_base + blockIdx.x) & (LPHQ_RUN_ARENAS - 1u)].runs, (unsigned long long)nlead) : 0ull;
+    }
     auto lookup_queued = [&](uint32_t n) {  // the first n queue entries (n uniform)
         for (uint32_t x = tid; x < n; x += (uint32_t)BLOCK) {
             const uint32_t q = sm_queue[x];
@@ -462,8 +485,8 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
             modes |= valid ? mode : 0u;  // (what an invalid window read is whatever phases B-C left in that slot)
         }
     }
+    uint32_t coll = 0;                // which of the lane's windows sit under a colliding minimizer (worked out off the common path)
     if (__any((modes & 2u) != 0u)) {  // windows under a colliding minimizer: the fallback function of the k-mer (src/partitioned_mphf.cpp:312-316)
-        uint32_t coll = 0;            // which of the lane's windows (worked out here, off the common path)
 #pragma unroll
         for (uint32_t jw = 0; jw < 8; ++jw)
             if (code[jw] < 0xFFFEu && (uint32_t)(sm_hash[hslot8<BLOCK>(code[jw])] >> LPHQ_TAIL_MODE_SHIFT) == 2u) coll |= 1u << jw;
@@ -478,6 +501,7 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
                 hv[jw] = finish_hval<K128>(img, H, c, lo, hi, 0u);
             }
     }
+    if constexpr (SINK == kSinkCodes) {
     if (one_record) {
         // A lane holds 8 consecutive codes: stored from the registers, every 16-byte store of a wave would touch 64 different 64-byte segments (lane
         // stride 64 B) -- measured, that made phase F 45 % slower than the 4-per-lane kernel's (profiles/r03_stream8.txt).  The codes go through LDS
@@ -523,6 +547,172 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
 #pragma unroll
             for (uint32_t jw = 0; jw < 8; ++jw)
                 if (code[jw] != 0xFFFEu) __builtin_nontemporal_store(hv[jw], out + oidx[jw]);
+        }
+    }
+    } else {
+        // ---- the other two sinks: where each of the lane's windows sits in the code space (what the codes sink computes on its way to the stores) ----
+        uint64_t oidx[8];
+        if (one_record) {
+            const uint64_t first0 = sm_roff[2] + (t0 - shift - sm_roff[0]);  // window 0 of the tile (wraps harmlessly for windows before the record)
+#pragma unroll
+            for (uint32_t jw = 0; jw < 8; ++jw) oidx[jw] = first0 + a + jw;
+        } else {
+            const bool cached = rhi - rlo < (uint32_t)kS8RecCap;
+            uint32_t j = jrec;
+            uint64_t rs = cached ? sm_rtab[j] : seq_off[rlo + j], re = cached ? sm_rtab[j + 1] : seq_off[rlo + j + 1];
+#pragma unroll
+            for (uint32_t jw = 0; jw < 8; ++jw) {
+                oidx[jw] = 0;
+                if (code[jw] == 0xFFFEu) continue;
+                const uint64_t g = t0 + a + jw - shift;
+                rec_walk(sm_rtab, seq_off, rlo, cached, g, j, rs, re);
+                oidx[jw] = tile_record_out<kS8RecCap>(sm_rtab, out_off, rlo, rhi, j) + (g - rs);
+            }
+        }
+        if constexpr (SINK == kSinkRuns) {
+            // One lphq_run per leader: the windows from the leader up to the next leader, the next window that is no window (non-ACGT base, record end,
+            // tile end) or the end of the wave, whichever comes first -- inside it the minimizer stays where it is, so the code moves by -1 (mode 0:
+            // base + p, and p shrinks as the window slides) or +1 (mode 1) per window: the case-0 updates of include/partitioned_mphf.hpp:131-145.
+            const uint32_t lane = tid & 63u;
+            const uint32_t arena = (uint32_t)((tile_base + blockIdx.x) & (uint64_t)(LPHQ_RUN_ARENAS - 1u));
+            uint32_t vmask = 0;  // the lane's windows that exist: windows of a record without a non-ACGT base
+            if (plain) vmask = a < TW ? 0xFFu : 0u;
+            else {
+#pragma unroll
+                for (uint32_t jw = 0; jw < 8; ++jw) vmask |= code[jw] < 0xFFFEu ? 1u << jw : 0u;
+            }
+            // colliding windows (rare): their codes go to the arena's explicit-code array, the wave's in window order -- a colliding run's codes are
+            // consecutive there because its windows are consecutive windows of one wave
+            uint64_t xat = 0;  // arena-local index of the lane's first explicit code
+            if (__any(coll != 0u)) {
+                const uint32_t mine = (uint32_t)__popc(coll), incl = wave_inclusive_add(mine), tot = __shfl(incl, 63, 64);
+                unsigned long long b = 0;
+                if (lane == 0u) b = atomicAdd((unsigned long long*)&sink.counts[arena].codes, (unsigned long long)tot);
+                xat = __shfl(b, 0, 64) + incl - mine;
+                uint64_t x = xat;
+                uint64_t* const xdst = sink.codes + (uint64_t)arena * sink.arena_codes;
+#pragma unroll
+                for (uint32_t jw = 0; jw < 8; ++jw)
+                    if ((coll >> jw) & 1u) {
+                        if (x < sink.arena_codes) xdst[x] = hv[jw];
+                        ++x;
+                    }
+            }
+            // run lengths: a window ends the run to its left if it leads one itself or does not exist
+            const uint32_t bmask = (lmask | ~vmask) & 0xFFu;
+            const uint64_t ball = __ballot(bmask != 0u);
+            const uint64_t rest = lane == 63u ? 0ull : (ball >> (lane + 1u));  // lanes to the right that hold such a window
+            const uint32_t fb = bmask ? (uint32_t)__ffsll((long long)bmask) - 1u : 8u;
+            const uint32_t d = rest ? (uint32_t)__ffsll((long long)rest) - 1u : 0u;
+            const uint32_t fbn = __shfl(fb, (int)((lane + 1u + d) & 63u), 64);
+            const uint32_t ahead = rest ? 8u * d + fbn : 8u * (63u - lane);  // windows between this lane's last and the next break (the wave's end if there is none)
+            // slot of the lane's first run: the tile's reservation + the leaders of the waves before + the leaders of the lanes before (window order)
+            const uint32_t mine = (uint32_t)__popc(lmask), incl = wave_inclusive_add(mine);
+            uint64_t slot = sm_tile_at + incl - mine;
+#pragma unroll
+            for (uint32_t wv = 0; wv + 1u < (uint32_t)BLOCK / 64u; ++wv) slot += (tid >> 6) > wv ? sm_wlead[wv] : 0u;
+            lphq_run* const rdst = sink.runs + (uint64_t)arena * sink.arena_runs;
+            if (lmask) {
+#pragma unroll
+                for (uint32_t jw = 0; jw < 8; ++jw)
+                    if ((lmask >> jw) & 1u) {
+                        const uint32_t nb = jw == 7u ? 0u : (bmask >> (jw + 1u));
+                        const uint32_t len = nb ? (uint32_t)__ffsll((long long)nb) : (8u - jw) + ahead;
+                        const uint32_t mode = (uint32_t)(sm_hash[hslot8<BLOCK>(code[jw] & (uint32_t)(kS8Pos - 1))] >> LPHQ_TAIL_MODE_SHIFT);
+                        lphq_run r;
+                        r.code = mode == 2u ? xat + (uint64_t)__popc(coll & ((1u << jw) - 1u)) : hv[jw];
+                        r.where = (oidx[jw] & 0xFFFFFFFFFFull) | ((uint64_t)len << 40) | ((uint64_t)(mode == 2u ? (uint32_t)LPHQ_RUN_EXPLICIT : (mode ^ 1u)) << 62);
+                        if (slot < sink.arena_runs) rdst[slot] = r;
+                        ++slot;
+                    }
+            }
+        } else {
+            // table[code] per window; element size uniform over the launch.  A lane's eight elements are 8 << el contiguous bytes of the output:
+            // staged through LDS like the codes and copied out in 16-byte pieces when the tile lies in one record.
+            const uint32_t el = sink.elem_log2;
+            uint64_t pv[8], pk[8];  // the lane's eight elements, and the same as a little-endian byte stream of 8 << el bytes
+            {
+#pragma unroll
+                for (uint32_t jw = 0; jw < 8; ++jw) {
+                    const uint64_t c = hv[jw];
+                    const bool in = c < sink.n_slots;  // (LPHQ_INVALID and a non-member's wrapped code are not slots)
+                    const uint64_t i = in ? c : 0ull;
+                    uint64_t v;
+                    if (el == 0u) v = sink.table[i];
+                    else if (el == 1u) v = ((const uint16_t*)sink.table)[i];
+                    else if (el == 2u) v = ((const uint32_t*)sink.table)[i];
+                    else v = ((const uint64_t*)sink.table)[i];
+                    pv[jw] = in ? v : sink.missing;
+                }
+                if (el == 3u) {
+#pragma unroll
+                    for (uint32_t i = 0; i < 8; ++i) pk[i] = pv[i];
+                } else if (el == 2u) {
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; ++i) pk[i] = (pv[2 * i] & 0xFFFFFFFFull) | (pv[2 * i + 1] << 32);
+                } else if (el == 1u) {
+#pragma unroll
+                    for (uint32_t i = 0; i < 2; ++i)
+                        pk[i] = (pv[4 * i] & 0xFFFFull) | ((pv[4 * i + 1] & 0xFFFFull) << 16) | ((pv[4 * i + 2] & 0xFFFFull) << 32) | (pv[4 * i + 3] << 48);
+                } else {
+                    pk[0] = 0;
+#pragma unroll
+                    for (uint32_t i = 0; i < 8; ++i) pk[0] |= (pv[i] & 0xFFull) << (8u * i);
+                }
+            }
+            struct __attribute__((packed, aligned(1))) u64a1 { uint64_t v; };
+            struct __attribute__((packed, aligned(1))) u32a1 { uint32_t v; };
+            struct __attribute__((packed, aligned(1))) u16a1 { uint16_t v; };
+            auto store_elem = [&](uint64_t widx, uint64_t v) {  // one element, at window index widx of the output
+                uint8_t* const p = sink.out + (widx << el);
+                if (el == 0u) *p = (uint8_t)v;
+                else if (el == 1u) ((u16a1*)p)->v = (uint16_t)v;
+                else if (el == 2u) ((u32a1*)p)->v = (uint32_t)v;
+                else ((u64a1*)p)->v = v;
+            };
+            if (one_record) {
+                __syncthreads();  // (every lane has read the bases of its leaders)
+                uint64_t* const sm64 = sm_hash;
+                const uint32_t nq = 1u << el;  // 8-byte words per lane
+#pragma unroll
+                for (uint32_t i = 0; i < 8; ++i)
+                    if (i < nq) sm64[tid * nq + i] = pk[i];
+                __syncthreads();
+                // bytes [w_lo << el, w_hi << el) of the staged tile -> the output, 16 at a time
+                const uint32_t lo_b = w_lo << el, hi_b = w_hi << el;
+                uint8_t* const dstb = sink.out + ((oidx[0] - a) << el);  // byte address of window 0 of the tile
+                typedef uint64_t u64x2a1 __attribute__((vector_size(16), aligned(1)));
+                for (uint32_t c = tid; c < (((uint32_t)kS8Pos << el) >> 4); c += (uint32_t)BLOCK) {
+                    const uint32_t b0 = 16u * c;
+                    if (b0 >= hi_b || b0 + 16u <= lo_b) continue;
+                    const uint64_t v0 = sm64[2u * c], v1 = sm64[2u * c + 1u];
+                    if (b0 >= lo_b && b0 + 16u <= hi_b) {
+                        u64x2a1 v;
+                        v[0] = v0;
+                        v[1] = v1;
+                        __builtin_nontemporal_store(v, (u64x2a1*)(dstb + b0));
+                    } else {  // a piece at the edge of the record: element by element
+                        for (uint32_t e = 0; e < (16u >> el); ++e) {
+                            const uint32_t w = (b0 >> el) + e, bit = (e << el) * 8u;
+                            if (w >= w_lo && w < w_hi) store_elem(oidx[0] - a + w, (bit < 64u ? v0 >> bit : v1 >> (bit - 64u)));
+                        }
+                    }
+                }
+            } else {
+                bool all8 = oidx[7] == oidx[0] + 7u;
+#pragma unroll
+                for (uint32_t jw = 0; jw < 8; ++jw) all8 = all8 && code[jw] != 0xFFFEu;
+                if (all8) {  // eight windows of one record: 8 << el contiguous bytes
+                    uint8_t* const p = sink.out + (oidx[0] << el);
+#pragma unroll
+                    for (uint32_t i = 0; i < 8; ++i)
+                        if (i < (1u << el)) ((u64a1*)(p + 8u * i))->v = pk[i];
+                } else {
+#pragma unroll
+                    for (uint32_t jw = 0; jw < 8; ++jw)
+                        if (code[jw] != 0xFFFEu) store_elem(oidx[jw], pv[jw]);
+                }
+            }
         }
     }
 }
