@@ -61,10 +61,51 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 # VALU issue peak in lane-instructions/s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (one wave64 instruction = 4 cycles of a SIMD)
 VALU_PEAK_LANE_INSTR = 256 * 4 * 16 * 2.4e9
 RECORD_KMERS = 100_000  # k-mers per synthetic record
-# Line requests per second the fabric behind the L2s sustains for scattered 128-B gathers (measured: profiles/r01_microbench2.txt 55-68 G lines/s beyond L2;
-# the k=31 random kernel sits at 57.9 G lines/s, profiles/r04_pmc_c2_raw.txt x r04_c2_kernel_stats.txt): the ceiling of a kernel whose index is on chip
-FABRIC_LINE_PEAK = 57.9e9
+# Line requests per second the fabric behind the L2s sustains for scattered 128-B gathers, and the rate of the bare dependent chain of a lookup (pilot word ->
+# block line): re-measured on the box by tools/gather_ceiling.hip with the section sizes of the image at hand (`bench.py --probe-ceiling` ->
+# profiles/gather_ceiling.json) -- an INDEPENDENT ceiling.  The constant below is only the fallback when that file is absent or was taken with another version
+# of the probe: it is the k=31 random kernel's own best observed line rate (r04 counters x r04 kernel time), so a `frac_line_requests` against it is ~1 by
+# construction and the line says "inferred".
+FABRIC_LINE_PEAK_FALLBACK = 57.9e9
+RUN_ARENAS = 32  # LPHQ_RUN_ARENAS (include/lphq.h)
+# single-GPU rates (units/s) of the workloads as measured in round 5 (profiles/r05_final_bench_default.json): what the strong-scaling plan sizes its fixed
+# job with (a shard must be long against launch + barrier cost), never a reported number
+NOMINAL_RATE = {"C2": 38e9, "C3": 172e9, "C5": 38.8e9, "C4-random": 23.4e9, "C4-stream": 265e9}
+STRONG_STREAM_UNITS_LOG2 = 32  # the fixed job of a streaming workload: whole passes over the index records adding up to >= 2^32 windows
 STRONG_CHUNK_LOG2 = 24  # the fixed probe set of the strong-scaling line is drawn in chunks of 2^24 probes, chunk c from seed 5000 + c: any rank can draw any part of it
+
+
+def probe_sha():
+    """version of the ceiling probe: sha256 (16 hex digits) over tools/gather_ceiling.hip and the image layout whose section sizes it is run with"""
+    hsh = hashlib.sha256()
+    for pth in (os.path.join(ROOT, "tools", "gather_ceiling.hip"), os.path.join(ROOT, "lphash_amd", "csrc", "image_layout.h")):
+        hsh.update(open(pth, "rb").read())
+    return hsh.hexdigest()[:16]
+
+
+def image_sections(info, W, partitioned):
+    """(small, big) bytes of an image as the lookup chain sees it: the pilot side (codeword arrays + hashed-pilot dictionaries + header) and the line side
+    (fused / pair blocks + tail table), from lphq_get_info alone (image_layout.h: one 128-B block per 64 minimizers, 32 when W > 15; 64-B pair blocks of 32)."""
+    M, T = int(info.distinct_minimizers), int(info.minimizer_table_size)
+    if partitioned:
+        per = 32 if W > 15 else 64
+        blocks = ((M + per - 1) // per + 1) * 128
+    else:
+        blocks = ((M + 31) // 32 + 1) * 64
+    big = blocks + (T - M) * 8
+    return max(int(info.image_bytes) - big, 4096), big
+
+
+def ceiling_for(wl_key):
+    """The committed probe results for one index ('p|k31|m20|n100000000'), or None when profiles/gather_ceiling.json is absent / taken with another probe."""
+    try:
+        cj = json.load(open(os.path.join(ROOT, "profiles", "gather_ceiling.json")))
+    except (OSError, ValueError):
+        return None
+    if cj.get("probe_sha") != probe_sha():
+        return None
+    e = cj.get("entries", {}).get(wl_key)
+    return dict(e, source="profiles/gather_ceiling.json (tools/gather_ceiling.hip, bench.py --probe-ceiling)") if e else None
 
 
 def sha256_file(path):
@@ -96,8 +137,22 @@ def strong_plan(wl, world, strong_total_log2):
     if wl["mode"] == "random":
         total = 1 << strong_total_log2
         return {"unit": "probes", "total": total, "shards": [list(shard_range(total, r, world)) for r in range(world)]}
-    lens = [wl["rec_len"]] * wl["n_records"]
-    return {"unit": "records", "total": wl["n_records"], "shards": [list(shard_records(lens, r, world)) for r in range(world)]}
+    # streaming: the fixed job is `passes` whole passes over the index records laid end to end (one index pass is 0.5 ms of one GPU at k = 31: cut eight
+    # ways that would be launch overhead, not scaling -- VERDICT r05 item 4); a shard is a contiguous range of that list of passes x records
+    wpr = wl["rec_len"] - wl["k"] + 1
+    passes = max(1, -(-(1 << STRONG_STREAM_UNITS_LOG2) // (wl["n_records"] * wpr)))
+    lens = [wl["rec_len"]] * (wl["n_records"] * passes)
+    return {"unit": "records", "passes": passes, "total": wl["n_records"] * passes, "shards": [list(shard_records(lens, r, world)) for r in range(world)]}
+
+
+def strong_shard_ms(wl, sp, rank):
+    """What a rank's shard of the strong-scaling job costs one GPU, by the round-5 single-GPU rates (NOMINAL_RATE): the plan's own estimate, so that a
+    test can hold it against launch + barrier cost (profiles/r06_launch_barrier_cost.json)"""
+    lo, hi = sp["shards"][rank]
+    units = (hi - lo) if sp["unit"] == "probes" else (hi - lo) * (wl["rec_len"] - wl["k"] + 1)
+    name = config_name(wl)
+    rate = NOMINAL_RATE.get(name + ("-random" if name == "C4" and wl["mode"] == "random" else "-stream" if name == "C4" else ""), NOMINAL_RATE["C2"])
+    return units / rate * 1e3
 
 
 def log(*a):
@@ -108,12 +163,15 @@ def log(*a):
 # the plan: pure functions of the arguments (no GPU, no torch) -- every rank must resolve the same one
 # ----------------------------------------------------------------------------------------------------------
 def make_workload(name, mode, kind, k, m, kmers, batch_log2, steps, warmup, cpu_sample_log2, gpu_build, nonmember_frac=0.0,
-                  shuffle_records=False, bbhash_gamma=1.0, headline=False, index_set="uniform"):
+                  shuffle_records=False, bbhash_gamma=1.0, headline=False, index_set="uniform", sink="codes"):
     n_records = max(1, kmers // RECORD_KMERS)
     return {"name": name, "mode": mode, "kind": kind, "k": k, "m": m, "kmers": n_records * RECORD_KMERS, "n_records": n_records,
             "rec_len": RECORD_KMERS + k - 1, "kmer_bits": 64 if k <= 31 else 128, "batch_log2": batch_log2, "steps": steps, "warmup": warmup,
             "cpu_sample_log2": cpu_sample_log2, "gpu_build": bool(gpu_build), "nonmember_frac": nonmember_frac,
-            "shuffle_records": bool(shuffle_records), "bbhash_gamma": bbhash_gamma, "headline": headline, "index_set": index_set}
+            "shuffle_records": bool(shuffle_records), "bbhash_gamma": bbhash_gamma, "headline": headline, "index_set": index_set,
+            # what the streaming pass leaves behind: "codes" (8 B per k-mer, the BASELINE metric), "runs" (lphq_query_records_runs: 16 B per super-k-mer) or
+            # "gather<E>" (lphq_query_records_gather: table[code], E-byte elements; the codes never reach memory)
+            "sink": sink}
 
 
 def config_name(wl):
@@ -152,9 +210,13 @@ def secondary_workloads(args, head):
     st, wu = args.steps, args.warmup
     c4 = args.secondary_c4_kmers
     return [make_workload("C3", "stream", "p", 31, 20, 100_000_000, 0, st, wu, 22, args.gpu_build),
+            # the same pass with the result the reference's streaming branch computes before it expands it: runs; and fused with its consumer
+            make_workload("C3-runs", "stream", "p", 31, 20, 100_000_000, 0, st, wu, 20, args.gpu_build, sink="runs"),
             make_workload("C5", "random", "u", 31, 20, 100_000_000, 28, st, wu, 22, args.gpu_build),
             make_workload("C4-random", "random", "p", 63, 20, c4, 28, st, wu, 21, True),
             make_workload("C4-stream", "stream", "p", 63, 20, c4, 0, st, wu, 21, True),
+            make_workload("C4-stream-runs", "stream", "p", 63, 20, c4, 0, st, wu, 19, True, sink="runs"),
+            make_workload("C4-stream-gather1", "stream", "p", 63, 20, c4, 0, st, wu, 19, True, sink="gather1"),
             # BASELINE.md section 3's secondary inputs: half the probes uniformly random non-members; the index records in shuffled order
             make_workload("C2-nonmember50", "random", "p", 31, 20, 100_000_000, 28, st, wu, 22, args.gpu_build, nonmember_frac=0.5),
             make_workload("C3-shuffled", "stream", "p", 31, 20, 100_000_000, 0, st, wu, 22, args.gpu_build, shuffle_records=True)]
@@ -165,7 +227,9 @@ def plan_of(args):
     wls = [head] + secondary_workloads(args, head)
     plan = {"gpus": args.gpus, "cache_dir": args.cache_dir, "workloads": wls, "index_paths": [index_path(args.cache_dir, w) for w in wls]}
     if args.gpus > 1 or args.dist_single or args.strong:
-        plan["strong"] = [strong_plan(w, args.gpus, strong_total_log2_of(args, w)) for w in wls]
+        plan["strong"] = [dict(strong_plan(w, args.gpus, strong_total_log2_of(args, w)), name=w["name"]) for w in wls if w["sink"] == "codes"]
+        for sp_, w in zip(plan["strong"], [w for w in wls if w["sink"] == "codes"]):
+            sp_["planned_shard_ms"] = [strong_shard_ms(w, sp_, r_) for r_ in range(args.gpus)]
     return plan
 
 
@@ -453,18 +517,26 @@ def strong_pass(job, wl, h, recs, d_seq, o, stream, rec_order):
             if mine:
                 h.query_packed(d_k.data_ptr(), mine, d_o.data_ptr(), stream)
     else:
-        n_mine = hi - lo
+        # records lo .. hi - 1 of the list "passes x all index records": whole and partial passes, one launch each (a batch list)
         wpr = rec_len - k + 1
+        n_mine = hi - lo
         mine = n_mine * wpr
-        total_units = n_records * wpr
-        seq_off = torch.arange(0, n_mine + 1, dtype=torch.int64, device=dev) * rec_len
-        out_off = torch.arange(0, n_mine + 1, dtype=torch.int64, device=dev) * wpr
+        total_units = sp["total"] * wpr
+        pieces = []  # (first record, records, first window of the piece in this rank's output)
+        at, r = 0, lo
+        while r < hi:
+            a_ = r % n_records
+            n_ = min(hi - r, n_records - a_)
+            pieces.append((a_, n_, at))
+            at += n_ * wpr
+            r += n_
+        seq_off = torch.arange(0, n_records + 1, dtype=torch.int64, device=dev) * rec_len
+        out_off = torch.arange(0, n_records + 1, dtype=torch.int64, device=dev) * wpr
         d_o = torch.empty(max(mine, 1), dtype=torch.int64, device=dev)
-        base = d_seq.data_ptr() + lo * rec_len
 
         def step():
-            if n_mine:
-                h.query_records(base, n_mine * rec_len, seq_off.data_ptr(), n_mine, d_o.data_ptr(), out_off.data_ptr(), True, stream)
+            for a_, n_, at_ in pieces:
+                h.query_records(d_seq.data_ptr() + a_ * rec_len, n_ * rec_len, seq_off.data_ptr(), n_, d_o.data_ptr() + at_ * 8, out_off.data_ptr(), True, stream)
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -489,6 +561,24 @@ def strong_pass(job, wl, h, recs, d_seq, o, stream, rec_order):
         every = [torch.zeros_like(me) for _ in range(world)]
         dist.all_gather(every, me)
         per_rank = [float(e.item()) for e in every]
+    # what a step costs besides its kernel on this box: the same bracket (barrier, synchronize, events) around ONE minimal launch of the same entry point
+    # (64 probes / one record) -- the yardstick the plan's shard sizes are held against (tests/test_dist_cpu.py, profiles/r06_launch_barrier_cost.json)
+    if mode == "random":
+        tiny = (lambda: h.query_packed(d_k.data_ptr(), min(mine, 64), d_o.data_ptr(), stream)) if mine else (lambda: None)
+    else:
+        tiny = (lambda: h.query_records(d_seq.data_ptr(), rec_len, seq_off.data_ptr(), 1, d_o.data_ptr(), out_off.data_ptr(), True, stream)) if mine else (lambda: None)
+    tiny()
+    torch.cuda.synchronize()
+    job.barrier()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        tiny()
+    torch.cuda.synchronize()
+    job.barrier()
+    empty_step_ms = (time.perf_counter() - t1) / steps * 1e3
+    for _ in range(1):  # (the tiny launch overwrote the head of d_o: the step once more before the checks)
+        step()
+    torch.cuda.synchronize()
     # parity: this rank's shard against the oracle (a sample), all shards together against the closed forms
     ok = True
     if o is not None and mine:
@@ -496,8 +586,9 @@ def strong_pass(job, wl, h, recs, d_seq, o, stream, rec_order):
         if mode == "random":
             exp = o.query_packed(d_k[:S * wpk].cpu().numpy().view(np.uint64))
         else:
-            nr = max(1, min(hi - lo, S // (rec_len - k + 1)))
-            exp = np.concatenate([o(recs[(lo + i) if rec_order is None else int(rec_order[lo + i])], True) for i in range(nr)])
+            nr = max(1, min(pieces[0][1], S // (rec_len - k + 1)))
+            first = pieces[0][0]
+            exp = np.concatenate([o(recs[(first + i) if rec_order is None else int(rec_order[first + i])], True) for i in range(nr)])
             S = len(exp)
         ok = bool(np.array_equal(d_o[:S].cpu().numpy().view(np.uint64), exp))
     sums_ok = None
@@ -512,21 +603,25 @@ def strong_pass(job, wl, h, recs, d_seq, o, stream, rec_order):
                 t += torch.stack([c_.sum(), (c_ * c_).sum()])
             if dist is not None:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)  # (wrapping int64 addition)
-            n = total_units
-            want = [(n * (n - 1) // 2) % (1 << 64), ((n - 1) * n * (2 * n - 1) // 6) % (1 << 64)]
+            n, P = nk, sp["passes"]  # every pass covers [0, n) once
+            want = [(P * (n * (n - 1) // 2)) % (1 << 64), (P * ((n - 1) * n * (2 * n - 1) // 6)) % (1 << 64)]
             got = [int(x) % (1 << 64) for x in t.tolist()]
             sums_ok = got == want
             ok = ok and sums_ok
     if not all_ranks_ok(dist, torch, dev, ok):
         job.fail(3, f"{wl['name']} strong-scaling pass: GPU results differ from the oracle, leave [0, n) or do not cover it (this rank: {ok}, checksums: {sums_ok})")
-    log(f"{tag} shard [{lo}, {hi}) of {sp['total']} {sp['unit']}: {mine} units, kernel {kernel_ms:.3f} ms; all ranks == oracle on their samples"
+    log(f"{tag} shard [{lo}, {hi}) of {sp['total']} {sp['unit']}" + (f" ({sp['passes']} passes over the index records)" if "passes" in sp else "")
+        + f": {mine} units, {kernel_ms:.3f} ms per step on this rank (all ranks: {', '.join(f'{x:.3f}' for x in per_rank)}; max {max(per_rank):.3f}); all ranks == oracle on their samples"
         + ("" if sums_ok is None else "; codes of all shards = a permutation of [0, n) by sum and sum of squares"))
     del d_o
     if rank != 0:
         return None
     return {"scaling": "strong", "value": total_units * steps / elapsed, "unit": "k-mer lookups/s", "n_gpus": world, "total_units_per_step": total_units,
             "split": f"{sp['unit']} by " + ("shard_range" if mode == "random" else "shard_records") + " (lphash_amd/dist.py), contiguous, no overlap",
-            "shards": sp["shards"], "ms_per_step": elapsed / steps * 1e3, "kernel_ms_per_rank": per_rank, "kernel_ms_max": max(per_rank),
+            "shards": sp["shards"], "passes": sp.get("passes"), "ms_per_step": elapsed / steps * 1e3, "kernel_ms_per_rank": per_rank, "kernel_ms_max": max(per_rank),
+            "kernel_ms_min": min(per_rank), "empty_step_ms": empty_step_ms, "planned_shard_ms": [strong_shard_ms(wl, sp, r_) for r_ in range(world)],
+            "probes": ("members only (the fixed probe set of the strong pass is drawn from the index; the weak line above carries this workload's non-members)"
+                       if mode == "random" and wl["nonmember_frac"] > 0 else None),
             "parity_vs_oracle": True if o is not None else None, "all_shards_cover_0_n": sums_ok,
             "note": "fixed job: the same total work at every N (the weak line above fixes the work PER GPU); at N = 1 this is one GPU doing all of it"}
 
@@ -585,6 +680,16 @@ def run_workload(job, wl):
         from lphash_amd.dist import broadcast_image
 
         dist.barrier()  # the index file exists and rank 0 is attached
+        if rank == 0 and not getattr(job, "peer_logged", False):
+            # so that the first record of a real N-GPU run explains itself: which pairs of the node's GPUs can reach each other directly, and that the
+            # collective spans all ranks
+            job.peer_logged = True
+            nd = torch.cuda.device_count()
+            pairs = {f"{i}->{j}": bool(torch.cuda.can_device_access_peer(i, j)) for i in range(nd) for j in range(nd) if i != j}
+            job.peer_access = {"devices_visible": nd, "pairs_with_peer_access": sum(pairs.values()), "pairs": len(pairs), "all_pairs": all(pairs.values()) if pairs else None,
+                               "without_peer_access": [p_ for p_, ok_ in pairs.items() if not ok_][:16]}
+            log(f"{tag} peer access (hipDeviceCanAccessPeer) over {nd} visible devices: {job.peer_access}; collective ranks {dist.get_world_size()} == world {world}: "
+                f"{dist.get_world_size() == world}; backend {dist.get_backend()}")
         torch.cuda.synchronize()
         t0 = time.time()
         # RCCL over xGMI: the only collective of the data path.  No fallback: a failure ends this rank (and, through the launcher, the job)
@@ -641,9 +746,31 @@ def run_workload(job, wl):
         out_off = torch.arange(0, n_records + 1, dtype=torch.int64, device=dev) * (rec_len - k + 1)
         units = n_records * (rec_len - k + 1)
         d_out = torch.empty(units, dtype=torch.int64, device=dev)
+        sink = wl["sink"]
+        if sink == "runs":
+            # arenas for ~2 / (W + 1) runs per window + the cuts at tile and wave ends, 15 % of slack (include/lphq.h); explicit codes: an eighth of that
+            per_arena = int(units * (2.0 / (W + 1) + 1.0 / 400.0) * 1.15 / RUN_ARENAS) + 4096
+            xper_arena = per_arena // 8 + 4096
+            d_runs = torch.empty(RUN_ARENAS * per_arena * 2, dtype=torch.int64, device=dev)
+            d_xc = torch.empty(RUN_ARENAS * xper_arena, dtype=torch.int64, device=dev)
+            d_counts = torch.empty(RUN_ARENAS * 16, dtype=torch.int64, device=dev)
 
-        def step():
-            h.query_records(d_seq.data_ptr(), total_bases, seq_off.data_ptr(), n_records, d_out.data_ptr(), out_off.data_ptr(), True, stream)
+            def step():
+                h.query_records_runs(d_seq.data_ptr(), total_bases, seq_off.data_ptr(), n_records, out_off.data_ptr(), d_runs.data_ptr(), RUN_ARENAS * per_arena,
+                                     d_xc.data_ptr(), RUN_ARENAS * xper_arena, d_counts.data_ptr(), stream)
+        elif sink.startswith("gather"):
+            elem = int(sink[6:])
+            tdt = {1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[elem]
+            # the per-k-mer data a caller indexes by the codes: a fixed function of the slot (checkable anywhere without a second copy)
+            d_table = ((torch.arange(nk, dtype=torch.int64, device=dev) * 2654435761) >> 9).bitwise_and((1 << (8 * elem - 1)) - 1 if elem < 8 else (1 << 62) - 1).to(tdt)
+            d_pay = torch.empty(units, dtype=tdt, device=dev)
+
+            def step():
+                h.query_records_gather(d_seq.data_ptr(), total_bases, seq_off.data_ptr(), n_records, out_off.data_ptr(), d_table.data_ptr(), elem, d_pay.data_ptr(), 0, stream)
+        else:
+
+            def step():
+                h.query_records(d_seq.data_ptr(), total_bases, seq_off.data_ptr(), n_records, d_out.data_ptr(), out_off.data_ptr(), True, stream)
 
     for _ in range(warmup):
         step()
@@ -670,6 +797,27 @@ def run_workload(job, wl):
         dist.all_gather(every, mine)  # a straggler shows here, not only in the max
         kernel_ms_per_rank = [float(e.item()) for e in every]
 
+    # ---- the other sinks: what the timed launches left behind, turned into codes for the parity legs below (outside the timed region) ----
+    sink_ok, sink_info = True, None
+    if mode == "stream" and wl["sink"] == "runs":
+        cnt = d_counts.cpu().numpy().reshape(RUN_ARENAS, 16)
+        n_runs, n_xc = int(cnt[:, 0].sum()), int(cnt[:, 1].sum())
+        d_st = torch.zeros(1, dtype=torch.int64, device=dev)
+        h.expand_runs(d_runs.data_ptr(), RUN_ARENAS * per_arena, d_xc.data_ptr(), RUN_ARENAS * xper_arena, d_counts.data_ptr(), d_out.data_ptr(), units, d_st.data_ptr(), stream)
+        torch.cuda.synchronize()
+        sink_ok = int(d_st.item()) == 0 and int(cnt[:, 0].max()) <= per_arena and int(cnt[:, 1].max()) <= xper_arena
+        sink_info = {"runs_per_step": n_runs, "windows_per_run": units / max(n_runs, 1), "explicit_codes_per_step": n_xc, "arena_fill_max": float(cnt[:, 0].max()) / per_arena,
+                     "run_bytes_per_window": 16.0 * n_runs / units + 8.0 * n_xc / units,
+                     "checked": "lphq_expand_runs of the timed launch's runs == the oracle on the sample" + ("; all windows together cover [0, n)" if not wl["shuffle_records"] else "")}
+        del d_st
+    elif mode == "stream" and wl["sink"].startswith("gather"):
+        h.query_records(d_seq.data_ptr(), total_bases, seq_off.data_ptr(), n_records, d_out.data_ptr(), out_off.data_ptr(), True, stream)
+        torch.cuda.synchronize()
+        sink_ok = True
+        for a_ in range(0, units, 1 << 28):  # payload of the timed launch == table[codes of the plain streaming pass], every window
+            sink_ok = sink_ok and bool(torch.equal(d_pay[a_:a_ + (1 << 28)], d_table[d_out[a_:a_ + (1 << 28)]]))
+        sink_info = {"elem_bytes": elem, "checked": "payload of the timed launch == table[codes] for every window; codes == the oracle on the sample"}
+
     # ---- parity of what was just measured, on EVERY rank (oracle = checker), + the CPU baseline on rank 0 ----
     cpu = cpu_all = cpu_b1 = cli_b1 = binding_b1 = None
     parity = None
@@ -694,7 +842,9 @@ def run_workload(job, wl):
             S = len(exp)
             got = d_out[:S].cpu().numpy().view(np.uint64)
             what = f"first {nrec_s} records of the batch, oracle streaming branch, single thread"
-        parity = bool(np.array_equal(got, exp))
+        parity = bool(np.array_equal(got, exp)) and sink_ok
+        if mode == "stream" and wl["sink"] != "codes" and not bool(int(d_out.min()) == 0 and int(d_out.max()) == nk - 1):  # the index records: every code is a slot
+            parity = False
         if mode == "random" and wl["nonmember_frac"] == 0.0:
             parity = parity and bool(int(d_out.max()) < nk) and bool(int(d_out.min()) >= 0)  # positive probes: every code of the batch is a valid slot
         log(f"{tag} cpu oracle: {S / cpu_s / 1e6:.2f} M lookups/s on {S} units; GPU == oracle on the sample of this rank's timed batch: {parity}")
@@ -723,7 +873,7 @@ def run_workload(job, wl):
         job.fail(3, f"{wl['name']}: GPU results differ from the oracle on at least one rank (this rank: {parity}; index digest pinned: {digest_ok})")
 
     strong = None
-    if dist is not None or args.strong:
+    if (dist is not None or args.strong) and wl["sink"] == "codes":  # (the sinks share the codes workload's strong line: same lookups)
         strong = strong_pass(job, wl, h, recs, d_seq, o, stream, rec_order)
 
     if rank == 0 and o is not None and wl["headline"] and args.b1_records > 0 and not competitor:
@@ -778,8 +928,11 @@ def run_workload(job, wl):
         exb = os.path.join(ROOT, "examples", f"query_example{kmer_bits}")
         if os.path.exists(exb):
             binding_b1 = {"note": "examples/query_example (gpu_mphf<> binding, compiled with g++ against include/lphq.h) on the same .fa.gz; batched = "
-                                  "submit / collect over lphq_session_*, all codes returned to the host; per_record = the reference's literal loop"}
-            for label, extra, reps in (("batched", [], 3), ("per_record", ["--per-record"], 1)):
+                                  "submit / collect over lphq_session_*, all codes returned to the host (streaming batches cross PCIe as runs and are expanded by "
+                                  "host threads); batched_runs = collect_runs, nothing expanded; per_record = the reference's literal loop"}
+            # batched: codes expanded on the host for every k-mer (the reference's vector<uint64_t>); batched_runs: the streaming pass collected as runs
+            # (gpu_mphf::collect_runs -- what the reference computes before it expands it; the random pass is the batched one's)
+            for label, extra, reps in (("batched", [], 3), ("batched_runs", ["--runs"], 3), ("per_record", ["--per-record"], 1)):
                 runs = csv_runs([exb, "query-p" if kind == L.PARTITIONED else "query-u", "-i", path, "-q", fa] + extra, reps)
                 if runs:
                     binding_b1[label + "_streaming_ns_per_kmer"] = float(np.median([a for a, _ in runs]))
@@ -840,6 +993,13 @@ def run_workload(job, wl):
             bpl = (8 if k <= 31 else 16) + 8 + chain
         else:
             bpl, chain, mix = algorithmic_bytes_per_lookup(h, mode, k, W, kind == L.PARTITIONED)
+        sk = (W + 1) / 2.0  # windows per super-k-mer on random sequence
+        if mode == "stream" and wl["sink"] == "runs":
+            # 1 B of base in, one lookup chain and ONE 16-byte run out per super-k-mer (k = 63 / m = 20: 1 + 74.7 / 22.5 + 16 / 22.5 = 5.0 B per k-mer)
+            bpl = 1 + (chain + 16) / sk
+        elif mode == "stream" and wl["sink"].startswith("gather"):
+            # 1 B of base in, the chain per super-k-mer, the k-mer's element read once (consecutive codes: contiguous) and written once
+            bpl = 1 + chain / sk + 2 * elem
         cfg_name = config_name(wl)
         if job.hbm is None and not args.no_hbm_probe:
             job.hbm = hbm_ceiling_gbs(torch, dev)
@@ -865,7 +1025,9 @@ def run_workload(job, wl):
                 + ((f"2^{wl['batch_log2']} random positive packed k-mer lookups per GPU per step" if wl["nonmember_frac"] == 0.0 else
                     f"2^{wl['batch_log2']} random packed k-mer lookups per GPU per step, {wl['nonmember_frac']:.0%} of them uniformly random non-members")
                    if mode == "random"
-                   else "all windows of the index records per step, streaming kernel" + (", records in shuffled order" if rec_order is not None else "")),
+                   else "all windows of the index records per step, streaming kernel" + (", records in shuffled order" if rec_order is not None else "")
+                   + ("" if wl["sink"] == "codes" else ", result as runs of affine codes (lphq_query_records_runs: one 16-byte entry per super-k-mer)" if wl["sink"] == "runs"
+                      else f", fused with the payload gather (lphq_query_records_gather: table[code], {wl['sink'][6:]}-byte elements, {nk} of them)")),
                 "k": k, "m": m, "kmers": nk, "units_per_step_per_gpu": units, "kmer_bits": kmer_bits,
                 "index_image_bytes": int(h.info.image_bytes), "type_mix": mix,
             },
@@ -879,10 +1041,12 @@ def run_workload(job, wl):
             "collective_backend": (dist.get_backend() if dist is not None else None),
             "replicas_agree": replicas_agree,
         }
+        if getattr(job, "peer_access", None) is not None:
+            out["peer_access"] = job.peer_access
         traffic = valu = traffic_stale = traffic_src = l2_miss = rocprof_us = None
         try:  # HBM bytes and VALU instructions per unit from the committed PMC passes of this exact workload (never measured inside this run)
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            key = f"{mode}|{wl['kind']}|k{k}|m{m}|n{nk}|b{wl['batch_log2'] if mode == 'random' else 0}"
+            key = f"{mode}|{wl['kind']}|k{k}|m{m}|n{nk}|b{wl['batch_log2'] if mode == 'random' else 0}" + ("" if wl["sink"] == "codes" else "|" + wl["sink"])
             variant = wl["nonmember_frac"] != 0.0 or rec_order is not None or wl["index_set"] != "uniform"
             if key in tj and not variant:  # (counter passes exist for the default kernels on the primary workloads only)
                 # the passes are evidence for the kernels they were taken on: an entry whose device sources are not the ones in this tree is reported
@@ -905,11 +1069,17 @@ def run_workload(job, wl):
         # per base when streaming) and the 8-byte code -- as if the index cost nothing.  An image below the 256-MiB Infinity Cache does stay on chip
         # between steps, so for it the index part of `achieved` is fabric traffic, not HBM traffic, and frac_compulsory is the honest HBM fraction.
         compulsory = ((8 if k <= 31 else 16) + 8) if mode == "random" else (1.0 * (units + n_records * (k - 1)) / units + 8)
+        if mode == "stream" and wl["sink"] == "runs":
+            compulsory += 16 / sk - 8
+        elif mode == "stream" and wl["sink"].startswith("gather"):
+            compulsory += 2 * elem - 8
         image_bytes = int(h.info.image_bytes)
         if mode == "random":
             kernel_name = "k_query_packed"
         else:
             kernel_name = "k_query_tiles_stream8" if W >= 8 else "k_query_tiles_stream"  # (kStream8MinW, lphash_amd/csrc/stream8_device.cuh)
+            if wl["sink"] != "codes":
+                kernel_name = "k_query_tiles_stream8<.., kSinkRuns>" if wl["sink"] == "runs" else "k_query_tiles_stream8<.., kSinkGather>"
         # What binds the kernel, from the evidence in this line -- the HBM `frac` stays the figure north_star asks for:
         #   valu_issue            the committed SQ_INSTS_VALU pass x this run's rate is >= 0.88 of the VALU issue peak at 2.4 GHz (boxes of this pool clock
         #                         the VALU-bound kernels +-4 %: C4 random measures 0.89-0.97, C4 streaming 0.80-0.85)
@@ -917,13 +1087,18 @@ def run_workload(job, wl):
         #                         rate against the line-request rate the fabric sustains for scattered gathers (FABRIC_LINE_PEAK)
         #   hbm                   otherwise (the image exceeds the Infinity Cache, or no counters for this tree / variant)
         residency = "infinity_cache" if image_bytes < (256 << 20) else "hbm"
+        ceil_key = f"{wl['kind']}|k{k}|m{m}|n{nk}" + ("" if wl["index_set"] == "uniform" else "|" + wl["index_set"])
+        ceiling = None if competitor else ceiling_for(ceil_key)
+        FABRIC_LINE_PEAK = ceiling["lines_per_s"] if ceiling else FABRIC_LINE_PEAK_FALLBACK
+        peak_note = ("measured by tools/gather_ceiling.hip on a table of this image's line side" if ceiling else
+                     "INFERRED: no probe result for this index (profiles/gather_ceiling.json) -- the fallback is the k=31 random kernel's own best observed rate")
         valu_frac = (valu[0] * units / kernel_s / VALU_PEAK_LANE_INSTR) if (valu is not None and valu[0]) else None
         line_rate = (l2_miss * units / kernel_s) if l2_miss else None
         if valu_frac is not None and valu_frac >= 0.88:
             bound, why = "valu_issue", f"roofline_valu.frac {valu_frac:.2f} >= 0.88" + ("" if not line_rate else f"; {line_rate / 1e9:.1f} G line requests/s of {FABRIC_LINE_PEAK / 1e9:.1f}")
         elif residency == "infinity_cache":
             bound = "fabric_line_requests"
-            why = (f"index on chip; {l2_miss} L2 misses per unit x rate = {line_rate / 1e9:.1f} G lines/s of {FABRIC_LINE_PEAK / 1e9:.1f} G lines/s" if line_rate else
+            why = (f"index on chip; {l2_miss} L2 misses per unit x rate = {line_rate / 1e9:.1f} G lines/s of {FABRIC_LINE_PEAK / 1e9:.1f} G lines/s ({'probe' if ceiling else 'inferred ceiling'})" if line_rate else
                    "index on chip (no counter pass for this tree / variant: the line rate is not stated)")
         else:
             bound, why = "hbm", ("index beyond the Infinity Cache: its lines come from HBM" + ("" if valu_frac is None else f"; roofline_valu.frac {valu_frac:.2f}")
@@ -946,7 +1121,14 @@ def run_workload(job, wl):
                                                     f"the {image_bytes / 1e6:.1f}-MB image exceeds the 256-MiB Infinity Cache: index lines come from HBM")}
         if line_rate:
             out["roofline"].update({"l2_misses_per_unit": l2_miss, "line_requests_per_s": line_rate, "line_requests_peak": FABRIC_LINE_PEAK,
-                                    "frac_line_requests": line_rate / FABRIC_LINE_PEAK})
+                                    "line_requests_peak_source": peak_note, "frac_line_requests": line_rate / FABRIC_LINE_PEAK})
+        if ceiling and mode == "random":
+            # the kernel against the bare dependent chain of its lookups (pilot word -> block line, NO hashing, no other work) measured by the probe on tables
+            # of this image's section sizes: how much of what the memory system allows for this access shape the whole lookup reaches
+            out["roofline"].update({"gather_chain_items_per_s": ceiling["chain_items_per_s"], "frac_of_gather_chain": units / kernel_s / ceiling["chain_items_per_s"],
+                                    "gather_chain_source": ceiling["source"], "gather_chain_tables": {"small_bytes": ceiling["small_bytes"], "big_bytes": ceiling["big_bytes"]}})
+        if sink_info is not None:
+            out["sink"] = dict(sink_info, kind=wl["sink"])
         if traffic_stale is not None:
             out["roofline"]["traffic_stale"] = traffic_stale
         if valu is not None and valu[0]:
@@ -1001,10 +1183,68 @@ def run_workload(job, wl):
     return out
 
 
+def probe_ceiling(args, torch, np, L, result_out):
+    """bench.py --probe-ceiling: the independent ceilings of the random-lookup kernels on this box (see FABRIC_LINE_PEAK_FALLBACK above)."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "tools", "gather_ceiling")
+    if not os.path.exists(exe):
+        log(f"[bench] {exe} is missing: python -c 'import __graft_entry__ as g; g.build()' builds it")
+        return 2
+    os.makedirs(args.cache_dir, exist_ok=True)
+    from lphash_amd.synth import synthetic_records
+
+    entries, sizes = {}, []
+    for name, kind, k, kmers in (("C2", "p", 31, 100_000_000), ("C5", "u", 31, 100_000_000), ("C4", "p", 63, args.secondary_c4_kmers)):
+        wl = make_workload(name, "random", kind, k, 20, kmers, 28, 1, 0, 20, True)
+        path = index_path(args.cache_dir, wl)
+        if not os.path.exists(path):
+            flat, _ = synthetic_records(seed=1, n_records=wl["n_records"], length=wl["rec_len"], views=False)
+            L.build(RecordSet(wl["n_records"], wl["rec_len"], flat=flat), k, 20, path + ".tmp", kind=L.PARTITIONED if kind == "p" else L.UNPARTITIONED, kmer_bits=wl["kmer_bits"],
+                    threads=0, device=0)
+            os.replace(path + ".tmp", path)
+            del flat
+        h = (L.Mphf if kind == "p" else L.MphfAlt).load(path, kmer_bits=wl["kmer_bits"])
+        small, big = image_sections(h.info, k - 20 + 1, kind == "p")
+        key = f"{kind}|k{k}|m20|n{wl['kmers']}"
+        entries[key] = {"workload": name, "image_bytes": int(h.info.image_bytes), "small_bytes": small, "big_bytes": big}
+        sizes += [str(small), str(big)]
+        h.close()
+    r = subprocess.run([exe] + sizes, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        log(f"[bench] gather_ceiling failed ({r.returncode}): {r.stderr[-500:]}")
+        return 2
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    gathers = [ln for ln in lines if ln["probe"] == "gather"]
+    for (key, e), g in zip(entries.items(), gathers):
+        e.update({"small_bytes": g["small_bytes"], "big_bytes": g["big_bytes"], "lines_per_s": g["lines_per_s"], "chain_items_per_s": g["chain_items_per_s"], "items": g["items"]})
+    out = {"probe_sha": probe_sha(), "device": torch.cuda.get_device_name(0), "entries": entries, "append": [ln for ln in lines if ln["probe"] == "append"],
+           "note": "tools/gather_ceiling.hip run by bench.py --probe-ceiling: lines_per_s = scattered 128-B-line gathers from a table of big_bytes; chain_items_per_s = "
+                   "the dependent chain small[4 B] -> big[128-B line] (a lookup's pilot word -> block line) with no hashing; append = one atomicAdd per workgroup"}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "gather_ceiling.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    result_out.write(json.dumps(out) + "\n")
+    result_out.flush()
+    return 0
+
+
+def summary_table(out):
+    """<= 1,500 characters, one row per workload: what the driver's 2,000-character tail of stderr must still hold when the JSON line is 20 KB."""
+    rows = [("headline " + out["config"]["workload"].split(":")[0], out)] + [(e["name"], e) for e in out.get("secondary", [])]
+    lines = ["[bench summary] workload            G units/s  frac   bound                 parity pinned"]
+    for name, e in rows:
+        r = e.get("roofline", {})
+        lines.append(f"[bench summary] {name[:19]:<19} {e['value'] / 1e9:9.2f}  {r.get('frac', 0):.3f}  {str(r.get('bound'))[:21]:<21} {str(e.get('parity_vs_oracle')):<6} {e.get('index_digest_pinned')}")
+    for err in out.get("secondary_errors", []):
+        lines.append(f"[bench summary] {err['name'][:19]:<19} FAILED: {err['error'][:60]}")
+    return "\n".join(lines)[:1500]
+
+
 def secondary_entry(out, wl):
     keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "kernel_ms", "kernel_ms_min", "kernel_ms_max", "parity_vs_oracle",
             "parity_ranks_checked", "replicas_agree", "roofline", "roofline_valu", "cpu_baseline", "index_build_s", "image_broadcast_ms", "scaling", "strong",
-            "index_sha256", "index_digest_pinned")
+            "index_sha256", "index_digest_pinned", "sink", "binding_end_to_end")
     e = {"name": wl["name"], "workload": out["config"]["workload"], "units_per_step_per_gpu": out["config"]["units_per_step_per_gpu"],
          "index_image_bytes": out["config"]["index_image_bytes"]}
     e.update({k_: out[k_] for k_ in keep if k_ in out})
@@ -1050,6 +1290,10 @@ def main():
     ap.add_argument("--plan-records", action="store_true",
                     help="with --plan-only: also run the record-set logic of the first workload (rank 0 generates and shares through --cache-dir, the other "
                          "ranks stream the file) and report source, CRC-32 and peak RSS per rank")
+    ap.add_argument("--probe-ceiling", action="store_true",
+                    help="re-measure the gather ceilings on this box (tools/gather_ceiling: scattered 128-B lines and the bare pilot -> block chain on tables of the "
+                         "section sizes of the C2 / C5 / C4 images, one atomic append per workgroup) and write gpurun_out/gather_ceiling.json -- copy it to "
+                         "profiles/ to make it what roofline.frac_of_gather_chain and the line-request ceiling are read from")
     ap.add_argument("--plan-only", action="store_true",
                     help="resolve workloads and cache paths, check that all ranks agree (gloo when WORLD_SIZE > 1), print the plan and stop before the first GPU call")
     args = ap.parse_args()
@@ -1105,7 +1349,7 @@ def main():
                 records_report = [mine]
         strong_report = None
         if "strong" in plan:  # what THIS rank would take of every workload's fixed job, as it works it out from its own RANK (gathered: the test checks the partition)
-            mine = {"rank": rank, "shards": [strong_plan(w, world, strong_total_log2_of(args, w))["shards"][rank] for w in plan["workloads"]]}
+            mine = {"rank": rank, "shards": [strong_plan(w, world, strong_total_log2_of(args, w))["shards"][rank] for w in plan["workloads"] if w["sink"] == "codes"]}
             if dist is not None:
                 gathered = [None] * world
                 dist.all_gather_object(gathered, mine)
@@ -1127,6 +1371,8 @@ def main():
     import lphash_amd as L
 
     assert torch.cuda.is_available(), "bench.py needs a GPU: the query path has no CPU fallback"
+    if args.probe_ceiling:
+        sys.exit(probe_ceiling(args, torch, np, L, result_out))
     # LPHQ_BENCH_SHARE_DEVICE0=1 (test hook for boxes with ONE GPU): every rank works on cuda:0 and the process group runs over gloo (RCCL refuses two ranks
     # on one device) -- everything but the transport of the collectives is then the N > 1 run: N processes, the records shared through the cache directory, the
     # image broadcast into another process's memory, per-rank batches and oracle checks, the sharded strong-scaling pass, the verdict collectives.
@@ -1194,6 +1440,7 @@ def main():
         out["bench_wall_s"] = time.time() - t_job
         result_out.write(json.dumps(out) + "\n")
         result_out.flush()
+        log(summary_table(out))  # the last thing on stderr
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -36,13 +36,17 @@ public:
     }
 
     // replaces essentials::load(hf, path)                                   (src/query.cpp:37)
-    void load(const char* path, int device = 0) {
+    void load(const char* path, int device = 0) { load(path, std::vector<int>{device}); }
+    // ... with a replica of the function on every GPU named: submit() / collect() then spread their batches over them in turn (one immutable `MPHF hf`
+    // shared by all callers, include/partitioned_mphf.hpp:21-23); operator() below keeps to the first
+    void load(const char* path, const std::vector<int>& devices) {
         lphq_session_close(s_);
         s_ = nullptr;
         lphq_close(h_);
         h_ = nullptr;
-        if (lphq_open(path, KIND, (int)sizeof(KmerT) * 8, &h_) != LPHQ_OK || lphq_attach(h_, device) != LPHQ_OK) throw std::runtime_error(lphq_last_error());
-        // several GPUs in one process: lphq_attach_devices(h_, devs, n); a calling thread then selects its GPU with hipSetDevice
+        devices_ = devices.empty() ? std::vector<int>{0} : devices;
+        if (lphq_open(path, KIND, (int)sizeof(KmerT) * 8, &h_) != LPHQ_OK || lphq_attach_devices(h_, devices_.data(), (int)devices_.size()) != LPHQ_OK)
+            throw std::runtime_error(lphq_last_error());
     }
 
     // replaces MPHF::operator()(contig, length, streaming)                   (src/query.cpp:52,72; include/partitioned_mphf.hpp:21-23)
@@ -69,16 +73,51 @@ public:
         const uint64_t *codes_ = nullptr, *offs_ = nullptr;
         std::size_t n_ = 0;
     };
+    // The streaming result of one batch as the reference COMPUTES it (include/partitioned_mphf.hpp:131-145): one lphq_run per stretch of k-mers whose codes
+    // go up or down by one -- what res.push_back(mm_ctx.hval) spells out k-mer by k-mer.  windows() is the sum of the vector sizes a loop over operator() would
+    // have seen (src/query.cpp:53); a caller that indexes per-k-mer data reads table[code .. code + length) per run.  Valid until the next submit().
+    class run_batch {
+    public:
+        std::size_t records() const { return n_; }
+        std::size_t runs() const { return n_runs_; }
+        const lphq_run& operator[](std::size_t i) const { return runs_[i]; }
+        uint64_t windows() const { return windows_; }
+        const uint64_t* explicit_codes() const { return codes_; }
+        uint64_t record_begin(std::size_t r) const { return offs_[r]; }  // where record r's windows begin in the space LPHQ_RUN_FIRST counts in
+        // code of window i (< LPHQ_RUN_LENGTH) of run r
+        uint64_t code(const lphq_run& r, uint32_t i) const {
+            const uint32_t kind = LPHQ_RUN_KIND(r);
+            return kind == LPHQ_RUN_UP ? r.code + i : kind == LPHQ_RUN_DOWN ? r.code - i : codes_[r.code + i];
+        }
+
+    private:
+        friend class gpu_mphf;
+        const lphq_run* runs_ = nullptr;
+        const uint64_t *codes_ = nullptr, *offs_ = nullptr;
+        std::size_t n_runs_ = 0, n_codes_ = 0, n_ = 0;
+        uint64_t windows_ = 0;
+    };
     // Set-up before a timer starts: the session and its buffers for batches of up to total_bases bases in n_records records (optional).
     void reserve(std::size_t total_bases, std::size_t n_records) {
-        if (!s_ && lphq_session_open(h_, kDepth, &s_) != LPHQ_OK) throw std::runtime_error(lphq_last_error());
+        open_session();
         if (lphq_session_reserve(s_, total_bases, n_records) != LPHQ_OK) throw std::runtime_error(lphq_last_error());
     }
-    // Queue one batch (the records' memory must stay valid until the batch is collected; depth() batches may be in flight).
+    // Queue one batch (the records' memory must stay valid until the batch is collected; depth() batches may be in flight per GPU).
     void submit(const char* const* records, const std::size_t* lengths, std::size_t n, bool streaming = true) {
-        if (!s_ && lphq_session_open(h_, kDepth, &s_) != LPHQ_OK) throw std::runtime_error(lphq_last_error());
+        open_session();
         if (lphq_session_submit(s_, records, lengths, n, streaming ? 1 : 0) != LPHQ_OK) throw std::runtime_error(lphq_last_error());
     }
+    // ... to be collected as runs (streaming pass only)
+    void submit_runs(const char* const* records, const std::size_t* lengths, std::size_t n) {
+        open_session();
+        if (lphq_session_submit_runs(s_, records, lengths, n) != LPHQ_OK) throw std::runtime_error(lphq_last_error());
+    }
+    run_batch collect_runs() {
+        run_batch b;
+        if (lphq_session_collect_runs(s_, &b.runs_, &b.n_runs_, &b.codes_, &b.n_codes_, &b.windows_, &b.offs_, &b.n_) != LPHQ_OK) throw std::runtime_error(lphq_last_error());
+        return b;
+    }
+    int in_flight_capacity() const { return kDepth * (int)devices_.size(); }
     void submit(const std::vector<std::string_view>& records, bool streaming = true) {
         ptrs_.resize(records.size());
         lens_.resize(records.size());
@@ -121,7 +160,13 @@ private:
         if (lphq_get_info(h_, &i) != LPHQ_OK) throw std::runtime_error(lphq_last_error());
         return i;
     }
+    void open_session() {
+        if (s_) return;
+        const int rc = devices_.size() > 1 ? lphq_session_open_devices(h_, kDepth, devices_.data(), (int)devices_.size(), &s_) : lphq_session_open(h_, kDepth, &s_);
+        if (rc != LPHQ_OK) throw std::runtime_error(lphq_last_error());
+    }
     static constexpr int kDepth = 2;
+    std::vector<int> devices_{0};
     lphq_index* h_ = nullptr;
     lphq_session* s_ = nullptr;
     std::vector<const char*> ptrs_;

@@ -5,9 +5,10 @@
 // (lphash_amd/csrc/fastx.hpp) because the reference's external/kseq.h is not part of this tree.
 //
 //   g++ -std=c++17 -O2 -Iinclude -Ilphash_amd/csrc examples/query_main.cpp -Llphash_amd -llphq -lz -lpthread -o examples/query_example
-//   examples/query_example query-p|query-u -i index.lph -q queries.fa[.gz] [--dump prefix] [--per-record]
+//   examples/query_example query-p|query-u -i index.lph -q queries.fa[.gz] [--dump prefix] [--per-record] [--runs] [--devices 0,1,...]
 //                          (--dump: codes of both passes as prefix.streaming.u64 / prefix.random.u64; --per-record: the reference's loop, literally --
-//                           one operator() per record; the default hands the binding batches of records and keeps two in flight)
+//                           one operator() per record; the default hands the binding batches of records and keeps two in flight per GPU;
+//                           --runs: the streaming pass is collected as runs of codes (what the reference computes, never expanded) -- same count)
 //   examples/query_example build-p|build-u -i unitigs.fa[.gz] -k K -m M -o index.lph [-s seed] [-c c] [-t threads] [-d tmp] [--max-memory GB]
 //                          (the build side of the binding, src/build.cpp:24-28: same file as the reference's build-p / build-u)
 //   -DLPHASH_KMER64 selects `typedef uint64_t kmer_t` (include/compile_constants.tpd:2); the default is __uint128_t, as the reference ships.
@@ -33,27 +34,36 @@ namespace lphash {
 
 // One pass with MANY records per call: the batch reader (all host threads: mapped text, BGZF and plain .gz alike) parses into page-locked arenas,
 // the binding copies a batch to the device while the previous one is being looked up and the one before is being consumed here.
+// as_runs: the streaming pass collected as the reference COMPUTES it -- runs of codes that go up or down by one (gpu_mphf::collect_runs) -- instead of expanded
+// into one code per k-mer; the count the driver prints is the same
 template <typename MPHF>
-bool batched_pass(MPHF& hf, const std::string& query_filename, bool streaming, FILE* dump, uint64_t& total, long long& micros) {
+bool batched_pass(MPHF& hf, const std::string& query_filename, bool streaming, FILE* dump, uint64_t& total, long long& micros, bool as_runs) {
     lphq::FastxBatchReader reader(query_filename.c_str(), lphq::usable_cpus() < 16 ? lphq::usable_cpus() : 16, &lphq_host_alloc, &lphq_host_free, 1 << 16,
                                   lphq::usable_cpus());  // (parser: at most 16 threads; .gz decoder: every usable CPU -- fastx_batch.hpp)
     if (!reader.ok()) return false;
     const size_t batch_bases = (size_t)16 << 20;
+    const int cap = hf.in_flight_capacity();  // depth x GPUs batches in flight; the reader keeps that many arenas alive
+    reader.set_live_batches(cap);
     reader.prealloc(batch_bases);  // (set-up, like gzopen + kseq_init before t.start(), src/query.cpp:43-48)
     hf.reserve(batch_bases + batch_bases / 4, (size_t)1 << 16);  // ... and the binding's device and page-locked result buffers
-    lphq::FastxBatch bufs[2];
-    std::vector<const char*> ptrs[2];
-    std::vector<size_t> lens[2];
+    std::vector<lphq::FastxBatch> bufs((size_t)cap);
+    std::vector<std::vector<const char*>> ptrs((size_t)cap);
+    std::vector<std::vector<size_t>> lens((size_t)cap);
+    const bool runs = as_runs && streaming && !dump;
     const auto t0 = std::chrono::high_resolution_clock::now();
     auto consume = [&] {
+        if (runs) {
+            total += hf.collect_runs().windows();  // hashes.size() summed over the batch's records, without the hashes ever being spelled out
+            return;
+        }
         const auto b = hf.collect();
         total += b.total();  // hashes.size() summed over the batch's records
         if (dump && b.total()) fwrite(b.begin(0), sizeof(uint64_t), b.total(), dump);
     };
     int in_flight = 0;
-    for (int i = 0;; i ^= 1) {
-        // (the reader keeps the two most recent batches alive: batch i - 2's memory is reused now, so it must have been collected)
-        if (in_flight == 2) {
+    for (int i = 0;; i = (i + 1) % cap) {
+        // (the reader keeps the `cap` most recent batches alive: batch i - cap's memory is reused now, so it must have been collected)
+        if (in_flight == cap) {
             consume();
             --in_flight;
         }
@@ -67,7 +77,8 @@ bool batched_pass(MPHF& hf, const std::string& query_filename, bool streaming, F
             lens[i].push_back((size_t)len);
             p += len;
         }
-        hf.submit(ptrs[i].data(), lens[i].data(), ptrs[i].size(), streaming);
+        if (runs) hf.submit_runs(ptrs[i].data(), lens[i].data(), ptrs[i].size());
+        else hf.submit(ptrs[i].data(), lens[i].data(), ptrs[i].size(), streaming);
         ++in_flight;
     }
     while (in_flight--) consume();
@@ -76,9 +87,9 @@ bool batched_pass(MPHF& hf, const std::string& query_filename, bool streaming, F
 }
 
 template <typename MPHF>
-int query(const std::string& mphf_filename, const std::string& query_filename, const std::string& dump_prefix, bool per_record) {
+int query(const std::string& mphf_filename, const std::string& query_filename, const std::string& dump_prefix, bool per_record, bool as_runs, const std::vector<int>& devices) {
     MPHF hf;
-    hf.load(mphf_filename.c_str());  // essentials::load(hf, mphf_filename.c_str())                      src/query.cpp:37
+    hf.load(mphf_filename.c_str(), devices);  // essentials::load(hf, mphf_filename.c_str())                      src/query.cpp:37
     {
         // still loading: the first launch of a kernel loads its code object (milliseconds); one dummy record through every path before any timer starts,
         // as `lphash query-*` does
@@ -101,7 +112,7 @@ int query(const std::string& mphf_filename, const std::string& query_filename, c
                 dump = fopen((dump_prefix + (streaming ? ".streaming.u64" : ".random.u64")).c_str(), "wb");
                 if (!dump) return 2;
             }
-            const bool opened = batched_pass(hf, query_filename, streaming, dump, total[pass], micros[pass]);
+            const bool opened = batched_pass(hf, query_filename, streaming, dump, total[pass], micros[pass], as_runs);
             if (dump) fclose(dump);
             if (!opened) {
                 std::cerr << "Unable to open the input file " << query_filename << "\n";
@@ -170,11 +181,12 @@ int main(int argc, char** argv) {
     int k = 0, m = 0, threads = 1;
     uint64_t seed = 42, max_memory_gb = 0;
     double c = 3.0;
-    bool per_record = false;
+    bool per_record = false, as_runs = false;
+    std::vector<int> devices{0};
     for (int i = 2; i < argc; i += 2) {
         const std::string a = argv[i];
-        if (a == "--per-record") {
-            per_record = true;
+        if (a == "--per-record" || a == "--runs") {
+            (a == "--runs" ? as_runs : per_record) = true;
             --i;
             continue;
         }
@@ -183,6 +195,15 @@ int main(int argc, char** argv) {
         if (a == "-i") mphf = v;
         else if (a == "-q") queries = v;
         else if (a == "--dump") dump = v;
+        else if (a == "--devices") {  // GPUs the batches are spread over, e.g. 0,1,2,3 (an ordinal may repeat: one more lane on that GPU)
+            devices.clear();
+            for (size_t at = 0; at < v.size();) {
+                const size_t c = v.find(',', at);
+                devices.push_back(std::stoi(v.substr(at, c == std::string::npos ? std::string::npos : c - at)));
+                if (c == std::string::npos) break;
+                at = c + 1;
+            }
+        }
         else if (a == "-o") out = v;
         else if (a == "-k") k = std::stoi(v);
         else if (a == "-m") m = std::stoi(v);
@@ -194,7 +215,7 @@ int main(int argc, char** argv) {
     }
     const bool is_query = tool == "query-p" || tool == "query-u", is_build = tool == "build-p" || tool == "build-u";
     if ((!is_query && !is_build) || mphf.empty() || (is_query && queries.empty()) || (is_build && (out.empty() || k <= 0 || m <= 0))) {
-        std::cerr << "usage: " << argv[0] << " query-p|query-u -i <mphf> -q <fasta|fastq[.gz]> [--dump prefix] [--per-record]\n"
+        std::cerr << "usage: " << argv[0] << " query-p|query-u -i <mphf> -q <fasta|fastq[.gz]> [--dump prefix] [--per-record] [--runs] [--devices 0,1,...]\n"
                   << "       " << argv[0] << " build-p|build-u -i <fasta[.gz]> -k K -m M -o <mphf> [-s seed] [-c c] [-t threads] [-d tmp] [--max-memory GB]\n";
         return 1;  // ParseError, src/query.cpp:31-33
     }
@@ -208,8 +229,8 @@ int main(int argc, char** argv) {
             std::cerr << "built " << out << ": " << st.num_kmers << " k-mers, " << st.distinct_minimizers << " minimizers\n";
             return 0;
         }
-        if (tool == "query-p") return lphash::query<lphash::gpu_mphf<LPHQ_PARTITIONED, kmer_t>>(mphf, queries, dump, per_record);
-        return lphash::query<lphash::gpu_mphf<LPHQ_UNPARTITIONED, kmer_t>>(mphf, queries, dump, per_record);
+        if (tool == "query-p") return lphash::query<lphash::gpu_mphf<LPHQ_PARTITIONED, kmer_t>>(mphf, queries, dump, per_record, as_runs, devices);
+        return lphash::query<lphash::gpu_mphf<LPHQ_UNPARTITIONED, kmer_t>>(mphf, queries, dump, per_record, as_runs, devices);
     } catch (const std::exception& e) {
         std::cerr << e.what() << "\n";
         return 1;

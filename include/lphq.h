@@ -249,6 +249,11 @@ int lphq_query_contig(const lphq_index* idx, const char* contig, size_t length, 
  *   LPHQ_ERR_STATE when nothing is in flight. */
 typedef struct lphq_session lphq_session;
 int lphq_session_open(const lphq_index* idx, int depth /* 1..4 */, lphq_session** out);
+/* ABI 4: one session over SEVERAL replicas of the index (lphq_attach_devices first): batches go to devices[0], devices[1], ... in turn -- batch b to
+ * devices[b % n_devices], each device with a stream of its own and `depth` batches in flight -- and are collected in submission order, so the caller's
+ * submit / collect loop spreads over the GPUs of a node unchanged (up to depth * n_devices submits before the first collect).  The reference object this
+ * stands for is the one immutable `MPHF hf` all callers share (include/partitioned_mphf.hpp:21-23).  LPHQ_ERR_STATE if a device has no replica. */
+int lphq_session_open_devices(const lphq_index* idx, int depth /* 1..4, per device */, const int* devices, int n_devices, lphq_session** out);
 void lphq_session_close(lphq_session* s);
 /* Allocate now what batches of up to total_bases bases in up to n_records records need (device buffers and the pinned result buffer of EVERY
  * slot): page-locked allocations are slow (tens of ms for hundreds of MB), a caller with a timer does them before it starts the timer, like the
@@ -256,6 +261,19 @@ void lphq_session_close(lphq_session* s);
 int lphq_session_reserve(lphq_session* s, size_t total_bases, size_t n_records);
 int lphq_session_submit(lphq_session* s, const char* const* records, const size_t* lengths, size_t n_records, int streaming);
 int lphq_session_collect(lphq_session* s, const uint64_t** codes, const uint64_t** offsets /* n_records + 1 entries */, size_t* n_records);
+/* The same pipeline with the streaming result left as the reference COMPUTES it (ABI 4; lphq_run above): submit_runs = submit(streaming = 1) whose
+ * batch crosses PCIe as runs -- 16 B per super-k-mer instead of 8 B per k-mer --; collect_runs hands out ONE dense array of runs (no arenas on the
+ * host; in no particular order; kind EXPLICIT: code indexes *explicit_codes), *n_windows = the windows all runs hold together (the reference's
+ * vector.size() summed over the batch: windows holding a non-ACGT base are in no run), and *offsets[r] = where record r's windows begin in the
+ * space LPHQ_RUN_FIRST counts in: max(0, len_r - k + 1) slots per record, non-ACGT windows included.  Pointers valid until the next submit.
+ * lphq_session_collect works on such a batch too: it expands the runs on the host (all usable threads, up to 16) and returns codes and compacted
+ * offsets exactly as for a batch submitted with lphq_session_submit -- which, for LP-MPHF handles and streaming != 0, uses this transport itself
+ * (LPHQ_SESSION_TRANSPORT=codes in the environment keeps the 8-byte codes on the wire: A/B runs).  collect_runs on a batch that was not submitted
+ * as runs: LPHQ_ERR_STATE.  A batch of low-complexity sequence (up to one run per window) that outgrows the arenas sized for random sequence is
+ * answered again, synchronously, with worst-case arenas: slower, never wrong. */
+int lphq_session_submit_runs(lphq_session* s, const char* const* records, const size_t* lengths, size_t n_records);
+int lphq_session_collect_runs(lphq_session* s, const lphq_run** runs, size_t* n_runs, const uint64_t** explicit_codes, size_t* n_codes,
+                              uint64_t* n_windows /* may be NULL */, const uint64_t** offsets /* n_records + 1 entries */, size_t* n_records);
 /* Page-locked host memory for record buffers handed to lphq_session_submit (hipHostMalloc); NULL when it cannot be had. */
 void* lphq_host_alloc(size_t bytes);
 void lphq_host_free(void* p);

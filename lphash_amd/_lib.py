@@ -13,6 +13,8 @@ LIB_PATH = os.environ.get("LPHQ_LIB_PATH") or os.path.join(_HERE, "liblphq.so") 
 OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(8)
 PARTITIONED, UNPARTITIONED, PTHASH, BBHASH = 0, 1, 2, 3
 INVALID = 0xFFFFFFFFFFFFFFFF
+RUN_ARENAS = 32  # LPHQ_RUN_ARENAS; an lphq_run is 16 bytes (code, where), an lphq_run_counts 128 (runs, codes, 14 reserved words)
+RUN_UP, RUN_DOWN, RUN_EXPLICIT = 0, 1, 2
 
 
 class LphqError(RuntimeError):
@@ -59,6 +61,11 @@ SIGNATURES = {
     "lphq_abi_version": (C.c_int, []),
     "lphq_gather_payload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
     "lphq_count_valid_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "lphq_query_records_runs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                          C.c_void_p, C.c_void_p]),
+    "lphq_expand_runs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "lphq_query_records_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p,
+                                            C.c_void_p]),
     "lphq_query_contig": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
                                     C.POINTER(C.c_size_t)]),
     "lphq_build": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int, C.c_uint64,
@@ -71,10 +78,14 @@ SIGNATURES = {
     "lphq_build_bbhash": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_int, C.c_char_p,
                                     C.POINTER(BuildStats)]),
     "lphq_session_open": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "lphq_session_open_devices": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     "lphq_session_close": (None, [C.c_void_p]),
     "lphq_session_reserve": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t]),
     "lphq_session_submit": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int]),
     "lphq_session_collect": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_size_t)]),
+    "lphq_session_submit_runs": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t]),
+    "lphq_session_collect_runs": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_size_t),
+                                            C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_size_t)]),
     "lphq_host_alloc": (C.c_void_p, [C.c_size_t]),
     "lphq_host_free": (None, [C.c_void_p]),
     "lphq_replica_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -239,8 +239,9 @@ class _MphfBase:
         return out[: n.value].copy()
 
     # -- MPHF::operator() over many records per call, batches in flight (lphq_session_*) -----------
-    def session(self, depth=2):
-        return Session(self, depth)
+    def session(self, depth=2, devices=None):
+        """devices: HIP ordinals of attached replicas the session spreads its batches over (None: one replica, as lphq_session_open picks it)."""
+        return Session(self, depth, devices)
 
     def replica_info(self):
         """[(device, how)] in attach order; how: 0 uploaded, 1 peer copy with peer access, 2 peer copy staged by the runtime, 3 adopted."""
@@ -259,6 +260,22 @@ class _MphfBase:
         check(lib.lphq_query_records(self._h, C.c_void_p(d_seq), total_bases, C.c_void_p(d_seq_offsets), n_records,
                                      C.c_void_p(d_out), C.c_void_p(d_out_offsets), 1 if streaming else 0, C.c_void_p(stream)))
 
+    def query_records_runs(self, d_seq, total_bases, d_seq_offsets, n_records, d_out_offsets, d_runs, cap_runs, d_codes, cap_codes, d_counts, stream=0):
+        """The streaming pass with the run-encoded result (lphq_query_records_runs): 16-byte lphq_run entries in RUN_ARENAS arenas of cap_runs / RUN_ARENAS
+        entries, explicit codes of colliding windows in arenas of cap_codes / RUN_ARENAS, RUN_ARENAS x 128-byte counters at d_counts."""
+        check(lib.lphq_query_records_runs(self._h, C.c_void_p(d_seq), total_bases, C.c_void_p(d_seq_offsets), n_records, C.c_void_p(d_out_offsets),
+                                          C.c_void_p(d_runs), cap_runs, C.c_void_p(d_codes), cap_codes, C.c_void_p(d_counts), C.c_void_p(stream)))
+
+    def expand_runs(self, d_runs, cap_runs, d_codes, cap_codes, d_counts, d_out, n_out, d_status=0, stream=0):
+        """d_out[0..n_out) from the runs: what query_records(streaming=True) writes for the same batch (lphq_expand_runs)."""
+        check(lib.lphq_expand_runs(self._h, C.c_void_p(d_runs), cap_runs, C.c_void_p(d_codes), cap_codes, C.c_void_p(d_counts), C.c_void_p(d_out), n_out,
+                                   C.c_void_p(d_status), C.c_void_p(stream)))
+
+    def query_records_gather(self, d_seq, total_bases, d_seq_offsets, n_records, d_out_offsets, d_table, elem_bytes, d_payload_out, missing=0, stream=0):
+        """d_payload_out[window] = d_table[code of the window], streaming lookup and gather in one kernel (lphq_query_records_gather)."""
+        check(lib.lphq_query_records_gather(self._h, C.c_void_p(d_seq), total_bases, C.c_void_p(d_seq_offsets), n_records, C.c_void_p(d_out_offsets),
+                                            C.c_void_p(d_table), int(elem_bytes), int(missing) & 0xFFFFFFFFFFFFFFFF, C.c_void_p(d_payload_out), C.c_void_p(stream)))
+
     def pack_kmers(self, d_seq, d_pos, n, d_kmers, stream=0):
         check(lib.lphq_pack_kmers(self._h, C.c_void_p(d_seq), C.c_void_p(d_pos), n, C.c_void_p(d_kmers), C.c_void_p(stream)))
 
@@ -268,11 +285,15 @@ class Session:
     kernel, copy out, nothing waited for); collect() waits for the oldest batch and returns one uint64 array per record -- what a loop over
     MPHF::operator() would have returned."""
 
-    def __init__(self, mphf, depth=2):
+    def __init__(self, mphf, depth=2, devices=None):
         self._s = C.c_void_p()
         self._mphf = mphf  # the session uses the index's device image: keep the index alive as long as the session (lphq.h: close sessions first)
         self._keep = []  # the records of the batches in flight (their memory must outlive the copies)
-        check(lib.lphq_session_open(mphf._h, depth, C.byref(self._s)))
+        if devices is None:
+            check(lib.lphq_session_open(mphf._h, depth, C.byref(self._s)))
+        else:
+            devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+            check(lib.lphq_session_open_devices(mphf._h, depth, devs, len(devices), C.byref(self._s)))
 
     def reserve(self, total_bases, n_records):
         check(lib.lphq_session_reserve(self._s, total_bases, n_records))
@@ -284,6 +305,28 @@ class Session:
         lens = (C.c_size_t * max(n, 1))(*[len(r) for r in recs])
         check(lib.lphq_session_submit(self._s, ptrs, lens, n, 1 if streaming else 0))
         self._keep.append((recs, ptrs, lens))
+
+    def submit_runs(self, records):
+        """submit(streaming=True) whose result is collected as runs (lphq_session_submit_runs)."""
+        recs = [bytes(r) for r in records]
+        n = len(recs)
+        ptrs = (C.c_char_p * max(n, 1))(*recs)
+        lens = (C.c_size_t * max(n, 1))(*[len(r) for r in recs])
+        check(lib.lphq_session_submit_runs(self._s, ptrs, lens, n))
+        self._keep.append((recs, ptrs, lens))
+
+    def collect_runs(self):
+        """The oldest batch as the reference computes it: (runs, explicit_codes, n_windows, offsets) -- runs: structured array (code, where) of lphq_run
+        entries in one dense array, offsets: where each record's windows begin in the space LPHQ_RUN_FIRST counts in (lphq_session_collect_runs)."""
+        runs, nr, xc, nx = C.c_void_p(), C.c_size_t(), C.POINTER(C.c_uint64)(), C.c_size_t()
+        nw, offs, n = C.c_uint64(), C.POINTER(C.c_uint64)(), C.c_size_t()
+        check(lib.lphq_session_collect_runs(self._s, C.byref(runs), C.byref(nr), C.byref(xc), C.byref(nx), C.byref(nw), C.byref(offs), C.byref(n)))
+        self._keep.pop(0)
+        dt = np.dtype([("code", "<u8"), ("where", "<u8")])
+        r = np.frombuffer((C.c_char * (nr.value * 16)).from_address(runs.value), dtype=dt).copy() if nr.value else np.zeros(0, dtype=dt)
+        x = np.ctypeslib.as_array(xc, shape=(nx.value,)).copy() if nx.value else np.zeros(0, dtype=np.uint64)
+        o = np.ctypeslib.as_array(offs, shape=(n.value + 1,)).copy() if n.value else np.zeros(1, dtype=np.uint64)
+        return r, x, int(nw.value), o
 
     def collect(self):
         codes, offs, n = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)(), C.c_size_t()

@@ -2,12 +2,14 @@
 // No CPU query path exists here: every query entry point launches HIP kernels or fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <memory>
 #include <new>
 #include <string>
 #include <utility>
@@ -15,9 +17,11 @@
 
 #include "../../include/lphq.h"
 #include "bbhash.hpp"
+#include "host_cpus.hpp"
 #include "image.hpp"
 #include "kernels.hpp"
 #include "lph_format.hpp"
+#include "work_pool.hpp"
 
 using namespace lphq;
 
@@ -828,7 +832,13 @@ extern "C" int lphq_query_contig(const lphq_index* cidx, const char* contig, siz
 // ------------------------------------------------------------------------------------------
 // sessions: batches of host records, `depth` of them in flight (include/lphq.h, ABI 3)
 // ------------------------------------------------------------------------------------------
+struct SessionLane {
+    int device = -1;
+    const uint8_t* d_image = nullptr;
+    hipStream_t stream = nullptr;
+};
 struct SessionSlot {
+    const SessionLane* lane = nullptr;
     char* d_seq = nullptr;
     size_t d_seq_cap = 0;
     uint64_t* d_out = nullptr;
@@ -845,15 +855,39 @@ struct SessionSlot {
     std::vector<const char*> recs;  // the caller's records (valid until collect): needed again only when the batch holds a non-ACGT byte
     std::vector<size_t> lens;
     std::vector<uint64_t> compact_offs;
+    // run-encoded transport (streaming batches of LP-MPHF handles): the kernel appends to arenas, k_compact_runs makes them one dense array, and that
+    // array -- 16 B per run of ~(W + 1) / 2 windows instead of 8 B per window -- is what crosses PCIe; collect() expands it on the host
+    lphq_run* d_runs = nullptr;        // LPHQ_RUN_ARENAS x per_arena
+    size_t d_runs_cap = 0;
+    uint64_t* d_xc = nullptr;          // explicit codes, LPHQ_RUN_ARENAS x xper_arena
+    size_t d_xc_cap = 0;
+    lphq_run_counts* d_counts = nullptr;  // + 4 totals behind the counters
+    size_t d_counts_cap = 0;
+    lphq_run* d_dense = nullptr;
+    size_t d_dense_cap = 0;
+    uint64_t* d_xdense = nullptr;
+    size_t d_xdense_cap = 0;
+    lphq_run* h_runs = nullptr;        // pinned
+    size_t h_runs_cap = 0;
+    uint64_t* h_xc = nullptr;          // pinned
+    size_t h_xc_cap = 0;
+    unsigned long long* h_totals = nullptr;  // pinned: runs, explicit codes, overflow flag, windows
+    size_t h_totals_cap = 0;
+    size_t per_arena = 0, xper_arena = 0, copied_runs = 0, copied_xc = 0;
+    bool runs_mode = false;   // this batch travels as runs
+    bool expanded = false;    // ... and h_out already holds its expansion
 };
 struct lphq_session {
     lphq_index* idx = nullptr;
-    int device = -1;                    // of the replica picked at open; by value: lphq_attach* may grow (and move) idx->reps afterwards
-    const uint8_t* d_image = nullptr;
-    hipStream_t stream = nullptr;
-    int depth = 2;
+    // One lane per replica the session works on (lphq_session_open: one; lphq_session_open_devices: several): batches go to the lanes in turn -- batch b to
+    // lane b % lanes, each lane with its own stream and `depth` slots -- and are collected in submission order, so a caller's submit / collect loop spreads
+    // over the GPUs of a node without knowing it.  The replica's device and image by value: lphq_attach* may grow (and move) idx->reps afterwards.
+    std::vector<SessionLane> lanes;
+    int depth = 2;                       // batches in flight per lane
     uint64_t submitted = 0, collected = 0;
-    SessionSlot slot[4];
+    std::vector<SessionSlot> slot;       // depth x lanes; slot i belongs to lane i % lanes
+    size_t xc_hint = 0;                  // explicit codes of the last runs batch (how much of the code array the next batch copies back unasked)
+    std::unique_ptr<WorkPool> pool;      // host threads that expand runs into codes (created by the first collect that needs them)
 };
 
 extern "C" void* lphq_host_alloc(size_t bytes) {
@@ -869,11 +903,18 @@ extern "C" void lphq_host_free(void* p) {
     if (p) (void)hipHostFree(p);
 }
 
-extern "C" int lphq_session_open(const lphq_index* cidx, int depth, lphq_session** out) {
-    lphq_index* idx = const_cast<lphq_index*>(cidx);
-    REQUIRE_ATTACHED(idx);
-    if (!out) return fail(LPHQ_ERR_ARG, "null argument");
-    *out = nullptr;
+// the replica a session lane on `device` uses: the n-th replica there (LPHQ_TEST_SELF_PEER boxes hold several on one device), nullptr if there is none
+static const Replica* nth_replica_on(const lphq_index* idx, int device, int nth) {
+    const Replica* last = nullptr;
+    for (const Replica& r : idx->reps)
+        if (r.device == device) {
+            last = &r;
+            if (nth-- == 0) return &r;
+        }
+    return last;
+}
+
+static int session_open(lphq_index* idx, int depth, const std::vector<const Replica*>& reps, lphq_session** out) {
     if (depth < 1 || depth > 4) return fail(LPHQ_ERR_ARG, "depth must be 1..4");
     // the reference first, then the check: a lphq_close that slips in between finds the count >= 2 and cannot free the index under this call
     idx->refs.fetch_add(1, std::memory_order_acq_rel);
@@ -887,13 +928,21 @@ extern "C" int lphq_session_open(const lphq_index* cidx, int depth, lphq_session
         return fail(LPHQ_ERR_ARG, "out of memory");
     }
     s->idx = idx;
-    const Replica* rep = pick_replica(idx);
-    s->device = rep->device;
-    s->d_image = rep->d_image;
     s->depth = depth;
-    DeviceGuard g(s->device);
-    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
-    for (int i = 0; i < depth && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&s->slot[i].done, hipEventDisableTiming);
+    s->lanes.resize(reps.size());
+    s->slot.resize(reps.size() * (size_t)depth);
+    hipError_t e = hipSuccess;
+    for (size_t l = 0; l < reps.size() && e == hipSuccess; ++l) {
+        s->lanes[l].device = reps[l]->device;
+        s->lanes[l].d_image = reps[l]->d_image;
+        DeviceGuard g(s->lanes[l].device);
+        e = hipStreamCreateWithFlags(&s->lanes[l].stream, hipStreamNonBlocking);
+    }
+    for (size_t i = 0; i < s->slot.size() && e == hipSuccess; ++i) {
+        s->slot[i].lane = &s->lanes[i % s->lanes.size()];
+        DeviceGuard g(s->slot[i].lane->device);
+        e = hipEventCreateWithFlags(&s->slot[i].done, hipEventDisableTiming);
+    }
     if (e != hipSuccess) {
         lphq_session_close(s);
         return fail_hip(e, "lphq_session_open");
@@ -902,20 +951,57 @@ extern "C" int lphq_session_open(const lphq_index* cidx, int depth, lphq_session
     return LPHQ_OK;
 }
 
+extern "C" int lphq_session_open(const lphq_index* cidx, int depth, lphq_session** out) {
+    lphq_index* idx = const_cast<lphq_index*>(cidx);
+    REQUIRE_ATTACHED(idx);
+    if (!out) return fail(LPHQ_ERR_ARG, "null argument");
+    *out = nullptr;
+    return session_open(idx, depth, {pick_replica(idx)}, out);
+}
+
+extern "C" int lphq_session_open_devices(const lphq_index* cidx, int depth, const int* devices, int n_devices, lphq_session** out) {
+    lphq_index* idx = const_cast<lphq_index*>(cidx);
+    REQUIRE_ATTACHED(idx);
+    if (!out || (n_devices > 0 && !devices)) return fail(LPHQ_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (n_devices < 1 || n_devices > 64) return fail(LPHQ_ERR_ARG, "1..64 devices");
+    std::vector<const Replica*> reps;
+    for (int i = 0; i < n_devices; ++i) {
+        int nth = 0;
+        for (int j = 0; j < i; ++j) nth += devices[j] == devices[i];
+        const Replica* r = nth_replica_on(idx, devices[i], nth);
+        if (!r) return fail(LPHQ_ERR_STATE, "the index has no replica on device " + std::to_string(devices[i]) + " (lphq_attach_devices first)");
+        reps.push_back(r);
+    }
+    return session_open(idx, depth, reps, out);
+}
+
 extern "C" void lphq_session_close(lphq_session* s) {
     if (!s) return;
-    DeviceGuard g(s->device);
-    if (s->stream) {
-        (void)hipStreamSynchronize(s->stream);
-        (void)hipStreamDestroy(s->stream);
+    for (SessionLane& ln : s->lanes) {
+        DeviceGuard g(ln.device);
+        if (ln.stream) (void)hipStreamSynchronize(ln.stream);
     }
     for (SessionSlot& sl : s->slot) {
+        DeviceGuard g(sl.lane ? sl.lane->device : 0);
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.d_seq) (void)hipFree(sl.d_seq);
         if (sl.d_out) (void)hipFree(sl.d_out);
         if (sl.d_offs) (void)hipFree(sl.d_offs);
         if (sl.h_offs) (void)hipHostFree(sl.h_offs);
         if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.d_runs) (void)hipFree(sl.d_runs);
+        if (sl.d_xc) (void)hipFree(sl.d_xc);
+        if (sl.d_counts) (void)hipFree(sl.d_counts);
+        if (sl.d_dense) (void)hipFree(sl.d_dense);
+        if (sl.d_xdense) (void)hipFree(sl.d_xdense);
+        if (sl.h_runs) (void)hipHostFree(sl.h_runs);
+        if (sl.h_xc) (void)hipHostFree(sl.h_xc);
+        if (sl.h_totals) (void)hipHostFree(sl.h_totals);
+    }
+    for (SessionLane& ln : s->lanes) {
+        DeviceGuard g(ln.device);
+        if (ln.stream) (void)hipStreamDestroy(ln.stream);
     }
     lphq_index* idx = s->idx;
     delete s;
@@ -945,41 +1031,130 @@ static hipError_t grow_pinned(T*& p, size_t& cap, size_t want) {
     return e;
 }
 
+// How a streaming batch of `windows` windows over `bases` bases in n_records records is sized for the run-encoded transport.  Expected runs on random
+// sequence: 2 / (W + 1) per window, + the cuts at tile and wave ends (two per tile) and at record starts; the arenas take 1.4 x that (a tile's runs all land
+// in one arena, so small batches are uneven), the unasked copy back 1.15 x.  A batch that does not fit (low-complexity sequence: up to one run per window)
+// is answered again with worst-case arenas (session_wait) -- slower, never wrong.
+struct RunPlan {
+    size_t per_arena, xper_arena, copy_runs, copy_xc, tiles;
+};
+static RunPlan plan_runs(const lphq_image_header& H, uint64_t windows, uint64_t bases, size_t n_records, size_t xc_hint, bool worst_case) {
+    RunPlan p;
+    const uint64_t tw = (uint64_t)((1024 - (int)H.W + 1) & ~15);  // stream_tile_windows(W, 1024)
+    p.tiles = (size_t)((bases + 16 + tw - 1) / tw);
+    const uint64_t tiles_per_arena = (p.tiles + LPHQ_RUN_ARENAS - 1) / LPHQ_RUN_ARENAS;
+    if (worst_case) {  // every window a run of its own, every window under a colliding minimizer
+        p.per_arena = p.xper_arena = (size_t)std::min<uint64_t>(windows, 1024 * tiles_per_arena) + 8;
+        p.copy_runs = p.copy_xc = p.per_arena * LPHQ_RUN_ARENAS;
+        return p;
+    }
+    const uint64_t expected = 2 * windows / (H.W + 1) + 2 * p.tiles + n_records + 64;
+    p.per_arena = (size_t)(expected * 14 / 10 / LPHQ_RUN_ARENAS + 1024);
+    p.xper_arena = (size_t)(windows / (4 * LPHQ_RUN_ARENAS) + 1024);
+    p.copy_runs = (size_t)std::min<uint64_t>(p.per_arena * LPHQ_RUN_ARENAS, expected * 115 / 100 + 1024);
+    p.copy_xc = (size_t)std::min<uint64_t>(p.xper_arena * LPHQ_RUN_ARENAS, (uint64_t)xc_hint * 3 / 2 + windows / 1024 + 4096);
+    return p;
+}
+static hipError_t grow_runs(SessionSlot& sl, const RunPlan& p) {
+    hipError_t e = grow_device(sl.d_runs, sl.d_runs_cap, p.per_arena * LPHQ_RUN_ARENAS);
+    if (e == hipSuccess) e = grow_device(sl.d_xc, sl.d_xc_cap, p.xper_arena * LPHQ_RUN_ARENAS);
+    if (e == hipSuccess) e = grow_device(sl.d_counts, sl.d_counts_cap, (size_t)LPHQ_RUN_ARENAS + 1);  // the last entry holds the four totals
+    if (e == hipSuccess) e = grow_device(sl.d_dense, sl.d_dense_cap, p.per_arena * LPHQ_RUN_ARENAS);
+    if (e == hipSuccess) e = grow_device(sl.d_xdense, sl.d_xdense_cap, p.xper_arena * LPHQ_RUN_ARENAS);
+    if (e == hipSuccess) e = grow_pinned(sl.h_runs, sl.h_runs_cap, p.per_arena * LPHQ_RUN_ARENAS);
+    if (e == hipSuccess) e = grow_pinned(sl.h_xc, sl.h_xc_cap, p.copy_xc);
+    if (e == hipSuccess) e = grow_pinned(sl.h_totals, sl.h_totals_cap, 4);
+    return e;
+}
+// which transport lphq_session_submit(streaming = 1) uses for LP-MPHF handles: runs (default) or codes (LPHQ_SESSION_TRANSPORT=codes: A/B runs)
+static bool default_transport_is_runs() {
+    static const bool runs = [] {
+        const char* e = getenv("LPHQ_SESSION_TRANSPORT");
+        return !(e && std::string(e) == "codes");
+    }();
+    return runs;
+}
+
+// grow, keeping the first `keep` entries (a batch's unasked copy is already there when the rest is fetched)
+template <typename T>
+static hipError_t grow_pinned_keep(T*& p, size_t& cap, size_t want, size_t keep) {
+    if (want <= cap) return hipSuccess;
+    T* q = nullptr;
+    const size_t n = want + want / 4 + 64;
+    const hipError_t e = hipHostMalloc((void**)&q, n * sizeof(T), hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    if (p && keep) memcpy(q, p, keep * sizeof(T));
+    if (p) (void)hipHostFree(p);
+    p = q;
+    cap = n;
+    return hipSuccess;
+}
+
 extern "C" int lphq_session_reserve(lphq_session* s, size_t total_bases, size_t n_records) {
     if (!s) return fail(LPHQ_ERR_ARG, "null argument");
     if (s->submitted != s->collected) return fail(LPHQ_ERR_STATE, "batches in flight: collect them first");
-    DeviceGuard g(s->device);
-    for (int i = 0; i < s->depth; ++i) {
-        SessionSlot& sl = s->slot[i];
+    const bool runs = s->idx->hdr.kind < LPHQ_PTHASH;
+    for (SessionSlot& sl : s->slot) {
+        DeviceGuard g(sl.lane->device);
         HIP_TRY(grow_device(sl.d_seq, sl.d_seq_cap, total_bases + 64));
         HIP_TRY(grow_device(sl.d_out, sl.d_out_cap, total_bases + 16));  // (windows <= bases)
         HIP_TRY(grow_device(sl.d_offs, sl.d_offs_cap, 2 * (n_records + 1) + 1));
         HIP_TRY(grow_pinned(sl.h_offs, sl.h_offs_cap, 2 * (n_records + 1) + 1));
         HIP_TRY(grow_pinned(sl.h_out, sl.h_out_cap, total_bases + 16));
+        if (runs) HIP_TRY(grow_runs(sl, plan_runs(s->idx->hdr, total_bases, total_bases, n_records, 0, false)));
     }
+    if (runs && !s->pool) s->pool.reset(new (std::nothrow) WorkPool(std::min(usable_cpus(), 16)));  // (thread creation before the caller's timer, like the buffers)
     return LPHQ_OK;
 }
 
-extern "C" int lphq_session_submit(lphq_session* s, const char* const* records, const size_t* lengths, size_t n, int streaming) {
+// the runs of a batch into its slot: kernel -> arenas -> one dense array -> the first p.copy_* entries to pinned memory (the rest, if any, when the batch is collected)
+static int queue_runs(lphq_session* s, SessionSlot& sl, const RunPlan& p) {
+    const lphq_index* idx = s->idx;
+    const SessionLane& ln = *sl.lane;
+    const size_t n = sl.n_records;
+    const S8RunsArgs sink{sl.d_runs, sl.d_xc, sl.d_counts, (uint64_t)p.per_arena, (uint64_t)p.xper_arena};
+    unsigned long long* d_totals = (unsigned long long*)(sl.d_counts + LPHQ_RUN_ARENAS);
+    HIP_TRY_DRAIN(launch_query_records_runs(idx->hdr, ln.d_image, sl.d_seq, sl.total_bases, sl.d_offs, sl.d_offs + n + 1, n, sink, ln.stream), ln.stream);
+    HIP_TRY_DRAIN(launch_compact_runs(sl.d_runs, p.per_arena, sl.d_xc, p.xper_arena, sl.d_counts, sl.d_dense, p.per_arena * LPHQ_RUN_ARENAS, sl.d_xdense,
+                                      p.xper_arena * LPHQ_RUN_ARENAS, d_totals, ln.stream), ln.stream);
+    HIP_TRY_DRAIN(hipMemcpyAsync(sl.h_totals, d_totals, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ln.stream), ln.stream);
+    sl.copied_runs = std::min(p.copy_runs, sl.h_runs_cap);
+    sl.copied_xc = std::min(p.copy_xc, sl.h_xc_cap);
+    HIP_TRY_DRAIN(hipMemcpyAsync(sl.h_runs, sl.d_dense, sl.copied_runs * sizeof(lphq_run), hipMemcpyDeviceToHost, ln.stream), ln.stream);
+    HIP_TRY_DRAIN(hipMemcpyAsync(sl.h_xc, sl.d_xdense, sl.copied_xc * sizeof(uint64_t), hipMemcpyDeviceToHost, ln.stream), ln.stream);
+    sl.per_arena = p.per_arena;
+    sl.xper_arena = p.xper_arena;
+    return LPHQ_OK;
+}
+
+static int session_submit(lphq_session* s, const char* const* records, const size_t* lengths, size_t n, int streaming, bool want_runs) {
     if (!s || (n && (!records || !lengths))) return fail(LPHQ_ERR_ARG, "null argument");
     if (n > 0xFFFFFFFFull) return fail(LPHQ_ERR_ARG, "more than 2^32-1 records in one batch");
-    if (s->submitted - s->collected >= (uint64_t)s->depth) return fail(LPHQ_ERR_STATE, "all batches of the session are in flight: collect one first");
+    if (s->submitted - s->collected >= (uint64_t)s->slot.size()) return fail(LPHQ_ERR_STATE, "all batches of the session are in flight: collect one first");
     lphq_index* idx = s->idx;
     const uint32_t k = idx->hdr.k;
     if (idx->hdr.kind >= LPHQ_PTHASH) streaming = 1;  // (as lphq_query_contig: the competitor functions yield nothing for windows holding a non-ACGT base)
-    SessionSlot& sl = s->slot[s->submitted % (uint64_t)s->depth];
-    DeviceGuard g(s->device);
+    SessionSlot& sl = s->slot[s->submitted % (uint64_t)s->slot.size()];
+    const SessionLane& ln = *sl.lane;
+    DeviceGuard g(ln.device);
     uint64_t so = 0, oo = 0;
     for (size_t i = 0; i < n; ++i) {
         if (lengths[i] && !records[i]) return fail(LPHQ_ERR_ARG, "null record");
         so += lengths[i];
         oo += lengths[i] >= k ? lengths[i] - k + 1 : 0;
     }
+    const bool runs = want_runs && streaming && idx->hdr.kind < LPHQ_PTHASH && so < (1ull << 40);
+    RunPlan plan{};
     HIP_TRY(grow_device(sl.d_seq, sl.d_seq_cap, (size_t)so + 64));
-    HIP_TRY(grow_device(sl.d_out, sl.d_out_cap, (size_t)oo + 16));
     HIP_TRY(grow_device(sl.d_offs, sl.d_offs_cap, 2 * (n + 1) + 1));
     HIP_TRY(grow_pinned(sl.h_offs, sl.h_offs_cap, 2 * (n + 1) + 1));
-    HIP_TRY(grow_pinned(sl.h_out, sl.h_out_cap, (size_t)oo + 16));
+    if (runs) {
+        plan = plan_runs(idx->hdr, oo, so, n, s->xc_hint, false);
+        HIP_TRY(grow_runs(sl, plan));
+    } else {
+        HIP_TRY(grow_device(sl.d_out, sl.d_out_cap, (size_t)oo + 16));
+        HIP_TRY(grow_pinned(sl.h_out, sl.h_out_cap, (size_t)oo + 16));
+    }
     uint64_t a = 0, o = 0;
     for (size_t i = 0; i < n; ++i) {
         sl.h_offs[i] = a;
@@ -996,39 +1171,139 @@ extern "C" int lphq_session_submit(lphq_session* s, const char* const* records, 
     sl.n_out = (size_t)oo;
     sl.total_bases = (size_t)so;
     sl.streaming = streaming != 0;
+    sl.runs_mode = runs;
+    sl.expanded = false;
     // one copy per run of records that follow each other in the caller's memory
     size_t at = 0;
     for (size_t i = 0; i < n;) {
         const char* run = records[i];
         size_t len = lengths[i], j = i + 1;
         while (j < n && (lengths[j] == 0 || records[j] == run + len)) len += lengths[j++];
-        if (len) HIP_TRY_DRAIN(hipMemcpyAsync(sl.d_seq + at, run, len, hipMemcpyHostToDevice, s->stream), s->stream);
+        if (len) HIP_TRY_DRAIN(hipMemcpyAsync(sl.d_seq + at, run, len, hipMemcpyHostToDevice, ln.stream), ln.stream);
         at += len;
         i = j;
     }
-    HIP_TRY_DRAIN(hipMemcpyAsync(sl.d_offs, sl.h_offs, (2 * (n + 1) + 1) * 8, hipMemcpyHostToDevice, s->stream), s->stream);
-    if (oo) {
-        HIP_TRY_DRAIN(launch_query_records(idx->hdr, s->d_image, sl.d_seq, so, sl.d_offs, sl.d_offs + n + 1, n, sl.d_out, streaming, s->stream), s->stream);
-        if (streaming) {
-            HIP_TRY_DRAIN(launch_count_bad_bases(sl.d_seq, (size_t)so, (unsigned long long*)(sl.d_offs + 2 * n + 2), s->stream), s->stream);
-            HIP_TRY_DRAIN(hipMemcpyAsync(sl.h_offs + 2 * n + 2, sl.d_offs + 2 * n + 2, 8, hipMemcpyDeviceToHost, s->stream), s->stream);
+    HIP_TRY_DRAIN(hipMemcpyAsync(sl.d_offs, sl.h_offs, (2 * (n + 1) + 1) * 8, hipMemcpyHostToDevice, ln.stream), ln.stream);
+    if (runs) {
+        if (sl.h_totals) sl.h_totals[0] = sl.h_totals[1] = sl.h_totals[2] = sl.h_totals[3] = 0;
+        if (oo) {
+            const int rc = queue_runs(s, sl, plan);
+            if (rc) return rc;
+            HIP_TRY_DRAIN(launch_count_bad_bases(sl.d_seq, (size_t)so, (unsigned long long*)(sl.d_offs + 2 * n + 2), ln.stream), ln.stream);
+            HIP_TRY_DRAIN(hipMemcpyAsync(sl.h_offs + 2 * n + 2, sl.d_offs + 2 * n + 2, 8, hipMemcpyDeviceToHost, ln.stream), ln.stream);
         }
-        HIP_TRY_DRAIN(hipMemcpyAsync(sl.h_out, sl.d_out, (size_t)oo * 8, hipMemcpyDeviceToHost, s->stream), s->stream);
+    } else if (oo) {
+        HIP_TRY_DRAIN(launch_query_records(idx->hdr, ln.d_image, sl.d_seq, so, sl.d_offs, sl.d_offs + n + 1, n, sl.d_out, streaming, ln.stream), ln.stream);
+        if (streaming) {
+            HIP_TRY_DRAIN(launch_count_bad_bases(sl.d_seq, (size_t)so, (unsigned long long*)(sl.d_offs + 2 * n + 2), ln.stream), ln.stream);
+            HIP_TRY_DRAIN(hipMemcpyAsync(sl.h_offs + 2 * n + 2, sl.d_offs + 2 * n + 2, 8, hipMemcpyDeviceToHost, ln.stream), ln.stream);
+        }
+        HIP_TRY_DRAIN(hipMemcpyAsync(sl.h_out, sl.d_out, (size_t)oo * 8, hipMemcpyDeviceToHost, ln.stream), ln.stream);
     }
-    HIP_TRY_DRAIN(hipEventRecord(sl.done, s->stream), s->stream);
+    HIP_TRY_DRAIN(hipEventRecord(sl.done, ln.stream), ln.stream);
     sl.in_flight = true;
     ++s->submitted;
     return LPHQ_OK;
 }
 
-extern "C" int lphq_session_collect(lphq_session* s, const uint64_t** codes, const uint64_t** offsets, size_t* n_records) {
-    if (!s || !codes || !offsets || !n_records) return fail(LPHQ_ERR_ARG, "null argument");
-    if (s->submitted == s->collected) return fail(LPHQ_ERR_STATE, "no batch in flight");
-    SessionSlot& sl = s->slot[s->collected % (uint64_t)s->depth];
-    DeviceGuard g(s->device);
+extern "C" int lphq_session_submit(lphq_session* s, const char* const* records, const size_t* lengths, size_t n, int streaming) {
+    return session_submit(s, records, lengths, n, streaming, default_transport_is_runs());
+}
+extern "C" int lphq_session_submit_runs(lphq_session* s, const char* const* records, const size_t* lengths, size_t n) {
+    if (s && s->idx->hdr.kind >= LPHQ_PTHASH) return fail(LPHQ_ERR_ARG, "run-encoded results exist for LP-MPHF handles only (a competitor's codes are not affine)");
+    return session_submit(s, records, lengths, n, 1, true);
+}
+
+// Wait for the oldest batch; a runs batch is completed here: whatever the unasked copies left behind is fetched, and a batch whose arenas overflowed
+// (the estimate is for random sequence; a homopolymer run has one super-k-mer per window) is answered again with worst-case arenas.  Synchronous, rare.
+static int session_wait(lphq_session* s, SessionSlot& sl) {
+    const SessionLane& ln = *sl.lane;
     HIP_TRY(hipEventSynchronize(sl.done));
     sl.in_flight = false;
     ++s->collected;
+    if (!sl.runs_mode || sl.n_out == 0) return LPHQ_OK;
+    if (sl.h_totals[2]) {
+        const RunPlan p = plan_runs(s->idx->hdr, sl.n_out, sl.total_bases, sl.n_records, 0, true);
+        HIP_TRY(grow_runs(sl, p));
+        const int rc = queue_runs(s, sl, p);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(ln.stream));
+        if (sl.h_totals[2]) return fail(LPHQ_ERR_HIP, "internal: the run-encoded result overflowed worst-case arenas");
+    }
+    const size_t nr = (size_t)sl.h_totals[0], nx = (size_t)sl.h_totals[1];
+    if (nr > sl.copied_runs) {
+        HIP_TRY(grow_pinned_keep(sl.h_runs, sl.h_runs_cap, nr, sl.copied_runs));
+        HIP_TRY(hipMemcpyAsync(sl.h_runs + sl.copied_runs, sl.d_dense + sl.copied_runs, (nr - sl.copied_runs) * sizeof(lphq_run), hipMemcpyDeviceToHost, ln.stream));
+    }
+    if (nx > sl.copied_xc) {
+        HIP_TRY(grow_pinned_keep(sl.h_xc, sl.h_xc_cap, nx, sl.copied_xc));
+        HIP_TRY(hipMemcpyAsync(sl.h_xc + sl.copied_xc, sl.d_xdense + sl.copied_xc, (nx - sl.copied_xc) * sizeof(uint64_t), hipMemcpyDeviceToHost, ln.stream));
+    }
+    if (nr > sl.copied_runs || nx > sl.copied_xc) HIP_TRY(hipStreamSynchronize(ln.stream));
+    s->xc_hint = nx;
+    return LPHQ_OK;
+}
+
+extern "C" int lphq_session_collect_runs(lphq_session* s, const lphq_run** runs, size_t* n_runs, const uint64_t** explicit_codes, size_t* n_codes,
+                                         uint64_t* n_windows, const uint64_t** offsets, size_t* n_records) {
+    if (!s || !runs || !n_runs || !explicit_codes || !n_codes || !offsets || !n_records) return fail(LPHQ_ERR_ARG, "null argument");
+    if (s->submitted == s->collected) return fail(LPHQ_ERR_STATE, "no batch in flight");
+    SessionSlot& sl = s->slot[s->collected % (uint64_t)s->slot.size()];
+    if (!sl.runs_mode) return fail(LPHQ_ERR_STATE, "the oldest batch was not submitted with lphq_session_submit_runs: lphq_session_collect hands out its codes");
+    DeviceGuard g(sl.lane->device);
+    const int rc = session_wait(s, sl);
+    if (rc) return rc;
+    *runs = sl.h_runs;
+    *n_runs = sl.n_out ? (size_t)sl.h_totals[0] : 0;
+    *explicit_codes = sl.h_xc;
+    *n_codes = sl.n_out ? (size_t)sl.h_totals[1] : 0;
+    if (n_windows) *n_windows = sl.n_out ? (uint64_t)sl.h_totals[3] : 0;
+    *offsets = sl.h_offs + sl.n_records + 1;
+    *n_records = sl.n_records;
+    return LPHQ_OK;
+}
+
+// out[first + i] for every run, on the pool's threads (pieces of 2048 runs: ~13 K windows, ~100 KB of stores each at k = 31 / m = 20)
+static void expand_runs_host(const lphq_run* runs, size_t n, const uint64_t* xc, uint64_t* out, WorkPool* pool) {
+    constexpr size_t kPiece = 2048;
+    auto piece = [&](size_t pi) {
+        const size_t hi = std::min(n, (pi + 1) * kPiece);
+        for (size_t r = pi * kPiece; r < hi; ++r) {
+            const lphq_run run = runs[r];
+            uint64_t* dst = out + LPHQ_RUN_FIRST(run);
+            const uint32_t len = LPHQ_RUN_LENGTH(run), kind = LPHQ_RUN_KIND(run);
+            if (kind == LPHQ_RUN_UP) {
+                for (uint32_t i = 0; i < len; ++i) dst[i] = run.code + i;
+            } else if (kind == LPHQ_RUN_DOWN) {
+                for (uint32_t i = 0; i < len; ++i) dst[i] = run.code - i;
+            } else {
+                memcpy(dst, xc + run.code, (size_t)len * sizeof(uint64_t));
+            }
+        }
+    };
+    const size_t pieces = (n + kPiece - 1) / kPiece;
+    if (pool) pool->run(pieces, piece);
+    else
+        for (size_t pi = 0; pi < pieces; ++pi) piece(pi);
+}
+
+extern "C" int lphq_session_collect(lphq_session* s, const uint64_t** codes, const uint64_t** offsets, size_t* n_records) {
+    if (!s || !codes || !offsets || !n_records) return fail(LPHQ_ERR_ARG, "null argument");
+    if (s->submitted == s->collected) return fail(LPHQ_ERR_STATE, "no batch in flight");
+    SessionSlot& sl = s->slot[s->collected % (uint64_t)s->slot.size()];
+    DeviceGuard g(sl.lane->device);
+    {
+        const int rc = session_wait(s, sl);
+        if (rc) return rc;
+    }
+    if (sl.runs_mode && sl.n_out && !sl.expanded) {
+        // the batch crossed PCIe as runs; the caller wants the reference's vector: expanded here, by the pool's threads, into the slot's code buffer
+        // (window i of the batch at h_out[i]; windows holding a non-ACGT base are in no run and are dropped below, from the input bases as ever)
+        HIP_TRY(grow_pinned(sl.h_out, sl.h_out_cap, sl.n_out + 16));
+        if (!s->pool) s->pool.reset(new (std::nothrow) WorkPool(std::min(usable_cpus(), 16)));
+        expand_runs_host(sl.h_runs, (size_t)sl.h_totals[0], sl.h_xc, sl.h_out, s->pool.get());
+        sl.expanded = true;
+    }
     const size_t n = sl.n_records;
     const uint32_t k = s->idx->hdr.k;
     *codes = sl.h_out;

@@ -132,12 +132,17 @@ public:
     FastxBatchReader(const FastxBatchReader&) = delete;
     FastxBatchReader& operator=(const FastxBatchReader&) = delete;
 
+    // How many batches the caller holds at once (default 2: the one being consumed and the one being filled; a driver that keeps depth x GPUs batches in
+    // flight asks for that many + 1).  Before the first next() / prealloc().
+    void set_live_batches(int n) {
+        if (n >= 2 && arenas_[0].p == nullptr && arenas_[1].p == nullptr) arenas_.resize((size_t)n);
+    }
     // Allocate both arenas for batches of about batch_bases bases now (e.g. before a caller starts its timer: pinned host memory
     // is expensive to allocate); next() grows them if a batch needs more.
     void prealloc(size_t batch_bases) {
         const size_t want = map_ ? std::min(size_, batch_bases + (batch_bases >> 3) + (1 << 16)) : batch_bases + (batch_bases >> 3) + (1 << 16);
-        for (int i = 0; i < 2 && ok_; ++i) {
-            which_ ^= 1;
+        for (size_t i = 0; i < arenas_.size() && ok_; ++i) {
+            which_ = (which_ + 1) % (int)arenas_.size();
             (void)reserve(want);
         }
         if (!pool_ && threads_ > 1 && !serial_) pool_ = new WorkPool(threads_);  // the parse threads, parked
@@ -159,7 +164,7 @@ public:
     // Returns false when there is nothing left.
     bool next(FastxBatch& b, size_t batch_bases) {
         b.clear();
-        which_ ^= 1;
+        which_ = (which_ + 1) % (int)arenas_.size();
         if (bgzf_ && !windowed_ && !serial_ && !bgzf_index()) {  // first call on a BGZF file; on any irregularity the serial reader takes the whole file
             serial_ = new FastxReader(path_.c_str());
             if (!serial_->ok()) ok_ = false;
@@ -665,7 +670,7 @@ private:
     bool gz_done_ = false;
     FastxReader* serial_ = nullptr;
     bool serial_done_ = false, ok_ = false;
-    Arena arenas_[2];
+    std::vector<Arena> arenas_ = std::vector<Arena>(2);  // the batches a caller may hold at once (set_live_batches)
     int which_ = 0;
 };
 

@@ -188,6 +188,8 @@ hipError_t launch_expand_runs(const lphq_run* d_runs, uint64_t arena_runs, const
 hipError_t launch_compact_runs(const lphq_run* d_runs, uint64_t arena_runs, const uint64_t* d_codes, uint64_t arena_codes, const lphq_run_counts* d_counts,
                                lphq_run* d_dense_runs, uint64_t cap_dense_runs, uint64_t* d_dense_codes, uint64_t cap_dense_codes, unsigned long long* d_totals,
                                hipStream_t stream) {
+    const hipError_t e = hipMemsetAsync(d_totals, 0, 4 * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
     const int gx = grid_for((size_t)std::min<uint64_t>(std::max(arena_runs, arena_codes), (uint64_t)1 << 31), kBlock * 4, 256);
     k_compact_runs<><<<dim3((unsigned)gx, LPHQ_RUN_ARENAS), kBlock, 0, stream>>>(d_runs, arena_runs, d_codes, arena_codes, d_counts, d_dense_runs, cap_dense_runs, d_dense_codes,
                                                                              cap_dense_codes, d_totals);

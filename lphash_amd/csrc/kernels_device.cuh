@@ -924,7 +924,8 @@ __global__ __launch_bounds__(kBlock) void k_expand_runs(const lphq_run* __restri
 }
 
 // Sessions move a batch's runs over PCIe as ONE dense array: arena after arena, explicit-code indices rebased to the dense code array.  totals[0] = runs,
-// totals[1] = explicit codes, totals[2] = 1 if an arena had overflowed (the batch must be answered some other way).  Every workgroup works the 32 prefix sums
+// totals[1] = explicit codes, totals[2] = 1 if an arena had overflowed (the batch must be answered some other way), totals[3] = windows in all runs (what the
+// reference's vector.size() adds up to over the batch; zeroed by the launcher).  Every workgroup works the 32 prefix sums
 // out for itself (a few hundred instructions; no second launch, no scan library).
 template <int BLOCK = kBlock>
 __global__ __launch_bounds__(kBlock) void k_compact_runs(const lphq_run* __restrict__ runs, uint64_t arena_runs, const uint64_t* __restrict__ codes, uint64_t arena_codes,
@@ -958,11 +959,15 @@ __global__ __launch_bounds__(kBlock) void k_compact_runs(const lphq_run* __restr
     const uint32_t a = blockIdx.y;
     const uint64_t nr = sm_rbase[a + 1] - sm_rbase[a], nx = sm_xbase[a + 1] - sm_xbase[a];
     const lphq_run* const src = runs + (uint64_t)a * arena_runs;
+    unsigned long long windows = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + tid; i < nr; i += (uint64_t)gridDim.x * kBlock) {
         lphq_run r = src[i];
         if (LPHQ_RUN_KIND(r) == (uint32_t)LPHQ_RUN_EXPLICIT) r.code += sm_xbase[a];
         dense_runs[sm_rbase[a] + i] = r;
+        windows += LPHQ_RUN_LENGTH(r);
     }
+    for (int o = 32; o > 0; o >>= 1) windows += __shfl_down(windows, o, 64);
+    if ((tid & 63u) == 0u && windows) atomicAdd(&totals[3], windows);
     const uint64_t* const xsrc = codes + (uint64_t)a * arena_codes;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + tid; i < nx; i += (uint64_t)gridDim.x * kBlock) dense_codes[sm_xbase[a] + i] = xsrc[i];
 }

@@ -199,6 +199,7 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
     __shared__ uint64_t sm_rtab[2 * kS8RecCap + 1];   // multi-record tiles: the tile's slice of seq_off / out_off
     __shared__ uint32_t sm_wlead[BLOCK / 64];         // kSinkRuns: leaders per wave (a run's slot = the tile's reservation + the leaders of the waves before + its rank in its wave)
     __shared__ uint64_t sm_tile_at;                   // kSinkRuns: first entry of the tile's reservation in its arena
+    __shared__ uint32_t sm_anycoll;                   // kSinkRuns: a leader of the tile sits under a colliding minimizer (only then does phase F look at every window)
     const uint32_t tid = threadIdx.x;
     const uint32_t k = H.k, m = H.m, W = H.W;
     const uint32_t TW = stream_tile_windows(W, kS8Pos);
@@ -239,6 +240,7 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
             sm_roff[1] = e0;
             sm_roff[2] = out_off[r];
             sm_count = 0;
+            if (SINK == kSinkRuns) sm_anycoll = 0;
         }
     }
     if (tid < 12u) sm_badb[NDW + tid] = 0xFu;  // beyond the tile's dwords: not bases
@@ -421,6 +423,7 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
             extract_kmer<false>(sm_words, q, m, mm, hi);
             const LookupCtx c = lookup_ctx<KIND, K128, P>(img, H, mm);
             sm_hash[hslot8<BLOCK>(q)] = c.base | ((uint64_t)c.mode << LPHQ_TAIL_MODE_SHIFT);  // (bases are ranks < 2^62: the packing of the image's tail table)
+            if (SINK == kSinkRuns && c.mode == 2u) sm_anycoll = 1u;
         }
     };
     // (uniform) the common case: one round over the queue as phase D filled it (super-k-mers average (W + 1) / 2 windows).  More leaders than the queue
@@ -455,7 +458,18 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
     // ---- F: the lane's eight codes ----
     uint64_t hv[8];
     uint32_t modes = 0;  // OR of the mode fields of the lane's windows (bit 1: a colliding minimizer)
-    if (plain) {
+    if (SINK == kSinkRuns) {
+        // the runs sink needs a code per LEADER (worked out where the run is written) and, in the rare tile that holds a colliding leader, which of the
+        // lane's windows sit under a colliding minimizer: their codes are explicit
+        if (sm_anycoll) {
+#pragma unroll
+            for (uint32_t jw = 0; jw < 8; ++jw) {
+                const bool valid = plain ? a < TW : code[jw] < 0xFFFEu;
+                const uint32_t mode = (uint32_t)(sm_hash[hslot8<BLOCK>(code[jw] & (uint32_t)(kS8Pos - 1))] >> LPHQ_TAIL_MODE_SHIFT);
+                modes |= valid ? mode : 0u;
+            }
+        }
+    } else if (plain) {
         // the codes of lanes at or beyond TW are never stored (the stores below are bounded by w_hi = TW): nothing to invalidate per window
 #pragma unroll
         for (uint32_t jw = 0; jw < 8; ++jw) {
@@ -550,13 +564,11 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
         }
     }
     } else {
-        // ---- the other two sinks: where each of the lane's windows sits in the code space (what the codes sink computes on its way to the stores) ----
-        uint64_t oidx[8];
-        if (one_record) {
-            const uint64_t first0 = sm_roff[2] + (t0 - shift - sm_roff[0]);  // window 0 of the tile (wraps harmlessly for windows before the record)
-#pragma unroll
-            for (uint32_t jw = 0; jw < 8; ++jw) oidx[jw] = first0 + a + jw;
-        } else {
+        // ---- the other two sinks ----
+        // where the lane's windows sit in the code space (what the codes sink computes on its way to the stores): one record under the tile -> window i of
+        // the tile is at first0 + i; several -> the walk of phase C again, from the record found there
+        const uint64_t first0 = sm_roff[2] + (t0 - shift - sm_roff[0]);  // (wraps harmlessly for windows before the record)
+        auto walk_windows = [&](uint64_t (&oidx)[8]) {
             const bool cached = rhi - rlo < (uint32_t)kS8RecCap;
             uint32_t j = jrec;
             uint64_t rs = cached ? sm_rtab[j] : seq_off[rlo + j], re = cached ? sm_rtab[j + 1] : seq_off[rlo + j + 1];
@@ -568,7 +580,7 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
                 rec_walk(sm_rtab, seq_off, rlo, cached, g, j, rs, re);
                 oidx[jw] = tile_record_out<kS8RecCap>(sm_rtab, out_off, rlo, rhi, j) + (g - rs);
             }
-        }
+        };
         if constexpr (SINK == kSinkRuns) {
             // One lphq_run per leader: the windows from the leader up to the next leader, the next window that is no window (non-ACGT base, record end,
             // tile end) or the end of the wave, whichever comes first -- inside it the minimizer stays where it is, so the code moves by -1 (mode 0:
@@ -612,54 +624,67 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
 #pragma unroll
             for (uint32_t wv = 0; wv + 1u < (uint32_t)BLOCK / 64u; ++wv) slot += (tid >> 6) > wv ? sm_wlead[wv] : 0u;
             lphq_run* const rdst = sink.runs + (uint64_t)arena * sink.arena_runs;
+            auto emit = [&](uint32_t jw, uint64_t first) {  // the run led by the lane's window jw, whose index in the code space is `first`
+                const uint32_t nb = jw == 7u ? 0u : (bmask >> (jw + 1u));
+                const uint32_t len = nb ? (uint32_t)__ffsll((long long)nb) : (8u - jw) + ahead;
+                const uint32_t mode = (uint32_t)(sm_hash[hslot8<BLOCK>(code[jw] & (uint32_t)(kS8Pos - 1))] >> LPHQ_TAIL_MODE_SHIFT);
+                lphq_run r;
+                {
+                    const uint64_t packed = sm_hash[hslot8<BLOCK>(code[jw] & (uint32_t)(kS8Pos - 1))];
+                    const uint32_t p = (code[jw] & (uint32_t)(kS8Pos - 1)) - (a + jw);  // offset of the minimizer in the leader's window
+                    const uint64_t base = packed & LPHQ_TAIL_BASE_MASK;
+                    r.code = mode == 2u ? xat + (uint64_t)__popc(coll & ((1u << jw) - 1u)) : (mode == 0u ? base + p : base - p);
+                }
+                r.where = (first & 0xFFFFFFFFFFull) | ((uint64_t)len << 40) | ((uint64_t)(mode == 2u ? (uint32_t)LPHQ_RUN_EXPLICIT : (mode ^ 1u)) << 62);
+                if (slot < sink.arena_runs) rdst[slot] = r;
+                ++slot;
+            };
             if (lmask) {
+                if (one_record) {
 #pragma unroll
-                for (uint32_t jw = 0; jw < 8; ++jw)
-                    if ((lmask >> jw) & 1u) {
-                        const uint32_t nb = jw == 7u ? 0u : (bmask >> (jw + 1u));
-                        const uint32_t len = nb ? (uint32_t)__ffsll((long long)nb) : (8u - jw) + ahead;
-                        const uint32_t mode = (uint32_t)(sm_hash[hslot8<BLOCK>(code[jw] & (uint32_t)(kS8Pos - 1))] >> LPHQ_TAIL_MODE_SHIFT);
-                        lphq_run r;
-                        r.code = mode == 2u ? xat + (uint64_t)__popc(coll & ((1u << jw) - 1u)) : hv[jw];
-                        r.where = (oidx[jw] & 0xFFFFFFFFFFull) | ((uint64_t)len << 40) | ((uint64_t)(mode == 2u ? (uint32_t)LPHQ_RUN_EXPLICIT : (mode ^ 1u)) << 62);
-                        if (slot < sink.arena_runs) rdst[slot] = r;
-                        ++slot;
-                    }
+                    for (uint32_t jw = 0; jw < 8; ++jw)
+                        if ((lmask >> jw) & 1u) emit(jw, first0 + a + jw);
+                } else {
+                    uint64_t oidx[8];
+                    walk_windows(oidx);
+#pragma unroll
+                    for (uint32_t jw = 0; jw < 8; ++jw)
+                        if ((lmask >> jw) & 1u) emit(jw, oidx[jw]);
+                }
             }
         } else {
             // table[code] per window; element size uniform over the launch.  A lane's eight elements are 8 << el contiguous bytes of the output:
             // staged through LDS like the codes and copied out in 16-byte pieces when the tile lies in one record.
             const uint32_t el = sink.elem_log2;
-            uint64_t pv[8], pk[8];  // the lane's eight elements, and the same as a little-endian byte stream of 8 << el bytes
-            {
+            uint64_t pv[8];  // the lane's eight elements
 #pragma unroll
-                for (uint32_t jw = 0; jw < 8; ++jw) {
-                    const uint64_t c = hv[jw];
-                    const bool in = c < sink.n_slots;  // (LPHQ_INVALID and a non-member's wrapped code are not slots)
-                    const uint64_t i = in ? c : 0ull;
-                    uint64_t v;
-                    if (el == 0u) v = sink.table[i];
-                    else if (el == 1u) v = ((const uint16_t*)sink.table)[i];
-                    else if (el == 2u) v = ((const uint32_t*)sink.table)[i];
-                    else v = ((const uint64_t*)sink.table)[i];
-                    pv[jw] = in ? v : sink.missing;
-                }
-                if (el == 3u) {
+            for (uint32_t jw = 0; jw < 8; ++jw) {
+                const uint64_t c = hv[jw];
+                const bool in = c < sink.n_slots;  // (LPHQ_INVALID and a non-member's wrapped code are not slots)
+                const uint64_t i = in ? c : 0ull;
+                uint64_t v;
+                if (el == 0u) v = sink.table[i];
+                else if (el == 1u) v = ((const uint16_t*)sink.table)[i];
+                else if (el == 2u) v = ((const uint32_t*)sink.table)[i];
+                else v = ((const uint64_t*)sink.table)[i];
+                pv[jw] = in ? v : sink.missing;
+            }
+            // ... as a little-endian byte stream of 8 << el bytes: 1 << el words, in place
+            auto pack = [&]() {
+                if (el == 2u) {
 #pragma unroll
-                    for (uint32_t i = 0; i < 8; ++i) pk[i] = pv[i];
-                } else if (el == 2u) {
-#pragma unroll
-                    for (uint32_t i = 0; i < 4; ++i) pk[i] = (pv[2 * i] & 0xFFFFFFFFull) | (pv[2 * i + 1] << 32);
+                    for (uint32_t i = 0; i < 4; ++i) pv[i] = (pv[2 * i] & 0xFFFFFFFFull) | (pv[2 * i + 1] << 32);
                 } else if (el == 1u) {
 #pragma unroll
                     for (uint32_t i = 0; i < 2; ++i)
-                        pk[i] = (pv[4 * i] & 0xFFFFull) | ((pv[4 * i + 1] & 0xFFFFull) << 16) | ((pv[4 * i + 2] & 0xFFFFull) << 32) | (pv[4 * i + 3] << 48);
-                } else {
-                    pk[0] = 0;
+                        pv[i] = (pv[4 * i] & 0xFFFFull) | ((pv[4 * i + 1] & 0xFFFFull) << 16) | ((pv[4 * i + 2] & 0xFFFFull) << 32) | (pv[4 * i + 3] << 48);
+                } else if (el == 0u) {
+                    uint64_t w = 0;
 #pragma unroll
-                    for (uint32_t i = 0; i < 8; ++i) pk[0] |= (pv[i] & 0xFFull) << (8u * i);
+                    for (uint32_t i = 0; i < 8; ++i) w |= (pv[i] & 0xFFull) << (8u * i);
+                    pv[0] = w;
                 }
-            }
+            };
             struct __attribute__((packed, aligned(1))) u64a1 { uint64_t v; };
             struct __attribute__((packed, aligned(1))) u32a1 { uint32_t v; };
             struct __attribute__((packed, aligned(1))) u16a1 { uint16_t v; };
@@ -671,16 +696,17 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
                 else ((u64a1*)p)->v = v;
             };
             if (one_record) {
+                pack();
                 __syncthreads();  // (every lane has read the bases of its leaders)
                 uint64_t* const sm64 = sm_hash;
                 const uint32_t nq = 1u << el;  // 8-byte words per lane
 #pragma unroll
                 for (uint32_t i = 0; i < 8; ++i)
-                    if (i < nq) sm64[tid * nq + i] = pk[i];
+                    if (i < nq) sm64[tid * nq + i] = pv[i];
                 __syncthreads();
                 // bytes [w_lo << el, w_hi << el) of the staged tile -> the output, 16 at a time
                 const uint32_t lo_b = w_lo << el, hi_b = w_hi << el;
-                uint8_t* const dstb = sink.out + ((oidx[0] - a) << el);  // byte address of window 0 of the tile
+                uint8_t* const dstb = sink.out + (first0 << el);  // byte address of window 0 of the tile
                 typedef uint64_t u64x2a1 __attribute__((vector_size(16), aligned(1)));
                 for (uint32_t c = tid; c < (((uint32_t)kS8Pos << el) >> 4); c += (uint32_t)BLOCK) {
                     const uint32_t b0 = 16u * c;
@@ -694,19 +720,22 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
                     } else {  // a piece at the edge of the record: element by element
                         for (uint32_t e = 0; e < (16u >> el); ++e) {
                             const uint32_t w = (b0 >> el) + e, bit = (e << el) * 8u;
-                            if (w >= w_lo && w < w_hi) store_elem(oidx[0] - a + w, (bit < 64u ? v0 >> bit : v1 >> (bit - 64u)));
+                            if (w >= w_lo && w < w_hi) store_elem(first0 + w, (bit < 64u ? v0 >> bit : v1 >> (bit - 64u)));
                         }
                     }
                 }
             } else {
+                uint64_t oidx[8];
+                walk_windows(oidx);
                 bool all8 = oidx[7] == oidx[0] + 7u;
 #pragma unroll
                 for (uint32_t jw = 0; jw < 8; ++jw) all8 = all8 && code[jw] != 0xFFFEu;
                 if (all8) {  // eight windows of one record: 8 << el contiguous bytes
+                    pack();
                     uint8_t* const p = sink.out + (oidx[0] << el);
 #pragma unroll
                     for (uint32_t i = 0; i < 8; ++i)
-                        if (i < (1u << el)) ((u64a1*)(p + 8u * i))->v = pk[i];
+                        if (i < (1u << el)) ((u64a1*)(p + 8u * i))->v = pv[i];
                 } else {
 #pragma unroll
                     for (uint32_t jw = 0; jw < 8; ++jw)

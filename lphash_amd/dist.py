@@ -22,8 +22,16 @@ def shard_records(lengths, rank, world):
         return 0, 0
     cum = np.cumsum(lengths)
     total = int(cum[-1])
-    # shard r starts after the records that END at or before r / world of the bases (equal-length records split evenly: 1000 records, 2 ranks -> 500 + 500)
-    bounds = [int(np.searchsorted(cum, (total * r) // world, side="right")) for r in range(world)] + [len(lengths)]
+    # shard r starts at the record boundary NEAREST to r / world of the bases (equal-length records split evenly: 1000 records, 2 ranks -> 500 + 500; a long
+    # record that straddles the target goes to whichever side leaves the smaller imbalance, so every non-empty shard is within one record of its ideal)
+    bounds = []
+    for r in range(world):
+        target = (total * r) // world
+        i = int(np.searchsorted(cum, target, side="right"))  # records [0, i) end at or before the target
+        before = int(cum[i - 1]) if i > 0 else 0
+        after = int(cum[i]) if i < len(cum) else total
+        bounds.append(i if target - before <= after - target else i + 1)
+    bounds.append(len(lengths))
     bounds[0] = 0
     for i in range(1, len(bounds)):
         bounds[i] = max(bounds[i], bounds[i - 1])

@@ -147,7 +147,8 @@ extern "C" int emu_kernel_expand_runs(const lphq_run* runs, uint64_t cap_runs, c
 }
 
 extern "C" int emu_kernel_compact_runs(const lphq_run* runs, uint64_t cap_runs, const uint64_t* codes, uint64_t cap_codes, const lphq_run_counts* counts, lphq_run* dense_runs,
-                                       uint64_t cap_dense_runs, uint64_t* dense_codes, uint64_t cap_dense_codes, unsigned long long* totals /* 3 */) {
+                                       uint64_t cap_dense_runs, uint64_t* dense_codes, uint64_t cap_dense_codes, unsigned long long* totals /* 4 */) {
+    memset(totals, 0, 4 * sizeof *totals);
     for (unsigned a = 0; a < LPHQ_RUN_ARENAS; ++a) {
         emu::g_block_idx.y = a;
         emu::launch(2, kBlock, [&] {

@@ -45,10 +45,11 @@ def expand_runs_numpy(runs, codes, counts, n_out, invalid):
     return out
 
 
-def check_runs_against_codes(runs, codes, counts, exp, invalid):
+def check_runs_against_codes(runs, codes, counts, exp, invalid, valid=None):
     """The contract of lphq_query_records_runs against the expanded codes `exp` of the same batch (LPHQ_INVALID at windows that hold a non-ACGT base):
     counters inside the capacities, every valid window in exactly one run, no run over an invalid window, lengths >= 1, kinds in {UP, DOWN, EXPLICIT},
-    explicit runs inside their arena's code array.  Returns the number of runs per kind."""
+    explicit runs inside their arena's code array.  valid: bool per window, from the BASES (a non-member k-mer's wrapped arithmetic may legitimately yield
+    2^64 - 1, which a comparison with LPHQ_INVALID would take for a non-ACGT window); default: exp != invalid.  Returns the number of runs per kind."""
     n_out = len(exp)
     cover = np.zeros(n_out + 1, dtype=np.int64)
     kinds = [0, 0, 0]
@@ -65,6 +66,7 @@ def check_runs_against_codes(runs, codes, counts, exp, invalid):
         for kd in range(3):
             kinds[kd] += int((kind == kd).sum())
     cover = np.cumsum(cover)[:n_out]
-    valid = exp != np.uint64(invalid)
+    if valid is None:
+        valid = exp != np.uint64(invalid)
     assert np.array_equal(cover, valid.astype(np.int64)), "every window without a non-ACGT base belongs to exactly one run, the others to none"
     return kinds

@@ -33,6 +33,25 @@ def test_shard_records_partitions():
         assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
 
 
+def test_shard_records_skewed_lengths_stay_within_one_record_of_the_ideal():
+    """a record that straddles a shard boundary goes to the side that leaves the smaller imbalance -- [1000, 1, 1, 1] over two ranks is
+    (record 0) + (records 1-3), not (nothing) + (everything); every boundary lies within one record of its ideal base count."""
+    assert [shard_records([1000, 1, 1, 1], r, 2) for r in range(2)] == [(0, 1), (1, 4)]
+    rng = np.random.default_rng(7)
+    for trial in range(50):
+        lengths = np.where(rng.random(200) < 0.05, rng.integers(50_000, 500_000, 200), rng.integers(0, 300, 200))
+        total, cum = int(lengths.sum()), np.concatenate([[0], np.cumsum(lengths)])
+        for world in (2, 3, 8):
+            spans = [shard_records(lengths, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == len(lengths) and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            for r in range(1, world):
+                b = spans[r][0]
+                ideal = total * r // world
+                left = int(lengths[b - 1]) if b > 0 else 0
+                right = int(lengths[b]) if b < len(lengths) else 0
+                assert abs(int(cum[b]) - ideal) <= max(left, right), (trial, world, r)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -118,13 +137,18 @@ def test_bench_plan_names_every_baseline_configuration():
     assert r.returncode == 0, r.stderr[-2000:]
     plan = json.loads(r.stdout.strip().splitlines()[-1])["plan"]
     names = [w["name"] for w in plan["workloads"]]
-    assert names == ["C2", "C3", "C5", "C4-random", "C4-stream", "C2-nonmember50", "C3-shuffled"]  # the last two: BASELINE.md section 3's secondary inputs
-    assert plan["workloads"][5]["nonmember_frac"] == 0.5 and plan["workloads"][6]["shuffle_records"] is True
-    assert plan["index_paths"][5] == plan["index_paths"][0] == plan["index_paths"][6] and "strong" not in plan  # (one rank, no --strong: the weak line only)
-    c4 = plan["workloads"][3]
+    # C3-runs / C4-stream-runs / C4-stream-gather1 (round 6): the streaming pass with the result the reference computes before it expands it, and fused with its
+    # consumer; the last two: BASELINE.md section 3's secondary inputs
+    assert names == ["C2", "C3", "C3-runs", "C5", "C4-random", "C4-stream", "C4-stream-runs", "C4-stream-gather1", "C2-nonmember50", "C3-shuffled"]
+    w = {x["name"]: x for x in plan["workloads"]}
+    ip = dict(zip(names, plan["index_paths"]))
+    assert w["C2-nonmember50"]["nonmember_frac"] == 0.5 and w["C3-shuffled"]["shuffle_records"] is True
+    assert [w[n]["sink"] for n in names] == ["codes", "codes", "runs", "codes", "codes", "codes", "runs", "gather1", "codes", "codes"]
+    assert ip["C2-nonmember50"] == ip["C2"] == ip["C3-shuffled"] == ip["C3-runs"] and "strong" not in plan  # (one rank, no --strong: the weak line only)
+    c4 = w["C4-random"]
     assert (c4["k"], c4["m"], c4["kmers"], c4["kmer_bits"], c4["batch_log2"], c4["steps"], c4["warmup"]) == (63, 20, 2_000_000_000, 128, 28, 20, 5)
-    assert plan["workloads"][1]["mode"] == "stream" and plan["workloads"][2]["kind"] == "u" and plan["workloads"][4]["mode"] == "stream"
-    assert plan["index_paths"][0] == plan["index_paths"][1] and plan["index_paths"][3] == plan["index_paths"][4]  # one index per (kind, k, m, n)
+    assert w["C3"]["mode"] == "stream" and w["C5"]["kind"] == "u" and w["C4-stream"]["mode"] == "stream"
+    assert ip["C2"] == ip["C3"] and ip["C4-random"] == ip["C4-stream"] == ip["C4-stream-runs"] == ip["C4-stream-gather1"]  # one index per (kind, k, m, n)
     assert len(set(plan["index_paths"])) == 3
     for extra in (["--mode", "stream"], ["--k", "63"], ["--no-secondary"], ["--no-cpu-baseline"], ["--kmers", "1000000"], ["--nonmember-frac", "0.5"]):
         r = _run_bench(["--plan-only"] + extra)
@@ -146,7 +170,7 @@ def test_bench_rank_logic_gloo_world2(tmp_path):
     line = json.loads(lines[0])
     assert line["ranks"] == 2 and line["ranks_agree"] is True
     assert line["plan"]["gpus"] == 2 and line["plan"]["cache_dir"] == str(tmp_path / "cache")
-    assert all(w["steps"] == 7 and w["warmup"] == 3 for w in line["plan"]["workloads"]) and len(line["plan"]["workloads"]) == 7
+    assert all(w["steps"] == 7 and w["warmup"] == 3 for w in line["plan"]["workloads"]) and len(line["plan"]["workloads"]) == 10
     assert all(p.startswith(str(tmp_path / "cache")) for p in line["plan"]["index_paths"])
     _check_strong_partition(line, 2)
     r = _run_bench(args, {"LPHQ_BENCH_TEST_FAIL_RANK": "1"})
@@ -159,17 +183,21 @@ def test_bench_rank_logic_gloo_world2(tmp_path):
 
 def _check_strong_partition(line, world):
     """The strong-scaling plan (fixed total work): per workload the ranks' shards -- as EACH RANK worked its own out -- are the plan's, contiguous, without
-    overlap, and cover the fixed job: 2^31 probes (random; = 8 GPUs x the weak line's 2^28) or all records (streaming)."""
+    overlap, and cover the fixed job: 2^31 probes (random; = 8 GPUs x the weak line's 2^28) or whole passes over the records adding up to >= 2^32 windows
+    (streaming; round 6: one pass -- 0.5 ms of one GPU at k = 31 -- cut eight ways measured launch overhead, not scaling).  The workloads that only change what
+    the streaming pass leaves behind (runs, payload) have no strong line of their own."""
     plan, by_rank = line["plan"], sorted(line["strong_shards_by_rank"], key=lambda e: e["rank"])
-    assert [e["rank"] for e in by_rank] == list(range(world)) and len(plan["strong"]) == len(plan["workloads"])
-    for wi, (wl, sp) in enumerate(zip(plan["workloads"], plan["strong"])):
+    wls = [w for w in plan["workloads"] if w["sink"] == "codes"]
+    assert [e["rank"] for e in by_rank] == list(range(world)) and len(plan["strong"]) == len(wls) and [sp["name"] for sp in plan["strong"]] == [w["name"] for w in wls]
+    for wi, (wl, sp) in enumerate(zip(wls, plan["strong"])):
         shards = [e["shards"][wi] for e in by_rank]
         assert shards == sp["shards"] and len(shards) == world
         assert shards[0][0] == 0 and shards[-1][1] == sp["total"] and all(a[1] == b[0] for a, b in zip(shards, shards[1:])) and all(a <= b for a, b in shards)
         if wl["mode"] == "random":
             assert sp["unit"] == "probes" and sp["total"] == 1 << (wl["batch_log2"] + 3)
         else:
-            assert sp["unit"] == "records" and sp["total"] == wl["n_records"]
+            wpr = wl["rec_len"] - wl["k"] + 1
+            assert sp["unit"] == "records" and sp["total"] == wl["n_records"] * sp["passes"] and sp["total"] * wpr >= 1 << 32 > (sp["passes"] - 1) * wl["n_records"] * wpr
         sizes = [b - a for a, b in shards]
         assert max(sizes) - min(sizes) <= 1  # equal-length records / probes: the shards differ by at most one unit
 
@@ -185,8 +213,15 @@ def test_bench_strong_plan_partitions_the_fixed_job_gloo_world8(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     _check_strong_partition(line, 8)
-    c4r, c4s = line["plan"]["strong"][3], line["plan"]["strong"][4]
-    assert c4r["shards"][3] == [3 << 28, 4 << 28] and c4s["shards"][7] == [17_500, 20_000]
+    by_name = {sp["name"]: sp for sp in line["plan"]["strong"]}
+    c4r, c4s, c3 = by_name["C4-random"], by_name["C4-stream"], by_name["C3"]
+    assert c4r["shards"][3] == [3 << 28, 4 << 28] and c4s["passes"] == 3 and c4s["shards"][7] == [52_500, 60_000] and c3["passes"] == 43
+    # a shard must be LONG against what a step costs besides the kernel: the launch + barrier cost of this pool, measured by the one-GPU --dist-single run of the
+    # round (profiles/r06_launch_barrier_cost.json: an empty step between the same barriers), x 10 -- the plan's own estimate from the round-5 single-GPU rates
+    cost = json.load(open(os.path.join(ROOT, "profiles", "r06_launch_barrier_cost.json")))
+    floor_ms = 10.0 * cost["empty_step_ms"]
+    for sp in line["plan"]["strong"]:
+        assert len(sp["planned_shard_ms"]) == 8 and min(sp["planned_shard_ms"]) >= max(2.0, floor_ms), (sp["name"], sp["planned_shard_ms"], floor_ms)
     for n, w in ((10, 3), (7, 8), (0, 4), (1 << 31, 6)):
         cuts = [shard_range(n, r_, w) for r_ in range(w)]
         assert cuts[0][0] == 0 and cuts[-1][1] == n and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))

@@ -1115,9 +1115,9 @@ def test_bbhash_of_no_keys_loads_its_own_file(tmp_path):
 def test_abi_version_and_both_count_valid_entry_points_are_exported():
     """ABI 2 added lphq_count_valid_on_stream and kept the four-argument lphq_count_valid of ABI 1 (a caller compiled against the first header must
     keep working: an entry point never changes its signature)."""
-    assert L.lib.lphq_abi_version() == 3
+    assert L.lib.lphq_abi_version() == 4
     hdr = open(os.path.join(ROOT, "include", "lphq.h")).read()
-    assert "#define LPHQ_ABI_VERSION 3" in hdr
+    assert "#define LPHQ_ABI_VERSION 4" in hdr
     assert "int lphq_count_valid(const lphq_index* idx, const uint64_t* d_codes, size_t n, uint64_t* count);" in hdr
     assert "int lphq_count_valid_on_stream(const lphq_index* idx, const uint64_t* d_codes, size_t n, void* stream, uint64_t* count);" in hdr
 

@@ -60,18 +60,22 @@ def emu_expand(lib, runs, codes, counts, n_out):
     return out[:-1], st.value
 
 
-def streaming_expectation(o, recs, k):
-    """What lphq_query_records(streaming = 1) writes for the batch: the oracle's codes, LPHQ_INVALID where a window holds a non-ACGT base."""
+def streaming_expectation(o, recs, k, with_valid=False):
+    """What lphq_query_records(streaming = 1) writes for the batch: the oracle's codes, LPHQ_INVALID where a window holds a non-ACGT base (with_valid: also
+    the bool per window that says so -- decided from the bases: a non-member's wrapped code may itself be 2^64 - 1)."""
     from real_fixture import valid_windows
 
-    parts = []
+    parts, vparts = [], []
     for q in recs:
         if len(q) < k:
             continue
         e = o(q, False).copy()  # random branch == streaming branch on clean windows (src/build.cpp:53-70); a non-ACGT window is INVALID in the device output
-        e[~valid_windows(q, k)] = np.uint64(L.INVALID)
+        v = valid_windows(q, k)
+        e[~v] = np.uint64(L.INVALID)
         parts.append(e)
-    return np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint64)
+        vparts.append(v)
+    exp = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint64)
+    return (exp, np.concatenate(vparts) if vparts else np.zeros(0, dtype=bool)) if with_valid else exp
 
 
 CONFIGS = [(31, 20, 64, 0), (63, 20, 128, 0), (31, 20, 64, 1), (21, 8, 64, 0), (47, 17, 128, 1), (31, 31, 64, 0), (15, 9, 64, 0), (9, 7, 64, 0),
@@ -92,21 +96,21 @@ def test_runs_and_gather_on_the_emulator(emur, tmp_path, k, m, bits, kind):
     noisy[5:5 + k + 3] = b"n" * (k + 3)
     batch = [b"", recs[0], recs[1][: k - 1], b"", recs[2][:k], bytes(noisy)] + recs[3:] + random_records(3, 6, 1, 1500) + [b""]
     batch += random_records(11, 150, 0, 5) + [recs[0][:k + 2]] + random_records(12, 40, k, k + 20) + [recs[1]]
-    exp = streaming_expectation(o, batch, k)
+    exp, valid = streaming_expectation(o, batch, k, with_valid=True)
     for mis in (0, 7):
         runs, codes, counts, out_off = emu_runs(emur, h, batch, k, mis)
         n_out = int(out_off[-1])
         assert n_out == len(exp)
-        check_runs_against_codes(runs, codes, counts, exp, L.INVALID)  # every valid window in exactly one run, affine as claimed, never across records
+        check_runs_against_codes(runs, codes, counts, exp, L.INVALID, valid)  # every valid window in exactly one run, affine as claimed, never across records
         assert np.array_equal(expand_runs_numpy(runs, codes, counts, n_out, L.INVALID), exp)
         got, st = emu_expand(emur, runs, codes, counts, n_out)
         assert st == 0 and np.array_equal(got, exp)
     # the dense form a session ships over PCIe
     r, c = np.ascontiguousarray(runs.reshape(-1)), np.ascontiguousarray(codes.reshape(-1))
     nr, nx = int(counts["runs"].sum()), int(counts["codes"].sum())
-    dense_r, dense_c, tot = np.zeros(nr + 1, dtype=RUN_DTYPE), np.zeros(nx + 1, dtype=np.uint64), np.zeros(3, dtype=np.uint64)
+    dense_r, dense_c, tot = np.zeros(nr + 1, dtype=RUN_DTYPE), np.zeros(nx + 1, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
     assert emur.emu_kernel_compact_runs(r.ctypes.data, r.size, c.ctypes.data, c.size, counts.ctypes.data, dense_r.ctypes.data, nr, dense_c.ctypes.data, nx, tot.ctypes.data) == 0
-    assert tot.tolist() == [nr, nx, 0]
+    assert tot.tolist() == [nr, nx, 0, int(valid.sum())]
     one = np.zeros(ARENAS, dtype=COUNTS_DTYPE)
     one[0]["runs"], one[0]["codes"] = nr, nx  # a dense array = one arena
     pad_r = np.zeros((ARENAS, nr + 1), dtype=RUN_DTYPE)
@@ -143,10 +147,10 @@ def test_runs_on_repeat_rich_sets_on_the_emulator(emur, tmp_path, k, m, bits, ki
     noisy = bytearray(recs[1])
     noisy[len(noisy) // 3:len(noisy) // 3 + k + 4] = b"N" * (k + 4)
     batch = recs[:12] + [bytes(noisy), recs[0][::-1], b"AC" * 400, recs[2][:k], b""]
-    exp = streaming_expectation(o, batch, k)
+    exp, valid = streaming_expectation(o, batch, k, with_valid=True)
     runs, codes, counts, out_off = emu_runs(emur, h, batch, k, 5)
     assert int(counts["codes"].sum()) > 0.03 * len(exp)
-    kinds = check_runs_against_codes(runs, codes, counts, exp, L.INVALID)
+    kinds = check_runs_against_codes(runs, codes, counts, exp, L.INVALID, valid)
     assert kinds[2] > 0 and kinds[0] > 0 and (kind == 1 or kinds[1] > 0)  # (the unpartitioned function only counts up: unpartitioned_mphf.hpp:130-137)
     got, st = emu_expand(emur, runs, codes, counts, len(exp))
     assert st == 0 and np.array_equal(got, exp)
