@@ -93,7 +93,8 @@ def image_sections(info, W, partitioned):
     else:
         blocks = ((M + 31) // 32 + 1) * 64
     big = blocks + (T - M) * 8
-    return max(int(info.image_bytes) - big, 4096), big
+    # the pilot side a lookup touches: not the u32 free-slot table of the minimizer function ((T - M) * 4 bytes in the image; tail[] answers those positions)
+    return max(int(info.image_bytes) - big - (T - M) * 4, 4096), big
 
 
 def ceiling_for(wl_key):

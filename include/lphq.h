@@ -267,9 +267,10 @@ int lphq_session_collect(lphq_session* s, const uint64_t** codes, const uint64_t
  * vector.size() summed over the batch: windows holding a non-ACGT base are in no run), and *offsets[r] = where record r's windows begin in the
  * space LPHQ_RUN_FIRST counts in: max(0, len_r - k + 1) slots per record, non-ACGT windows included.  Pointers valid until the next submit.
  * lphq_session_collect works on such a batch too: it expands the runs on the host (all usable threads, up to 16) and returns codes and compacted
- * offsets exactly as for a batch submitted with lphq_session_submit -- which, for LP-MPHF handles and streaming != 0, uses this transport itself
- * (LPHQ_SESSION_TRANSPORT=codes in the environment keeps the 8-byte codes on the wire: A/B runs).  collect_runs on a batch that was not submitted
- * as runs: LPHQ_ERR_STATE.  A batch of low-complexity sequence (up to one run per window) that outgrows the arenas sized for random sequence is
+ * offsets exactly as for a batch submitted with lphq_session_submit.  (lphq_session_submit itself keeps the 8-byte codes on the wire: with 16 cores'
+ * worth of host threads the copy engine delivers expanded codes faster than the host expands runs -- 0.18 against 0.20 ns per k-mer; runs pay off when
+ * the caller consumes them AS runs: 0.10.  LPHQ_SESSION_TRANSPORT=runs in the environment makes lphq_session_submit(streaming) use runs + host
+ * expansion: A/B runs, hosts with many cores.)  collect_runs on a batch that was not submitted as runs: LPHQ_ERR_STATE.  A batch of low-complexity sequence (up to one run per window) that outgrows the arenas sized for random sequence is
  * answered again, synchronously, with worst-case arenas: slower, never wrong. */
 int lphq_session_submit_runs(lphq_session* s, const char* const* records, const size_t* lengths, size_t n_records);
 int lphq_session_collect_runs(lphq_session* s, const lphq_run** runs, size_t* n_runs, const uint64_t** explicit_codes, size_t* n_codes,

@@ -879,13 +879,13 @@ struct SessionSlot {
 };
 struct lphq_session {
     lphq_index* idx = nullptr;
-    // One lane per replica the session works on (lphq_session_open: one; lphq_session_open_devices: several): batches go to the lanes in turn -- batch b to
-    // lane b % lanes, each lane with its own stream and `depth` slots -- and are collected in submission order, so a caller's submit / collect loop spreads
-    // over the GPUs of a node without knowing it.  The replica's device and image by value: lphq_attach* may grow (and move) idx->reps afterwards.
-    std::vector<SessionLane> lanes;
-    int depth = 2;                       // batches in flight per lane
+    // The replicas the session works on (lphq_session_open: one; lphq_session_open_devices: several): batches go to them in turn -- batch b to replica
+    // b % replicas, `depth` in flight on each -- and are collected in submission order, so a caller's submit / collect loop spreads over the GPUs of a
+    // node without knowing it.  The replica's device and image by value: lphq_attach* may grow (and move) idx->reps afterwards.
+    std::vector<SessionLane> lanes;      // one per slot: its replica and a stream of its own
+    int depth = 2;                       // batches in flight per replica
     uint64_t submitted = 0, collected = 0;
-    std::vector<SessionSlot> slot;       // depth x lanes; slot i belongs to lane i % lanes
+    std::vector<SessionSlot> slot;       // depth x replicas; slot i works on replica i % replicas
     size_t xc_hint = 0;                  // explicit codes of the last runs batch (how much of the code array the next batch copies back unasked)
     std::unique_ptr<WorkPool> pool;      // host threads that expand runs into codes (created by the first collect that needs them)
 };
@@ -929,17 +929,20 @@ static int session_open(lphq_index* idx, int depth, const std::vector<const Repl
     }
     s->idx = idx;
     s->depth = depth;
-    s->lanes.resize(reps.size());
+    // one lane (replica + stream) per SLOT: slot i works on replica i % replicas, on a stream of its own -- the batches of one GPU alternate between `depth`
+    // streams, so the copy in of one overlaps the copy out of the one before (a run-encoded result is 2.6 B per k-mer out against 1 B in: with both on one
+    // stream the binding's streaming pass measured 0.105 ns per k-mer, on two 0.082, profiles/r06_binding_rates.txt)
+    s->lanes.resize(reps.size() * (size_t)depth);
     s->slot.resize(reps.size() * (size_t)depth);
     hipError_t e = hipSuccess;
-    for (size_t l = 0; l < reps.size() && e == hipSuccess; ++l) {
-        s->lanes[l].device = reps[l]->device;
-        s->lanes[l].d_image = reps[l]->d_image;
+    for (size_t l = 0; l < s->lanes.size() && e == hipSuccess; ++l) {
+        s->lanes[l].device = reps[l % reps.size()]->device;
+        s->lanes[l].d_image = reps[l % reps.size()]->d_image;
         DeviceGuard g(s->lanes[l].device);
         e = hipStreamCreateWithFlags(&s->lanes[l].stream, hipStreamNonBlocking);
     }
     for (size_t i = 0; i < s->slot.size() && e == hipSuccess; ++i) {
-        s->slot[i].lane = &s->lanes[i % s->lanes.size()];
+        s->slot[i].lane = &s->lanes[i];
         DeviceGuard g(s->slot[i].lane->device);
         e = hipEventCreateWithFlags(&s->slot[i].done, hipEventDisableTiming);
     }
@@ -1066,11 +1069,14 @@ static hipError_t grow_runs(SessionSlot& sl, const RunPlan& p) {
     if (e == hipSuccess) e = grow_pinned(sl.h_totals, sl.h_totals_cap, 4);
     return e;
 }
-// which transport lphq_session_submit(streaming = 1) uses for LP-MPHF handles: runs (default) or codes (LPHQ_SESSION_TRANSPORT=codes: A/B runs)
+// Which transport lphq_session_submit(streaming = 1) + lphq_session_collect use for LP-MPHF handles.  Codes (8 B per k-mer over PCIe) is the default: a
+// caller that wants every code spelled out in host memory gets it fastest from the copy engine -- measured on the GPU box (16 cores' worth of CPU time,
+// profiles/r06_binding_rates.txt): codes 0.18 ns per k-mer, runs expanded by 16 host threads 0.20.  LPHQ_SESSION_TRANSPORT=runs moves the batch as runs and
+// expands on the host (hosts with more cores than PCIe).  A caller that can USE runs asks for them (lphq_session_submit_runs / _collect_runs: 0.10).
 static bool default_transport_is_runs() {
     static const bool runs = [] {
         const char* e = getenv("LPHQ_SESSION_TRANSPORT");
-        return !(e && std::string(e) == "codes");
+        return e && std::string(e) == "runs";
     }();
     return runs;
 }

@@ -458,6 +458,7 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
     // ---- F: the lane's eight codes ----
     uint64_t hv[8];
     uint32_t modes = 0;  // OR of the mode fields of the lane's windows (bit 1: a colliding minimizer)
+    uint32_t coll = 0;   // which of the lane's windows sit under a colliding minimizer (worked out off the common path)
     if (SINK == kSinkRuns) {
         // the runs sink needs a code per LEADER (worked out where the run is written) and, in the rare tile that holds a colliding leader, which of the
         // lane's windows sit under a colliding minimizer: their codes are explicit
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
             for (uint32_t jw = 0; jw < 8; ++jw) {
                 const bool valid = plain ? a < TW : code[jw] < 0xFFFEu;
                 const uint32_t mode = (uint32_t)(sm_hash[hslot8<BLOCK>(code[jw] & (uint32_t)(kS8Pos - 1))] >> LPHQ_TAIL_MODE_SHIFT);
-                modes |= valid ? mode : 0u;
+                coll |= (valid && mode == 2u) ? 1u << jw : 0u;
             }
         }
     } else if (plain) {
@@ -499,8 +500,7 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
             modes |= valid ? mode : 0u;  // (what an invalid window read is whatever phases B-C left in that slot)
         }
     }
-    uint32_t coll = 0;                // which of the lane's windows sit under a colliding minimizer (worked out off the common path)
-    if (__any((modes & 2u) != 0u)) {  // windows under a colliding minimizer: the fallback function of the k-mer (src/partitioned_mphf.cpp:312-316)
+    if (SINK != kSinkRuns && __any((modes & 2u) != 0u)) {  // windows under a colliding minimizer: the fallback function of the k-mer (src/partitioned_mphf.cpp:312-316)
 #pragma unroll
         for (uint32_t jw = 0; jw < 8; ++jw)
             if (code[jw] < 0xFFFEu && (uint32_t)(sm_hash[hslot8<BLOCK>(code[jw])] >> LPHQ_TAIL_MODE_SHIFT) == 2u) coll |= 1u << jw;
@@ -605,8 +605,14 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
                 uint64_t* const xdst = sink.codes + (uint64_t)arena * sink.arena_codes;
 #pragma unroll
                 for (uint32_t jw = 0; jw < 8; ++jw)
-                    if ((coll >> jw) & 1u) {
-                        if (x < sink.arena_codes) xdst[x] = hv[jw];
+                    if ((coll >> jw) & 1u) {  // the fallback function of the k-mer (src/partitioned_mphf.cpp:312-316), stored as soon as it is known
+                        LookupCtx c;
+                        c.base = sm_hash[hslot8<BLOCK>(code[jw] & (uint32_t)(kS8Pos - 1))] & LPHQ_TAIL_BASE_MASK;
+                        c.mode = 2u;
+                        uint64_t lo = 0, hi = 0;
+                        extract_kmer<K128>(sm_words, a + jw, k, lo, hi);
+                        const uint64_t v = finish_hval<K128>(img, H, c, lo, hi, 0u);
+                        if (x < sink.arena_codes) xdst[x] = v;
                         ++x;
                     }
             }
