@@ -12,7 +12,6 @@
 //   examples/query_example build-p|build-u -i unitigs.fa[.gz] -k K -m M -o index.lph [-s seed] [-c c] [-t threads] [-d tmp] [--max-memory GB]
 //                          (the build side of the binding, src/build.cpp:24-28: same file as the reference's build-p / build-u)
 //   -DLPHASH_KMER64 selects `typedef uint64_t kmer_t` (include/compile_constants.tpd:2); the default is __uint128_t, as the reference ships.
-#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -47,15 +46,6 @@ bool batched_pass(MPHF& hf, const std::string& query_filename, bool streaming, F
     reader.set_live_batches(cap);
     reader.prealloc(batch_bases);  // (set-up, like gzopen + kseq_init before t.start(), src/query.cpp:43-48)
     hf.reserve(batch_bases + batch_bases / 4, (size_t)1 << 16);  // ... and the binding's device and page-locked result buffers
-    struct Spill {  // where records that straddle two pieces of the parallel reader are joined (page-locked, like the arenas)
-        char* p = nullptr;
-        size_t cap = 0, used = 0;
-    };
-    std::vector<Spill> spill((size_t)cap);
-    for (Spill& sp : spill) {
-        sp.cap = batch_bases / 4;
-        sp.p = (char*)lphq_host_alloc(sp.cap);
-    }
     std::vector<lphq::FastxBatch> bufs((size_t)cap);
     std::vector<std::vector<const char*>> ptrs((size_t)cap);
     std::vector<std::vector<size_t>> lens((size_t)cap);
@@ -78,62 +68,14 @@ bool batched_pass(MPHF& hf, const std::string& query_filename, bool streaming, F
             --in_flight;
         }
         if (!reader.next(bufs[i], batch_bases)) break;
-        // one pointer per record.  The pieces different threads parsed lie apart in the arena; the binding copies every run of adjacent records with one
-        // asynchronous copy, so nothing has to move -- except a record that straddles two pieces: its parts are joined in a small page-locked side buffer
-        // (sliding the whole batch together instead, FastxBatch::compact, is a 16-MB memmove per batch on the caller's thread: 0.09 ns per k-mer).  A record
-        // too long for the side buffer falls back to that.
+        bufs[i].compact();  // pieces parsed by different threads slide together: records are adjacent in memory, the binding copies them in one go
         ptrs[i].clear();
         lens[i].clear();
-        {
-            lphq::FastxBatch& b = bufs[i];
-            Spill& sp = spill[(size_t)i];
-            sp.used = 0;
-            bool fits = true;
-            size_t si = 0, so = 0;
-            for (uint64_t len : b.lens) {
-                while (si < b.segs.size() && so == b.segs[si].n) {
-                    ++si;
-                    so = 0;
-                }
-                if (len == 0 || si >= b.segs.size()) {
-                    ptrs[i].push_back("");
-                } else if (so + len <= b.segs[si].n) {
-                    ptrs[i].push_back(b.segs[si].p + so);
-                    so += (size_t)len;
-                } else {  // the record goes on in the following piece(s)
-                    if (!sp.p || sp.used + len > sp.cap) {
-                        fits = false;
-                        break;
-                    }
-                    char* dst = sp.p + sp.used;
-                    ptrs[i].push_back(dst);
-                    uint64_t left = len;
-                    while (left && si < b.segs.size()) {
-                        const size_t take = (size_t)std::min<uint64_t>(left, b.segs[si].n - so);
-                        memcpy(dst, b.segs[si].p + so, take);
-                        dst += take;
-                        left -= take;
-                        so += take;
-                        if (left) {
-                            ++si;
-                            so = 0;
-                        }
-                    }
-                    sp.used += (size_t)len;
-                }
-                lens[i].push_back((size_t)len);
-            }
-            if (!fits) {
-                b.compact();
-                ptrs[i].clear();
-                lens[i].clear();
-                const char* p = b.segs.empty() ? nullptr : b.segs[0].p;
-                for (uint64_t len : b.lens) {
-                    ptrs[i].push_back(p);
-                    lens[i].push_back((size_t)len);
-                    p += len;
-                }
-            }
+        const char* p = bufs[i].segs.empty() ? nullptr : bufs[i].segs[0].p;
+        for (uint64_t len : bufs[i].lens) {
+            ptrs[i].push_back(p);
+            lens[i].push_back((size_t)len);
+            p += len;
         }
         if (runs) hf.submit_runs(ptrs[i].data(), lens[i].data(), ptrs[i].size());
         else hf.submit(ptrs[i].data(), lens[i].data(), ptrs[i].size(), streaming);
@@ -141,7 +83,6 @@ bool batched_pass(MPHF& hf, const std::string& query_filename, bool streaming, F
     }
     while (in_flight--) consume();
     micros = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::high_resolution_clock::now() - t0).count();
-    for (Spill& sp : spill) lphq_host_free(sp.p);
     return true;
 }
 

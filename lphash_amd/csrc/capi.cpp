@@ -882,7 +882,7 @@ struct lphq_session {
     // The replicas the session works on (lphq_session_open: one; lphq_session_open_devices: several): batches go to them in turn -- batch b to replica
     // b % replicas, `depth` in flight on each -- and are collected in submission order, so a caller's submit / collect loop spreads over the GPUs of a
     // node without knowing it.  The replica's device and image by value: lphq_attach* may grow (and move) idx->reps afterwards.
-    std::vector<SessionLane> lanes;      // one per slot: its replica and a stream of its own
+    std::vector<SessionLane> lanes;      // one per replica: its device, its image and a stream
     int depth = 2;                       // batches in flight per replica
     uint64_t submitted = 0, collected = 0;
     std::vector<SessionSlot> slot;       // depth x replicas; slot i works on replica i % replicas
@@ -929,20 +929,21 @@ static int session_open(lphq_index* idx, int depth, const std::vector<const Repl
     }
     s->idx = idx;
     s->depth = depth;
-    // one lane (replica + stream) per SLOT: slot i works on replica i % replicas, on a stream of its own -- the batches of one GPU alternate between `depth`
-    // streams, so the copy in of one overlaps the copy out of the one before (a run-encoded result is 2.6 B per k-mer out against 1 B in: with both on one
-    // stream the binding's streaming pass measured 0.105 ns per k-mer, on two 0.082, profiles/r06_binding_rates.txt)
-    s->lanes.resize(reps.size() * (size_t)depth);
+    // one lane (replica + stream) per replica; slot i works on lane i % replicas.  (A stream per SLOT was measured again in round 6, with the run-encoded
+    // transport -- 2.6 B per k-mer out against 1 B in, so that overlapping the two directions could pay: the binding's streaming pass went from 0.18 to 0.26 ns
+    // per k-mer with codes and from 0.12 to 0.22 with runs, profiles/r06_binding_rates.txt.  What does pay is more batches in flight: two lanes on one GPU,
+    // `--devices 0,0`, 0.082.)
+    s->lanes.resize(reps.size());
     s->slot.resize(reps.size() * (size_t)depth);
     hipError_t e = hipSuccess;
     for (size_t l = 0; l < s->lanes.size() && e == hipSuccess; ++l) {
-        s->lanes[l].device = reps[l % reps.size()]->device;
-        s->lanes[l].d_image = reps[l % reps.size()]->d_image;
+        s->lanes[l].device = reps[l]->device;
+        s->lanes[l].d_image = reps[l]->d_image;
         DeviceGuard g(s->lanes[l].device);
         e = hipStreamCreateWithFlags(&s->lanes[l].stream, hipStreamNonBlocking);
     }
     for (size_t i = 0; i < s->slot.size() && e == hipSuccess; ++i) {
-        s->slot[i].lane = &s->lanes[i];
+        s->slot[i].lane = &s->lanes[i % s->lanes.size()];
         DeviceGuard g(s->slot[i].lane->device);
         e = hipEventCreateWithFlags(&s->slot[i].done, hipEventDisableTiming);
     }
