@@ -50,7 +50,7 @@ def device_source_sha():
 
     hsh = hashlib.sha256()
     csrc = os.path.join(ROOT, "lphash_amd", "csrc")
-    for pth in sorted([os.path.join(csrc, f) for f in ("kernels_device.cuh", "device_query.cuh", "stream8_device.cuh", "kernels.hip", "stream8.hip", "image_layout.h")] +
+    for pth in sorted([os.path.join(csrc, f) for f in ("kernels_device.cuh", "device_query.cuh", "stream8_device.cuh", "stream_sinks.h", "kernels.hip", "stream8.hip", "image_layout.h")] +
                       glob.glob(os.path.join(csrc, "gfx950", "*.cuh"))):
         hsh.update(os.path.basename(pth).encode())
         hsh.update(open(pth, "rb").read())
@@ -193,13 +193,14 @@ def index_path(cache_dir, wl):
 
 def headline_workload(args):
     wl = make_workload("headline", args.mode, args.kind, args.k, args.m, args.kmers, args.batch_log2, args.steps, args.warmup, args.cpu_sample_log2,
-                       args.gpu_build, args.nonmember_frac, args.shuffle_records, args.bbhash_gamma, headline=True, index_set=args.index_set)
-    wl["name"] = config_name(wl)
+                       args.gpu_build, args.nonmember_frac, args.shuffle_records, args.bbhash_gamma, headline=True, index_set=args.index_set,
+                       sink=args.sink if args.mode == "stream" else "codes")
+    wl["name"] = config_name(wl) + ("" if wl["sink"] == "codes" else "-" + wl["sink"])
     return wl
 
 
 def is_default_headline(wl):
-    return (wl["mode"], wl["kind"], wl["k"], wl["m"], wl["kmers"], wl["batch_log2"], wl["nonmember_frac"], wl["index_set"]) == ("random", "p", 31, 20, 100_000_000, 28, 0.0, "uniform")
+    return (wl["mode"], wl["kind"], wl["k"], wl["m"], wl["kmers"], wl["batch_log2"], wl["nonmember_frac"], wl["index_set"], wl["sink"]) == ("random", "p", 31, 20, 100_000_000, 28, 0.0, "uniform", "codes")
 
 
 def secondary_workloads(args, head):
@@ -939,6 +940,19 @@ def run_workload(job, wl):
                     binding_b1[label + "_streaming_ns_per_kmer"] = float(np.median([a for a, _ in runs]))
                     binding_b1[label + "_random_ns_per_kmer"] = float(np.median([b for _, b in runs]))
                     binding_b1[label + "_runs"] = runs
+            # the same records as plain FASTA: what the transport of the result costs once the .gz decoder (0.13 ns per k-mer on this file) is out of the way
+            fa_plain = fa[:-3]
+            if not os.path.exists(fa_plain):
+                with gzip.open(fa, "rb") as fi, open(fa_plain + ".tmp", "wb") as fo:
+                    fo.write(fi.read())
+                os.replace(fa_plain + ".tmp", fa_plain)
+            plain = {}
+            for label, extra in (("batched", []), ("batched_runs", ["--runs"]), ("batched_runs_two_lanes", ["--runs", "--devices", f"{local_rank},{local_rank}"])):
+                runs = csv_runs([exb, "query-p" if kind == L.PARTITIONED else "query-u", "-i", path, "-q", fa_plain] + extra, 3)
+                if runs:
+                    plain[label + "_streaming_ns_per_kmer"] = float(np.median([a for a, _ in runs]))
+                    plain[label + "_runs"] = runs
+            binding_b1["plain_fasta"] = plain
             log(f"{tag} binding: {binding_b1}")
         log(f"{tag} B1 reference-faithful driver: {cpu_b1['streaming_ns_per_kmer']:.1f} / {cpu_b1['random_ns_per_kmer']:.1f} ns per k-mer (streaming / random); CLI: {cli_b1}")
 
@@ -1258,6 +1272,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--mode", choices=["random", "stream"], default="random")
+    ap.add_argument("--sink", default="codes", help="--mode stream: what the pass leaves behind -- codes (the BASELINE metric), runs (lphq_query_records_runs) or gather1 / "
+                                                    "gather2 / gather4 / gather8 (lphq_query_records_gather, element bytes)")
     ap.add_argument("--kmers", type=int, default=100_000_000, help="k-mers in the index (C2: 100 M)")
     ap.add_argument("--batch-log2", type=int, default=28, help="random mode: 2^x lookups per step per GPU")
     ap.add_argument("--k", type=int, default=31)
@@ -1398,6 +1414,8 @@ def main():
     if dist is not None and not all_ranks_ok(dist, torch, dev, plans_agree(dist, torch, dev, plan)):
         job.fail(2, "the ranks resolved different plans (arguments / cache paths differ between ranks)")
     os.makedirs(args.cache_dir, exist_ok=True)
+    if args.sink not in ("codes", "runs", "gather1", "gather2", "gather4", "gather8") or (args.sink != "codes" and (args.mode != "stream" or args.kind not in ("p", "u"))):
+        job.fail(2, "--sink runs / gather<E> goes with --mode stream and an LP-MPHF (--kind p | u)")
     if args.mode != "random" and args.kind in ("pthash", "bbhash"):
         job.fail(2, "--kind pthash / bbhash is measured in random mode only")
 

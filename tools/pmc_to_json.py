@@ -13,12 +13,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import device_source_sha  # noqa: E402
 
 tag, d = sys.argv[1], sys.argv[2]
-WL = {  # raw file suffix -> (key of bench.py, units per launch, kernel name fragment)
+# the streaming kernel's last template argument is its sink (stream8_device.cuh: 0 codes, 1 runs, 2 payload); a run of a sink workload also launches the codes
+# kernel once (its check pass), so the pattern names the sink
+S8 = r"k_query_tiles_stream8<[^>]*, %d>"
+WL = {  # raw file suffix -> (key of bench.py, units per launch, kernel name pattern)
     "c2": ("random|p|k31|m20|n100000000|b28", 1 << 28, "k_query_packed"),
-    "c3": ("stream|p|k31|m20|n100000000|b0", 100_000_000, "k_query_tiles_stream"),
+    "c3": ("stream|p|k31|m20|n100000000|b0", 100_000_000, S8 % 0),
     "c5": ("random|u|k31|m20|n100000000|b28", 1 << 28, "k_query_packed"),
     "c4r": ("random|p|k63|m20|n2000000000|b28", 1 << 28, "k_query_packed"),
-    "c4s": ("stream|p|k63|m20|n2000000000|b0", 2_000_000_000, "k_query_tiles_stream"),
+    "c4s": ("stream|p|k63|m20|n2000000000|b0", 2_000_000_000, S8 % 0),
+    "c3runs": ("stream|p|k31|m20|n100000000|b0|runs", 100_000_000, S8 % 1),
+    "c4sruns": ("stream|p|k63|m20|n2000000000|b0|runs", 2_000_000_000, S8 % 1),
+    "c4sg1": ("stream|p|k63|m20|n2000000000|b0|gather1", 2_000_000_000, S8 % 2),
 }
 out = {"_comment": "HBM/fabric bytes per unit ((FETCH_SIZE x 2 + WRITE_SIZE) x 1024 / units, per MI355X_MICROARCH.md's HBM section) and VALU lane-instructions per "
                    "unit (SQ_INSTS_VALU x 64 / units: a wave64 instruction = 64 lane-instructions whatever the live lanes) from separate rocprofv3 --pmc passes "
@@ -32,7 +38,7 @@ for suf, (key, units, frag) in WL.items():
     c = {}
     for line in open(path):
         m = re.match(r"(\S+)\s+n=\s*\d+\s+avg=\s*([0-9.]+)\s+(.*)", line)
-        if m and frag in m.group(3):
+        if m and re.search(frag, m.group(3)):
             c[m.group(1)] = float(m.group(2))
     if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         continue
@@ -46,7 +52,7 @@ for suf, (key, units, frag) in WL.items():
     if os.path.exists(stats):
         for line in open(stats):
             f = line.split()
-            if len(f) > 12 and frag in line and f[0].isdigit():
+            if len(f) > 12 and re.search(frag, line) and f[0].isdigit():
                 e["kernel_us_rocprof"] = float(f[2])
                 e["kernel_us_rocprof_calls"] = int(f[0])
                 e["kernel_stats_source"] = f"profiles/{tag}_{suf}_kernel_stats.txt"
