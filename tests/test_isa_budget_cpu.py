@@ -26,6 +26,10 @@ BUDGET = {
     "k_count_valid": (64, 0),
     "k_count_bad_bases": (64, 0),
     "k_gather_payload": (64, 0),
+    "k_expand_runs": (64, 8 * 1024),   # lphq_expand_runs: 256 runs (code, where, inclusive length sum) per workgroup in LDS
+    # sessions: arenas -> one dense array.  Thread 0's prefix sums over the 32 arenas are unrolled by the compiler into registers (119 VGPRs, 68 SGPRs spilled to
+    # lanes, 4 waves per SIMD): a helper of a few dozen workgroups per batch behind a PCIe copy -- not a kernel whose occupancy matters, left as it compiles
+    "k_compact_runs": (128, 1024),
     "k_extract_runs": (64, 40 * 1024),  # the streaming kernel's phases A-C + run starts (index construction, extract.hip)
     "k_assemble_runs": (64, 0),
     "k_group_flags": (64, 0),
@@ -38,20 +42,22 @@ BUDGET = {
 }
 # SGPR spills go to VGPR lanes, not to memory.  k_query_packed takes the 1.2-KB header by value (measured 2 % faster than reading the header from the
 # image); since round 3 the fallback function's descriptor is read from the image in the rare path that needs it and nothing spills.
-SGPR_SPILLS = {"k_query_packed": 0}
+# k_compact_runs (a session's helper, a few dozen workgroups per batch): thread 0's 32-step prefix loop is unrolled into scalar registers; not a hot kernel.
+SGPR_SPILLS = {"k_query_packed": 0, "k_compact_runs": 80}
 
 
 _CACHE = {}
 
 
-def resource_usage(src, asm_path=None):
-    """kernel-resource-usage remarks of the device compile of `src` (cached per test session); asm_path: also keep the gfx950 assembly there."""
-    key = (src, asm_path is not None)
+def resource_usage(src, asm_path=None, sink=0):
+    """kernel-resource-usage remarks of the device compile of `src` (cached per test session); asm_path: also keep the gfx950 assembly there.
+    sink: stream8.hip's -DLPHQ_S8_SINK (0 codes, 1 runs, 2 payload: one translation unit each)."""
+    key = (src, asm_path is not None, sink)
     if key in _CACHE:
         return _CACHE[key]
     out_args = ["--cuda-device-only", "-S", "-o", asm_path] if asm_path else ["-c", "-o", os.devnull]
     if src == "stream8.hip":
-        out_args = ["-DLPHQ_S8_KIND=0"] + out_args  # (the partitioned half; the unpartitioned one is the same kernels with a smaller lookup)
+        out_args = ["-DLPHQ_S8_KIND=0", f"-DLPHQ_S8_SINK={sink}"] + out_args  # (the partitioned half; the unpartitioned one is the same kernels with a smaller lookup)
     r = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I.", "-Rpass-analysis=kernel-resource-usage", src] + out_args,
                        cwd=CSRC, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -114,6 +120,25 @@ def test_stream8_variants_fit_their_occupancy_targets(stream8_asm):
             assert ctrl in body, (frag, ctrl)
         assert len(re.findall(r"v_cmp_ne_u32[^\n]*\n\s*v_addc_co_u32", body)) >= 8, frag
         assert "scratch_" not in body
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("sink,name", [(1, "runs"), (2, "payload")])
+def test_stream8_sink_variants_keep_the_occupancy(sink, name):
+    """The other two sinks of the streaming kernel (round 6: lphq_query_records_runs, lphq_query_records_gather): the wide-window variants stay within 64 VGPRs
+    and 10240 B of LDS without scratch (16 workgroups per CU, like the codes sink); the narrow-window ones may take a few registers more (the runs sink: 68 VGPRs,
+    7 waves per SIMD -- forcing 64 spills) but never scratch."""
+    usage = resource_usage("stream8.hip", sink=sink)
+    seen = 0
+    for kname, u in usage.items():
+        if "k_query_tiles_stream8" not in kname:
+            continue
+        seen += 1
+        assert u.get("ScratchSize", 0) == 0 and u.get("VGPRs Spill", 0) == 0 and u.get("LDS Size", 0) <= 10240, (kname, u)
+        wide = "ELi6ELi128ELb0E" in kname
+        assert u["VGPRs"] <= (64 if wide else 72), (kname, u)
+        assert u.get("Occupancy", 8) >= (8 if wide else 7), (kname, u)
+    assert seen == 2 * (8 + 1), name
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
