@@ -279,13 +279,15 @@ def test_bench_collective_path_with_one_rank(tmp_path, mode):
     assert len(line["kernel_ms_per_rank"]) == 1 and line["kernel_ms_min"] == line["kernel_ms_max"] == line["kernel_ms_per_rank"][0] > 0
     assert line["parity_ranks_checked"] == 1 and line["cpu_baseline"]["value"] > 0 and "secondary" not in line
     # the strong-scaling pass (a fixed job sharded over the ranks) with the one rank: its shard is the whole job -- 2^(20+3) probes of the common seeded set,
-    # or every window of the 20 records; checked against the oracle, streaming also as a permutation of [0, n) by the all-reduced checksums
+    # or 64 whole passes over the 20 records (the fixed job of a streaming workload is whole passes adding up to 2^32 windows, at most 64 of them: round 6);
+    # checked against the oracle, streaming also as passes x a permutation of [0, n) by the all-reduced checksums
     st = line["strong"]
     assert line["scaling"] == "weak" and st["scaling"] == "strong" and st["n_gpus"] == 1 and st["parity_vs_oracle"] is True and st["value"] > 0
     if mode == "random":
         assert st["total_units_per_step"] == 1 << 23 and st["shards"] == [[0, 1 << 23]] and st["all_shards_cover_0_n"] is None
     else:
-        assert st["total_units_per_step"] == 2_000_000 and st["shards"] == [[0, 20]] and st["all_shards_cover_0_n"] is True
+        assert st["passes"] == 64 and st["total_units_per_step"] == 64 * 2_000_000 and st["shards"] == [[0, 64 * 20]] and st["all_shards_cover_0_n"] is True
+        assert st["empty_step_ms"] > 0 and len(st["planned_shard_ms"]) == 1
     assert line["roofline"]["bound"] in ("fabric_line_requests", "hbm", "valu_issue") and line["roofline"]["frac_from_ms_per_step"] > 0
     assert line["index_sha256"] and line["index_digest_pinned"] is None  # (2 M k-mers: not one of the pinned full-size sets)
 
@@ -319,7 +321,7 @@ def test_bench_two_ranks_on_one_gpu(tmp_path, mode):
     if mode == "random":
         assert st["total_units_per_step"] == 1 << 23 and st["shards"] == [[0, 1 << 22], [1 << 22, 1 << 23]]
     else:
-        assert st["total_units_per_step"] == 3_000_000 and st["shards"] == [[0, 15], [15, 30]] and st["all_shards_cover_0_n"] is True
+        assert st["passes"] == 64 and st["total_units_per_step"] == 64 * 3_000_000 and st["shards"] == [[0, 960], [960, 1920]] and st["all_shards_cover_0_n"] is True
     assert "shared_file" in r.stderr or "records_seed1_30x" in r.stderr or os.path.exists(os.path.join(str(tmp_path), "records_seed1_30x100030.u8"))
 
 

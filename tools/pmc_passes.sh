@@ -12,7 +12,7 @@ run() { # name counters...
   local d=$R/gpurun_out/pmc_${TAG}_${name}
   timeout 900 rocprofv3 --kernel-trace --pmc "$@" -d $d -o pmc -- python3 $R/bench.py "${BENCH_ARGS[@]}" --steps 3 --warmup 1 --no-cpu-baseline --no-hbm-probe --gpu-build > /dev/null 2> $R/gpurun_out/pmc_${TAG}_${name}.err
   db=$(find $d -name '*_results.db' | head -1)
-  [ -n "$db" ] && python3 $R/tools/rocpd_pmc.py $db | grep -E "lphq::k_query" | cut -c1-120 >> $OUT
+  [ -n "$db" ] && python3 $R/tools/rocpd_pmc.py $db | grep -E "lphq::k_query" | cut -c1-170 >> $OUT
   rm -rf $d
 }
 BENCH_ARGS=("$@")
