@@ -1061,8 +1061,9 @@ def run_workload(job, wl):
         traffic = valu = traffic_stale = traffic_src = l2_miss = rocprof_us = None
         try:  # HBM bytes and VALU instructions per unit from the committed PMC passes of this exact workload (never measured inside this run)
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            key = f"{mode}|{wl['kind']}|k{k}|m{m}|n{nk}|b{wl['batch_log2'] if mode == 'random' else 0}" + ("" if wl["sink"] == "codes" else "|" + wl["sink"])
-            variant = wl["nonmember_frac"] != 0.0 or rec_order is not None or wl["index_set"] != "uniform"
+            key = (f"{mode}|{wl['kind']}|k{k}|m{m}|n{nk}|b{wl['batch_log2'] if mode == 'random' else 0}" + ("" if wl["sink"] == "codes" else "|" + wl["sink"])
+                   + ("" if wl["nonmember_frac"] == 0.0 else f"|nonmember{wl['nonmember_frac']}") + ("" if rec_order is None else "|shuffled"))
+            variant = wl["index_set"] != "uniform"
             if key in tj and not variant:  # (counter passes exist for the default kernels on the primary workloads only)
                 # the passes are evidence for the kernels they were taken on: an entry whose device sources are not the ones in this tree is reported
                 # as stale and contributes no number

@@ -12,6 +12,7 @@
 //   examples/query_example build-p|build-u -i unitigs.fa[.gz] -k K -m M -o index.lph [-s seed] [-c c] [-t threads] [-d tmp] [--max-memory GB]
 //                          (the build side of the binding, src/build.cpp:24-28: same file as the reference's build-p / build-u)
 //   -DLPHASH_KMER64 selects `typedef uint64_t kmer_t` (include/compile_constants.tpd:2); the default is __uint128_t, as the reference ships.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -37,11 +38,10 @@ namespace lphash {
 // as_runs: the streaming pass collected as the reference COMPUTES it -- runs of codes that go up or down by one (gpu_mphf::collect_runs) -- instead of expanded
 // into one code per k-mer; the count the driver prints is the same
 template <typename MPHF>
-bool batched_pass(MPHF& hf, const std::string& query_filename, bool streaming, FILE* dump, uint64_t& total, long long& micros, bool as_runs) {
+bool batched_pass(MPHF& hf, const std::string& query_filename, bool streaming, FILE* dump, uint64_t& total, long long& micros, bool as_runs, size_t batch_bases) {
     lphq::FastxBatchReader reader(query_filename.c_str(), lphq::usable_cpus() < 16 ? lphq::usable_cpus() : 16, &lphq_host_alloc, &lphq_host_free, 1 << 16,
                                   lphq::usable_cpus());  // (parser: at most 16 threads; .gz decoder: every usable CPU -- fastx_batch.hpp)
     if (!reader.ok()) return false;
-    const size_t batch_bases = (size_t)16 << 20;
     const int cap = hf.in_flight_capacity();  // depth x GPUs batches in flight; the reader keeps that many arenas alive
     reader.set_live_batches(cap);
     reader.prealloc(batch_bases);  // (set-up, like gzopen + kseq_init before t.start(), src/query.cpp:43-48)
@@ -87,7 +87,8 @@ bool batched_pass(MPHF& hf, const std::string& query_filename, bool streaming, F
 }
 
 template <typename MPHF>
-int query(const std::string& mphf_filename, const std::string& query_filename, const std::string& dump_prefix, bool per_record, bool as_runs, const std::vector<int>& devices) {
+int query(const std::string& mphf_filename, const std::string& query_filename, const std::string& dump_prefix, bool per_record, bool as_runs, const std::vector<int>& devices,
+          size_t batch_bases) {
     MPHF hf;
     hf.load(mphf_filename.c_str(), devices);  // essentials::load(hf, mphf_filename.c_str())                      src/query.cpp:37
     {
@@ -112,7 +113,7 @@ int query(const std::string& mphf_filename, const std::string& query_filename, c
                 dump = fopen((dump_prefix + (streaming ? ".streaming.u64" : ".random.u64")).c_str(), "wb");
                 if (!dump) return 2;
             }
-            const bool opened = batched_pass(hf, query_filename, streaming, dump, total[pass], micros[pass], as_runs);
+            const bool opened = batched_pass(hf, query_filename, streaming, dump, total[pass], micros[pass], as_runs, batch_bases);
             if (dump) fclose(dump);
             if (!opened) {
                 std::cerr << "Unable to open the input file " << query_filename << "\n";
@@ -183,6 +184,7 @@ int main(int argc, char** argv) {
     double c = 3.0;
     bool per_record = false, as_runs = false;
     std::vector<int> devices{0};
+    size_t batch_bases = (size_t)16 << 20;  // bases per batch of the batched loop (--batch-bases: tests use small ones to put many batches in flight)
     for (int i = 2; i < argc; i += 2) {
         const std::string a = argv[i];
         if (a == "--per-record" || a == "--runs") {
@@ -195,6 +197,7 @@ int main(int argc, char** argv) {
         if (a == "-i") mphf = v;
         else if (a == "-q") queries = v;
         else if (a == "--dump") dump = v;
+        else if (a == "--batch-bases") batch_bases = (size_t)std::max<long long>(1, std::stoll(v));
         else if (a == "--devices") {  // GPUs the batches are spread over, e.g. 0,1,2,3 (an ordinal may repeat: one more lane on that GPU)
             devices.clear();
             for (size_t at = 0; at < v.size();) {
@@ -229,8 +232,8 @@ int main(int argc, char** argv) {
             std::cerr << "built " << out << ": " << st.num_kmers << " k-mers, " << st.distinct_minimizers << " minimizers\n";
             return 0;
         }
-        if (tool == "query-p") return lphash::query<lphash::gpu_mphf<LPHQ_PARTITIONED, kmer_t>>(mphf, queries, dump, per_record, as_runs, devices);
-        return lphash::query<lphash::gpu_mphf<LPHQ_UNPARTITIONED, kmer_t>>(mphf, queries, dump, per_record, as_runs, devices);
+        if (tool == "query-p") return lphash::query<lphash::gpu_mphf<LPHQ_PARTITIONED, kmer_t>>(mphf, queries, dump, per_record, as_runs, devices, batch_bases);
+        return lphash::query<lphash::gpu_mphf<LPHQ_UNPARTITIONED, kmer_t>>(mphf, queries, dump, per_record, as_runs, devices, batch_bases);
     } catch (const std::exception& e) {
         std::cerr << e.what() << "\n";
         return 1;

@@ -197,9 +197,10 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
     __shared__ uint32_t sm_rec[2], sm_count, sm_slot_count;  // (a counter of its own for the slot-by-slot path: lanes may still be reading sm_count)
     __shared__ uint64_t sm_roff[3];                   // seq_off[rlo], seq_off[rlo+1], out_off[rlo]
     __shared__ uint64_t sm_rtab[2 * kS8RecCap + 1];   // multi-record tiles: the tile's slice of seq_off / out_off
-    __shared__ uint32_t sm_wlead[BLOCK / 64];         // kSinkRuns: leaders per wave (a run's slot = the tile's reservation + the leaders of the waves before + its rank in its wave)
-    __shared__ uint64_t sm_tile_at;                   // kSinkRuns: first entry of the tile's reservation in its arena
-    __shared__ uint32_t sm_anycoll;                   // kSinkRuns: a leader of the tile sits under a colliding minimizer (only then does phase F look at every window)
+    // kSinkRuns (unused, hence absent, in the other sinks):
+    __shared__ uint8_t sm_break[BLOCK];               // bit jw of byte l: window 8 l + jw ends the run to its left (it leads one itself, or it is no window)
+    __shared__ uint64_t sm_tile_at, sm_xbase;         // first entry of the tile's reservation in its arena; first explicit code of the round's reservation
+    __shared__ uint32_t sm_xcount, sm_xcursor;        // explicit codes the round's colliding runs need; the cursor they are dealt from
     const uint32_t tid = threadIdx.x;
     const uint32_t k = H.k, m = H.m, W = H.W;
     const uint32_t TW = stream_tile_windows(W, kS8Pos);
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
             sm_roff[1] = e0;
             sm_roff[2] = out_off[r];
             sm_count = 0;
-            if (SINK == kSinkRuns) sm_anycoll = 0;
+            if (SINK == kSinkRuns) sm_xcount = 0;
         }
     }
     if (tid < 12u) sm_badb[NDW + tid] = 0xFu;  // beyond the tile's dwords: not bases
@@ -397,14 +398,23 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
         const uint32_t wave_leaders = __shfl(incl, 63, 64);
         uint32_t b = 0;
         if (lane == 0 && wave_leaders) b = atomicAdd(&sm_count, wave_leaders);
-        if (SINK == kSinkRuns && lane == 0) sm_wlead[tid >> 6] = wave_leaders;
         uint32_t at = __shfl(b, 0, 64) + incl - mine;  // queue entry of the lane's first leader
         if (at < QCAP) {  // (a lane writes at most 8 entries from there: the queue has 8 entries of slack; a tile with more than QCAP leaders is redone below)
 #pragma unroll
             for (uint32_t jw = 0; jw < 8; ++jw) {
-                if ((lmask >> jw) & 1u) sm_queue[at] = (uint16_t)code[jw];
+                // (the runs sink also needs to know WHICH window leads: its entry is the window and the minimizer's offset in it, 10 + 6 bits)
+                if ((lmask >> jw) & 1u) sm_queue[at] = SINK == kSinkRuns ? (uint16_t)((a + jw) | ((code[jw] - (a + jw)) << 10)) : (uint16_t)code[jw];
                 at += (lmask >> jw) & 1u;
             }
+        }
+        if constexpr (SINK == kSinkRuns) {  // where runs end: at every window that leads one or does not exist (non-ACGT base, beyond the record or the tile)
+            uint32_t vmask = 0;
+            if (plain) vmask = a < TW ? 0xFFu : 0u;
+            else {
+#pragma unroll
+                for (uint32_t jw = 0; jw < 8; ++jw) vmask |= code[jw] < 0xFFFEu ? 1u << jw : 0u;
+            }
+            sm_break[tid] = (uint8_t)((lmask | ~vmask) & 0xFFu);
         }
     }
     __syncthreads();
@@ -412,18 +422,121 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
     // ---- E: one lookup per super-k-mer, dense lanes; a round = up to BLOCK leaders, one per lane ----
     const uint32_t nlead = sm_count;
     if constexpr (SINK == kSinkRuns) {
-        // one reservation per tile, asked for here and used in phase F: the atomic's round trip hides behind the lookups.  (One counter per arena, not one
+        // one reservation per tile, asked for here and used after the lookups: the atomic's round trip hides behind them.  (One counter per arena, not one
         // for the batch: atomics on one address serialise at ~80 M/s on this chip, tools/gather_ceiling.hip.)
         if (tid == 0) sm_tile_at = nlead ? atomicAdd((unsigned long long*)&sink.counts[(tile_base + blockIdx.x) & (LPHQ_RUN_ARENAS - 1u)].runs, (unsigned long long)nlead) : 0ull;
     }
     auto lookup_queued = [&](uint32_t n) {  // the first n queue entries (n uniform)
         for (uint32_t x = tid; x < n; x += (uint32_t)BLOCK) {
-            const uint32_t q = sm_queue[x];
+            const uint32_t e = sm_queue[x];
+            const uint32_t q = SINK == kSinkRuns ? (e & 1023u) + (e >> 10) : e;
             uint64_t mm, hi;
             extract_kmer<false>(sm_words, q, m, mm, hi);
             const LookupCtx c = lookup_ctx<KIND, K128, P>(img, H, mm);
             sm_hash[hslot8<BLOCK>(q)] = c.base | ((uint64_t)c.mode << LPHQ_TAIL_MODE_SHIFT);  // (bases are ranks < 2^62: the packing of the image's tail table)
-            if (SINK == kSinkRuns && c.mode == 2u) sm_anycoll = 1u;
+        }
+    };
+    // kSinkRuns: one lphq_run per queue entry, written by the lanes that did the lookups -- DENSE lanes, one leader each (written from the windows' own lanes,
+    // phase F, a run cost every wave eight divergent copies of this: +26 lane-instructions per window, profiles/r06_pmc_c4sruns_raw.txt of the first version).
+    // A run = the windows from its leader to the next window that leads or does not exist, or to the end of the wave: inside it the minimizer stays where it is, so
+    // the code moves by -1 (mode 0: base + p, and p shrinks as the window slides) or +1 (mode 1) per window -- the case-0 updates of
+    // include/partitioned_mphf.hpp:131-145.  Colliding leaders (mode 2) only count their windows in the first pass; the second pass, entered when the tile has
+    // one, gives them their place in the arena's explicit-code array and looks their k-mers up one by one (src/partitioned_mphf.cpp:312-316).
+    const uint64_t first0 = sm_roff[2] + (t0 - shift - sm_roff[0]);  // index of window 0 of the tile in the code space (one record under the tile; wraps harmlessly before it)
+    auto run_length = [&](uint32_t i) {  // windows from i to the next set bit of sm_break, inside the wave's 512 windows
+        const uint32_t end = (i | 511u) + 1u;
+        uint32_t w = i + 1u, next = end;
+        if (w < end) {
+            uint32_t bits = (uint32_t)sm_break[w >> 3] >> (w & 7u);
+            if (bits) next = w + (uint32_t)__ffsll((long long)bits) - 1u;
+            else
+                for (w = (w | 7u) + 1u; w < end; w += 8u) {
+                    bits = sm_break[w >> 3];
+                    if (bits) {
+                        next = w + (uint32_t)__ffsll((long long)bits) - 1u;
+                        break;
+                    }
+                }
+        }
+        return next - i;
+    };
+    auto run_first = [&](uint32_t i) {  // index of window i of the tile in the code space
+        uint64_t first = first0 + i;
+        if (!one_record) {
+            const uint64_t g = t0 + i - shift;
+            uint64_t rs, re;
+            const uint32_t j = tile_record<kS8RecCap>(sm_rtab, seq_off, rlo, rhi, g, rs, re);
+            first = tile_record_out<kS8RecCap>(sm_rtab, out_off, rlo, rhi, j) + (g - rs);
+        }
+        return first;
+    };
+    auto emit_queued = [&](uint32_t n, uint32_t round_base, bool second) {
+        if constexpr (SINK == kSinkRuns) {
+            const uint32_t arena = (uint32_t)((tile_base + blockIdx.x) & (uint64_t)(LPHQ_RUN_ARENAS - 1u)), lane = tid & 63u;
+            lphq_run* const rdst = sink.runs + (uint64_t)arena * sink.arena_runs;
+            for (uint32_t x0 = 0; x0 < n; x0 += (uint32_t)BLOCK) {  // (uniform: the second pass works wave by wave)
+                const uint32_t x = x0 + tid;
+                uint32_t i = 0, p = 0, mode = 0, len = 0;
+                uint64_t base = 0;
+                if (x < n) {
+                    const uint32_t e = sm_queue[x];
+                    i = e & 1023u;
+                    p = e >> 10;
+                    const uint64_t packed = sm_hash[hslot8<BLOCK>(i + p)];
+                    mode = (uint32_t)(packed >> LPHQ_TAIL_MODE_SHIFT);
+                    base = packed & LPHQ_TAIL_BASE_MASK;
+                    if (!second || mode == 2u) len = run_length(i);  // (the second pass is for the explicit runs only)
+                }
+                const uint64_t slot = sm_tile_at + round_base + x;
+                if (!second) {  // affine runs are written; explicit runs count the codes they will need
+                    if (len && mode != 2u) {
+                        lphq_run r;
+                        r.code = mode == 0u ? base + p : base - p;
+                        r.where = (run_first(i) & 0xFFFFFFFFFFull) | ((uint64_t)len << 40) | ((uint64_t)(mode ^ 1u) << 62);
+                        if (slot < sink.arena_runs) rdst[slot] = r;
+                    } else if (len) {
+                        atomicAdd(&sm_xcount, len);
+                    }
+                    continue;
+                }
+                // second pass: the wave's explicit runs take consecutive places in the round's reservation (a prefix sum over the lanes), and their windows -- all
+                // of them together -- are dealt to the wave's lanes 64 at a time: a lane finds the run its item belongs to by a binary search over the lanes'
+                // exclusive sums (six ds_bpermute) and looks its k-mer up in the fallback function; dense lanes whatever the runs' lengths
+                const uint32_t incl = wave_inclusive_add(len), total = __shfl(incl, 63, 64);
+                if (total == 0u) continue;  // (uniform over the wave)
+                uint32_t wb = 0;
+                if (lane == 0u) wb = atomicAdd(&sm_xcursor, total);
+                const uint64_t wbase = sm_xbase + __shfl(wb, 0, 64);
+                const uint32_t excl = incl - len;
+                if (len) {
+                    lphq_run r;
+                    r.code = wbase + excl;
+                    r.where = (run_first(i) & 0xFFFFFFFFFFull) | ((uint64_t)len << 40) | ((uint64_t)LPHQ_RUN_EXPLICIT << 62);
+                    if (slot < sink.arena_runs) rdst[slot] = r;
+                }
+                uint64_t* const xdst = sink.codes + (uint64_t)arena * sink.arena_codes;
+                LookupCtx c;
+                c.base = H.collision_base;
+                c.mode = 2u;
+                for (uint32_t e0 = 0; e0 < total; e0 += 64u) {
+                    const uint32_t e = e0 + lane;
+                    uint32_t lo = 0, hi = 63u;  // the last lane whose exclusive sum is <= e owns item e (lanes without an explicit run repeat their neighbour's sum)
+#pragma unroll
+                    for (int step = 0; step < 6; ++step) {
+                        const uint32_t mid = (lo + hi + 1u) >> 1;
+                        const uint32_t v = __shfl(excl, (int)mid, 64);
+                        if (v <= e) lo = mid;
+                        else hi = mid - 1u;
+                    }
+                    const uint32_t wi = __shfl(i, (int)lo, 64) + (e - __shfl(excl, (int)lo, 64));
+                    if (e < total) {
+                        uint64_t klo = 0, khi = 0;
+                        extract_kmer<K128>(sm_words, wi, k, klo, khi);
+                        const uint64_t v = finish_hval<K128>(img, H, c, klo, khi, 0u);  // src/partitioned_mphf.cpp:312-316
+                        if (wbase + e < sink.arena_codes) xdst[wbase + e] = v;
+                    }
+                }
+            }
         }
     };
     // (uniform) the common case: one round over the queue as phase D filled it (super-k-mers average (W + 1) / 2 windows).  More leaders than the queue
@@ -431,6 +544,7 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
     // three barriers.  ONE copy of the lookup serves both (round 3 had two, and the rare one's registers were what the compiler spilled).
     const bool overflow = nlead > QCAP;
     const uint32_t rounds = overflow ? 8u : 1u;
+    uint32_t emitted = 0;  // kSinkRuns: runs of the rounds before (a run's slot = the tile's reservation + emitted + its queue entry)
 #pragma unroll 1
     for (uint32_t jw = 0; jw < rounds; ++jw) {
         uint32_t n = nlead;
@@ -447,30 +561,37 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
             uint32_t b = 0;
             if ((tid & 63u) == 0 && bal) b = atomicAdd(&sm_slot_count, (uint32_t)__popcll(bal));
             b = __shfl(b, 0, 64);
-            if (ld) sm_queue[b + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint16_t)cj;
+            if (ld)
+                sm_queue[b + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] =
+                    SINK == kSinkRuns ? (uint16_t)((a + jw) | ((cj - (a + jw)) << 10)) : (uint16_t)cj;
             __syncthreads();
             n = sm_slot_count;
         }
         lookup_queued(n);
         __syncthreads();
+        if constexpr (SINK == kSinkRuns) {
+            emit_queued(n, emitted, false);
+            __syncthreads();
+            if (sm_xcount != 0u) {  // (uniform) some run of the round is explicit -- its leader counted its windows: reserve their codes, then the second pass
+                if (tid == 0) {
+                    sm_xbase = atomicAdd((unsigned long long*)&sink.counts[(tile_base + blockIdx.x) & (LPHQ_RUN_ARENAS - 1u)].codes, (unsigned long long)sm_xcount);
+                    sm_xcursor = 0;
+                }
+                __syncthreads();
+                emit_queued(n, emitted, true);
+                __syncthreads();
+                if (tid == 0) sm_xcount = 0;  // (for the next round; ordered by its first barrier)
+            }
+            emitted += n;
+        }
     }
+    if constexpr (SINK == kSinkRuns) return;  // the runs sink has no phase F: everything it writes comes from the leaders' lanes
 
     // ---- F: the lane's eight codes ----
     uint64_t hv[8];
     uint32_t modes = 0;  // OR of the mode fields of the lane's windows (bit 1: a colliding minimizer)
     uint32_t coll = 0;   // which of the lane's windows sit under a colliding minimizer (worked out off the common path)
-    if (SINK == kSinkRuns) {
-        // the runs sink needs a code per LEADER (worked out where the run is written) and, in the rare tile that holds a colliding leader, which of the
-        // lane's windows sit under a colliding minimizer: their codes are explicit
-        if (sm_anycoll) {
-#pragma unroll
-            for (uint32_t jw = 0; jw < 8; ++jw) {
-                const bool valid = plain ? a < TW : code[jw] < 0xFFFEu;
-                const uint32_t mode = (uint32_t)(sm_hash[hslot8<BLOCK>(code[jw] & (uint32_t)(kS8Pos - 1))] >> LPHQ_TAIL_MODE_SHIFT);
-                coll |= (valid && mode == 2u) ? 1u << jw : 0u;
-            }
-        }
-    } else if (plain) {
+    if (plain) {
         // the codes of lanes at or beyond TW are never stored (the stores below are bounded by w_hi = TW): nothing to invalidate per window
 #pragma unroll
         for (uint32_t jw = 0; jw < 8; ++jw) {
@@ -500,7 +621,7 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
             modes |= valid ? mode : 0u;  // (what an invalid window read is whatever phases B-C left in that slot)
         }
     }
-    if (SINK != kSinkRuns && __any((modes & 2u) != 0u)) {  // windows under a colliding minimizer: the fallback function of the k-mer (src/partitioned_mphf.cpp:312-316)
+    if (__any((modes & 2u) != 0u)) {  // windows under a colliding minimizer: the fallback function of the k-mer (src/partitioned_mphf.cpp:312-316)
 #pragma unroll
         for (uint32_t jw = 0; jw < 8; ++jw)
             if (code[jw] < 0xFFFEu && (uint32_t)(sm_hash[hslot8<BLOCK>(code[jw])] >> LPHQ_TAIL_MODE_SHIFT) == 2u) coll |= 1u << jw;
@@ -563,11 +684,10 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
                 if (code[jw] != 0xFFFEu) __builtin_nontemporal_store(hv[jw], out + oidx[jw]);
         }
     }
-    } else {
-        // ---- the other two sinks ----
+    } else if constexpr (SINK == kSinkGather) {
+        // ---- the payload sink ----
         // where the lane's windows sit in the code space (what the codes sink computes on its way to the stores): one record under the tile -> window i of
         // the tile is at first0 + i; several -> the walk of phase C again, from the record found there
-        const uint64_t first0 = sm_roff[2] + (t0 - shift - sm_roff[0]);  // (wraps harmlessly for windows before the record)
         auto walk_windows = [&](uint64_t (&oidx)[8]) {
             const bool cached = rhi - rlo < (uint32_t)kS8RecCap;
             uint32_t j = jrec;
@@ -581,84 +701,7 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
                 oidx[jw] = tile_record_out<kS8RecCap>(sm_rtab, out_off, rlo, rhi, j) + (g - rs);
             }
         };
-        if constexpr (SINK == kSinkRuns) {
-            // One lphq_run per leader: the windows from the leader up to the next leader, the next window that is no window (non-ACGT base, record end,
-            // tile end) or the end of the wave, whichever comes first -- inside it the minimizer stays where it is, so the code moves by -1 (mode 0:
-            // base + p, and p shrinks as the window slides) or +1 (mode 1) per window: the case-0 updates of include/partitioned_mphf.hpp:131-145.
-            const uint32_t lane = tid & 63u;
-            const uint32_t arena = (uint32_t)((tile_base + blockIdx.x) & (uint64_t)(LPHQ_RUN_ARENAS - 1u));
-            uint32_t vmask = 0;  // the lane's windows that exist: windows of a record without a non-ACGT base
-            if (plain) vmask = a < TW ? 0xFFu : 0u;
-            else {
-#pragma unroll
-                for (uint32_t jw = 0; jw < 8; ++jw) vmask |= code[jw] < 0xFFFEu ? 1u << jw : 0u;
-            }
-            // colliding windows (rare): their codes go to the arena's explicit-code array, the wave's in window order -- a colliding run's codes are
-            // consecutive there because its windows are consecutive windows of one wave
-            uint64_t xat = 0;  // arena-local index of the lane's first explicit code
-            if (__any(coll != 0u)) {
-                const uint32_t mine = (uint32_t)__popc(coll), incl = wave_inclusive_add(mine), tot = __shfl(incl, 63, 64);
-                unsigned long long b = 0;
-                if (lane == 0u) b = atomicAdd((unsigned long long*)&sink.counts[arena].codes, (unsigned long long)tot);
-                xat = __shfl(b, 0, 64) + incl - mine;
-                uint64_t x = xat;
-                uint64_t* const xdst = sink.codes + (uint64_t)arena * sink.arena_codes;
-#pragma unroll
-                for (uint32_t jw = 0; jw < 8; ++jw)
-                    if ((coll >> jw) & 1u) {  // the fallback function of the k-mer (src/partitioned_mphf.cpp:312-316), stored as soon as it is known
-                        LookupCtx c;
-                        c.base = sm_hash[hslot8<BLOCK>(code[jw] & (uint32_t)(kS8Pos - 1))] & LPHQ_TAIL_BASE_MASK;
-                        c.mode = 2u;
-                        uint64_t lo = 0, hi = 0;
-                        extract_kmer<K128>(sm_words, a + jw, k, lo, hi);
-                        const uint64_t v = finish_hval<K128>(img, H, c, lo, hi, 0u);
-                        if (x < sink.arena_codes) xdst[x] = v;
-                        ++x;
-                    }
-            }
-            // run lengths: a window ends the run to its left if it leads one itself or does not exist
-            const uint32_t bmask = (lmask | ~vmask) & 0xFFu;
-            const uint64_t ball = __ballot(bmask != 0u);
-            const uint64_t rest = lane == 63u ? 0ull : (ball >> (lane + 1u));  // lanes to the right that hold such a window
-            const uint32_t fb = bmask ? (uint32_t)__ffsll((long long)bmask) - 1u : 8u;
-            const uint32_t d = rest ? (uint32_t)__ffsll((long long)rest) - 1u : 0u;
-            const uint32_t fbn = __shfl(fb, (int)((lane + 1u + d) & 63u), 64);
-            const uint32_t ahead = rest ? 8u * d + fbn : 8u * (63u - lane);  // windows between this lane's last and the next break (the wave's end if there is none)
-            // slot of the lane's first run: the tile's reservation + the leaders of the waves before + the leaders of the lanes before (window order)
-            const uint32_t mine = (uint32_t)__popc(lmask), incl = wave_inclusive_add(mine);
-            uint64_t slot = sm_tile_at + incl - mine;
-#pragma unroll
-            for (uint32_t wv = 0; wv + 1u < (uint32_t)BLOCK / 64u; ++wv) slot += (tid >> 6) > wv ? sm_wlead[wv] : 0u;
-            lphq_run* const rdst = sink.runs + (uint64_t)arena * sink.arena_runs;
-            auto emit = [&](uint32_t jw, uint64_t first) {  // the run led by the lane's window jw, whose index in the code space is `first`
-                const uint32_t nb = jw == 7u ? 0u : (bmask >> (jw + 1u));
-                const uint32_t len = nb ? (uint32_t)__ffsll((long long)nb) : (8u - jw) + ahead;
-                const uint32_t mode = (uint32_t)(sm_hash[hslot8<BLOCK>(code[jw] & (uint32_t)(kS8Pos - 1))] >> LPHQ_TAIL_MODE_SHIFT);
-                lphq_run r;
-                {
-                    const uint64_t packed = sm_hash[hslot8<BLOCK>(code[jw] & (uint32_t)(kS8Pos - 1))];
-                    const uint32_t p = (code[jw] & (uint32_t)(kS8Pos - 1)) - (a + jw);  // offset of the minimizer in the leader's window
-                    const uint64_t base = packed & LPHQ_TAIL_BASE_MASK;
-                    r.code = mode == 2u ? xat + (uint64_t)__popc(coll & ((1u << jw) - 1u)) : (mode == 0u ? base + p : base - p);
-                }
-                r.where = (first & 0xFFFFFFFFFFull) | ((uint64_t)len << 40) | ((uint64_t)(mode == 2u ? (uint32_t)LPHQ_RUN_EXPLICIT : (mode ^ 1u)) << 62);
-                if (slot < sink.arena_runs) rdst[slot] = r;
-                ++slot;
-            };
-            if (lmask) {
-                if (one_record) {
-#pragma unroll
-                    for (uint32_t jw = 0; jw < 8; ++jw)
-                        if ((lmask >> jw) & 1u) emit(jw, first0 + a + jw);
-                } else {
-                    uint64_t oidx[8];
-                    walk_windows(oidx);
-#pragma unroll
-                    for (uint32_t jw = 0; jw < 8; ++jw)
-                        if ((lmask >> jw) & 1u) emit(jw, oidx[jw]);
-                }
-            }
-        } else {
+        {
             // table[code] per window; element size uniform over the launch.  A lane's eight elements are 8 << el contiguous bytes of the output:
             // staged through LDS like the codes and copied out in 16-byte pieces when the tile lies in one record.
             const uint32_t el = sink.elem_log2;

@@ -8,10 +8,10 @@
 set -eu
 R=$(cd "$(dirname "$0")/../.." && pwd)
 cd "$R/tests/emu"
-SRC="emu_lookup.cpp emu_kernels.cpp emu_search.cpp emu_runtime.cpp"
+SRC="emu_lookup.cpp emu_kernels.cpp emu_sinks.cpp emu_search.cpp emu_runtime.cpp"
 g++ -O1 -g -std=c++17 -fPIC -I. -I../../lphash_amd/csrc -fsanitize=undefined -fno-sanitize-recover=undefined -fno-sanitize=alignment -shared $SRC -o /tmp/libemu_ubsan.so
 g++ -O1 -g -std=c++17 -fPIC -I. -I../../lphash_amd/csrc -fsanitize=address -shared $SRC -o /tmp/libemu_asan.so
 cd "$R"
 K=${1:-"not nothing"}
-LPHQ_EMU_LIB=/tmp/libemu_ubsan.so LD_PRELOAD=$(gcc -print-file-name=libubsan.so) UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 python -m pytest tests/test_emu_cpu.py -x -q -k "$K"
-LPHQ_EMU_LIB=/tmp/libemu_asan.so LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1 python -m pytest tests/test_emu_cpu.py -x -q -k "$K"
+LPHQ_EMU_LIB=/tmp/libemu_ubsan.so LD_PRELOAD=$(gcc -print-file-name=libubsan.so) UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 python -m pytest tests/test_emu_cpu.py tests/test_runs_cpu.py -x -q -k "$K"
+LPHQ_EMU_LIB=/tmp/libemu_asan.so LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1 python -m pytest tests/test_emu_cpu.py tests/test_runs_cpu.py -x -q -k "$K"

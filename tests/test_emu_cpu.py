@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def emu():
     d = os.path.join(ROOT, "tests", "emu")
-    subprocess.check_call(["make", "-C", d], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-j4", "-C", d], stdout=subprocess.DEVNULL)
     lib = C.CDLL(os.environ.get("LPHQ_EMU_LIB") or os.path.join(d, "libemu.so"))  # LPHQ_EMU_LIB: e.g. a -fsanitize=undefined build of tests/emu
     lib.emu_query_packed.restype = C.c_int
     lib.emu_query_packed.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]

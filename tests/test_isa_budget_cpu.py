@@ -47,21 +47,22 @@ SGPR_SPILLS = {"k_query_packed": 0, "k_compact_runs": 80}
 
 
 _CACHE = {}
+_ASM_DIR = None
 
 
-def resource_usage(src, asm_path=None, sink=0):
-    """kernel-resource-usage remarks of the device compile of `src` (cached per test session); asm_path: also keep the gfx950 assembly there.
-    sink: stream8.hip's -DLPHQ_S8_SINK (0 codes, 1 runs, 2 payload: one translation unit each)."""
-    key = (src, asm_path is not None, sink)
-    if key in _CACHE:
-        return _CACHE[key]
+def _compile(src, want_asm, sink):
+    """one device compile of `src` with kernel-resource-usage remarks -> (usage per kernel, assembly text or None)"""
+    import tempfile
+
+    asm_path = None
+    if want_asm:
+        asm_path = os.path.join(_asm_dir(), f"{src}.{sink}.s")
     out_args = ["--cuda-device-only", "-S", "-o", asm_path] if asm_path else ["-c", "-o", os.devnull]
     if src == "stream8.hip":
         out_args = ["-DLPHQ_S8_KIND=0", f"-DLPHQ_S8_SINK={sink}"] + out_args  # (the partitioned half; the unpartitioned one is the same kernels with a smaller lookup)
     r = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I.", "-Rpass-analysis=kernel-resource-usage", src] + out_args,
                        cwd=CSRC, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
-    _CACHE[key] = None
     out, cur = {}, None
     for line in r.stderr.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
@@ -71,24 +72,51 @@ def resource_usage(src, asm_path=None, sink=0):
         m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
         if m and cur is not None:
             cur[m.group(1).strip()] = int(m.group(2))
-    _CACHE[key] = out
-    return out
+    return out, (open(asm_path).read() if asm_path else None)
+
+
+def _asm_dir():
+    global _ASM_DIR
+    if _ASM_DIR is None:
+        import tempfile
+
+        _ASM_DIR = tempfile.mkdtemp(prefix="lphq_isa_")
+    return _ASM_DIR
+
+
+# every compile the tests of this module ask for: started together on first use (eight CPUs; one after the other they were 75 s of the CPU suite)
+_WANTED = [("kernels.hip", True, 0), ("stream8.hip", True, 0), ("stream8.hip", False, 1), ("stream8.hip", False, 2), ("search.hip", False, 0), ("extract.hip", False, 0)]
+
+
+def resource_usage(src, want_asm=False, sink=0):
+    """kernel-resource-usage remarks of the device compile of `src` (cached per test session; all compiles of the module run concurrently on first use).
+    want_asm: also return the gfx950 assembly.  sink: stream8.hip's -DLPHQ_S8_SINK (0 codes, 1 runs, 2 payload: one translation unit each)."""
+    if not _CACHE:
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=6) as ex:
+            futs = {key: ex.submit(_compile, *key) for key in _WANTED}
+        for key, f in futs.items():
+            _CACHE[key] = f.result()
+    key = (src, want_asm, sink)
+    if key not in _CACHE:
+        alt = (src, True, sink)  # (a compile that kept its assembly serves a caller that only wants the remarks)
+        if alt in _CACHE:
+            return _CACHE[alt] if want_asm else _CACHE[alt][0]
+        _CACHE[key] = _compile(*key)
+    return _CACHE[key] if want_asm else _CACHE[key][0]
 
 
 @pytest.fixture(scope="module")
-def kernels_asm(tmp_path_factory):
+def kernels_asm():
     """gfx950 assembly of kernels.hip (one device-only compile, shared with the budget test of the same file)."""
-    path = str(tmp_path_factory.mktemp("isa") / "kernels.s")
-    usage = resource_usage("kernels.hip", path)
-    return usage, open(path).read()
+    return resource_usage("kernels.hip", want_asm=True)
 
 
 @pytest.fixture(scope="module")
-def stream8_asm(tmp_path_factory):
+def stream8_asm():
     """... and of stream8.hip (the eight-per-lane streaming kernel's translation unit)."""
-    path = str(tmp_path_factory.mktemp("isa8") / "stream8.s")
-    usage = resource_usage("stream8.hip", path)
-    return usage, open(path).read()
+    return resource_usage("stream8.hip", want_asm=True)
 
 
 def _kernel_body(asm, mangled_fragment):

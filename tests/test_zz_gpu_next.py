@@ -363,6 +363,27 @@ def test_integration_stub_query_driver(tmp_path, name):
         assert len(f5) == 5 and f5[0] == str(q) and f5[1] == lph and int(f5[2]) == len(want_s) and float(f5[3]) > 0 and float(f5[4]) > 0, (extra, f5)
         assert np.array_equal(np.fromfile(str(tmp_path / "codes.streaming.u64"), dtype="<u8"), want_s), extra
         assert np.array_equal(np.fromfile(str(tmp_path / "codes.random.u64"), dtype="<u8"), want_r), extra
+    # ABI 4: many small batches over THREE lanes (one session over three replica slots of the one GPU: lphq_session_open_devices) -- the codes come back in the
+    # order of the file --, and the streaming pass collected as runs (--runs: the same k-mer count without a code ever expanded)
+    from util import random_records
+
+    big = queries + random_records(77, 150, 50, 4000) + queries
+    fb = tmp_path / "big.fa"
+    with open(fb, "wb") as f:
+        for i, q in enumerate(big):
+            f.write(b">b%d\n%s\n" % (i, q))
+    big_s = np.concatenate([o(q, True) for q in big if len(q) >= int(z["k"])] or [np.zeros(0, np.uint64)])
+    for extra in (["--devices", "0,0,0", "--batch-bases", "9000"], ["--batch-bases", "9000"]):
+        for f in ("codes.streaming.u64", "codes.random.u64"):
+            if (tmp_path / f).exists():
+                (tmp_path / f).unlink()
+        r = subprocess.run([exe, "query-p" if kind == 0 else "query-u", "-i", lph, "-q", str(fb), "--dump", str(tmp_path / "codes")] + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and int(r.stdout.strip().split(",")[2]) == len(big_s), (extra, r.stdout, r.stderr)
+        assert np.array_equal(np.fromfile(str(tmp_path / "codes.streaming.u64"), dtype="<u8"), big_s), extra
+        assert np.array_equal(np.fromfile(str(tmp_path / "codes.random.u64"), dtype="<u8"), np.concatenate([o(q, False) for q in big if len(q) >= int(z["k"])])), extra
+    for extra in (["--runs"], ["--runs", "--devices", "0,0,0", "--batch-bases", "9000"]):
+        r = subprocess.run([exe, "query-p" if kind == 0 else "query-u", "-i", lph, "-q", str(fb)] + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and int(r.stdout.strip().split(",")[2]) == len(big_s), (extra, r.stdout, r.stderr)
     # exit code 2 for a query file that cannot be opened (src/query.cpp:43-46)
     r = subprocess.run([exe, "query-p" if kind == 0 else "query-u", "-i", lph, "-q", str(tmp_path / "missing.fa")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "Unable to open the input file" in r.stderr

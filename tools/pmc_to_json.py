@@ -25,6 +25,8 @@ WL = {  # raw file suffix -> (key of bench.py, units per launch, kernel name pat
     "c3runs": ("stream|p|k31|m20|n100000000|b0|runs", 100_000_000, S8 % 1),
     "c4sruns": ("stream|p|k63|m20|n2000000000|b0|runs", 2_000_000_000, S8 % 1),
     "c4sg1": ("stream|p|k63|m20|n2000000000|b0|gather1", 2_000_000_000, S8 % 2),
+    "c2nm": ("random|p|k31|m20|n100000000|b28|nonmember0.5", 1 << 28, "k_query_packed"),       # BASELINE.md section 3's secondary inputs
+    "c3sh": ("stream|p|k31|m20|n100000000|b0|shuffled", 100_000_000, S8 % 0),
 }
 out = {"_comment": "HBM/fabric bytes per unit ((FETCH_SIZE x 2 + WRITE_SIZE) x 1024 / units, per MI355X_MICROARCH.md's HBM section) and VALU lane-instructions per "
                    "unit (SQ_INSTS_VALU x 64 / units: a wave64 instruction = 64 lane-instructions whatever the live lanes) from separate rocprofv3 --pmc passes "

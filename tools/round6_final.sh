@@ -11,7 +11,7 @@ cd "$R"
 mkdir -p gpurun_out
 step() { echo "[$(date +%H:%M:%S)] $*" | tee -a gpurun_out/${TAG}_final.log; }
 C4="--k 63 --kmers 2000000000"
-WLS=("c2|" "c3|--mode stream" "c5|--kind u" "c4r|$C4" "c4s|$C4 --mode stream" "c3runs|--mode stream --sink runs" "c4sruns|$C4 --mode stream --sink runs" "c4sg1|$C4 --mode stream --sink gather1")
+WLS=("c2|" "c3|--mode stream" "c5|--kind u" "c4r|$C4" "c4s|$C4 --mode stream" "c3runs|--mode stream --sink runs" "c4sruns|$C4 --mode stream --sink runs" "c4sg1|$C4 --mode stream --sink gather1" "c2nm|--nonmember-frac 0.5" "c3sh|--mode stream --shuffle-records")
 step "ceiling probe"
 python bench.py --probe-ceiling > gpurun_out/${TAG}_probe_ceiling.json 2> gpurun_out/${TAG}_probe_ceiling.log && cp gpurun_out/gather_ceiling.json profiles/gather_ceiling.json
 if [ "${COUNTERS:-1}" = 1 ]; then
@@ -36,7 +36,7 @@ fi
 for w in "${WLS[@]}"; do name=${w%%|*}; echo "== $name"; cat gpurun_out/pmc_${TAG}_$name.txt 2>/dev/null; head -4 gpurun_out/${TAG}_${name}_kernel_stats.txt 2>/dev/null | cut -c1-170; done > gpurun_out/${TAG}_counters.log 2>&1
 if [ "${COUNTERS:-1}" = 1 ]; then
   python3 tools/pmc_to_json.py $TAG gpurun_out > gpurun_out/pmc_traffic_${TAG}.json 2>> gpurun_out/${TAG}_final.log
-  python3 -c "import json; d=json.load(open('gpurun_out/pmc_traffic_${TAG}.json')); assert len(d) >= 9, sorted(d)" && cp gpurun_out/pmc_traffic_${TAG}.json profiles/pmc_traffic.json
+  python3 -c "import json; d=json.load(open('gpurun_out/pmc_traffic_${TAG}.json')); assert len(d) >= 11, sorted(d)" && cp gpurun_out/pmc_traffic_${TAG}.json profiles/pmc_traffic.json
 fi
 step "pytest -m gpu"
 python -m pytest tests -x -q -m gpu --durations=10 > gpurun_out/${TAG}_final_pytest_gpu.txt 2>&1; tail -3 gpurun_out/${TAG}_final_pytest_gpu.txt | tee -a gpurun_out/${TAG}_final.log
