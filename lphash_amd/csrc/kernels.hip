@@ -164,7 +164,8 @@ static hipError_t launch_stream_sink(const lphq_image_header& H, const uint8_t* 
 
 hipError_t launch_query_records_runs(const lphq_image_header& H, const uint8_t* d_img, const char* d_seq, uint64_t total_bases, const uint64_t* d_seq_off,
                                      const uint64_t* d_out_off, size_t n_records, const S8RunsArgs& sink, hipStream_t stream) {
-    const hipError_t e = hipMemsetAsync(sink.counts, 0, sizeof(lphq_run_counts) * LPHQ_RUN_ARENAS, stream);
+    k_zero_run_counts<><<<1, 64, 0, stream>>>(sink.counts);
+    const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_stream_sink(H, d_img, d_seq, total_bases, d_seq_off, d_out_off, n_records, sink, stream, launch_stream8_runs_p, launch_stream8_runs_u);
 }

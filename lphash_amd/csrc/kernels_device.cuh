@@ -923,6 +923,14 @@ __global__ __launch_bounds__(kBlock) void k_expand_runs(const lphq_run* __restri
     if (bad && status) *status = 1ull;
 }
 
+// The arenas' counters back to zero before a streaming pass appends to them: a 64-thread kernel instead of hipMemsetAsync, whose barrier packets cost the
+// stream ~30 us per call (a C3-sized pass is 490 us)
+template <int UNUSED = 0>
+__global__ __launch_bounds__(64) void k_zero_run_counts(lphq_run_counts* __restrict__ counts) {
+    uint64_t* const w = (uint64_t*)counts;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(sizeof(lphq_run_counts) / 8u) * (uint32_t)LPHQ_RUN_ARENAS; i += 64u) w[i] = 0;
+}
+
 // Sessions move a batch's runs over PCIe as ONE dense array: arena after arena, explicit-code indices rebased to the dense code array.  totals[0] = runs,
 // totals[1] = explicit codes, totals[2] = 1 if an arena had overflowed (the batch must be answered some other way), totals[3] = windows in all runs (what the
 // reference's vector.size() adds up to over the batch; zeroed by the launcher).  Every workgroup works the 32 prefix sums
@@ -937,6 +945,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_runs(const lphq_run* __restr
     if (tid == 0) {
         uint64_t r = 0, x = 0;
         uint32_t over = 0;
+#pragma unroll 1  // (unrolled, the 32 steps lived in registers all at once: 119 VGPRs, 68 scalar registers spilled)
         for (uint32_t a = 0; a < (uint32_t)LPHQ_RUN_ARENAS; ++a) {
             sm_rbase[a] = r;
             sm_xbase[a] = x;

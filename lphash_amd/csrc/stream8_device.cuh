@@ -198,6 +198,7 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
     __shared__ uint64_t sm_roff[3];                   // seq_off[rlo], seq_off[rlo+1], out_off[rlo]
     __shared__ uint64_t sm_rtab[2 * kS8RecCap + 1];   // multi-record tiles: the tile's slice of seq_off / out_off
     // kSinkRuns (unused, hence absent, in the other sinks):
+    static_assert(SINK != kSinkRuns || kS8Pos <= 1024, "a queue entry of the runs sink holds the window in 10 bits and the minimizer's offset in 6 (W <= 63)");
     __shared__ uint8_t sm_break[BLOCK];               // bit jw of byte l: window 8 l + jw ends the run to its left (it leads one itself, or it is no window)
     __shared__ uint64_t sm_tile_at, sm_xbase;         // first entry of the tile's reservation in its arena; first explicit code of the round's reservation
     __shared__ uint32_t sm_xcount, sm_xcursor;        // explicit codes the round's colliding runs need; the cursor they are dealt from

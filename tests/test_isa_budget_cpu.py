@@ -27,9 +27,8 @@ BUDGET = {
     "k_count_bad_bases": (64, 0),
     "k_gather_payload": (64, 0),
     "k_expand_runs": (64, 8 * 1024),   # lphq_expand_runs: 256 runs (code, where, inclusive length sum) per workgroup in LDS
-    # sessions: arenas -> one dense array.  Thread 0's prefix sums over the 32 arenas are unrolled by the compiler into registers (119 VGPRs, 68 SGPRs spilled to
-    # lanes, 4 waves per SIMD): a helper of a few dozen workgroups per batch behind a PCIe copy -- not a kernel whose occupancy matters, left as it compiles
-    "k_compact_runs": (128, 1024),
+    "k_compact_runs": (64, 1024),      # sessions: arenas -> one dense array (the 32 prefix sums per workgroup in LDS)
+    "k_zero_run_counts": (64, 0),
     "k_extract_runs": (64, 40 * 1024),  # the streaming kernel's phases A-C + run starts (index construction, extract.hip)
     "k_assemble_runs": (64, 0),
     "k_group_flags": (64, 0),
@@ -42,8 +41,7 @@ BUDGET = {
 }
 # SGPR spills go to VGPR lanes, not to memory.  k_query_packed takes the 1.2-KB header by value (measured 2 % faster than reading the header from the
 # image); since round 3 the fallback function's descriptor is read from the image in the rare path that needs it and nothing spills.
-# k_compact_runs (a session's helper, a few dozen workgroups per batch): thread 0's 32-step prefix loop is unrolled into scalar registers; not a hot kernel.
-SGPR_SPILLS = {"k_query_packed": 0, "k_compact_runs": 80}
+SGPR_SPILLS = {"k_query_packed": 0}
 
 
 _CACHE = {}
