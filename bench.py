@@ -940,18 +940,25 @@ def run_workload(job, wl):
                     binding_b1[label + "_streaming_ns_per_kmer"] = float(np.median([a for a, _ in runs]))
                     binding_b1[label + "_random_ns_per_kmer"] = float(np.median([b for _, b in runs]))
                     binding_b1[label + "_runs"] = runs
-            # the same records as plain FASTA: what the transport of the result costs once the .gz decoder (0.13 ns per k-mer on this file) is out of the way
-            fa_plain = fa[:-3]
+            # plain FASTA of the first 1000 index records (100 Mbases: seven batches, a pipeline that reaches its steady state): what the transport of the result
+            # costs once the .gz decoder (0.13 ns per k-mer on the file above, and only two batches) is out of the way
+            n_plain = min(n_records, 1000)
+            fa_plain = os.path.join(args.cache_dir, f"b1_seed1_k{k}_r{n_plain}.fa")
             if not os.path.exists(fa_plain):
-                with gzip.open(fa, "rb") as fi, open(fa_plain + ".tmp", "wb") as fo:
-                    fo.write(fi.read())
+                with open(fa_plain + ".tmp", "wb") as fo:
+                    for i in range(n_plain):
+                        fo.write(b">s%d\n" % i)
+                        fo.write(recs[i])
+                        fo.write(b"\n")
                 os.replace(fa_plain + ".tmp", fa_plain)
-            plain = {}
+            n_keep, n_s = n_s, n_plain * (rec_len - k + 1)  # (csv_runs checks the k-mer count of the file it runs on)
+            plain = {"records": n_plain, "kmers": n_s}
             for label, extra in (("batched", []), ("batched_runs", ["--runs"]), ("batched_runs_two_lanes", ["--runs", "--devices", f"{local_rank},{local_rank}"])):
                 runs = csv_runs([exb, "query-p" if kind == L.PARTITIONED else "query-u", "-i", path, "-q", fa_plain] + extra, 3)
                 if runs:
                     plain[label + "_streaming_ns_per_kmer"] = float(np.median([a for a, _ in runs]))
                     plain[label + "_runs"] = runs
+            n_s = n_keep
             binding_b1["plain_fasta"] = plain
             log(f"{tag} binding: {binding_b1}")
         log(f"{tag} B1 reference-faithful driver: {cpu_b1['streaming_ns_per_kmer']:.1f} / {cpu_b1['random_ns_per_kmer']:.1f} ns per k-mer (streaming / random); CLI: {cli_b1}")
