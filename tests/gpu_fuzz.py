@@ -14,13 +14,14 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import lphash_amd as L  # noqa: E402
 import orc  # noqa: E402
+from runs_util import ARENAS, COUNTS_DTYPE, RUN_DTYPE, check_runs_against_codes, expand_runs_numpy  # noqa: E402
 from util import dedup_records, genomic_like_records, pack_kmers, random_records  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(20261002)
 t_end = time.time() + budget
-n_cfg = n_codes = n_genomic = n_fallback = 0
+n_cfg = n_codes = n_genomic = n_fallback = n_runs = n_explicit = 0
 tmp = tempfile.mkdtemp()
 while time.time() < t_end:
     bits = int(rng.choice([64, 128]))
@@ -96,6 +97,62 @@ while time.time() < t_end:
             else:
                 assert np.array_equal(got, o(r, False)), (k, m, bits, kind, streaming, i)
             n_codes += len(got)
+    if kind != 2:
+        # round 6: the streaming pass with its result as runs, expanded on the device and by the plain numpy expander, and fused with the payload gather -- against
+        # the streaming codes just checked (`res` of the random pass was last: take the streaming pass again)
+        d_c = torch.empty(int(out_off[-1]) + 1, dtype=torch.int64, device=dev)
+        h.query_records(buf.data_ptr() + mis, len(flat), d_so.data_ptr(), len(batch), d_c.data_ptr(), d_oo.data_ptr(), True)
+        n_out = int(out_off[-1])
+        tight = rng.random() < 0.3  # arenas sized as a session sizes them (may overflow on low-complexity input: must be reported) or for the worst case
+        per_arena = (int(n_out * 2.8 / (k - m + 2) / ARENAS) + 64) if tight else min(n_out, 1024 * (n_out // (ARENAS * 900) + 1)) + 8
+        d_runs = torch.zeros((ARENAS * per_arena + 1) * 2, dtype=torch.int64, device=dev)
+        d_xc = torch.full((ARENAS * per_arena + 1,), -9, dtype=torch.int64, device=dev)
+        d_cnt = torch.empty(ARENAS * 16, dtype=torch.int64, device=dev)
+        h.query_records_runs(buf.data_ptr() + mis, len(flat), d_so.data_ptr(), len(batch), d_oo.data_ptr(), d_runs.data_ptr(), ARENAS * per_arena, d_xc.data_ptr(),
+                             ARENAS * per_arena, d_cnt.data_ptr())
+        d_e = torch.full((n_out + 1,), -5, dtype=torch.int64, device=dev)
+        d_st = torch.ones(1, dtype=torch.int64, device=dev)
+        h.expand_runs(d_runs.data_ptr(), ARENAS * per_arena, d_xc.data_ptr(), ARENAS * per_arena, d_cnt.data_ptr(), d_e.data_ptr(), n_out, d_st.data_ptr())
+        torch.cuda.synchronize()
+        counts = d_cnt.cpu().numpy().view(COUNTS_DTYPE)
+        over = int(counts["runs"].max()) > per_arena or int(counts["codes"].max()) > per_arena
+        assert int(d_xc[-1]) == -9 and int(d_e[-1]) == -5 and (int(d_st.item()) == 1) == over, (k, m, bits, kind, "runs", over, int(d_st.item()))
+        if not over:
+            assert torch.equal(d_e[:-1], d_c[:-1]), (k, m, bits, kind, "expand_runs")
+            valid_all = np.concatenate([((np.concatenate([[0], np.cumsum(np.array([c not in b"ACGTUacgtu" for c in r]))])[k:] - np.concatenate([[0], np.cumsum(np.array([c not in b"ACGTUacgtu" for c in r]))])[:-k]) == 0)
+                                        for r in batch if len(r) >= k] or [np.zeros(0, dtype=bool)])
+            runs_np = d_runs[:-2].cpu().numpy().view(RUN_DTYPE).reshape(ARENAS, per_arena)
+            xc_np = d_xc[:-1].cpu().numpy().view(np.uint64).reshape(ARENAS, per_arena)
+            kinds = check_runs_against_codes(runs_np, xc_np, counts, d_c[:-1].cpu().numpy().view(np.uint64), L.INVALID, valid_all)
+            n_runs += sum(kinds)
+            n_explicit += int(counts["codes"].sum())
+            if n_out < 200_000:
+                assert np.array_equal(expand_runs_numpy(runs_np, xc_np, counts, n_out, L.INVALID), d_c[:-1].cpu().numpy().view(np.uint64))
+        nk = h.get_kmer_count()
+        eb = int(rng.choice([1, 2, 4, 8]))
+        dt = {1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[eb]
+        table = torch.randint(0, 100, (max(nk, 1),), device=dev, dtype=torch.int64).to(dt)
+        pay = torch.full((n_out + 8,), 111, dtype=dt, device=dev)
+        h.query_records_gather(buf.data_ptr() + mis, len(flat), d_so.data_ptr(), len(batch), d_oo.data_ptr(), table.data_ptr(), eb, pay.data_ptr(), missing=120)
+        torch.cuda.synchronize()
+        cc = d_c[:-1]
+        want = torch.where((cc >= 0) & (cc < nk), table[cc.clamp(0, max(nk - 1, 0))], torch.full_like(table[:1], 120).expand(n_out))
+        assert torch.equal(pay[:n_out], want) and bool((pay[n_out:] == 111).all()), (k, m, bits, kind, "gather", eb)
+        n_codes += 2 * n_out
+        # ... and through a session as runs: the dense array == the same codes
+        with h.session(depth=2) as ses:
+            ses.submit_runs(batch)
+            r_d, x_d, n_win, offs = ses.collect_runs()
+        one = np.zeros(ARENAS, dtype=COUNTS_DTYPE)
+        one[0]["runs"], one[0]["codes"] = len(r_d), len(x_d)
+        pr = np.zeros((ARENAS, len(r_d) + 1), dtype=RUN_DTYPE)
+        pc = np.zeros((ARENAS, len(x_d) + 1), dtype=np.uint64)
+        pr[0, :len(r_d)], pc[0, :len(x_d)] = r_d, x_d
+        got_d = expand_runs_numpy(pr, pc, one, n_out, L.INVALID) if n_out < 400_000 else None
+        cnp = cc.cpu().numpy().view(np.uint64)
+        if got_d is not None:
+            vm = got_d != np.uint64(L.INVALID)
+            assert np.array_equal(got_d[vm], cnp[vm]) and int(offs[-1]) == n_out, (k, m, bits, kind, "session runs")
     if kind != 2:  # the same batch through a session (ABI 3), two halves in flight: per record what the one-record call returns
         half = len(batch) // 2
         for streaming in (True, False):
@@ -124,4 +181,4 @@ while time.time() < t_end:
     h.close()
     n_cfg += 1
 print(f"gpu fuzz ok: {n_cfg} random configurations ({n_genomic} drawn with genomic-like records; {n_fallback} k-mers in fallback functions in total), "
-      f"{n_codes} codes compared with the oracle in {budget:.0f} s")
+      f"{n_codes} codes compared with the oracle in {budget:.0f} s; run-encoded results: {n_runs} runs, {n_explicit} explicit codes checked")

@@ -11,6 +11,7 @@
 //   san_host load  <file.lph> <kind> <kmer_bits>                             parse + cross-check + flat image
 //   san_host fuzz  <file.lph> <kind> <kmer_bits> <n> <seed>                  n corrupted copies through the loader
 //   san_host limits <file.lph> <kind> <kmer_bits>                            the parsed file with each count of the device layout's 32-bit limits forged past it
+//   san_host runs <n_windows> <seed> <threads>                               random run-encoded results (runs_host.hpp) expanded by the pool == a serial expansion; plan_runs
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -27,6 +28,7 @@
 #include "lph_format.hpp"
 #include "extract.hpp"
 #include "search.hpp"
+#include "runs_host.hpp"
 
 namespace lphq {
 static std::string g_err;
@@ -275,6 +277,49 @@ int main(int argc, char** argv) {
             (r == 1 ? ended : r == 0 ? full : errors)++;
         }
         printf("inflate fuzz: %d ended, %d out of room, %d errors\n", ended, full, errors);
+        return 0;
+    }
+    if (cmd == "runs" && argc == 5) {
+        // a batch of n windows cut into random runs (some windows in no run: they hold a non-ACGT base), kinds UP / DOWN / EXPLICIT, in shuffled order as the
+        // device leaves them: the pool's expansion must equal a serial one, touch nothing outside the runs and nothing beyond the buffer (exact-size heap blocks)
+        const size_t n = (size_t)atoll(argv[2]);
+        uint64_t x = strtoull(argv[3], nullptr, 10) * 0x9E3779B97F4A7C15ull + 1;
+        auto rnd = [&] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+        std::vector<lphq_run> runs;
+        std::vector<uint64_t> xc, want(n, 0xABABABABABABABABull);
+        for (size_t w = 0; w < n;) {
+            if (rnd() % 11 == 0) { ++w; continue; }
+            const uint32_t len = (uint32_t)std::min<uint64_t>(n - w, 1 + rnd() % (rnd() % 7 == 0 ? 512 : 24)), kind = (uint32_t)(rnd() % 3);
+            lphq_run r;
+            r.where = (uint64_t)w | ((uint64_t)len << 40) | ((uint64_t)kind << 62);
+            if (kind == LPHQ_RUN_EXPLICIT) {
+                r.code = xc.size();
+                for (uint32_t i = 0; i < len; ++i) { xc.push_back(rnd()); want[w + i] = xc.back(); }
+            } else {
+                r.code = rnd() % 3 == 0 ? rnd() % 5 : rnd();  // (wrapping below zero / above 2^64 - 1 like the reference's arithmetic)
+                for (uint32_t i = 0; i < len; ++i) want[w + i] = kind == LPHQ_RUN_UP ? r.code + i : r.code - i;
+            }
+            if (LPHQ_RUN_FIRST(r) != w || LPHQ_RUN_LENGTH(r) != len || LPHQ_RUN_KIND(r) != kind) return 3;
+            runs.push_back(r);
+            w += len;
+        }
+        for (size_t i = runs.size(); i > 1; --i) std::swap(runs[i - 1], runs[rnd() % i]);
+        std::vector<uint64_t> got(n, 0xABABABABABABABABull);
+        lphq::WorkPool pool(atoi(argv[4]));
+        lphq::expand_runs_host(runs.data(), runs.size(), xc.data(), got.data(), &pool);
+        if (got != want) return 4;
+        std::fill(got.begin(), got.end(), 0xABABABABABABABABull);
+        lphq::expand_runs_host(runs.data(), runs.size(), xc.data(), got.data(), nullptr);
+        if (got != want) return 5;
+        // the sizing of a session's arenas: whole arenas, room for the expectation on random sequence, and the worst case holds anything
+        lphq_image_header H{};
+        for (uint32_t W : {1u, 8u, 12u, 44u, 63u}) {
+            H.W = W;
+            const lphq::RunPlan p = lphq::plan_runs(H, n, n + 30, 7, 0, false), wc = lphq::plan_runs(H, n, n + 30, 7, 0, true);
+            if (p.per_arena * LPHQ_RUN_ARENAS < 2 * n / (W + 1) || p.copy_runs > p.per_arena * LPHQ_RUN_ARENAS || wc.per_arena < std::min<size_t>(n, 1024)) return 6;
+            if (wc.per_arena * LPHQ_RUN_ARENAS < std::min<size_t>(n, wc.per_arena * LPHQ_RUN_ARENAS)) return 7;
+        }
+        printf("runs ok: %zu runs, %zu explicit codes over %zu windows\n", runs.size(), xc.size(), n);
         return 0;
     }
     if (cmd == "load" && argc == 5) return load(slurp(argv[2]), atoi(argv[3]), atoi(argv[4]), true);

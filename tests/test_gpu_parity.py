@@ -313,6 +313,30 @@ def test_large_index_properties(tmp_path, kind, k, m, bits, n_rec):
         del seen
         outs.append(d_out)
     assert torch.equal(outs[0], outs[1])
+    # round 6, at the same full size: the streaming pass with its result as runs (lphq_query_records_runs) expands to exactly these codes, and the pass fused with
+    # the payload gather (lphq_query_records_gather) yields table[code] for every window
+    W = k - m + 1
+    per_arena = int(n * (2.0 / (W + 1) + 1.0 / 400.0) * 1.15 / 32) + 4096
+    d_runs = torch.empty(32 * per_arena * 2, dtype=torch.int64, device=dev)
+    d_xc = torch.empty(32 * (per_arena // 8 + 4096), dtype=torch.int64, device=dev)
+    d_counts = torch.empty(32 * 16, dtype=torch.int64, device=dev)
+    h.query_records_runs(d_seq.data_ptr(), int(d_seq.numel()), seq_off.data_ptr(), n_rec, out_off.data_ptr(), d_runs.data_ptr(), 32 * per_arena, d_xc.data_ptr(),
+                         32 * (per_arena // 8 + 4096), d_counts.data_ptr())
+    d_exp = torch.empty(n, dtype=torch.int64, device=dev)
+    d_st = torch.ones(1, dtype=torch.int64, device=dev)
+    h.expand_runs(d_runs.data_ptr(), 32 * per_arena, d_xc.data_ptr(), 32 * (per_arena // 8 + 4096), d_counts.data_ptr(), d_exp.data_ptr(), n, d_st.data_ptr())
+    torch.cuda.synchronize()
+    cnt = d_counts.cpu().numpy().reshape(32, 16)
+    assert int(d_st.item()) == 0 and torch.equal(d_exp, outs[0])
+    assert 0.8 * 2 * n / (W + 1) < int(cnt[:, 0].sum()) < 1.2 * (2 * n / (W + 1) + n / 400) and int(cnt[:, 1].sum()) == h.info.fallback_kmers  # (members: every fallback k-mer once)
+    del d_exp, d_runs, d_xc
+    table = (torch.arange(n, dtype=torch.int64, device=dev) * 2654435761 >> 11).to(torch.uint8)
+    d_pay = torch.empty(n, dtype=torch.uint8, device=dev)
+    h.query_records_gather(d_seq.data_ptr(), int(d_seq.numel()), seq_off.data_ptr(), n_rec, out_off.data_ptr(), table.data_ptr(), 1, d_pay.data_ptr(), missing=255)
+    torch.cuda.synchronize()
+    for a_ in range(0, n, 1 << 28):
+        assert torch.equal(d_pay[a_:a_ + (1 << 28)], table[outs[0][a_:a_ + (1 << 28)]])
+    del d_pay, table
     o = orc.Index(path, kind, bits)
     for i in sorted({0, 1, 37, n_rec // 3, n_rec // 2, n_rec - 2, n_rec - 1}):  # 700 K windows against the oracle's streaming branch
         assert np.array_equal(outs[0][i * 100_000:(i + 1) * 100_000].cpu().numpy().view(np.uint64), o(recs[i], True))

@@ -715,6 +715,10 @@ def test_host_sources_under_sanitizers(tmp_path):
             r = subprocess.run([exe, "limits", str(out), str(kind), str(bits)], capture_output=True, text=True, env=env)
             assert r.returncode == 0 and r.stdout.count(": refused") == 7 and "NOT REFUSED" not in r.stdout, (r.stdout, r.stderr[-2000:])
 
+    # round 6: the host side of the run-encoded result (runs_host.hpp): random runs expanded by the pool == a serial expansion, nothing written outside them
+    for n_w, seed, threads in ((200_000, 1, 8), (1, 2, 3), (5_000, 3, 1), (70_000, 4, 16)):
+        r = subprocess.run([exe, "runs", str(n_w), str(seed), str(threads)], capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and "runs ok" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, (n_w, r.returncode, r.stderr[-3000:])
     # the .gz decoder of the serial input path: a file through the threaded source (odd read sizes), then corrupted copies through the decoder
     import gzip
 
@@ -739,6 +743,8 @@ def test_host_sources_under_sanitizers(tmp_path):
     assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
     # ... and under ThreadSanitizer: the pool, the chain and the emits of the parallel decoder race-free
     if tsan_cc.wait() == 0:  # (a g++ without the TSan runtime: the ASan run above stands alone)
+        r = subprocess.run([texe, "runs", "300000", "9", "8"], capture_output=True, text=True, timeout=900)
+        assert "ThreadSanitizer" not in r.stderr and r.returncode == 0, r.stderr[-4000:]
         for threads, span in ((4, 40_000), (6, 9_000)):
             r = subprocess.run([texe, "inflate_par", str(gz), str(threads), str(span)], capture_output=True, text=True, timeout=900)
             assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
