@@ -180,7 +180,7 @@ int lphq_gather_payload(const lphq_index* idx, const uint64_t* d_codes, size_t n
  *
  * Layout: LPHQ_RUN_ARENAS arenas.  A workgroup appends the runs of its tile to arena (tile % LPHQ_RUN_ARENAS) with ONE atomic add per tile; one
  * counter for the whole batch would serialise -- measured 83 M atomics/s on one address, 4.2 G/s over 64 (tools/gather_ceiling.hip,
- * profiles/r06_gather_ceiling.txt) -- where a 2 G-window batch has 2.1 M tiles in 7 ms.  Arena a holds d_counts[a].runs runs at
+ * profiles/gather_ceiling.json) -- where a 2 G-window batch has 2.1 M tiles in 6 ms.  Arena a holds d_counts[a].runs runs at
  * d_runs[a * arena_runs ...] (in no particular order: each run says where it goes) and d_counts[a].codes explicit codes at d_codes[a * arena_codes ...],
  * arena_runs = cap_runs / LPHQ_RUN_ARENAS, arena_codes = cap_codes / LPHQ_RUN_ARENAS (both capacities: multiples of LPHQ_RUN_ARENAS).  A counter may
  * END ABOVE its arena's capacity: the entries beyond were not written and the result is incomplete -- check after the stream has finished, or let
