@@ -184,7 +184,9 @@ int lphq_gather_payload(const lphq_index* idx, const uint64_t* d_codes, size_t n
  * d_runs[a * arena_runs ...] (in no particular order: each run says where it goes) and d_counts[a].codes explicit codes at d_codes[a * arena_codes ...],
  * arena_runs = cap_runs / LPHQ_RUN_ARENAS, arena_codes = cap_codes / LPHQ_RUN_ARENAS (both capacities: multiples of LPHQ_RUN_ARENAS).  A counter may
  * END ABOVE its arena's capacity: the entries beyond were not written and the result is incomplete -- check after the stream has finished, or let
- * lphq_expand_runs report it.  Sizing: a batch of n windows yields about 2 n / (k - m + 2) + n / 500 runs on random sequence, at most n. */
+ * lphq_expand_runs report it.  Sizing: a batch of n windows yields about 2 n / (k - m + 2) + n / 500 runs on random sequence, at most n; a tile
+ * (~1000 windows) puts all its runs into one arena, so the arenas of a SMALL batch fill unevenly -- an arena that holds
+ * min(n, 1024 * ceil(tiles / LPHQ_RUN_ARENAS)) entries cannot overflow, whatever the sequence. */
 typedef struct lphq_run {
     uint64_t code;
     uint64_t where;
