@@ -932,8 +932,7 @@ static int session_open(lphq_index* idx, int depth, const std::vector<const Repl
     s->depth = depth;
     // one lane (replica + stream) per replica; slot i works on lane i % replicas.  (A stream per SLOT was measured again in round 6, with the run-encoded
     // transport -- 2.6 B per k-mer out against 1 B in, so that overlapping the two directions could pay: the binding's streaming pass went from 0.18 to 0.26 ns
-    // per k-mer with codes and from 0.12 to 0.22 with runs, profiles/r06_binding_rates.txt.  What does pay is more batches in flight: two lanes on one GPU,
-    // `--devices 0,0`, 0.082.)
+    // per k-mer with codes and from 0.12 to 0.22 with runs, profiles/r06_binding_rates.txt.)
     s->lanes.resize(reps.size());
     s->slot.resize(reps.size() * (size_t)depth);
     hipError_t e = hipSuccess;
