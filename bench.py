@@ -751,8 +751,8 @@ def run_workload(job, wl):
         sink = wl["sink"]
         if sink == "runs":
             # arenas for ~2 / (W + 1) runs per window + the cuts at tile and wave ends, 15 % of slack (include/lphq.h); explicit codes: an eighth of that
-            per_arena = int(units * (2.0 / (W + 1) + 1.0 / 400.0) * 1.15 / RUN_ARENAS) + 4096
-            xper_arena = per_arena // 8 + 4096
+            per_arena = int(units * (2.0 / (W + 1) + 1.0 / 400.0) * (1.15 if wl["index_set"] == "uniform" else 1.6) / RUN_ARENAS) + 4096
+            xper_arena = (per_arena // 8 if wl["index_set"] == "uniform" else units // RUN_ARENAS) + 4096  # (repeat-rich sets: up to every window under a colliding minimizer)
             d_runs = torch.empty(RUN_ARENAS * per_arena * 2, dtype=torch.int64, device=dev)
             d_xc = torch.empty(RUN_ARENAS * xper_arena, dtype=torch.int64, device=dev)
             d_counts = torch.empty(RUN_ARENAS * 16, dtype=torch.int64, device=dev)
