@@ -199,7 +199,7 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
     __shared__ uint64_t sm_rtab[2 * kS8RecCap + 1];   // multi-record tiles: the tile's slice of seq_off / out_off
     // kSinkRuns (unused, hence absent, in the other sinks):
     static_assert(SINK != kSinkRuns || kS8Pos <= 1024, "a queue entry of the runs sink holds the window in 10 bits and the minimizer's offset in 6 (W <= 63)");
-    __shared__ uint8_t sm_break[BLOCK];               // bit jw of byte l: window 8 l + jw ends the run to its left (it leads one itself, or it is no window)
+    __shared__ uint64_t sm_break[BLOCK / 8];          // bit w % 64 of word w / 64: window w ends the run to its left (it leads one itself, or it is no window); lane l writes byte l
     __shared__ uint64_t sm_tile_at, sm_xbase;         // first entry of the tile's reservation in its arena; first explicit code of the round's reservation
     __shared__ uint32_t sm_xcount, sm_xcursor;        // explicit codes the round's colliding runs need; the cursor they are dealt from
     const uint32_t tid = threadIdx.x;
@@ -404,7 +404,8 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
 #pragma unroll
             for (uint32_t jw = 0; jw < 8; ++jw) {
                 // (the runs sink also needs to know WHICH window leads: its entry is the window and the minimizer's offset in it, 10 + 6 bits)
-                if ((lmask >> jw) & 1u) sm_queue[at] = SINK == kSinkRuns ? (uint16_t)((a + jw) | ((code[jw] - (a + jw)) << 10)) : (uint16_t)code[jw];
+                // (window | offset << 10 = minimizer position * 1024 - window * 1023: no bits overlap)
+                if ((lmask >> jw) & 1u) sm_queue[at] = SINK == kSinkRuns ? (uint16_t)((code[jw] << 10) - (a + jw) * 1023u) : (uint16_t)code[jw];
                 at += (lmask >> jw) & 1u;
             }
         }
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
 #pragma unroll
                 for (uint32_t jw = 0; jw < 8; ++jw) vmask |= code[jw] < 0xFFFEu ? 1u << jw : 0u;
             }
-            sm_break[tid] = (uint8_t)((lmask | ~vmask) & 0xFFu);
+            ((uint8_t*)sm_break)[tid] = (uint8_t)((lmask | ~vmask) & 0xFFu);
         }
     }
     __syncthreads();
@@ -444,15 +445,15 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
     // include/partitioned_mphf.hpp:131-145.  Colliding leaders (mode 2) only count their windows in the first pass; the second pass, entered when the tile has
     // one, gives them their place in the arena's explicit-code array and looks their k-mers up one by one (src/partitioned_mphf.cpp:312-316).
     const uint64_t first0 = sm_roff[2] + (t0 - shift - sm_roff[0]);  // index of window 0 of the tile in the code space (one record under the tile; wraps harmlessly before it)
-    auto run_length = [&](uint32_t i) {  // windows from i to the next set bit of sm_break, inside the wave's 512 windows
+    auto run_length = [&](uint32_t i) {  // windows from i to the next set bit of sm_break, inside the wave's 512 windows (eight 64-bit words: a run rarely leaves its word)
         const uint32_t end = (i | 511u) + 1u;
         uint32_t w = i + 1u, next = end;
         if (w < end) {
-            uint32_t bits = (uint32_t)sm_break[w >> 3] >> (w & 7u);
+            uint64_t bits = sm_break[w >> 6] >> (w & 63u);
             if (bits) next = w + (uint32_t)__ffsll((long long)bits) - 1u;
             else
-                for (w = (w | 7u) + 1u; w < end; w += 8u) {
-                    bits = sm_break[w >> 3];
+                for (w = (w | 63u) + 1u; w < end; w += 64u) {
+                    bits = sm_break[w >> 6];
                     if (bits) {
                         next = w + (uint32_t)__ffsll((long long)bits) - 1u;
                         break;
@@ -564,7 +565,7 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
             b = __shfl(b, 0, 64);
             if (ld)
                 sm_queue[b + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] =
-                    SINK == kSinkRuns ? (uint16_t)((a + jw) | ((cj - (a + jw)) << 10)) : (uint16_t)cj;
+                    SINK == kSinkRuns ? (uint16_t)((cj << 10) - (a + jw) * 1023u) : (uint16_t)cj;
             __syncthreads();
             n = sm_slot_count;
         }
