@@ -788,7 +788,8 @@ def run_workload(job, wl):
     torch.cuda.synchronize()
     job.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    step_ms = [float(a.elapsed_time(b)) for a, b in evs]
+    kernel_ms = float(np.mean(step_ms))
     kernel_ms_per_rank = [kernel_ms]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -1054,6 +1055,8 @@ def run_workload(job, wl):
                 "index_image_bytes": int(h.info.image_bytes), "type_mix": mix,
             },
             "kernel_ms": kernel_ms,
+            "kernel_ms_steps": [round(x, 4) for x in step_ms],  # every timed step (HIP events): a host stall between two launches of one step shows here, not in a mean
+            "kernel_ms_median": float(np.median(step_ms)),
             "kernel_ms_per_rank": kernel_ms_per_rank,
             "kernel_ms_min": min(kernel_ms_per_rank),
             "kernel_ms_max": max(kernel_ms_per_rank),
@@ -1265,7 +1268,7 @@ def summary_table(out):
 
 
 def secondary_entry(out, wl):
-    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "kernel_ms", "kernel_ms_min", "kernel_ms_max", "parity_vs_oracle",
+    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "kernel_ms", "kernel_ms_steps", "kernel_ms_median", "kernel_ms_min", "kernel_ms_max", "parity_vs_oracle",
             "parity_ranks_checked", "replicas_agree", "roofline", "roofline_valu", "cpu_baseline", "index_build_s", "image_broadcast_ms", "scaling", "strong",
             "index_sha256", "index_digest_pinned", "sink", "binding_end_to_end")
     e = {"name": wl["name"], "workload": out["config"]["workload"], "units_per_step_per_gpu": out["config"]["units_per_step_per_gpu"],
