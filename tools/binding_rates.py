@@ -49,8 +49,8 @@ def main():
         os.replace(gz + ".tmp", gz)
     exe = os.path.join(ROOT, "examples", "query_example64")
     for file in [fa] + ([gz] if os.path.exists(gz) else []):
-        for label, env, extra in (("codes over PCIe", {"LPHQ_SESSION_TRANSPORT": "codes"}, []), ("runs over PCIe, expanded on the host", {}, []),
-                                  ("runs over PCIe, handed out as runs", {}, ["--runs"]), ("runs, expanded, two lanes", {}, ["--devices", "0,0"]),
+        for label, env, extra in (("codes over PCIe", {"LPHQ_SESSION_TRANSPORT": "codes"}, []), ("runs over PCIe, expanded on the host", {"LPHQ_SESSION_TRANSPORT": "runs"}, []),
+                                  ("runs over PCIe, handed out as runs", {}, ["--runs"]), ("runs, expanded, two lanes", {"LPHQ_SESSION_TRANSPORT": "runs"}, ["--devices", "0,0"]),
                                   ("runs as runs, two lanes", {}, ["--runs", "--devices", "0,0"])):
             vals = []
             for _ in range(args.reps):
