@@ -30,6 +30,7 @@ total units / max-over-ranks time -- "query batches sharded across the GPUs" as 
 and cache paths, checks that every rank resolved the same plan and prints it -- what tests/test_dist_cpu.py runs.
 """
 import argparse
+import gc
 import hashlib
 import json
 import os
@@ -780,14 +781,21 @@ def run_workload(job, wl):
     job.barrier()
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    host_ms, gc_seen = [], []
+    gc_cb = lambda phase, info: gc_seen.append((phase, info.get("generation"), time.perf_counter()))
+    gc.callbacks.append(gc_cb)
     t0 = time.perf_counter()
     for a, b in evs:
+        h0 = time.perf_counter()
         a.record()  # HIP events on the stream the kernel is launched on (torch's current stream)
         step()
         b.record()
+        host_ms.append((time.perf_counter() - h0) * 1e3)  # what the host spent queueing this step: a stall between two launches of one step shows here AND in the events
     torch.cuda.synchronize()
     job.barrier()
     elapsed = time.perf_counter() - t0
+    gc.callbacks.remove(gc_cb)
+    gc_ms = sum((e[2] - s_[2]) * 1e3 for s_, e in zip(gc_seen[0::2], gc_seen[1::2]))  # (start, stop) pairs of Python's collector inside the timed region
     step_ms = [float(a.elapsed_time(b)) for a, b in evs]
     kernel_ms = float(np.mean(step_ms))
     kernel_ms_per_rank = [kernel_ms]
@@ -969,10 +977,10 @@ def run_workload(job, wl):
     if dist is not None:
         # a probe set common to all ranks, in both modes (random: the timed batches differ per rank; streaming: the weak line streams the same records
         # on every rank -- their checksum rides along -- but the strong line's shards differ): packed k-mers of seeded windows through the random kernel
-        gc = torch.Generator(device=dev)
-        gc.manual_seed(777)
+        gcm = torch.Generator(device=dev)
+        gcm.manual_seed(777)
         Qc = 1 << 20
-        win = torch.randint(0, nk, (Qc,), generator=gc, device=dev, dtype=torch.int64)
+        win = torch.randint(0, nk, (Qc,), generator=gcm, device=dev, dtype=torch.int64)
         posc = (win // RECORD_KMERS) * rec_len + win % RECORD_KMERS
         d_kc = torch.empty(Qc * (kmer_bits // 64), dtype=torch.int64, device=dev)
         h.pack_kmers(d_seq.data_ptr(), posc.data_ptr(), Qc, d_kc.data_ptr(), stream)
@@ -1057,6 +1065,7 @@ def run_workload(job, wl):
             "kernel_ms": kernel_ms,
             "kernel_ms_steps": [round(x, 4) for x in step_ms],  # every timed step (HIP events): a host stall between two launches of one step shows here, not in a mean
             "kernel_ms_median": float(np.median(step_ms)),
+            "host_queue_ms_steps": [round(x, 4) for x in host_ms], "python_gc_in_timed_region": {"collections": len(gc_seen) // 2, "ms": round(gc_ms, 3)},
             "kernel_ms_per_rank": kernel_ms_per_rank,
             "kernel_ms_min": min(kernel_ms_per_rank),
             "kernel_ms_max": max(kernel_ms_per_rank),
@@ -1268,7 +1277,7 @@ def summary_table(out):
 
 
 def secondary_entry(out, wl):
-    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "kernel_ms", "kernel_ms_steps", "kernel_ms_median", "kernel_ms_min", "kernel_ms_max", "parity_vs_oracle",
+    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "kernel_ms", "kernel_ms_steps", "kernel_ms_median", "host_queue_ms_steps", "python_gc_in_timed_region", "kernel_ms_min", "kernel_ms_max", "parity_vs_oracle",
             "parity_ranks_checked", "replicas_agree", "roofline", "roofline_valu", "cpu_baseline", "index_build_s", "image_broadcast_ms", "scaling", "strong",
             "index_sha256", "index_digest_pinned", "sink", "binding_end_to_end")
     e = {"name": wl["name"], "workload": out["config"]["workload"], "units_per_step_per_gpu": out["config"]["units_per_step_per_gpu"],
