@@ -1,6 +1,6 @@
 """One-off robustness run on the GPU (not part of the test suite: minutes of oracle time): random (k, m, width, kind) configurations, random record
 batches with ragged lengths, empty records, non-ACGT bases and every pointer alignment, through lphq_query_records (streaming and random), lphq_query_packed,
-lphq_query_contig and lphq_session_* -- every code compared with the CPU oracle.   gpurun --timeout 1500 -- python tests/gpu_fuzz.py [seconds]"""
+lphq_query_contig and lphq_session_* -- every code compared with the CPU oracle.   gpurun --timeout 1500 -- python tests/gpu_fuzz.py [seconds [seed]]"""
 import os
 import sys
 import tempfile
@@ -19,7 +19,7 @@ from util import dedup_records, genomic_like_records, pack_kmers, random_records
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
 dev = torch.device("cuda", 0)
-rng = np.random.default_rng(20261002)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20261002)  # (a second run takes another seed: other configurations)
 t_end = time.time() + budget
 n_cfg = n_codes = n_genomic = n_fallback = n_runs = n_explicit = 0
 tmp = tempfile.mkdtemp()
