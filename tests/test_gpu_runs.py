@@ -397,3 +397,42 @@ print("lanes ok", order)
         env = dict(os.environ, LPHQ_TEST_SELF_PEER="1", LPHQ_SESSION_TRANSPORT=transport)
         r = subprocess.run([sys.executable, "-c", script, ROOT, str(tmp_path)], capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0 and "lanes ok [0, 1, 2, 3, 4, 5, 6]" in r.stdout, (transport, r.stdout[-500:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("name", ["se_k47_m20_b128_u", "se_k31_m20_b64_p"])
+def test_fallback_rich_batch_under_load(tmp_path, name):
+    """The short unitigs of the real fixture (repeat regions: most of the function's colliding minimizers) a hundred times over -- thousands of workgroups, every tile
+    multi-record, ~1 window in 10 through the fallback function (src/partitioned_mphf.cpp:312-316) -- through the three sinks: every copy == the oracle, three
+    launches each.  (A patched payload sink was right on 47 tiles and wrong on 1 fallback window in 100 on this batch: profiles/r06_transposed_gather_attempt.txt.)"""
+    from real_fixture import CASES, OUT, load_inputs, unitig_records
+
+    torch, dev = torch_dev()
+    kind, k, m, bits, ust = CASES[name]
+    recs = unitig_records(load_inputs(), ust)
+    path = os.path.join(OUT, name + ".lph")
+    if not os.path.exists(path):
+        path = str(tmp_path / "x.lph")
+        L.build(recs, k, m, path, kind=kind, kmer_bits=bits, threads=8, device=0)
+    h = (L.Mphf if kind == 0 else L.MphfAlt).load(path, kmer_bits=bits, device=0)
+    o = orc.Index(path, kind, bits)
+    short = [r for r in recs if len(r) < 900]
+    one = np.concatenate([o(q, False) for q in short])
+    reps = 100
+    want = torch.from_numpy(np.tile(one, reps).view(np.int64)).to(dev)
+    nk = h.get_kmer_count()
+    n_fallback = int((one >= np.uint64(nk - o.fallback_keys)).sum()) if hasattr(o, "fallback_keys") else None
+    assert n_fallback is None or n_fallback * 20 > len(one)  # a batch that leans on the fallback function
+    b = DeviceBatch(torch, dev, short * reps, k, 5)
+    assert b.n_out == len(one) * reps
+    table = torch.arange(nk, dtype=torch.int64, device=dev)  # the element IS the slot
+    for _ in range(3):
+        assert torch.equal(gpu_codes(h, torch, dev, b), want)
+        runs, codes, counts, dv = gpu_runs(h, torch, dev, b, per_arena=b.n_out // ARENAS + 4096)
+        d_e, st = gpu_expand(h, torch, dev, dv, b.n_out)
+        assert st == 0 and torch.equal(d_e, want)
+        for eb, dt in ((8, torch.int64), (1, torch.uint8)):
+            t = table if eb == 8 else (table % 251).to(dt)
+            out = torch.full((b.n_out + 16,), 99, dtype=dt, device=dev)
+            h.query_records_gather(b.d_seq, b.n_bases, b.d_so.data_ptr(), b.n_records, b.d_oo.data_ptr(), t.data_ptr(), eb, out.data_ptr(), missing=7)
+            torch.cuda.synchronize()
+            assert torch.equal(out[:b.n_out], t[want]) and bool((out[b.n_out:] == 99).all()), eb
