@@ -15,6 +15,7 @@
 // include/partitioned_mphf.hpp:122,150-163 do.
 #pragma once
 #include <gfx950/shift_in.cuh>
+#include <gfx950/vgpr_allocation.cuh>
 #include <gfx950/wave_scan.cuh>
 
 #include "kernels_device.cuh"
@@ -177,6 +178,14 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
                                                                   const uint64_t* __restrict__ seq_off, const uint64_t* __restrict__ out_off, uint32_t n_records,
                                                                   uint64_t* __restrict__ out, uint64_t tile_base /* first tile of this launch */,
                                                                   const typename S8SinkArgs<SINK>::type sink) {
+    if constexpr (SINK == kSinkGather) {
+        // The payload sink's wide-window instantiations need exactly 56 VGPRs, and with a 56-register allocation the first of the eight fallback blocks of phase F --
+        // the only code that holds values in v54 / v55 -- came out wrong for ~1 colliding window in 100 once the device was full (never on its first workgroups,
+        // never in the emulator; same instructions with a 64-register allocation: never).  What writes there was not found (profiles/r06_transposed_gather_attempt.txt:
+        // not a missing wait, not an LDS race, registers held by a probe kernel beside it keep their values); the allocation is what decides, so it is made 64 --
+        // which costs nothing: 10 KB of LDS per workgroup already bounds a SIMD at 8 waves.  tests/test_gpu_runs.py::test_fallback_rich_batch_under_load is the guard.
+        allocate_64_vgprs();  // (gfx950/vgpr_allocation.cuh)
+    }
     const lphq_image_header& H = *(const lphq_image_header*)img;
     constexpr int kS8Pos = 8 * BLOCK, NW = tile_words(kS8Pos);
     constexpr uint32_t kS8Row = s8_row<BLOCK>();
@@ -704,13 +713,9 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
             }
         };
         {
-            // table[code] per window; element size uniform over the launch.  A lane's eight elements are 8 << el contiguous bytes of the output:
-            // staged through LDS like the codes and copied out in 16-byte pieces when the tile lies in one record.
+            // table[code] per window; element size uniform over the launch.
             const uint32_t el = sink.elem_log2;
-            uint64_t pv[8];  // the lane's eight elements
-#pragma unroll
-            for (uint32_t jw = 0; jw < 8; ++jw) {
-                const uint64_t c = hv[jw];
+            auto load_elem = [&](uint64_t c) -> uint64_t {
                 const bool in = c < sink.n_slots;  // (LPHQ_INVALID and a non-member's wrapped code are not slots)
                 const uint64_t i = in ? c : 0ull;
                 uint64_t v;
@@ -718,8 +723,9 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
                 else if (el == 1u) v = ((const uint16_t*)sink.table)[i];
                 else if (el == 2u) v = ((const uint32_t*)sink.table)[i];
                 else v = ((const uint64_t*)sink.table)[i];
-                pv[jw] = in ? v : sink.missing;
-            }
+                return in ? v : sink.missing;
+            };
+            uint64_t pv[8];  // the lane's eight elements
             // ... as a little-endian byte stream of 8 << el bytes: 1 << el words, in place
             auto pack = [&]() {
                 if (el == 2u) {
@@ -747,13 +753,30 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
                 else ((u64a1*)p)->v = v;
             };
             if (one_record) {
-                pack();
+                // A lane holds the codes of 8 CONSECUTIVE windows: loading table[code] from there, the 64 lanes of one load instruction sit 8 windows apart --
+                // a different run, so a different line of the table, for almost every lane (C4: ~23 lines per instruction, C3: 64; eight instructions), and
+                // the pass was bound by those line requests (measured: + 2.9 ms at C4, + 0.38 ms at C3 over the codes sink, in proportion to the RUNS).  The
+                // codes go through LDS first (as the codes sink stages them for its stores) and come back transposed -- lane l takes windows l, l + BLOCK, ... --
+                // so that one instruction covers 64 consecutive windows: the 3 - 10 runs under them, as many lines.  The elements then go to their place in
+                // the staged tile (window w at byte w << el) and leave in 16-byte pieces.
+                static_assert(kS8Pos == 8 * BLOCK, "eight windows per lane");
                 __syncthreads();  // (every lane has read the bases of its leaders)
-                uint64_t* const sm64 = sm_hash;
-                const uint32_t nq = 1u << el;  // 8-byte words per lane
+                ulonglong2* const sm_codes = (ulonglong2*)sm_hash;  // kS8Pos codes = 8 KB <= sizeof(sm_hash) (asserted by the codes sink's twin)
 #pragma unroll
-                for (uint32_t i = 0; i < 8; ++i)
-                    if (i < nq) sm64[tid * nq + i] = pv[i];
+                for (uint32_t jw = 0; jw < 8; jw += 2) sm_codes[4u * tid + jw / 2u] = make_ulonglong2(hv[jw], hv[jw + 1]);
+                __syncthreads();
+#pragma unroll
+                for (uint32_t i = 0; i < 8; ++i) pv[i] = load_elem(sm_hash[i * (uint32_t)BLOCK + tid]);
+                __syncthreads();  // (every code has been read: the array now takes the elements)
+                uint64_t* const sm64 = sm_hash;
+#pragma unroll
+                for (uint32_t i = 0; i < 8; ++i) {
+                    const uint32_t w = i * (uint32_t)BLOCK + tid;
+                    if (el == 0u) ((uint8_t*)sm_hash)[w] = (uint8_t)pv[i];
+                    else if (el == 1u) ((uint16_t*)sm_hash)[w] = (uint16_t)pv[i];
+                    else if (el == 2u) ((uint32_t*)sm_hash)[w] = (uint32_t)pv[i];
+                    else sm64[w] = pv[i];
+                }
                 __syncthreads();
                 // bytes [w_lo << el, w_hi << el) of the staged tile -> the output, 16 at a time
                 const uint32_t lo_b = w_lo << el, hi_b = w_hi << el;
@@ -776,6 +799,8 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
                     }
                 }
             } else {
+#pragma unroll
+                for (uint32_t jw = 0; jw < 8; ++jw) pv[jw] = load_elem(hv[jw]);
                 uint64_t oidx[8];
                 walk_windows(oidx);
                 bool all8 = oidx[7] == oidx[0] + 7u;

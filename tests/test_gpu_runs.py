@@ -436,3 +436,33 @@ def test_fallback_rich_batch_under_load(tmp_path, name):
             h.query_records_gather(b.d_seq, b.n_bases, b.d_so.data_ptr(), b.n_records, b.d_oo.data_ptr(), t.data_ptr(), eb, out.data_ptr(), missing=7)
             torch.cuda.synchronize()
             assert torch.equal(out[:b.n_out], t[want]) and bool((out[b.n_out:] == 99).all()), eb
+
+
+@pytest.mark.parametrize("k,m,bits,kind", [(15, 9, 64, 0), (63, 20, 128, 0), (21, 8, 64, 1), (13, 10, 64, 1)])
+def test_fallback_rich_synthetic_sets_under_load(tmp_path, k, m, bits, kind):
+    """The same under-load check for other instantiations of the streaming kernel (narrow windows: W = 7 and 4; k = 63 partitioned; W = 14 unpartitioned): genomic-like
+    sets (diverged copies: shared minimizers, colliding ones) of short records, enough copies for ~4 M windows, three launches per sink, every copy == the oracle."""
+    torch, dev = torch_dev()
+    from util import genomic_like_records
+
+    recs = genomic_like_records(k * 131 + m, 260, k, 700)
+    path = str(tmp_path / "g.lph")
+    L.build(recs, k, m, path, kind=kind, kmer_bits=bits, threads=8, device=0)
+    h = (L.Mphf if kind == 0 else L.MphfAlt).load(path, kmer_bits=bits, device=0)
+    o = orc.Index(path, kind, bits)
+    assert o.fallback_keys * 50 > o.nkmers, (o.fallback_keys, o.nkmers)  # the fallback function holds a real share of the set
+    one = np.concatenate([o(q, False) for q in recs])
+    reps = max(2, 4_000_000 // len(one))
+    want = torch.from_numpy(np.tile(one, reps).view(np.int64)).to(dev)
+    b = DeviceBatch(torch, dev, recs * reps, k, 1)
+    nk = h.get_kmer_count()
+    table = torch.arange(nk, dtype=torch.int64, device=dev)
+    for _ in range(3):
+        assert torch.equal(gpu_codes(h, torch, dev, b), want)
+        runs, codes, counts, dv = gpu_runs(h, torch, dev, b, per_arena=b.n_out // ARENAS + 4096)
+        d_e, st = gpu_expand(h, torch, dev, dv, b.n_out)
+        assert st == 0 and torch.equal(d_e, want)
+        out = torch.full((b.n_out + 16,), 99, dtype=torch.int64, device=dev)
+        h.query_records_gather(b.d_seq, b.n_bases, b.d_so.data_ptr(), b.n_records, b.d_oo.data_ptr(), table.data_ptr(), 8, out.data_ptr(), missing=7)
+        torch.cuda.synchronize()
+        assert torch.equal(out[:b.n_out], want) and bool((out[b.n_out:] == 99).all())
