@@ -438,9 +438,10 @@ def test_fallback_rich_batch_under_load(tmp_path, name):
             assert torch.equal(out[:b.n_out], t[want]) and bool((out[b.n_out:] == 99).all()), eb
 
 
-@pytest.mark.parametrize("k,m,bits,kind", [(15, 9, 64, 0), (63, 20, 128, 0), (21, 8, 64, 1), (13, 10, 64, 1)])
+@pytest.mark.parametrize("k,m,bits,kind", [(15, 9, 64, 0), (63, 20, 128, 0), (21, 8, 64, 1), (13, 10, 64, 1), (31, 20, 64, 1), (38, 20, 128, 1), (47, 17, 128, 1), (31, 15, 64, 0),
+                                           (37, 20, 128, 0)])
 def test_fallback_rich_synthetic_sets_under_load(tmp_path, k, m, bits, kind):
-    """The same under-load check for other instantiations of the streaming kernel (narrow windows: W = 7 and 4; k = 63 partitioned; W = 14 unpartitioned): genomic-like
+    """The same under-load check for other instantiations of the streaming kernel (narrow windows: W = 7 and 4; k = 63; both kinds and key widths at W = 12 ... 31: other members of the (W - 8) % 8 family): genomic-like
     sets (diverged copies: shared minimizers, colliding ones) of short records, enough copies for ~4 M windows, three launches per sink, every copy == the oracle."""
     torch, dev = torch_dev()
     from util import genomic_like_records
