@@ -726,22 +726,6 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
                 return in ? v : sink.missing;
             };
             uint64_t pv[8];  // the lane's eight elements
-            // ... as a little-endian byte stream of 8 << el bytes: 1 << el words, in place
-            auto pack = [&]() {
-                if (el == 2u) {
-#pragma unroll
-                    for (uint32_t i = 0; i < 4; ++i) pv[i] = (pv[2 * i] & 0xFFFFFFFFull) | (pv[2 * i + 1] << 32);
-                } else if (el == 1u) {
-#pragma unroll
-                    for (uint32_t i = 0; i < 2; ++i)
-                        pv[i] = (pv[4 * i] & 0xFFFFull) | ((pv[4 * i + 1] & 0xFFFFull) << 16) | ((pv[4 * i + 2] & 0xFFFFull) << 32) | (pv[4 * i + 3] << 48);
-                } else if (el == 0u) {
-                    uint64_t w = 0;
-#pragma unroll
-                    for (uint32_t i = 0; i < 8; ++i) w |= (pv[i] & 0xFFull) << (8u * i);
-                    pv[0] = w;
-                }
-            };
             struct __attribute__((packed, aligned(1))) u64a1 { uint64_t v; };
             struct __attribute__((packed, aligned(1))) u32a1 { uint32_t v; };
             struct __attribute__((packed, aligned(1))) u16a1 { uint16_t v; };
@@ -752,13 +736,14 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
                 else if (el == 2u) ((u32a1*)p)->v = (uint32_t)v;
                 else ((u64a1*)p)->v = v;
             };
-            if (one_record) {
+            {
                 // A lane holds the codes of 8 CONSECUTIVE windows: loading table[code] from there, the 64 lanes of one load instruction sit 8 windows apart --
                 // a different run, so a different line of the table, for almost every lane (C4: ~23 lines per instruction, C3: 64; eight instructions), and
                 // the pass was bound by those line requests (measured: + 2.9 ms at C4, + 0.38 ms at C3 over the codes sink, in proportion to the RUNS).  The
                 // codes go through LDS first (as the codes sink stages them for its stores) and come back transposed -- lane l takes windows l, l + BLOCK, ... --
                 // so that one instruction covers 64 consecutive windows: the 3 - 10 runs under them, as many lines.  The elements then go to their place in
-                // the staged tile (window w at byte w << el) and leave in 16-byte pieces.
+                // the staged tile (window w at byte w << el); a tile under one record leaves in 16-byte pieces, a tile of many records lane by lane (each lane
+                // takes its eight elements back and stores them where the walk of the records says).
                 static_assert(kS8Pos == 8 * BLOCK, "eight windows per lane");
                 __syncthreads();  // (every lane has read the bases of its leaders)
                 ulonglong2* const sm_codes = (ulonglong2*)sm_hash;  // kS8Pos codes = 8 KB <= sizeof(sm_hash) (asserted by the codes sink's twin)
@@ -768,16 +753,18 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
 #pragma unroll
                 for (uint32_t i = 0; i < 8; ++i) pv[i] = load_elem(sm_hash[i * (uint32_t)BLOCK + tid]);
                 __syncthreads();  // (every code has been read: the array now takes the elements)
-                uint64_t* const sm64 = sm_hash;
 #pragma unroll
                 for (uint32_t i = 0; i < 8; ++i) {
                     const uint32_t w = i * (uint32_t)BLOCK + tid;
                     if (el == 0u) ((uint8_t*)sm_hash)[w] = (uint8_t)pv[i];
                     else if (el == 1u) ((uint16_t*)sm_hash)[w] = (uint16_t)pv[i];
                     else if (el == 2u) ((uint32_t*)sm_hash)[w] = (uint32_t)pv[i];
-                    else sm64[w] = pv[i];
+                    else sm_hash[w] = pv[i];
                 }
                 __syncthreads();
+            }
+            uint64_t* const sm64 = sm_hash;
+            if (one_record) {
                 // bytes [w_lo << el, w_hi << el) of the staged tile -> the output, 16 at a time
                 const uint32_t lo_b = w_lo << el, hi_b = w_hi << el;
                 uint8_t* const dstb = sink.out + (first0 << el);  // byte address of window 0 of the tile
@@ -799,23 +786,31 @@ __global__ __launch_bounds__(BLOCK, DIRECT ? 1 : 8) void k_query_tiles_stream8(c
                     }
                 }
             } else {
+                // the lane's eight elements as they lie in the staged tile: 8 << el bytes = 1 << el words
+                const uint32_t nq = 1u << el;
 #pragma unroll
-                for (uint32_t jw = 0; jw < 8; ++jw) pv[jw] = load_elem(hv[jw]);
+                for (uint32_t i = 0; i < 8; ++i)
+                    if (i < nq) pv[i] = sm64[tid * nq + i];
+                auto elem_of = [&](uint32_t jw) -> uint64_t {  // (jw is a constant after unrolling)
+                    if (el == 3u) return pv[jw];
+                    if (el == 2u) return (pv[jw >> 1] >> ((jw & 1u) * 32u)) & 0xFFFFFFFFull;
+                    if (el == 1u) return (pv[jw >> 2] >> ((jw & 3u) * 16u)) & 0xFFFFull;
+                    return (pv[0] >> (jw * 8u)) & 0xFFull;
+                };
                 uint64_t oidx[8];
                 walk_windows(oidx);
                 bool all8 = oidx[7] == oidx[0] + 7u;
 #pragma unroll
                 for (uint32_t jw = 0; jw < 8; ++jw) all8 = all8 && code[jw] != 0xFFFEu;
                 if (all8) {  // eight windows of one record: 8 << el contiguous bytes
-                    pack();
                     uint8_t* const p = sink.out + (oidx[0] << el);
 #pragma unroll
                     for (uint32_t i = 0; i < 8; ++i)
-                        if (i < (1u << el)) ((u64a1*)(p + 8u * i))->v = pv[i];
+                        if (i < nq) ((u64a1*)(p + 8u * i))->v = pv[i];
                 } else {
 #pragma unroll
                     for (uint32_t jw = 0; jw < 8; ++jw)
-                        if (code[jw] != 0xFFFEu) store_elem(oidx[jw], pv[jw]);
+                        if (code[jw] != 0xFFFEu) store_elem(oidx[jw], elem_of(jw));
                 }
             }
         }

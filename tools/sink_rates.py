@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--kind", default="p")
     ap.add_argument("--kmers", type=int, default=100_000_000)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--read-len", type=int, default=0, help="query the index records cut into reads of this many bases (every tile multi-record) instead of whole")
     ap.add_argument("--cache-dir", default=os.environ.get("LPHQ_BENCH_CACHE", "/tmp/lphq_bench_cache"))
     args = ap.parse_args()
     import numpy as np
@@ -46,6 +47,12 @@ def main():
     h = (L.Mphf if kind == L.PARTITIONED else L.MphfAlt).load(path, kmer_bits=bits, device=0)
     d_seq = recs.to_device(torch, dev)
     total = int(d_seq.numel())
+    if args.read_len:  # the same bases as reads: pieces of read_len bases of the records, back to back (all members; windows across two pieces are not asked)
+        assert args.read_len >= k and rec_len >= args.read_len
+        per = rec_len // args.read_len
+        d_seq = d_seq.view(n_records, rec_len)[:, : per * args.read_len].contiguous().view(-1)
+        total = int(d_seq.numel())
+        n_records, rec_len = n_records * per, args.read_len
     wpr = rec_len - k + 1
     n_out = n_records * wpr
     seq_off = torch.arange(0, n_records + 1, dtype=torch.int64, device=dev) * rec_len
@@ -77,7 +84,7 @@ def main():
         torch.cuda.synchronize()
         return float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
-    res = {"k": k, "m": args.m, "kind": args.kind, "kmers": nk, "windows": n_out, "image_MB": h.info.image_bytes / 1e6}
+    res = {"k": k, "m": args.m, "kind": args.kind, "kmers": nk, "read_len": args.read_len, "records": n_records, "windows": n_out, "image_MB": h.info.image_bytes / 1e6}
     res["codes_ms"] = timed(lambda: h.query_records(d_seq.data_ptr(), total, seq_off.data_ptr(), n_records, d_out.data_ptr(), out_off.data_ptr(), True, stream))
     res["runs_ms"] = timed(lambda: h.query_records_runs(d_seq.data_ptr(), total, seq_off.data_ptr(), n_records, out_off.data_ptr(), d_runs.data_ptr(), arenas * per_arena,
                                                         d_xc.data_ptr(), arenas * per_arena, d_counts.data_ptr(), stream))
