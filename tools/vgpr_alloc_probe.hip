@@ -257,3 +257,10 @@ int main(int argc, char** argv) {
     run("allocation 64 (v8..v55 held, v63 touched)", k64, hist, reps, dwell);
     return 0;
 }
+
+// the same kernels from another program (tools/debug_corun_gpu.py: the probe on one stream, the kernel under suspicion on another, in ONE process so that their waves share SIMDs)
+extern "C" int probe_launch(void* stream, unsigned* d_hist, unsigned blocks, unsigned dwell, int alloc64) {
+    if (alloc64) hipLaunchKernelGGL(k64, dim3(blocks), dim3(128), 0, (hipStream_t)stream, d_hist, dwell);
+    else hipLaunchKernelGGL(k56, dim3(blocks), dim3(128), 0, (hipStream_t)stream, d_hist, dwell);
+    return (int)hipGetLastError();
+}
