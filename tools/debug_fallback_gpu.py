@@ -1,4 +1,4 @@
-"""Debug aid for profiles/r06_transposed_gather_attempt.txt: a build with -DLPHQ_DEBUG_S64 -DLPHQ_DEBUG_WHAT=<expr> dumps one value per window under a colliding
+"""Debug aid for profiles/r06_transposed_gather_attempt.txt: a build with the hooks of profiles/attempts/r06_debug_hooks.patch (-DLPHQ_DEBUG_S64 -DLPHQ_DEBUG_WHAT=<expr>) dumps one value per window under a colliding
 minimizer (by base position); the dump of launch n is written to LPHQ_DBG_FILE by launch n + 1.  Compared here with the truth for the windows launch n got wrong."""
 import os
 import sys
