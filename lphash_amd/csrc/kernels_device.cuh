@@ -888,7 +888,7 @@ __global__ __launch_bounds__(kBlock) void k_expand_runs(const lphq_run* __restri
         if (c0 + tid < n) r = src[c0 + tid];
         uint32_t len = LPHQ_RUN_LENGTH(r);
         const uint64_t first = LPHQ_RUN_FIRST(r);
-        if (first + len > n_out || (LPHQ_RUN_KIND(r) == LPHQ_RUN_EXPLICIT && r.code + len > arena_codes) || LPHQ_RUN_KIND(r) == 3u) {  // not a run of this batch: skipped
+        if (first + len > n_out || (LPHQ_RUN_KIND(r) == LPHQ_RUN_EXPLICIT && (r.code > arena_codes || len > arena_codes - r.code)) || LPHQ_RUN_KIND(r) == 3u) {  // (no sum that could wrap)  // not a run of this batch: skipped
             bad = bad || len != 0u;
             len = 0;
         }

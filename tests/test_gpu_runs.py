@@ -467,3 +467,22 @@ def test_fallback_rich_synthetic_sets_under_load(tmp_path, k, m, bits, kind):
         h.query_records_gather(b.d_seq, b.n_bases, b.d_so.data_ptr(), b.n_records, b.d_oo.data_ptr(), table.data_ptr(), 8, out.data_ptr(), missing=7)
         torch.cuda.synchronize()
         assert torch.equal(out[:b.n_out], want) and bool((out[b.n_out:] == 99).all())
+
+
+def test_forged_runs_are_skipped_and_reported():
+    """lphq_expand_runs takes its runs from the caller: entries whose fields would wrap a sum (explicit-code index 2^64 - 1), point beyond an arena or beyond the output, or
+    carry no kind are skipped and reported -- nothing is read or written outside the buffers (the device keeps answering afterwards)."""
+    from test_runs_cpu import forged_runs
+
+    torch, dev = torch_dev()
+    h = L.Mphf.load(os.path.join(ROOT, "tests", "golden", "p_k31_m20_b64.lph"), kmer_bits=64, device=0)
+    runs, codes, counts, n_out, want = forged_runs()
+    d_runs = torch.from_numpy(np.ascontiguousarray(runs).view(np.int64).reshape(-1).copy()).to(dev)
+    d_codes = torch.from_numpy(codes.view(np.int64).reshape(-1).copy()).to(dev)
+    d_counts = torch.from_numpy(np.ascontiguousarray(counts).view(np.int64).reshape(-1).copy()).to(dev)
+    d_out = torch.full((n_out + 1,), -5, dtype=torch.int64, device=dev)
+    d_st = torch.zeros(1, dtype=torch.int64, device=dev)
+    h.expand_runs(d_runs.data_ptr(), ARENAS * 8, d_codes.data_ptr(), ARENAS * 8, d_counts.data_ptr(), d_out.data_ptr(), n_out, d_st.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_st.item()) == 1 and int(d_out[-1]) == -5
+    assert np.array_equal(d_out[:-1].cpu().numpy().view(np.uint64), want)

@@ -169,6 +169,33 @@ def test_runs_capacity_overflow_is_reported_on_the_emulator(emur, tmp_path):
     assert st == 1
 
 
+def forged_runs():
+    """Runs no kernel of the library writes (lphq_expand_runs takes its runs from the caller): an explicit run whose code index + length wraps 2^64, one whose index lies beyond the
+    arena, a run beyond the output, a run of kind 3 -- and one good run.  -> (runs[ARENAS, 8], codes[ARENAS, 8], counts, n_out, expected output)."""
+    runs = np.zeros((ARENAS, 8), dtype=RUN_DTYPE)
+    codes = np.arange(ARENAS * 8, dtype=np.uint64).reshape(ARENAS, 8) + np.uint64(1000)
+    counts = np.zeros(ARENAS, dtype=COUNTS_DTYPE)
+    n_out = 64
+    where = lambda first, length, kind: np.uint64(first | (length << 40) | (kind << 62))
+    runs[0][0] = (np.uint64(0xFFFFFFFFFFFFFFFF), where(0, 2, 2))   # explicit, code index 2^64 - 1: index + length wraps to 1
+    runs[0][1] = (np.uint64(9), where(4, 3, 2))                    # explicit, index beyond the arena's 8 codes
+    runs[0][2] = (np.uint64(7), where(60, 10, 0))                  # up-run that leaves the output
+    runs[0][3] = (np.uint64(7), where(8, 2, 3))                    # no such kind
+    runs[0][4] = (np.uint64(500), where(20, 5, 0))                 # good: windows 20..24 = 500..504
+    runs[0][5] = (np.uint64(6), where(30, 2, 2))                   # good: explicit codes 6, 7 of arena 0
+    counts[0]["runs"], counts[0]["codes"] = 6, 8
+    want = np.full(n_out, L.INVALID, dtype=np.uint64)
+    want[20:25] = np.arange(500, 505, dtype=np.uint64)
+    want[30:32] = codes[0][6:8]
+    return runs, codes, counts, n_out, want
+
+
+def test_forged_runs_are_skipped_and_reported_on_the_emulator(emur):
+    runs, codes, counts, n_out, want = forged_runs()
+    got, st = emu_expand(emur, runs, codes, counts, n_out)
+    assert st == 1 and np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("mode,seed", [(1, 0), (2, 424242)])
 def test_sinks_under_other_thread_schedules(emur, tmp_path, mode, seed):
     """A missing barrier in the new sinks becomes a mismatch when the threads of a workgroup run in reverse / reshuffled order between synchronisation points."""
